@@ -1,0 +1,403 @@
+/*
+ * pm_oracle.c -- CPU restatement of the per-sample loops of pymodem's demod_chain hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under pymodem_amd/ may include, link or call this file;
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
+ *
+ * Every function restates the algorithm of the reference file:line it cites (paths relative to
+ * the reference checkout, ninocarrillo/pymodem @ 2025-01-31).  The arithmetic is IEEE-754 binary64
+ * with the reference's operation order; build with -ffp-contract=off so that no multiply-add is
+ * fused unless written as fma().
+ *
+ * Parity status: pinned by tests/golden/*.npz, which tests/golden/make_goldens.py produced by
+ * importing the reference itself (NumPy 2.2.6 / SciPy 1.15.3) -- see tests/test_oracle_*.py.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#define PM_TWO_PI (2.0 * 3.141592653589793)   /* Python: 2.0 * math.pi */
+
+/* ------------------------------------------------------------------------------------------
+ * FIR, numpy.convolve(x, h, 'valid') semantics: y[k] = sum_j h[j] * x[k+M-1-j].
+ * Summation order is the BUILD's canonical order (ascending input index, one fma per tap),
+ * which the HIP kernels reproduce bit for bit.  NumPy's own order is unspecified (BLAS ddot),
+ * so against the reference this is a tolerance comparison, against the GPU an exact one.
+ * ---------------------------------------------------------------------------------------- */
+__attribute__((target_clones("fma", "default")))
+void pmo_fir_f64(const double *x, int64_t n, const double *h, int m, double *y)
+{
+    int64_t nout = n - m + 1;
+    for (int64_t k = 0; k < nout; ++k) {
+        double acc = 0.0;
+        for (int i = 0; i < m; ++i)
+            acc = fma(h[m - 1 - i], x[k + i], acc);
+        y[k] = acc;
+    }
+}
+
+__attribute__((target_clones("fma", "default")))
+void pmo_fir_i16(const int16_t *x, int64_t n, const double *h, int m, double *y)
+{
+    int64_t nout = n - m + 1;
+    for (int64_t k = 0; k < nout; ++k) {
+        double acc = 0.0;
+        for (int i = 0; i < m; ++i)
+            acc = fma(h[m - 1 - i], (double)x[k + i], acc);
+        y[k] = acc;
+    }
+}
+
+/* AFSK mark/space quadrature correlators, afsk.py:153-162.  Four FIRs on the same input,
+ * sqrt(i*i + q*q) for each tone (separately rounded square, add, sqrt), mark - space. */
+__attribute__((target_clones("fma", "default")))
+void pmo_afsk_correlate(const double *x, int64_t n, const double *mi, const double *mq,
+                        const double *si, const double *sq, int m, double *y)
+{
+    int64_t nout = n - m + 1;
+    for (int64_t k = 0; k < nout; ++k) {
+        double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+        for (int i = 0; i < m; ++i) {
+            double v = x[k + i];
+            a = fma(mi[m - 1 - i], v, a);
+            b = fma(mq[m - 1 - i], v, b);
+            c = fma(si[m - 1 - i], v, c);
+            d = fma(sq[m - 1 - i], v, d);
+        }
+        double mark = sqrt(a * a + b * b);
+        double space = sqrt(c * c + d * d);
+        y[k] = mark - space;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * AGC, agc.py:26-37 (peak_detect) and :61-80 (apply).  In place.
+ * state[0] = envelope, state[1] = sustain_count (both carried across calls, like self.*).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    double attack_rate, decay_rate, sustain_time, sample_rate, target_amplitude;
+} pmo_agc_params;
+
+void pmo_agc_apply(double *buf, int64_t n, const pmo_agc_params *p, double *state, double *env_out)
+{
+    if (n <= 0) return;
+    double scaled_attack = p->attack_rate / p->sample_rate;     /* agc.py:15 */
+    double scaled_decay = p->decay_rate / p->sample_rate;       /* agc.py:16 */
+    double sustain_inc = 1 / p->sample_rate;                    /* agc.py:17 */
+    double normal = buf[0];                                     /* agc.py:67 max(buffer), signed */
+    for (int64_t i = 1; i < n; ++i)
+        if (buf[i] > normal) normal = buf[i];
+    double env = state[0], sustain = state[1];
+    double att = scaled_attack * normal, dec = scaled_decay * normal;
+    for (int64_t i = 0; i < n; ++i) {
+        double s = buf[i];
+        double cmp = fabs(s);
+        if (cmp > env) {                                        /* agc.py:28-32 */
+            env += att;
+            if (env > cmp) env = cmp;
+            sustain = 0.0;
+        }
+        if (sustain >= p->sustain_time) {                       /* agc.py:33-36 */
+            env -= dec;
+            if (env < 0) env = 0;
+        }
+        sustain += sustain_inc;                                 /* agc.py:37 */
+        if (env != 0) buf[i] = p->target_amplitude * s / env;   /* agc.py:75-76 */
+        if (env_out) env_out[i] = env / normal;                 /* agc.py:77-78 */
+    }
+    state[0] = env;
+    state[1] = sustain;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * NCO (nco.py:34-53), 1st-order IIR (iir.py:38-54), PI controller (pi_control.py:25-33).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    double phase_scaling;     /* 2.0*pi / sample_rate            nco.py:31 */
+    double index_scaling;     /* wavetable_size / (2.0*pi)       nco.py:27 */
+    double set_frequency;
+    const double *table;      /* amplitude*sin(i*2.0*pi/size), computed by the caller with math.sin */
+    int size;
+    /* state */
+    double phase, control, sine, cosine;
+} pmo_nco;
+
+static inline void nco_update(pmo_nco *o)
+{
+    o->phase += o->phase_scaling * (o->set_frequency + o->control);   /* nco.py:35 */
+    while (o->phase >= PM_TWO_PI) o->phase = o->phase - PM_TWO_PI;     /* nco.py:36-37 */
+    while (o->phase < 0) o->phase = o->phase + PM_TWO_PI;              /* nco.py:38-39 */
+    int idx = (int)(o->phase * o->index_scaling);                      /* nco.py:40 int() truncates */
+    if (idx >= 0 && idx < o->size) o->sine = o->table[idx];            /* nco.py:41-45: on IndexError the old value stays */
+    int cidx = (int)(idx + (o->size / 4.0));                           /* nco.py:46 */
+    while (cidx >= o->size) cidx -= o->size;
+    while (cidx < 0) cidx += o->size;
+    o->cosine = o->table[cidx];                                        /* nco.py:51 */
+}
+
+typedef struct { double b0, b1, a1; double x0, x1, y0; } pmo_iir1;
+
+static inline double iir_update(pmo_iir1 *f, double sample)
+{
+    f->x1 = f->x0;                      /* iir.py:40-42 */
+    f->x0 = sample;
+    double v = 0.0;
+    v += f->x0 * f->b0;                 /* iir.py:45-46 */
+    v += f->x1 * f->b1;
+    double y1 = f->y0;                  /* iir.py:48-49 */
+    v += y1 * f->a1;                    /* iir.py:51-52 */
+    f->y0 = v;
+    return v;
+}
+
+typedef struct { double p_rate, i_rate, i_limit, gain; double integral, proportional; } pmo_pi;
+
+static inline double pi_update_saturate(pmo_pi *c, double sample)
+{
+    c->proportional = c->gain * c->p_rate * sample;          /* pi_control.py:26 (left to right) */
+    c->integral += c->gain * (c->i_rate * sample);           /* pi_control.py:27 */
+    if (c->integral > c->i_limit) c->integral = c->i_limit;
+    if (c->integral < -c->i_limit) c->integral = -c->i_limit;
+    return c->proportional + c->integral;                    /* pi_control.py:32 */
+}
+
+/* Parameter/state block shared by the three carrier loops.  Plain doubles so Python can fill it. */
+typedef struct {
+    /* NCO */
+    double phase_scaling, index_scaling, set_frequency;
+    /* IIR */
+    double b0, b1, a1;
+    /* PI */
+    double p_rate, i_rate, i_limit, gain;
+    /* state (in/out) */
+    double phase, control, sine, cosine;
+    double x0, x1, y0;
+    double integral, proportional;
+} pmo_loop;
+
+static void loop_open(const pmo_loop *L, const double *table, pmo_nco *o, pmo_iir1 *f, pmo_pi *c)
+{
+    o->phase_scaling = L->phase_scaling; o->index_scaling = L->index_scaling;
+    o->set_frequency = L->set_frequency; o->table = table; o->size = 256;
+    o->phase = L->phase; o->control = L->control; o->sine = L->sine; o->cosine = L->cosine;
+    f->b0 = L->b0; f->b1 = L->b1; f->a1 = L->a1; f->x0 = L->x0; f->x1 = L->x1; f->y0 = L->y0;
+    c->p_rate = L->p_rate; c->i_rate = L->i_rate; c->i_limit = L->i_limit; c->gain = L->gain;
+    c->integral = L->integral; c->proportional = L->proportional;
+}
+
+static void loop_close(pmo_loop *L, const pmo_nco *o, const pmo_iir1 *f, const pmo_pi *c)
+{
+    L->phase = o->phase; L->control = o->control; L->sine = o->sine; L->cosine = o->cosine;
+    L->x0 = f->x0; L->x1 = f->x1; L->y0 = f->y0;
+    L->integral = c->integral; L->proportional = c->proportional;
+}
+
+/* NCO alone, driven by a control sequence (unit-test hook for nco.py:34-53). */
+void pmo_nco_run(pmo_loop *L, const double *table, const double *control, int64_t n,
+                 double *sine, double *cosine, double *phase)
+{
+    pmo_nco o; pmo_iir1 f; pmo_pi c;
+    loop_open(L, table, &o, &f, &c);
+    for (int64_t k = 0; k < n; ++k) {
+        o.control = control[k];
+        nco_update(&o);
+        sine[k] = o.sine; cosine[k] = o.cosine; phase[k] = o.phase;
+    }
+    loop_close(L, &o, &f, &c);
+}
+
+void pmo_iir_run(pmo_loop *L, const double *x, int64_t n, double *y)
+{
+    pmo_nco o; pmo_iir1 f; pmo_pi c;
+    loop_open(L, 0, &o, &f, &c);
+    for (int64_t k = 0; k < n; ++k) y[k] = iir_update(&f, x[k]);
+    loop_close(L, &o, &f, &c);
+}
+
+void pmo_pi_run(pmo_loop *L, const double *x, int64_t n, double *y, double *integral)
+{
+    pmo_nco o; pmo_iir1 f; pmo_pi c;
+    loop_open(L, 0, &o, &f, &c);
+    for (int64_t k = 0; k < n; ++k) { y[k] = pi_update_saturate(&c, x[k]); integral[k] = c.integral; }
+    loop_close(L, &o, &f, &c);
+}
+
+/* BPSK Costas loop, psk.py:173-189.  out[k] = i_mixer. */
+void pmo_costas_bpsk(pmo_loop *L, const double *table, const double *x, int64_t n, double *out)
+{
+    pmo_nco o; pmo_iir1 f; pmo_pi c;
+    loop_open(L, table, &o, &f, &c);
+    for (int64_t k = 0; k < n; ++k) {
+        double s = x[k];
+        nco_update(&o);
+        double i_mixer = s * o.cosine;          /* ComplexOutput.real = cosine   psk.py:177 */
+        double q_mixer = s * (-o.sine);         /* ComplexOutput.imag = -sine    psk.py:182 */
+        double loop_mixer = i_mixer * q_mixer;  /* psk.py:183 */
+        double lp = iir_update(&f, loop_mixer);
+        o.control = pi_update_saturate(&c, lp); /* psk.py:187 */
+        out[k] = i_mixer;
+    }
+    loop_close(L, &o, &f, &c);
+}
+
+/* AFSK PLL, afsk_pll.py:153-165.  out[k] = PI proportional term. */
+void pmo_pll_afsk(pmo_loop *L, const double *table, const double *x, int64_t n, double *out)
+{
+    pmo_nco o; pmo_iir1 f; pmo_pi c;
+    loop_open(L, table, &o, &f, &c);
+    for (int64_t k = 0; k < n; ++k) {
+        nco_update(&o);
+        double mixer = x[k] * o.sine;           /* afsk_pll.py:156 */
+        double lp = iir_update(&f, mixer);
+        o.control = pi_update_saturate(&c, lp); /* afsk_pll.py:160 */
+        out[k] = c.proportional;                /* afsk_pll.py:163 */
+    }
+    loop_close(L, &o, &f, &c);
+}
+
+/* Phase-detector lookup, phase_detector.py:124-149.  table is [64][64] row-major int32,
+ * table[r][i] as built by phase_detector.py:36-44 (granularity 64). */
+static inline int pd_lookup(const int32_t *table, double re, double im)
+{
+    const int g = 64;
+    double fr = floor(re * g * 0.5), fi = floor(im * g * 0.5);
+    /* int(floor(x)) then clip; clip in double first so that huge values do not overflow int */
+    if (fr > 1e9) fr = 1e9; if (fr < -1e9) fr = -1e9;
+    if (fi > 1e9) fi = 1e9; if (fi < -1e9) fi = -1e9;
+    int r = (int)fr, i = (int)fi;
+    if (r >= g) r = g - 1;
+    if (i >= g) i = g - 1;
+    if (r <= -g) r = -(g - 1);
+    if (i <= -g) i = -(g - 1);
+    if (r >= 0) {
+        if (i >= 0) return table[r * g + i];        /* Q1 */
+        return table[(-i) * g + r];                 /* Q4 */
+    }
+    if (i >= 0) return table[i * g + (-r)];         /* Q2 */
+    return table[(-r) * g + (-i)];                  /* Q3 */
+}
+
+void pmo_pd_run(const int32_t *table, const double *re, const double *im, int64_t n, int32_t *err)
+{
+    for (int64_t k = 0; k < n; ++k) err[k] = pd_lookup(table, re[k], im[k]);
+}
+
+/* MPSK carrier loop, psk.py:734-747 with complexmath.py:15-19. */
+void pmo_mpsk_loop(pmo_loop *L, const double *table, const int32_t *pd_table,
+                   const double *re_in, const double *im_in, int64_t n, double *i_out, double *q_out)
+{
+    pmo_nco o; pmo_iir1 f; pmo_pi c;
+    loop_open(L, table, &o, &f, &c);
+    for (int64_t k = 0; k < n; ++k) {
+        double sr = re_in[k], si = im_in[k];
+        nco_update(&o);
+        double ar = o.cosine, ai = -o.sine;                 /* nco.py:52-53 */
+        double re = (sr * ar) - (si * ai);                  /* complexmath.py:16 */
+        double im = (ar * si) + (sr * ai);                  /* complexmath.py:17 */
+        int e = pd_lookup(pd_table, re, im);                /* psk.py:739 */
+        double lp = iir_update(&f, (double)e);
+        o.control = nearbyint(pi_update_saturate(&c, lp));  /* psk.py:740 round() = half-to-even */
+        i_out[k] = re;
+        q_out[k] = im;
+    }
+    loop_close(L, &o, &f, &c);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Slicers.  state: [0]=phase_clock [1]=last_i [2]=last_q [3]=working_byte [4]=bit_count
+ *                  [5]=streamaddress [6]=state_register   (all stored as double / exact ints)
+ * ---------------------------------------------------------------------------------------- */
+/* BinarySlicer.slice, slicer.py:59-107.  Returns number of bytes emitted (cap = capacity). */
+int64_t pmo_slice_binary(const double *x, int64_t n, double sps, double lock_rate, double *state,
+                         uint8_t *out_data, int64_t *out_addr, int64_t cap)
+{
+    double clk = state[0], last = state[1];
+    unsigned byte = (unsigned)state[3];
+    int bits = (int)state[4];
+    int64_t addr = (int64_t)state[5];
+    double thr = (sps / 2.0) - 0.5;                        /* slicer.py:52 */
+    int64_t cnt = 0;
+    for (int64_t k = 0; k < n; ++k) {
+        double s = x[k];
+        addr += 1;
+        clk += 1.0;
+        if (clk >= thr) {
+            clk -= sps;
+            byte = (byte << 1) & 0xFF;
+            if (s >= 0) byte |= 1;
+            bits += 1;
+            if (bits >= 8) {
+                bits = 0;
+                if (cnt < cap) { out_data[cnt] = (uint8_t)byte; out_addr[cnt] = addr; }
+                cnt++;
+            }
+        }
+        if ((last < 0.0 && s >= 0.0) || (last >= 0.0 && s < 0.0))
+            clk = clk * lock_rate;
+        last = s;
+    }
+    state[0] = clk; state[1] = last; state[3] = byte; state[4] = bits; state[5] = (double)addr;
+    return cnt;
+}
+
+/* QuadratureSlicer.slice, slicer.py:193-242. */
+int64_t pmo_slice_quadrature(const double *xi, const double *xq, int64_t n, double sps, double lock_rate,
+                             int bits_per_symbol, int state_mask, const int32_t *demap, double *state,
+                             uint8_t *out_data, int64_t *out_addr, int64_t cap)
+{
+    double clk = state[0], last_i = state[1], last_q = state[2];
+    unsigned long byte = (unsigned long)state[3];
+    int bits = (int)state[4];
+    int64_t addr = (int64_t)state[5];
+    unsigned sreg = (unsigned)state[6];
+    double thr = (sps / 2.0) - 0.5;
+    int64_t cnt = 0;
+    for (int64_t k = 0; k < n; ++k) {
+        double si = xi[k], sq = xq[k];
+        addr += 1;
+        clk += 1.0;
+        if (clk >= thr) {
+            clk -= sps;
+            sreg = (sreg << 2) & (unsigned)state_mask;
+            if (si >= 0) sreg |= 2;
+            if (sq >= 0) sreg |= 1;
+            byte = byte << bits_per_symbol;
+            byte |= (unsigned long)demap[sreg];
+            bits += bits_per_symbol;
+            if (bits >= 8) {
+                bits = 0;
+                byte &= 0xFF;
+                if (cnt < cap) { out_data[cnt] = (uint8_t)byte; out_addr[cnt] = addr; }
+                cnt++;
+            }
+        }
+        if (((last_i < 0.0 && si >= 0.0) || (last_i >= 0.0 && si < 0.0)) ||
+            ((last_q < 0.0 && sq >= 0.0) || (last_q >= 0.0 && sq < 0.0)))
+            clk = clk * lock_rate;
+        last_i = si;
+        last_q = sq;
+    }
+    state[0] = clk; state[1] = last_i; state[2] = last_q; state[3] = (double)(byte & 0xFF);
+    state[4] = bits; state[5] = (double)addr; state[6] = sreg;
+    return cnt;
+}
+
+/* LFSR.stream_unscramble_8bit, lfsr.py:22-52.  sr is the free-running shift register (in/out). */
+void pmo_lfsr(const uint8_t *in, int64_t n, uint64_t poly, int invert, uint64_t *sr, uint8_t *out)
+{
+    uint64_t reg = *sr;
+    unsigned working = 0;
+    for (int64_t k = 0; k < n; ++k) {
+        unsigned b = in[k];
+        for (int bit = 0; bit < 8; ++bit) {
+            working = (working << 1) & 0xFE;
+            if (b & 0x80) reg ^= poly;
+            working |= (unsigned)(reg & 1);
+            b <<= 1;
+            reg >>= 1;
+        }
+        working &= 0xFF;
+        out[k] = (uint8_t)(invert ? (0xFF ^ working) : working);
+    }
+    *sr = reg;
+}

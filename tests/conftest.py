@@ -1,0 +1,60 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    """Lazy loader for the committed .npz fixtures (tests/golden/make_goldens.py made them)."""
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = np.load(os.path.join(GOLDEN, name + ".npz"))
+        return cache[name]
+    return load
+
+
+@pytest.fixture(scope="session")
+def config_lines():
+    def load(name):
+        with open(os.path.join(GOLDEN, "configs", name)) as f:
+            return [l for l in (json.loads(s) for s in f if s.strip()) if l.get("object_type") == "demod_chain"]
+    return load
+
+
+def noise_i16(n, seed=1234, sigma=8000.0):
+    """The synthetic buffer BASELINE.md prescribes."""
+    x = np.random.default_rng(seed).standard_normal(n) * sigma
+    return np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+
+
+def read_wav_pcm16(path):
+    """Minimal RIFF/PCM16 mono reader (tests only)."""
+    import struct
+    with open(path, "rb") as f:
+        b = f.read()
+    assert b[:4] == b"RIFF" and b[8:12] == b"WAVE"
+    pos = 12
+    rate = None
+    while pos < len(b):
+        cid, sz = b[pos:pos + 4], struct.unpack("<I", b[pos + 4:pos + 8])[0]
+        if cid == b"fmt ":
+            fmt, ch, rate, _, _, bits = struct.unpack("<HHIIHH", b[pos + 8:pos + 24])
+            assert fmt == 1 and ch == 1 and bits == 16
+        elif cid == b"data":
+            return rate, np.frombuffer(b[pos + 8:pos + 8 + sz], dtype="<i2").copy()
+        pos += 8 + sz + (sz & 1)
+    raise ValueError("no data chunk")

@@ -1,0 +1,447 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by IMPORTING the reference (ninocarrillo/pymodem) in the
+build container.  Only DATA (inputs + expected outputs) is written to tests/golden/;
+no reference source or bytecode is copied.  The reference does not exist on the GPU
+box, so nothing at test time imports it -- tests read the .npz/.json files this
+script wrote.
+
+Run (build container only):
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_goldens.py
+
+Versions used for the committed goldens: Python 3.10.12, NumPy 2.2.6, SciPy 1.15.3.
+"""
+import contextlib
+import hashlib
+import io
+import json
+import os
+import shutil
+import sys
+
+sys.dont_write_bytecode = True
+REF = os.environ.get("PYMODEM_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+
+import numpy as np  # noqa: E402
+from scipy.io.wavfile import read as readwav  # noqa: E402
+
+import modems_codecs.chain_builder as cb  # noqa: E402
+import modems_codecs.agc as ref_agc  # noqa: E402
+import modems_codecs.nco as ref_nco  # noqa: E402
+import modems_codecs.iir as ref_iir  # noqa: E402
+import modems_codecs.pi_control as ref_pi  # noqa: E402
+import modems_codecs.rrc as ref_rrc  # noqa: E402
+import modems_codecs.hilbert as ref_hilbert  # noqa: E402
+import modems_codecs.phase_detector as ref_pd  # noqa: E402
+import modems_codecs.lfsr as ref_lfsr  # noqa: E402
+import modems_codecs.crc_functions as ref_crc  # noqa: E402
+import modems_codecs.rs_functions as ref_rs  # noqa: E402
+import modems_codecs.gf_functions as ref_gf  # noqa: E402
+import modems_codecs.slicer as ref_slicer  # noqa: E402
+import modems_codecs.ax25 as ref_ax25  # noqa: E402
+import modems_codecs.il2p as ref_il2p  # noqa: E402
+from modems_codecs.data_classes import AddressedData, IQData  # noqa: E402
+from modems_codecs.packet_meta import PacketMetaArray  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+WAV = os.path.join(REF, "audio_samples", "afsk_300_il2pc_noise.wav")
+
+WORKING_CONFIGS = [
+    "afsk_1200.json", "afsk_1200_ax25_opt.json", "afsk_1200_ax25_super_opt.json",
+    "afsk_1200_il2p.json", "afsk_300.json", "afsk_300_ax25.json", "afsk_300_pll.json",
+    "bpsk_300.json", "bpsk_1200.json", "fsk_4800.json", "fsk_9600.json",
+    "qpsk_600.json", "qpsk_2400.json", "qpsk_3600.json",
+]
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def noise(n, seed=1234, sigma=8000.0):
+    x = np.random.default_rng(seed).standard_normal(n) * sigma
+    return np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+
+
+def load_config(name):
+    with open(os.path.join(REF, "configs", name)) as f:
+        return [json.loads(line) for line in f if line.strip()]
+
+
+def build_chain(rate, line):
+    with quiet():
+        modem = cb.ModemConfigurator(rate, line["modem"])
+        try:
+            srate = modem.output_sample_rate
+        except Exception:
+            srate = rate
+        slicer = cb.SlicerConfigurator(srate, line["slicer"])
+        stream = cb.StreamConfigurator(line["stream"])
+        codec = cb.CodecConfigurator(line["codec"], line["object_name"])
+    return [line["object_name"], modem, slicer, stream, codec]
+
+
+def pkts_to_dict(pkts, prefix, d):
+    """Flatten a list[PacketMeta] into arrays under keys prefix_*."""
+    d[prefix + "_n"] = np.array(len(pkts), dtype=np.int64)
+    d[prefix + "_addr"] = np.array([p.streamaddress for p in pkts], dtype=np.int64)
+    d[prefix + "_len"] = np.array([len(p.data) for p in pkts], dtype=np.int64)
+    d[prefix + "_corrected"] = np.array([p.BytesCorrected for p in pkts], dtype=np.int64)
+    flat = []
+    for p in pkts:
+        flat.extend(int(b) for b in p.data)
+    d[prefix + "_data"] = np.array(flat, dtype=np.uint8)
+
+
+def run_chain(chain, audio, d, prefix, keep_demod=True, decim=1):
+    """Run demod -> slice -> stream -> codec exactly as chain_execute does; record each stage."""
+    with quiet():
+        demod = chain[1].demod(audio)
+        if isinstance(demod, IQData):
+            i = np.asarray(demod.i_data, dtype=np.float64)
+            q = np.asarray(demod.q_data, dtype=np.float64)
+            d[prefix + "_n_demod"] = np.array(len(i), dtype=np.int64)
+            if keep_demod:
+                d[prefix + "_demod_i"] = i[::decim].copy()
+                d[prefix + "_demod_q"] = q[::decim].copy()
+        else:
+            y = np.asarray(demod, dtype=np.float64)
+            d[prefix + "_n_demod"] = np.array(len(y), dtype=np.int64)
+            if keep_demod:
+                d[prefix + "_demod"] = y[::decim].copy()
+        sliced = chain[2].slice(demod)
+        d[prefix + "_slice_data"] = np.array([s.data for s in sliced], dtype=np.uint8)
+        d[prefix + "_slice_addr"] = np.array([s.address for s in sliced], dtype=np.int64)
+        stream = chain[3].stream_unscramble_8bit(sliced)
+        d[prefix + "_lfsr_data"] = np.array([s.data for s in stream], dtype=np.uint8)
+        pkts = chain[4].decode(stream)
+    pkts_to_dict(pkts, prefix + "_pkt", d)
+    return pkts
+
+
+# ----------------------------------------------------------------------------------------
+def gen_taps():
+    """Tap vectors of every modem preset at several sample rates (host-side tap design)."""
+    d = {}
+    rates = [8000, 11025, 22050, 44100, 48000, 96000]
+    with quiet():
+        for rate in rates:
+            for cfg in ["300", "1200"]:
+                m = cb.ModemConfigurator(rate, {"type": "afsk", "config": cfg, "options": {}})
+                k = f"afsk_{cfg}_{rate}"
+                d[k + "_bpf"] = m.input_bpf
+                d[k + "_lpf"] = m.output_lpf
+                d[k + "_mi"] = m.mark_correlator_i
+                d[k + "_mq"] = m.mark_correlator_q
+                d[k + "_si"] = m.space_correlator_i
+                d[k + "_sq"] = m.space_correlator_q
+            # retuned AFSK as used by afsk_1200*.json
+            m = cb.ModemConfigurator(rate, {"type": "afsk", "config": "1200", "options": {
+                "space_gain": "1.75", "mark_freq": "1300.0", "space_freq": "2100.0",
+                "correlator_span": "1.5"}})
+            k = f"afsk_1200opt_{rate}"
+            d[k + "_mi"] = m.mark_correlator_i
+            d[k + "_mq"] = m.mark_correlator_q
+            d[k + "_si"] = m.space_correlator_i
+            d[k + "_sq"] = m.space_correlator_q
+            for cfg in ["9600", "4800", "4800-rrc", "9600-rrc", "4800-gauss", "9600-gauss"]:
+                if rate < 22050 and cfg.startswith("9600"):
+                    continue
+                try:
+                    m = cb.ModemConfigurator(rate, {"type": "fsk", "config": cfg, "options": {}})
+                except ValueError:
+                    continue    # cutoff above Nyquist at this rate: the reference raises too
+                d[f"fsk_{cfg}_{rate}_lpf"] = np.asarray(m.input_lpf, dtype=np.float64)
+            for cfg in ["300", "1200"]:
+                m = cb.ModemConfigurator(rate, {"type": "bpsk", "config": cfg, "options": {}})
+                d[f"bpsk_{cfg}_{rate}_bpf"] = m.input_bpf
+                d[f"bpsk_{cfg}_{rate}_rrc"] = np.asarray(m.rrc.taps, dtype=np.float64)
+            for cfg in ["qpsk_3600", "qpsk_600", "qpsk_2400", "bpsk_300", "bpsk_1200"]:
+                m = cb.ModemConfigurator(rate, {"type": "mpsk", "config": cfg, "options": {}})
+                k = f"mpsk_{cfg}_{rate}"
+                d[k + "_bpf"] = m.input_bpf
+                d[k + "_hilbert"] = np.asarray(m.Hilbert.taps, dtype=np.float64)
+                d[k + "_delay"] = np.array(m.Hilbert.delay, dtype=np.int64)
+                d[k + "_rrc"] = np.asarray(m.rrc.taps, dtype=np.float64)
+            m = cb.ModemConfigurator(rate, {"type": "afsk_pll", "config": "300", "options": {}})
+            d[f"pll_300_{rate}_bpf"] = m.input_bpf
+            d[f"pll_300_{rate}_lpf"] = m.output_lpf
+        # RRC windows other than rect (rrc.py:51-93)
+        for w in ["rect", "hann", "blackmann", "blackmann-harris", "flattop", "tukey"]:
+            r = ref_rrc.RRC(sample_rate=48000, symbol_rate=1200, symbol_span=6, rolloff_rate=0.3, window=w)
+            d[f"rrc_window_{w}"] = np.asarray(r.taps, dtype=np.float64)
+        for n in [21, 49, 131, 163, 217]:
+            h = ref_hilbert.Hilbert(tap_count=n)
+            d[f"hilbert_{n}"] = np.asarray(h.taps, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "taps.npz"), **d)
+    print("taps.npz:", len(d), "arrays")
+
+
+# ----------------------------------------------------------------------------------------
+def gen_primitives():
+    d = {}
+    rng = np.random.default_rng(99)
+    with quiet():
+        # AGC (agc.py:61-80) on a bursty buffer so attack, sustain and decay all trigger
+        for rate, name in [(8000.0, "8k"), (48000.0, "48k")]:
+            n = 60000
+            env = np.concatenate([np.full(n // 4, 0.05), np.full(n // 4, 1.0), np.full(n // 4, 0.2), np.full(n - 3 * (n // 4), 0.6)])
+            buf = rng.standard_normal(n) * env * 3000.0
+            d[f"agc_{name}_in"] = buf.copy()
+            a = ref_agc.AGC(sample_rate=rate, attack_rate=500.0, sustain_time=0.5, decay_rate=50.0,
+                            target_amplitude=1.0, record_envelope=True)
+            a.apply(buf)
+            d[f"agc_{name}_out"] = buf
+            d[f"agc_{name}_env"] = np.asarray(a.envelope_buffer, dtype=np.float64)
+        # AGC with an all-negative buffer (normal = max(buffer) < 0) and a zero prefix (envelope == 0 branch)
+        buf = -np.abs(rng.standard_normal(2000)) * 100.0 - 1.0
+        d["agc_neg_in"] = buf.copy()
+        a = ref_agc.AGC(sample_rate=8000.0, attack_rate=500.0, sustain_time=0.01, decay_rate=50.0, target_amplitude=1.0)
+        a.apply(buf)
+        d["agc_neg_out"] = buf
+        buf = np.concatenate([np.zeros(50), rng.standard_normal(1950) * 10.0])
+        d["agc_zero_in"] = buf.copy()
+        a = ref_agc.AGC(sample_rate=8000.0, attack_rate=500.0, sustain_time=0.01, decay_rate=50.0, target_amplitude=1.0)
+        a.apply(buf)
+        d["agc_zero_out"] = buf
+
+        # NCO (nco.py:34-53) driven by a seeded control sequence
+        ctl = rng.standard_normal(5000) * 40.0
+        o = ref_nco.NCO(sample_rate=48000.0, amplitude=1.0, set_frequency=1500.0, wavetable_size=256)
+        d["nco_table"] = np.asarray(o.wavetable, dtype=np.float64)
+        s, c, ph = [], [], []
+        for k in range(len(ctl)):
+            o.control = float(ctl[k])
+            o.update()
+            s.append(o.sine_output)
+            c.append(o.cosine_output)
+            ph.append(o.phase_accumulator)
+        d["nco_ctl"] = ctl
+        d["nco_sin"] = np.asarray(s)
+        d["nco_cos"] = np.asarray(c)
+        d["nco_phase"] = np.asarray(ph)
+
+        # IIR_1 (iir.py:38-54)
+        x = rng.standard_normal(4000)
+        for rate, fc, g, name in [(48000.0, 250.0, 1.0, "a"), (8000.0, 150.0, 2.0, "b")]:
+            f = ref_iir.IIR_1(sample_rate=rate, filter_type="lpf", cutoff=fc, gain=g)
+            y = []
+            for v in x:
+                f.update(float(v))
+                y.append(f.output)
+            d[f"iir_{name}_coefs"] = np.array([f.b_coefs[0], f.b_coefs[1], f.a_coefs[1]])
+            d[f"iir_{name}_out"] = np.asarray(y)
+        d["iir_in"] = x
+
+        # PI (pi_control.py:25-33)
+        p = ref_pi.PI_control(p=0.06, i=0.06 / 1000, i_limit=31.25, gain=7200)
+        y = []
+        ig = []
+        xs = rng.standard_normal(4000) * 0.05
+        for v in xs:
+            y.append(p.update_saturate(float(v)))
+            ig.append(p.integral)
+        d["pi_in"] = xs
+        d["pi_out"] = np.asarray(y)
+        d["pi_integral"] = np.asarray(ig)
+
+        # Phase detector table + lookups (phase_detector.py:12-45,124-149)
+        pd = ref_pd.PhaseDetector("qpsk", 64, 32)
+        d["pd_table"] = np.asarray(pd.qpsk_error_table, dtype=np.int64)
+        re = rng.standard_normal(4000) * 1.2
+        im = rng.standard_normal(4000) * 1.2
+        re[:8] = [0.0, -0.0, 1.0 / 32, -1.0 / 32, 2.5, -2.5, 63.0 / 32, -63.0 / 32]
+        im[:8] = [0.0, 0.5, -1.0 / 32, 1.0 / 32, -2.5, 2.5, 64.0 / 32, -64.0 / 32]
+        d["pd_re"] = re
+        d["pd_im"] = im
+        d["pd_err"] = np.array([pd.get_qpsk_angle_error(float(a), float(b)) for a, b in zip(re, im)], dtype=np.int64)
+
+        # LFSR (lfsr.py:22-52)
+        data = rng.integers(0, 256, size=3000, dtype=np.int64)
+        d["lfsr_in"] = data.astype(np.uint8)
+        for poly, inv, name in [(0x1, False, "p1"), (0x3, True, "p3i"), (0x63003, True, "g3ruh"), (0x3, False, "p3"), (0x1, True, "p1i")]:
+            l = ref_lfsr.LFSR(poly=poly, invert=inv)
+            out = l.stream_unscramble_8bit([AddressedData(int(b), 7 * k + 3) for k, b in enumerate(data)])
+            d[f"lfsr_{name}_out"] = np.array([o.data for o in out], dtype=np.uint8)
+            d[f"lfsr_{name}_addr"] = np.array([o.address for o in out], dtype=np.int64)
+
+        # CRC (crc_functions.py:9-76)
+        msgs = [rng.integers(0, 256, size=n, dtype=np.int64).tolist() for n in [1, 2, 17, 18, 64, 255, 300]]
+        crcs = []
+        for m in msgs:
+            mm = list(m)
+            ref_crc.AppendCRC(mm)
+            chk = ref_crc.CheckCRC(mm)
+            assert chk[2]
+            crcs.append(chk[1])
+        d["crc_msgs_flat"] = np.array(sum(msgs, []), dtype=np.uint8)
+        d["crc_msgs_len"] = np.array([len(m) for m in msgs], dtype=np.int64)
+        d["crc_values"] = np.array(crcs, dtype=np.int64)
+
+        # GF / RS (gf_functions.py:47-74, rs_functions.py:9-150)
+        gf = ref_gf.initialize(8, 0x11D)
+        d["gf_table"] = np.array(gf["table"], dtype=np.int64)
+        d["gf_index"] = np.array(gf["index"], dtype=np.int64)
+        d["gf_inverse"] = np.array(gf["inverse"], dtype=np.int64)
+        for roots in [2, 16]:
+            rs = ref_rs.initialize(0, roots, 8, 0x11D)
+            d[f"rs_genpoly_{roots}"] = np.array(rs["genpoly"], dtype=np.int64)
+        # RS decode behaviour on corrupted codewords.  A systematic codeword is built by
+        # polynomial division with the reference's generator polynomial (encoder is ours --
+        # the reference has none); what is pinned is the reference DECODER's output.
+        def rs_encode(rs, msg):
+            roots = rs["num_roots"]
+            g = rs["genpoly"]  # lowest order first, monic
+            rem = [0] * roots
+            for b in msg:
+                fb = b ^ rem[roots - 1]
+                for k in range(roots - 1, 0, -1):
+                    rem[k] = rem[k - 1] ^ ref_gf.mul(rs["gf"], fb, g[k])
+                rem[0] = ref_gf.mul(rs["gf"], fb, g[0])
+            return list(msg) + rem[::-1]
+        cases_in, cases_out, cases_ret, cases_len, cases_roots, cases_md = [], [], [], [], [], []
+        for roots, k, nerr_list in [(2, 13, [0, 1, 2]), (16, 32, [0, 1, 4, 8, 9, 12]), (16, 239, [0, 3, 8, 9]), (16, 1, [0, 2, 8])]:
+            rs = ref_rs.initialize(0, roots, 8, 0x11D)
+            for nerr in nerr_list:
+                for md in [0, 1]:
+                    msg = rng.integers(0, 256, size=k, dtype=np.int64).tolist()
+                    cw = rs_encode(rs, msg)
+                    assert ref_rs.decode(rs, list(cw), len(cw), 0) == 0
+                    pos = rng.choice(len(cw), size=nerr, replace=False)
+                    bad = list(cw)
+                    for pp in pos:
+                        bad[pp] ^= int(rng.integers(1, 256))
+                    buf = list(bad) + [0] * (255 - len(bad))
+                    ret = ref_rs.decode(rs, buf, len(cw), md)
+                    cases_in.append(bad + [0] * (255 - len(bad)))
+                    cases_out.append(buf)
+                    cases_ret.append(ret)
+                    cases_len.append(len(cw))
+                    cases_roots.append(roots)
+                    cases_md.append(md)
+        d["rs_case_in"] = np.array(cases_in, dtype=np.uint8)
+        d["rs_case_out"] = np.array(cases_out, dtype=np.uint8)
+        d["rs_case_ret"] = np.array(cases_ret, dtype=np.int64)
+        d["rs_case_len"] = np.array(cases_len, dtype=np.int64)
+        d["rs_case_roots"] = np.array(cases_roots, dtype=np.int64)
+        d["rs_case_mindist"] = np.array(cases_md, dtype=np.int64)
+
+        # Slicers on plain seeded noise, several rates incl. non-integer samples/symbol
+        x = rng.standard_normal(30000)
+        x[100:140] = 0.0          # exact zeros count as ">= 0"
+        x[200] = -0.0
+        d["slicer_in"] = x
+        for rate, cfg, lock, name in [(48000, "1200", "0.77", "b1200_48k"), (8000, "300", "0.90", "b300_8k"),
+                                      (44100, "1200", "0.75", "b1200_44k"), (48000, "9600", "0.88", "b9600_48k"),
+                                      (22050, "9600", "0.88", "b9600_22k")]:
+            s = ref_slicer.BinarySlicer(sample_rate=rate, config=cfg)
+            s.StringOptionsRetune({"lock_rate": lock})
+            out = s.slice(x)
+            d[f"slicer_{name}_data"] = np.array([o.data for o in out], dtype=np.uint8)
+            d[f"slicer_{name}_addr"] = np.array([o.address for o in out], dtype=np.int64)
+            d[f"slicer_{name}_clk"] = np.array(s.phase_clock)
+        y = rng.standard_normal(30000)
+        d["slicer_in_q"] = y
+        for rate, cfg, lock, name in [(48000, "qpsk_2400", "0.98", "q2400_48k"), (8000, "qpsk_600", "0.815", "q600_8k"),
+                                      (48000, "bpsk_1200", "0.9", "qb1200_48k"), (44100, "qpsk_3600", "0.985", "q3600_44k"),
+                                      (48000, "bpsk_300", "0.815", "qb300_48k"), (48000, "qpsk_4800", "0.99", "q4800_48k")]:
+            s = ref_slicer.QuadratureSlicer(sample_rate=rate, config=cfg)
+            s.StringOptionsRetune({"lock_rate": lock})
+            iq = IQData()
+            iq.i_data = x
+            iq.q_data = y
+            out = s.slice(iq)
+            d[f"slicer_{name}_data"] = np.array([o.data for o in out], dtype=np.uint8)
+            d[f"slicer_{name}_addr"] = np.array([o.address for o in out], dtype=np.int64)
+            d[f"slicer_{name}_clk"] = np.array(s.phase_clock)
+    np.savez_compressed(os.path.join(OUT, "primitives.npz"), **d)
+    print("primitives.npz:", len(d), "arrays")
+
+
+# ----------------------------------------------------------------------------------------
+def gen_synth_chains():
+    """Every working bundled config, every chain, on seeded noise at 48 kHz (N = 24 000: all stage
+    outputs kept) and N = 240 000 (slicer/lfsr/packets only).  8 kHz and 44.1 kHz for the first chain."""
+    manifest = {}
+    d = {}
+    for cfgname in WORKING_CONFIGS:
+        lines = [l for l in load_config(cfgname) if l.get("object_type") == "demod_chain"]
+        manifest[cfgname] = [l["object_name"] for l in lines]
+        for ci, line in enumerate(lines):
+            for rate, n, keep, tag in [(48000, 24000, True, "48k_s"), (48000, 240000, False, "48k_l"),
+                                       (8000, 16000, True, "8k_s"), (44100, 24000, True, "44k_s")]:
+                if ci > 0 and tag in ("8k_s", "44k_s"):
+                    continue
+                if rate == 8000 and ("9600" in cfgname or "4800" in cfgname or "3600" in cfgname):
+                    continue
+                audio = noise(n)
+                chain = build_chain(rate, line)
+                prefix = f"{cfgname[:-5]}__c{ci}__{tag}"
+                run_chain(chain, audio, d, prefix, keep_demod=keep)
+    np.savez_compressed(os.path.join(OUT, "synth_chains.npz"), **d)
+    with open(os.path.join(OUT, "synth_chains_manifest.json"), "w") as f:
+        json.dump({"noise": "default_rng(1234).standard_normal(n)*8000 -> rint -> clip -> int16", "configs": manifest}, f, indent=1)
+    print("synth_chains.npz:", len(d), "arrays")
+
+
+# ----------------------------------------------------------------------------------------
+def gen_wav_chains():
+    """The one bundled recording through the three configs that apply to it."""
+    rate, audio = readwav(WAV)
+    d = {}
+    summary = {"wav_sha1": hashlib.sha1(open(WAV, "rb").read()).hexdigest(), "rate": int(rate), "n": int(len(audio))}
+    for cfgname in ["afsk_300.json", "afsk_300_pll.json", "afsk_300_ax25.json"]:
+        lines = [l for l in load_config(cfgname) if l.get("object_type") == "demod_chain"]
+        results = PacketMetaArray()
+        for ci, line in enumerate(lines):
+            chain = build_chain(rate, line)
+            prefix = f"{cfgname[:-5]}__c{ci}"
+            pkts = run_chain(chain, audio, d, prefix, keep_demod=True, decim=499)
+            results.add(pkts)   # config order == sequential order
+        results.CalcCRCs()
+        results.Correlate(address_distance=rate / 40)
+        uniq = results.unique_packet_array
+        k = cfgname[:-5]
+        d[k + "__uniq_addr"] = np.array([p.streamaddress for p in uniq], dtype=np.int64)
+        d[k + "__uniq_crc"] = np.array([p.CalculatedCRC for p in uniq], dtype=np.int64)
+        d[k + "__uniq_len"] = np.array([len(p.data) for p in uniq], dtype=np.int64)
+        d[k + "__uniq_ncorr"] = np.array([len(p.CorrelatedDecoders) for p in uniq], dtype=np.int64)
+        summary[k] = {
+            "good": int(results.CountGood()), "bad": int(results.CountBad()),
+            "uniq_decoders": [list(p.CorrelatedDecoders) for p in uniq],
+            "hist": dict(results.DecoderHistogram), "uniq_hist": dict(results.DecoderUniqueHistogram),
+            "chains": [l["object_name"] for l in lines],
+        }
+        # per-packet validity flags in raw order
+        flat_valid = []
+        for arr in results.raw_packet_arrays:
+            for p in arr:
+                flat_valid.append([int(p.ValidCRC), int(p.ValidHeader), int(p.CalculatedCRC), int(p.CarriedCRC)])
+        d[k + "__raw_valid"] = np.array(flat_valid, dtype=np.int64).reshape(-1, 4)
+    np.savez_compressed(os.path.join(OUT, "wav_chains.npz"), **d)
+    with open(os.path.join(OUT, "wav_chains_summary.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+    print("wav_chains.npz:", len(d), "arrays;", {k: (v["good"], v["bad"]) for k, v in summary.items() if isinstance(v, dict)})
+
+
+def copy_data_files():
+    """Data files (not source): the bundled recording and the JSON-lines configs.  MIT, see the
+    reference's LICENSE.  They are inputs of the parity tests; the GPU box only has /root/repo."""
+    shutil.copyfile(WAV, os.path.join(OUT, "afsk_300_il2pc_noise.wav"))
+    os.makedirs(os.path.join(OUT, "configs"), exist_ok=True)
+    for name in WORKING_CONFIGS:
+        shutil.copyfile(os.path.join(REF, "configs", name), os.path.join(OUT, "configs", name))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["taps", "prims", "synth", "wav", "copy"]
+    if "taps" in which:
+        gen_taps()
+    if "prims" in which:
+        gen_primitives()
+    if "synth" in which:
+        gen_synth_chains()
+    if "wav" in which:
+        gen_wav_chains()
+    if "copy" in which:
+        copy_data_files()
