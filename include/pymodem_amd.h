@@ -1,0 +1,171 @@
+/*
+ * pymodem_amd.h -- C ABI of libpymodem_amd.so: the MI355X (gfx950) implementation of pymodem's
+ * demod_chain sample-processing path.  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * The reference (ninocarrillo/pymodem, pure Python) has no FFI: the "binding" a maintainer adds is
+ * a ctypes stub inside each stage class.  Every entry point below names the
+ * reference code it replaces (file:line relative to the reference checkout).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative pm_status on failure; pm_last_error() gives text
+ *   - HIP is initialised in pm_ctx_create(), never at dlopen() time (the reference forks one process
+ *     per chain after building its stage objects, pymodem.py:144-151)
+ *   - `const T *d_*` / `T *d_*` arguments are DEVICE pointers (from pm_malloc or any HIP allocation of
+ *     the same process, e.g. a torch tensor's data_ptr()); `h_*` arguments are HOST pointers
+ *   - a pm_ctx owns one HIP stream; calls on one ctx are ordered; a ctx is not thread-safe
+ *   - all floating point is IEEE binary64, evaluated in the reference's operation order; FIR sums use
+ *     the build's canonical order: ascending input index, one fused multiply-add per tap
+ */
+#ifndef PYMODEM_AMD_H
+#define PYMODEM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PM_VERSION 100          /* 0.1.0 */
+
+typedef enum pm_status {
+    PM_OK = 0,
+    PM_ERR_HIP = -1,            /* a HIP runtime call failed (text in pm_last_error) */
+    PM_ERR_ARG = -2,            /* bad argument (null pointer, n < taps, unsupported size) */
+    PM_ERR_NODEV = -3,          /* no gfx950 device visible */
+    PM_ERR_CAPACITY = -4,       /* caller's output buffer too small; required size reported */
+    PM_ERR_NOCONVERGE = -5      /* internal: slicer fixed point not reached within the iteration cap */
+} pm_status;
+
+typedef struct pm_ctx pm_ctx;
+
+/* ---- library / device ------------------------------------------------------------------------ */
+int pm_version(void);
+int pm_device_count(void);                               /* 0 when no GPU; never throws */
+int pm_last_error(char *buf, size_t cap);                /* copies the calling thread's last message */
+
+int pm_ctx_create(int device, pm_ctx **out);
+int pm_ctx_destroy(pm_ctx *ctx);
+int pm_ctx_sync(pm_ctx *ctx);                            /* hipStreamSynchronize on the ctx stream */
+void *pm_ctx_stream(pm_ctx *ctx);                        /* the hipStream_t, for interop */
+
+int pm_malloc(pm_ctx *ctx, size_t bytes, void **d_out);
+int pm_free(pm_ctx *ctx, void *d_ptr);
+int pm_h2d(pm_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);   /* async on the ctx stream */
+int pm_d2h(pm_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);   /* synchronous */
+int pm_memset(pm_ctx *ctx, void *d_dst, int value, size_t bytes);
+
+/* HIP-event timer on the ctx stream: start, enqueue work, stop -> elapsed milliseconds. */
+int pm_timer_start(pm_ctx *ctx);
+int pm_timer_stop(pm_ctx *ctx, float *ms);
+
+/* ---- FIR stages -------------------------------------------------------------------------------
+ * numpy.convolve(x, h, 'valid'): y[k] = sum_j h[j] * x[k+m-1-j], k = 0 .. n-m.  Replaces the 19
+ * numpy.convolve call sites (afsk.py:151-166, fsk.py:151, psk.py:165,193,710-751, afsk_pll.py:143,168).
+ * d_taps holds h in the reference's order.  flags: PM_FIR_NEGATE writes -y (fsk.py:153-154). */
+#define PM_FIR_NEGATE 1
+int pm_fir_valid_i16(pm_ctx *ctx, const int16_t *d_x, int64_t n, const double *d_taps, int m, double *d_y, int flags);
+int pm_fir_valid_f64(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_taps, int m, double *d_y, int flags);
+
+/* AFSK mark/space quadrature correlators fused with magnitude and difference (afsk.py:153-162):
+ * y[k] = sqrt(mi*x ^2 + mq*x ^2) - sqrt(si*x ^2 + sq*x ^2), each product a 'valid' convolution. */
+int pm_afsk_correlate(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_mark_i, const double *d_mark_q,
+                      const double *d_space_i, const double *d_space_q, int m, double *d_y);
+
+/* Sign bitmap of a float64 stream: bit k of the little-endian uint64 array = (x[k] >= 0), the only
+ * property of a sample the slicers read (slicer.py:85,99-102,210-232).  d_bits holds (n+63)/64 words. */
+int pm_signs_f64(pm_ctx *ctx, const double *d_x, int64_t n, uint64_t *d_bits);
+
+/* ---- AGC and carrier loops -------------------------------------------------------------------- */
+typedef struct pm_agc_params {       /* AGC.__init__, agc.py:7-24 */
+    double attack_rate, decay_rate, sustain_time, sample_rate, target_amplitude;
+} pm_agc_params;
+/* AGC.apply in place (agc.py:61-80): normal = max(buf), envelope follower, buf[i] = target*s/env.
+ * h_state[2] = {envelope, sustain_count}, read and written (carried like self.* in the reference). */
+int pm_agc_apply(pm_ctx *ctx, double *d_buf, int64_t n, const pm_agc_params *h_params, double *h_state);
+
+typedef struct pm_loop {             /* one carrier loop = NCO (nco.py) + IIR_1 (iir.py) + PI (pi_control.py) */
+    double phase_scaling;            /* 2*pi / sample_rate                       nco.py:31 */
+    double index_scaling;            /* 256 / (2*pi)                             nco.py:27 */
+    double set_frequency;            /* carrier_freq                             nco.py:13 */
+    double b0, b1, a1;               /* gain*b0, gain*b1, a1                     iir.py:15-29 */
+    double p_rate, i_rate, i_limit, gain;                                     /* pi_control.py:8-12 */
+    /* state, read and written */
+    double phase, control, sine, cosine;
+    double x0, x1, y0;
+    double integral, proportional;
+} pm_loop;
+
+/* nloops independent loops over the SAME input (chains that differ only in carrier_freq, e.g.
+ * configs/qpsk_2400.json) or, with x_stride != 0, over nloops inputs x + l*x_stride.  One lane per loop.
+ * d_table: the 256-entry wavetable amplitude*sin(2*pi*i/256) computed by the caller with libm sin (nco.py:22-24).
+ * Outputs are laid out [loop][n] with stride out_stride (elements). */
+int pm_costas_bpsk(pm_ctx *ctx, pm_loop *h_loops, int nloops, const double *d_table,
+                   const double *d_x, int64_t x_stride, int64_t n, double *d_out, int64_t out_stride);      /* psk.py:173-189 */
+int pm_pll_afsk(pm_ctx *ctx, pm_loop *h_loops, int nloops, const double *d_table,
+                const double *d_x, int64_t x_stride, int64_t n, double *d_out, int64_t out_stride);         /* afsk_pll.py:153-165 */
+/* d_pd_table: int32[64*64] phase-detector table, row-major [real][imag] (phase_detector.py:36-44). */
+int pm_mpsk_loop(pm_ctx *ctx, pm_loop *h_loops, int nloops, const double *d_table, const int32_t *d_pd_table,
+                 const double *d_re, const double *d_im, int64_t x_stride, int64_t n,
+                 double *d_i_out, double *d_q_out, int64_t out_stride);                                     /* psk.py:734-747 */
+
+/* ---- slicers ----------------------------------------------------------------------------------
+ * Symbol-timing PLL + bit decision + byte packing.  Input is the sign bitmap(s) of the demodulated
+ * stream.  Output: bytes and their 1-based stream addresses (index of the sample that completed the
+ * byte), exactly the AddressedData list of the reference.  Evaluated chunk-parallel as a fixed-point
+ * iteration on the per-chunk phase_clock; the fixed point is bitwise the sequential result. */
+typedef struct pm_slicer_params {
+    double samples_per_symbol;       /* sample_rate / symbol_rate              slicer.py:51 */
+    double lock_rate;                /*                                         slicer.py:22-33,124-165 */
+    int32_t bits_per_symbol;         /* 1 (binary, bpsk) or 2 (qpsk)            slicer.py:127-158 */
+    int32_t state_mask;              /* 0x3 or 0xF                              slicer.py:126-157 */
+    int32_t demap[16];               /* symbol demap table                      slicer.py:128 */
+} pm_slicer_params;
+/* h_count receives the number of bytes produced; if it exceeds cap the call returns PM_ERR_CAPACITY
+ * (the first cap entries are valid).  A safe cap is n*bits_per_symbol/8 + 1. */
+int pm_slice_binary(pm_ctx *ctx, const uint64_t *d_bits, int64_t n, const pm_slicer_params *h_params,
+                    uint8_t *d_data, int64_t *d_addr, int64_t cap, int64_t *h_count);                       /* slicer.py:59-107 */
+int pm_slice_quadrature(pm_ctx *ctx, const uint64_t *d_bits_i, const uint64_t *d_bits_q, int64_t n,
+                        const pm_slicer_params *h_params, uint8_t *d_data, int64_t *d_addr, int64_t cap,
+                        int64_t *h_count);                                                                  /* slicer.py:193-242 */
+/* Diagnostics of the last slicer call on this ctx: fixed-point iterations used, chunk length, chunks. */
+int pm_slicer_stats(pm_ctx *ctx, int32_t *iterations, int32_t *chunk_len, int64_t *chunks);
+
+/* ---- host-integer stages (native C++, no GPU) --------------------------------------------------
+ * These consume the slicer's byte stream; they are bit-serial state machines over KBs of data. */
+/* LFSR.stream_unscramble_8bit (lfsr.py:22-52).  *h_shift_register is read and written. */
+int pm_lfsr_unscramble(const uint8_t *h_in, int64_t n, uint64_t poly, int invert, uint64_t *h_shift_register, uint8_t *h_out);
+
+/* Packet record shared by the codecs and the de-dup (PacketMeta, packet_meta.py:178-195). */
+#define PM_PKT_MAX 1280
+typedef struct pm_packet {
+    int64_t streamaddress;
+    int32_t len;
+    int32_t bytes_corrected;
+    int32_t calculated_crc, carried_crc;
+    int32_t valid_crc, valid_header;
+    int32_t source_decoder;          /* chain index */
+    int32_t correlated_count;        /* filled by pm_correlate */
+    uint8_t data[PM_PKT_MAX];
+} pm_packet;
+
+typedef struct pm_codec pm_codec;
+/* kind 0 = AX25Codec (ax25.py:11-93), 1 = IL2PCodec (il2p.py:110-519). */
+int pm_codec_create(int kind, int crc, int disable_rs, int min_dist, int sync_tol, int source_decoder, pm_codec **out);
+int pm_codec_destroy(pm_codec *c);
+/* Feed n descrambled bytes with their stream addresses; appends decoded packets to h_out (cap entries).
+ * *h_count = packets produced by this call.  CRC and header validity are filled (packet_meta.py:197-208). */
+int pm_codec_decode(pm_codec *c, const uint8_t *h_data, const int64_t *h_addr, int64_t n,
+                    pm_packet *h_out, int64_t cap, int64_t *h_count);
+int pm_crc16_ccitt(const uint8_t *h_data, int64_t n);                    /* crc_functions.py:44-55 */
+
+/* PacketMetaArray.Correlate (packet_meta.py:230-271): h_pkts hold all chains' packets in config order
+ * (h_chain_counts[c] packets for chain c).  Writes indices of the unique packets, sorted by stream address,
+ * to h_unique_idx and sets correlated_count on them.  Returns the number of unique packets or < 0. */
+int64_t pm_correlate(pm_packet *h_pkts, const int64_t *h_chain_counts, int nchains, double address_distance,
+                     int64_t *h_unique_idx, int32_t *h_corr_decoders, int64_t corr_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYMODEM_AMD_H */

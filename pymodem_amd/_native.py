@@ -1,0 +1,109 @@
+"""ctypes binding of libpymodem_amd.so (declared in include/pymodem_amd.h).
+
+The library is built in-tree by `__graft_entry__.build()` (hipcc --offload-arch=gfx950).  Loading is
+lazy and does not touch HIP: the reference forks one process per chain after building the stage
+objects (pymodem.py:144-151), so nothing here may initialise the GPU at import time.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "libpymodem_amd.so")
+
+
+class AGCParams(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_double) for k in ("attack_rate", "decay_rate", "sustain_time", "sample_rate", "target_amplitude")]
+
+
+class Loop(ctypes.Structure):
+    """pm_loop"""
+    _fields_ = [(k, ctypes.c_double) for k in (
+        "phase_scaling", "index_scaling", "set_frequency", "b0", "b1", "a1", "p_rate", "i_rate", "i_limit", "gain",
+        "phase", "control", "sine", "cosine", "x0", "x1", "y0", "integral", "proportional")]
+
+
+class SlicerParams(ctypes.Structure):
+    _fields_ = [("samples_per_symbol", ctypes.c_double), ("lock_rate", ctypes.c_double),
+                ("bits_per_symbol", ctypes.c_int32), ("state_mask", ctypes.c_int32), ("demap", ctypes.c_int32 * 16)]
+
+
+PKT_MAX = 1280
+
+
+class Packet(ctypes.Structure):
+    """pm_packet"""
+    _fields_ = [("streamaddress", ctypes.c_int64), ("len", ctypes.c_int32), ("bytes_corrected", ctypes.c_int32),
+                ("calculated_crc", ctypes.c_int32), ("carried_crc", ctypes.c_int32), ("valid_crc", ctypes.c_int32),
+                ("valid_header", ctypes.c_int32), ("source_decoder", ctypes.c_int32), ("correlated_count", ctypes.c_int32),
+                ("data", ctypes.c_uint8 * PKT_MAX)]
+
+
+_vp, _i64, _int, _dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double
+_SIGS = {
+    "pm_version": ([], _int),
+    "pm_device_count": ([], _int),
+    "pm_last_error": ([ctypes.c_char_p, ctypes.c_size_t], _int),
+    "pm_ctx_create": ([_int, ctypes.POINTER(_vp)], _int),
+    "pm_ctx_destroy": ([_vp], _int),
+    "pm_ctx_sync": ([_vp], _int),
+    "pm_ctx_stream": ([_vp], _vp),
+    "pm_malloc": ([_vp, ctypes.c_size_t, ctypes.POINTER(_vp)], _int),
+    "pm_free": ([_vp, _vp], _int),
+    "pm_h2d": ([_vp, _vp, _vp, ctypes.c_size_t], _int),
+    "pm_d2h": ([_vp, _vp, _vp, ctypes.c_size_t], _int),
+    "pm_memset": ([_vp, _vp, _int, ctypes.c_size_t], _int),
+    "pm_timer_start": ([_vp], _int),
+    "pm_timer_stop": ([_vp, ctypes.POINTER(ctypes.c_float)], _int),
+    "pm_fir_valid_i16": ([_vp, _vp, _i64, _vp, _int, _vp, _int], _int),
+    "pm_fir_valid_f64": ([_vp, _vp, _i64, _vp, _int, _vp, _int], _int),
+    "pm_afsk_correlate": ([_vp, _vp, _i64, _vp, _vp, _vp, _vp, _int, _vp], _int),
+    "pm_signs_f64": ([_vp, _vp, _i64, _vp], _int),
+    "pm_agc_apply": ([_vp, _vp, _i64, ctypes.POINTER(AGCParams), ctypes.POINTER(_dbl)], _int),
+    "pm_costas_bpsk": ([_vp, ctypes.POINTER(Loop), _int, _vp, _vp, _i64, _i64, _vp, _i64], _int),
+    "pm_pll_afsk": ([_vp, ctypes.POINTER(Loop), _int, _vp, _vp, _i64, _i64, _vp, _i64], _int),
+    "pm_mpsk_loop": ([_vp, ctypes.POINTER(Loop), _int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64], _int),
+    "pm_slice_binary": ([_vp, _vp, _i64, ctypes.POINTER(SlicerParams), _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
+    "pm_slice_quadrature": ([_vp, _vp, _vp, _i64, ctypes.POINTER(SlicerParams), _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
+    "pm_slicer_stats": ([_vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_i64)], _int),
+    "pm_lfsr_unscramble": ([_vp, _i64, ctypes.c_uint64, _int, ctypes.POINTER(ctypes.c_uint64), _vp], _int),
+    "pm_codec_create": ([_int, _int, _int, _int, _int, _int, ctypes.POINTER(_vp)], _int),
+    "pm_codec_destroy": ([_vp], _int),
+    "pm_codec_decode": ([_vp, _vp, _vp, _i64, ctypes.POINTER(Packet), _i64, ctypes.POINTER(_i64)], _int),
+    "pm_crc16_ccitt": ([_vp, _i64], _int),
+    "pm_correlate": ([ctypes.POINTER(Packet), ctypes.POINTER(_i64), _int, _dbl, ctypes.POINTER(_i64),
+                      ctypes.POINTER(ctypes.c_int32), _i64], _i64),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def lib():
+    """The loaded library.  Raises NativeError when it has not been built -- there is no fallback."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise NativeError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950). pymodem_amd has no CPU fallback.")
+        handle = ctypes.CDLL(path)
+        for name, (args, res) in _SIGS.items():
+            fn = getattr(handle, name)      # AttributeError here = header and library out of sync
+            fn.argtypes = args
+            fn.restype = res
+        _LIB = handle
+    return _LIB
+
+
+def check(rc):
+    if rc < 0:
+        buf = ctypes.create_string_buffer(512)
+        lib().pm_last_error(buf, 512)
+        raise NativeError(f"pymodem_amd error {rc}: {buf.value.decode(errors='replace')}")
+    return rc

@@ -1,0 +1,72 @@
+"""Codec stage objects: AX25Codec (ax25.py:11-93) and IL2PCodec (il2p.py:110-519 with rs_functions.py,
+gf_functions.py, lfsr.py:54-92) of the reference, as native C++ state machines behind pm_codec_*."""
+import ctypes
+
+from ._native import Packet, check, lib
+from .data_classes import AddressedArray
+from .packet_meta import PacketMeta
+from .string_ops import check_boolean
+
+
+class _NativeCodec:
+    _kind = 0
+    _h = None
+
+    def _handle(self):
+        if self._h is None:
+            h = ctypes.c_void_p()
+            check(lib().pm_codec_create(self._kind, int(self.collect_trailing_crc), int(self.disable_rs), int(self.min_distance),
+                                        int(self.sync_tolerance), 0, ctypes.byref(h)))
+            self._h = h
+        return self._h
+
+    def decode(self, data):
+        """list[AddressedData] | AddressedArray -> list[PacketMeta] (data, streamaddress, SourceDecoder, BytesCorrected)."""
+        src = AddressedArray.coerce(data)
+        cap = max(64, len(src) // 16 + 16)
+        while True:
+            out = (Packet * cap)()
+            count = ctypes.c_int64()
+            if self._h is not None and getattr(self, "_retry_state", None):
+                pass
+            rc = lib().pm_codec_decode(self._handle(), src.data.ctypes.data_as(ctypes.c_void_p),
+                                       src.address.ctypes.data_as(ctypes.c_void_p), len(src), out, cap, ctypes.byref(count))
+            if rc == -4:                      # PM_ERR_CAPACITY cannot happen with this bound: a packet needs >= 17 bytes of stream
+                raise RuntimeError("codec output bound exceeded")
+            check(rc)
+            break
+        return [PacketMeta.from_native(out[k], self.identifier) for k in range(count.value)]
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                lib().pm_codec_destroy(self._h)
+        except Exception:
+            pass
+
+
+class AX25Codec(_NativeCodec):
+    _kind = 0
+
+    def __init__(self, **kwargs):
+        self.min_packet_length = kwargs.get('min_packet_length', 18)
+        self.max_packet_length = kwargs.get('max_packet_length', 1023)
+        self.identifier = kwargs.get('ident', 1)
+        self.collect_trailing_crc, self.disable_rs, self.min_distance, self.sync_tolerance = False, False, 0, 0
+
+
+class IL2PCodec(_NativeCodec):
+    _kind = 1
+
+    def __init__(self, **kwargs):
+        self.collect_trailing_crc = kwargs.get('crc', True)
+        self.identifier = kwargs.get('ident', 1)
+        self.min_distance = kwargs.get('min_dist', 0)
+        self.disable_rs = kwargs.get('disable_rs', False)
+        self.sync_tolerance = kwargs.get('sync_tol', 0)
+
+    def StringOptionsRetune(self, options):   # il2p.py:140-144
+        self.collect_trailing_crc = check_boolean(options.get('crc', 'yes'))
+        self.disable_rs = check_boolean(options.get('disable_rs', 'no'))
+        self.min_distance = int(options.get('min_dist', self.min_distance))
+        self.sync_tolerance = int(options.get('sync_tol', self.sync_tolerance))

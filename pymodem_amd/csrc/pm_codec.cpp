@@ -1,0 +1,555 @@
+// Host-integer stages of the demod_chain path, native C++ (no GPU): the byte stream the slicer produces
+// is KBs per minute of audio, and these are bit-serial state machines.
+//
+//   pm_lfsr_unscramble   LFSR.stream_unscramble_8bit          lfsr.py:22-52
+//   pm_codec_* (kind 0)  AX25Codec.decode                     ax25.py:25-93
+//   pm_codec_* (kind 1)  IL2PCodec.decode + RS + GF + Hamming  il2p.py:110-519, rs_functions.py:33-150, gf_functions.py
+//   pm_crc16_ccitt       CheckCRC / AppendCRC                  crc_functions.py:9-76
+//   pm_correlate         PacketMetaArray.Correlate             packet_meta.py:230-271
+//
+// Behaviour follows the reference including its quirks (noted inline), because packet parity is
+// "identical bytes, CRCs and stream addresses", not "a better decoder".
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/pymodem_amd.h"
+
+int pm_set_error(int code, const char *fmt, ...);
+
+namespace {
+
+// ---- CRC-16 (reflected CCITT 0x8408, init 0xFFFF, final xor 0xFFFF) -----------------------------
+int crc16(const uint8_t *d, int64_t n)
+{
+    unsigned crc = 0xFFFF;
+    for (int64_t k = 0; k < n; ++k) {
+        unsigned b = d[k];
+        for (int i = 0; i < 8; ++i) {
+            crc = ((crc ^ b) & 1) ? (crc >> 1) ^ 0x8408 : crc >> 1;
+            b >>= 1;
+        }
+    }
+    return (int)(crc ^ 0xFFFF);
+}
+
+// packet_meta.py:21-41.  The loop there never resets its sub-field index, so only bytes 0..6 are examined.
+bool valid_header(const uint8_t *d, int len)
+{
+    if (len <= 15) return false;
+    for (int k = 0; k < 7; ++k) {
+        const int ch = d[k] >> 1;
+        if ((ch < 32 || ch > 126) && ch != 0) return false;
+    }
+    return true;
+}
+
+void finalize(pm_packet &p)
+{
+    // PacketMeta.CalcCRC / Validate, packet_meta.py:197-208 (needs len >= 2, which every emitter guarantees)
+    p.carried_crc = p.len >= 2 ? p.data[p.len - 1] * 256 + p.data[p.len - 2] : 0;
+    p.calculated_crc = p.len >= 2 ? crc16(p.data, p.len - 2) : 0;
+    p.valid_crc = p.len >= 2 && p.carried_crc == p.calculated_crc;
+    p.valid_header = valid_header(p.data, p.len);
+    p.correlated_count = 0;
+}
+
+struct Sink {
+    pm_packet *out;
+    int64_t cap, n;
+    void push(const std::vector<uint8_t> &data, int64_t addr, int corrected, int source)
+    {
+        if (n < cap) {
+            pm_packet &p = out[n];
+            p.streamaddress = addr;
+            p.len = (int32_t)std::min<size_t>(data.size(), PM_PKT_MAX);
+            p.bytes_corrected = corrected;
+            p.source_decoder = source;
+            memcpy(p.data, data.data(), (size_t)p.len);
+            finalize(p);
+        }
+        ++n;
+    }
+};
+
+// ---- GF(2^8) / Reed-Solomon ----------------------------------------------------------------------
+struct GF256 {
+    int table[255], index[256], inverse[256];
+    GF256()
+    {
+        // gf_functions.py:47-74: a Galois LFSR stepped from a^0, filling the table from the top down
+        unsigned reg = 1;
+        memset(index, 0, sizeof(index));
+        for (int i = 254; i >= 0; --i) {
+            const unsigned fb = reg & 1;
+            reg >>= 1;
+            if (fb) reg ^= 0x11D >> 1;
+            table[i] = (int)reg;
+            index[reg] = i;
+        }
+        inverse[0] = 0;
+        for (int i = 1; i < 256; ++i) {
+            int j = 1;
+            while (mul(i, j) != 1) ++j;
+            inverse[i] = j;
+        }
+    }
+    int mul(int a, int b) const
+    {
+        if (a == 0 || b == 0) return 0;
+        int r = index[a] + index[b];
+        while (r > 254) r -= 255;
+        return table[r];
+    }
+};
+
+const GF256 &gf()
+{
+    static const GF256 g;
+    return g;
+}
+
+int wrap255(int x)
+{
+    while (x > 254) x -= 255;
+    return x;
+}
+
+// rs_functions.py:33-150 (first_root is 0 for both IL2P codes).  Corrects buf[0..n) in place.
+int rs_decode(int num_roots, uint8_t *buf, int n, int min_distance)
+{
+    const GF256 &g = gf();
+    const int first_root = 0, half = num_roots / 2;
+    int syn[16];
+    auto syndromes = [&]() {
+        for (int i = 0; i < num_roots; ++i) {
+            const int x = g.table[first_root + i];
+            int v = 0;
+            for (int j = 0; j < n - 1; ++j) v = g.mul(v ^ buf[j], x);
+            syn[i] = v ^ buf[n - 1];
+        }
+    };
+    syndromes();
+    int loc[17] = {0}, nxt[17] = {0}, corr[18] = {0}, where[17] = {0};
+    loc[0] = 1;
+    corr[1] = 1;
+    int order = 0;
+    for (int step = 1; step <= num_roots; ++step) {          // Berlekamp
+        const int y = step - 1;
+        int e = syn[y];
+        for (int i = 1; i <= order; ++i) e ^= g.mul(loc[i], syn[y - i]);
+        if (e != 0) {
+            for (int i = 0; i <= order; ++i) nxt[i] = loc[i] ^ g.mul(e, corr[i]);
+            e = g.inverse[e];
+            for (int i = 0; i <= half; ++i) corr[i] = g.mul(loc[i], e);
+            for (int i = 0; i <= half; ++i) loc[i] = nxt[i];
+        }
+        if (2 * order < step) order = step - order;
+        for (int i = num_roots; i > 0; --i) corr[i] = corr[i - 1];
+        corr[0] = 0;
+    }
+    int count = 0;
+    for (int j = 0; j < n; ++j) {                            // Chien search
+        int x = 0;
+        const int y = j + 256 - n;
+        for (int i = 1; i <= half; ++i)
+            if (loc[i]) x ^= g.table[wrap255(y * i + g.index[loc[i]])];
+        x ^= loc[0];
+        if (x == 0) {
+            if (count < 17) where[count] = j;
+            ++count;
+        }
+    }
+    if (count <= half - min_distance) {                      // Forney
+        for (int i = 0; i < count; ++i) {
+            corr[i] = syn[first_root + i];
+            for (int j = 1; j <= i; ++j) corr[i] ^= g.mul(syn[first_root + i - j], loc[j]);
+        }
+        for (int i = 0; i < count; ++i) {
+            const int e = n - where[i] - 1;
+            int z = corr[0];
+            for (int j = 1; j < count; ++j) {
+                int x = wrap255(e * j);
+                x = wrap255(256 - x - 1);
+                z ^= g.mul(corr[j], g.table[x]);
+            }
+            z = g.mul(z, g.table[e]);
+            int y = loc[1];
+            for (int j = 3; j <= half; j += 2) {
+                int x = wrap255(e * (j - 1));
+                x = wrap255(256 - x - 1);
+                y ^= g.mul(loc[j], g.table[x]);
+            }
+            y = g.index[y];
+            y = 256 - y - 1;
+            if (y == 255) y = 0;
+            y = g.table[y];
+            buf[where[i]] ^= (uint8_t)g.mul(y, z);
+        }
+    }
+    syndromes();
+    for (int i = 0; i < num_roots; ++i)
+        if (syn[i] != 0) return -1;
+    return count;
+}
+
+}  // namespace
+
+// ---- codecs ------------------------------------------------------------------------------------------
+struct pm_codec {
+    virtual ~pm_codec() {}
+    virtual void feed(uint8_t byte, int64_t addr, Sink &sink) = 0;
+};
+
+namespace {
+
+struct Ax25 : pm_codec {
+    int source;
+    unsigned wb = 0;
+    int nbytes = 0, ones = 0, nbits = 0;
+    std::vector<uint8_t> data;
+    static constexpr int kMin = 18, kMax = 1023;           // ax25.py:14-15
+    explicit Ax25(int src) : source(src) {}
+
+    void byte_done(bool from_one)
+    {
+        nbits = 0;
+        data.push_back((uint8_t)wb);
+        if (++nbytes > kMax) {
+            nbytes = 0;
+            if (from_one) ones = 0;                          // ax25.py:48-50: only the '1' branch clears it
+        }
+    }
+
+    void feed(uint8_t byte, int64_t addr, Sink &sink) override
+    {
+        unsigned b = byte;
+        for (int i = 0; i < 8; ++i, b <<= 1) {
+            if (b & 0x80) {
+                wb |= 0x80;
+                ++ones;
+                ++nbits;
+                if (ones > 6) {                              // abort: counters reset, collected bytes stay (ax25.py:36-39)
+                    nbits = 0;
+                    nbytes = 0;
+                }
+                if (nbits == 8) byte_done(true);
+                wb >>= 1;
+            } else {
+                if (ones < 5) {
+                    if (++nbits == 8) byte_done(false);
+                    wb >>= 1;
+                } else if (ones == 6) {                      // flag
+                    if (nbytes >= kMin && nbits == 7) sink.push(data, addr, 0, source);
+                    data.clear();
+                    nbytes = 0;
+                    nbits = 0;
+                }                                            // ones == 5: stuffed zero dropped; ones > 6: nothing
+                ones = 0;
+            }
+        }
+    }
+};
+
+const uint8_t kHamming74[128] = {   // il2p.py:23-40
+    0x0, 0x0, 0x0, 0x3, 0x0, 0x5, 0xe, 0x7, 0x0, 0x9, 0xe, 0xb, 0xe, 0xd, 0xe, 0xe, 0x0, 0x3, 0x3, 0x3, 0x4, 0xd, 0x6, 0x3,
+    0x8, 0xd, 0xa, 0x3, 0xd, 0xd, 0xe, 0xd, 0x0, 0x5, 0x2, 0xb, 0x5, 0x5, 0x6, 0x5, 0x8, 0xb, 0xb, 0xb, 0xc, 0x5, 0xe, 0xb,
+    0x8, 0x1, 0x6, 0x3, 0x6, 0x5, 0x6, 0x6, 0x8, 0x8, 0x8, 0xb, 0x8, 0xd, 0x6, 0xf, 0x0, 0x9, 0x2, 0x7, 0x4, 0x7, 0x7, 0x7,
+    0x9, 0x9, 0xa, 0x9, 0xc, 0x9, 0xe, 0x7, 0x4, 0x1, 0xa, 0x3, 0x4, 0x4, 0x4, 0x7, 0xa, 0x9, 0xa, 0xa, 0x4, 0xd, 0xa, 0xf,
+    0x2, 0x1, 0x2, 0x2, 0xc, 0x5, 0x2, 0x7, 0xc, 0x9, 0x2, 0xb, 0xc, 0xc, 0xc, 0xf, 0x1, 0x1, 0x2, 0x1, 0x4, 0x1, 0x6, 0xf,
+    0x8, 0x1, 0xa, 0xf, 0xc, 0xf, 0xf, 0xf};
+
+struct Il2p : pm_codec {
+    enum State { kSync, kHeader, kBig, kSmall, kCrc };
+    int source;
+    bool want_crc, disable_rs;
+    int min_dist, sync_tol;
+    State state = kSync;
+    uint32_t word = 0xFFFFFF;                               // il2p.py:120
+    uint8_t buf[255];
+    int nbits = 0, nbuf = 0, block_index = 0, block_count = 0, block_size = 0, big_blocks = 0;
+    int corrected = 0;                                      // NOT cleared when a block fails (il2p.py:203-212)
+    bool fail = false;
+    std::vector<uint8_t> data;
+
+    Il2p(int src, bool crc, bool norx, int md, int tol) : source(src), want_crc(crc), disable_rs(norx), min_dist(md), sync_tol(tol)
+    {
+        memset(buf, 0, sizeof(buf));
+    }
+
+    static void descramble(uint8_t *p, int n)
+    {   // il2p.py:160-163 + lfsr.py:54-92: x^9 + x^4 + 1 (0x211), register preset 0x1F0
+        unsigned reg = 0x1F0, w = 0;
+        for (int k = 0; k < n; ++k) {
+            unsigned b = p[k];
+            for (int i = 0; i < 8; ++i) {
+                w = (w << 1) & 0xFE;
+                if (b & 0x80) reg ^= 0x211;
+                w |= reg & 1;
+                b <<= 1;
+                reg >>= 1;
+            }
+            p[k] = (uint8_t)w;
+        }
+    }
+
+    void rs(int roots)
+    {
+        const int r = disable_rs ? 0 : rs_decode(roots, buf, nbuf, min_dist);
+        if (r < 0) fail = true;
+        else corrected += r;
+    }
+
+    void emit(int64_t addr, Sink &sink)
+    {
+        sink.push(data, addr, corrected, source);
+        corrected = 0;
+        data.clear();
+        state = kSync;
+    }
+
+    void finish(int64_t addr, Sink &sink)
+    {
+        if (want_crc) {
+            state = kCrc;
+        } else {                                             // il2p.py:427-431: append a computed CRC
+            const int c = crc16(data.data(), (int64_t)data.size());
+            data.push_back((uint8_t)(c & 0xFF));
+            data.push_back((uint8_t)(c >> 8));
+            emit(addr, sink);
+        }
+    }
+
+    // il2p.py:214-344: unpack the 13 header bytes and rebuild the AX.25 header.  Returns the payload byte count.
+    int header()
+    {
+        const uint8_t *b = buf;
+        const int type = (b[1] & 0x80) >> 7;
+        int count = 0, pid = 0, ctl = 0;
+        for (int i = 0; i < 10; ++i)
+            if (b[i + 2] & 0x80) count |= 0x200 >> i;
+        for (int i = 0; i < 4; ++i)
+            if (b[i + 1] & 0x40) pid |= 0x8 >> i;
+        for (int i = 0; i < 7; ++i)
+            if (b[i + 5] & 0x40) ctl |= 0x40 >> i;
+        enum { UI, S, U, I } kind = (b[0] & 0x40) ? UI : (pid == 0 ? S : (pid == 1 ? U : I));
+        static const uint8_t pid_table[16] = {0, 0, 0x10, 0x01, 0x06, 0x07, 0x08, 0xC3, 0xC4, 0xCA, 0xCB, 0xCC, 0xCD, 0xCE, 0xCF, 0xF0};
+        const bool pf = ctl & 0x40;
+        bool cbit = false;
+        int nr = 0, ns = 0, op = 0;
+        if (kind == I) {
+            ns = ctl & 0x7;
+            nr = (ctl >> 3) & 0x7;
+            cbit = true;
+        } else if (kind == S) {
+            nr = (ctl >> 3) & 0x7;
+            cbit = ctl & 0x4;
+            op = ctl & 0x3;
+        } else {
+            cbit = ctl & 0x4;
+            op = (ctl >> 3) & 0x7;
+        }
+        if (type == 1) {                                     // il2p.py:292-340
+            for (int i = 0; i < 6; ++i) data.push_back((uint8_t)(((b[i] & 0x3F) + 0x20) << 1));
+            data.push_back((uint8_t)(((b[12] >> 4) << 1) + 0x60 + (cbit ? 0x80 : 0)));
+            for (int i = 0; i < 6; ++i) data.push_back((uint8_t)(((b[i + 6] & 0x3F) + 0x20) << 1));
+            data.push_back((uint8_t)(((b[12] & 0xF) << 1) + 0x60 + (cbit ? 0 : 0x80) + 1));
+            static const uint8_t u_control[8] = {0x2F, 0x43, 0x0F, 0x63, 0x87, 0x03, 0xAF, 0xE3};
+            int cb;
+            if (kind == U || kind == UI) cb = u_control[op] | (pf ? 0x10 : 0);
+            else if (kind == S) cb = 0x1 | (op << 2) | (nr << 5) | (pf ? 0x10 : 0);
+            else cb = (ns << 1) | (nr << 5) | (pf ? 0x10 : 0);
+            data.push_back((uint8_t)cb);
+            if (pid_table[pid] != 0) data.push_back(pid_table[pid]);
+        }                                                    // type 0: transparent encapsulation, nothing added
+        return count;
+    }
+
+    void feed(uint8_t byte, int64_t addr, Sink &sink) override
+    {
+        unsigned b = byte;
+        for (int i = 0; i < 8; ++i, b <<= 1) {
+            const uint32_t mask = state == kSync ? 0xFFFFFFFFu : 0xFFu;
+            word = ((word << 1) & mask) | ((b & 0x80) ? 1u : 0u);      // il2p.py:146-152
+            ++nbits;
+            if (state == kSync) {
+                if (__builtin_popcount((word & 0xFFFFFF) ^ 0xF15E48) <= sync_tol ||
+                    __builtin_popcount(word ^ 0x5D57DF7Fu) <= sync_tol) {              // il2p.py:367-376
+                    nbits = 0;
+                    state = kHeader;
+                }
+                continue;
+            }
+            if (nbits != 8) continue;
+            nbits = 0;
+            buf[nbuf++] = (uint8_t)word;
+            switch (state) {
+            case kHeader: {
+                if (nbuf != 15) break;
+                rs(2);
+                descramble(buf, 13);
+                nbuf = 0;
+                block_index = 0;
+                const int count = header();                  // the header is rebuilt even when RS failed, then dropped
+                if (fail) {
+                    fail = false;
+                    state = kSync;
+                    data.clear();
+                } else if (count > 0) {                      // il2p.py:346-358
+                    block_count = (count + 238) / 239;
+                    block_size = count / block_count;
+                    big_blocks = count - block_count * block_size;
+                    if (big_blocks > 0) {
+                        ++block_size;
+                        state = kBig;
+                    } else {
+                        state = kSmall;
+                    }
+                } else {
+                    finish(addr, sink);
+                }
+                break;
+            }
+            case kBig:
+            case kSmall: {
+                if (nbuf != block_size + 16) break;
+                rs(16);
+                descramble(buf, nbuf);
+                data.insert(data.end(), buf, buf + block_size);
+                ++block_index;
+                nbuf = 0;
+                if (fail) {
+                    fail = false;
+                    data.clear();
+                    state = kSync;
+                } else if (state == kBig && block_index == big_blocks) {
+                    if (block_count > block_index) {
+                        --block_size;
+                        state = kSmall;
+                    } else {
+                        finish(addr, sink);
+                    }
+                } else if (state == kSmall && block_index == block_count) {
+                    finish(addr, sink);
+                }
+                break;
+            }
+            case kCrc: {
+                if (nbuf != 4) break;
+                nbuf = 0;
+                int c = 0;
+                for (int k = 0; k < 4; ++k) c += kHamming74[buf[k] & 0x7F] << (12 - 4 * k);     // il2p.py:509-512
+                data.push_back((uint8_t)(c & 0xFF));
+                data.push_back((uint8_t)(c >> 8));
+                emit(addr, sink);
+                break;
+            }
+            default:
+                break;
+            }
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int pm_lfsr_unscramble(const uint8_t *h_in, int64_t n, uint64_t poly, int invert, uint64_t *h_sr, uint8_t *h_out)
+{
+    if (n < 0 || (n > 0 && (!h_in || !h_out)) || !h_sr) return pm_set_error(PM_ERR_ARG, "pm_lfsr_unscramble: bad argument");
+    uint64_t reg = *h_sr;
+    unsigned w = 0;
+    for (int64_t k = 0; k < n; ++k) {
+        unsigned b = h_in[k];
+        for (int i = 0; i < 8; ++i) {
+            w = (w << 1) & 0xFE;
+            if (b & 0x80) reg ^= poly;
+            w |= (unsigned)(reg & 1);
+            b <<= 1;
+            reg >>= 1;
+        }
+        h_out[k] = (uint8_t)(invert ? (0xFF ^ w) : w);
+    }
+    *h_sr = reg;
+    return PM_OK;
+}
+
+int pm_codec_create(int kind, int crc, int disable_rs, int min_dist, int sync_tol, int source_decoder, pm_codec **out)
+{
+    if (!out || (kind != 0 && kind != 1)) return pm_set_error(PM_ERR_ARG, "pm_codec_create: kind must be 0 (ax25) or 1 (il2p)");
+    if (kind == 0) *out = new Ax25(source_decoder);
+    else *out = new Il2p(source_decoder, crc != 0, disable_rs != 0, min_dist, sync_tol);
+    return PM_OK;
+}
+
+int pm_codec_destroy(pm_codec *c)
+{
+    delete c;
+    return PM_OK;
+}
+
+int pm_codec_decode(pm_codec *c, const uint8_t *h_data, const int64_t *h_addr, int64_t n, pm_packet *h_out, int64_t cap, int64_t *h_count)
+{
+    if (!c || n < 0 || (n > 0 && (!h_data || !h_addr)) || !h_count || cap < 0 || (cap > 0 && !h_out))
+        return pm_set_error(PM_ERR_ARG, "pm_codec_decode: bad argument");
+    Sink sink{h_out, cap, 0};
+    for (int64_t k = 0; k < n; ++k) c->feed(h_data[k], h_addr[k], sink);
+    *h_count = sink.n;
+    if (sink.n > cap) return pm_set_error(PM_ERR_CAPACITY, "pm_codec_decode: %lld packets, capacity %lld", (long long)sink.n, (long long)cap);
+    return PM_OK;
+}
+
+int pm_crc16_ccitt(const uint8_t *h_data, int64_t n) { return crc16(h_data, n); }
+
+int64_t pm_correlate(pm_packet *p, const int64_t *counts, int nchains, double address_distance,
+                     int64_t *uniq, int32_t *corr_decoders, int64_t corr_cap)
+{
+    if (!p || !counts || !uniq || nchains < 0) return pm_set_error(PM_ERR_ARG, "pm_correlate: bad argument");
+    // packet_meta.py:230-271.  Chains in config order; the first chain's valid packets are all unique; a later
+    // packet is a duplicate of the FIRST unique packet (insertion order) from another decoder within
+    // address_distance and with equal calculated CRC.
+    std::vector<int64_t> u;
+    std::vector<std::vector<int32_t>> decoders;
+    int64_t base = 0;
+    for (int c = 0; c < nchains; ++c) {
+        for (int64_t k = 0; k < counts[c]; ++k) {
+            pm_packet &r = p[base + k];
+            if (!(r.valid_crc && r.valid_header)) continue;
+            bool unique = true;
+            if (c > 0) {
+                for (size_t j = 0; j < u.size(); ++j) {
+                    pm_packet &q = p[u[j]];
+                    if (q.source_decoder == r.source_decoder) continue;
+                    const int64_t d = r.streamaddress > q.streamaddress ? r.streamaddress - q.streamaddress : q.streamaddress - r.streamaddress;
+                    if ((double)d < address_distance && r.calculated_crc == q.calculated_crc) {
+                        unique = false;
+                        decoders[j].push_back(r.source_decoder);
+                        break;
+                    }
+                }
+            }
+            if (unique) {
+                u.push_back(base + k);
+                decoders.push_back({r.source_decoder});
+            }
+        }
+        base += counts[c];
+    }
+    std::vector<size_t> order(u.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return p[u[a]].streamaddress < p[u[b]].streamaddress; });
+    int64_t w = 0;
+    for (size_t i = 0; i < order.size(); ++i) {
+        const size_t j = order[i];
+        uniq[i] = u[j];
+        p[u[j]].correlated_count = (int32_t)decoders[j].size();
+        if (corr_decoders)
+            for (int32_t d : decoders[j])
+                if (w < corr_cap) corr_decoders[w++] = d;
+    }
+    return (int64_t)u.size();
+}
+
+}  // extern "C"

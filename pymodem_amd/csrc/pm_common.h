@@ -1,0 +1,39 @@
+// Internal declarations shared by the translation units of libpymodem_amd.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include "../../include/pymodem_amd.h"
+
+struct pm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // small pinned host mailbox + device scratch used by reductions / the slicer fixed point
+    void *h_pinned = nullptr;       // 4 KiB
+    void *d_scratch = nullptr;      // grows on demand
+    size_t scratch_bytes = 0;
+    // slicer diagnostics
+    int32_t sl_iterations = 0, sl_chunk_len = 0;
+    int64_t sl_chunks = 0;
+};
+
+int pm_set_error(int code, const char *fmt, ...);
+int pm_scratch_reserve(pm_ctx *ctx, size_t bytes);     // ensures ctx->d_scratch >= bytes (contents undefined)
+
+#define PM_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return pm_set_error(PM_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                                __FILE__, __LINE__);                                              \
+    } while (0)
+
+#define PM_ARG(cond)                                                                    \
+    do {                                                                                \
+        if (!(cond)) return pm_set_error(PM_ERR_ARG, "bad argument: %s (%s:%d)", #cond, \
+                                         __FILE__, __LINE__);                           \
+    } while (0)
+
+static inline int64_t pm_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

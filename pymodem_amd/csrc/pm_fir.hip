@@ -1,0 +1,251 @@
+// FIR stages of the demod_chain path as LDS-staged sliding-window kernels for gfx950.
+//
+//   pm_fir_valid_{i16,f64}  numpy.convolve(x, h, 'valid')          (19 call sites in the reference)
+//   pm_afsk_correlate       4 correlators + magnitudes + difference (afsk.py:153-162)
+//   pm_signs_f64            (x >= 0) bitmap, the slicers' only input (slicer.py:85,99-102)
+//
+// Arithmetic: binary64, one fma per tap, taps visited in ascending input index.  That order is the
+// build's canonical order; oracle/pm_oracle.c:pmo_fir_* uses the same one, so GPU and oracle agree
+// bit for bit.  Built with -ffp-contract=off: only the fma() written below fuses.
+//
+// Tiling: a 256-thread workgroup produces T = 256*R consecutive outputs.  The T+m-1 inputs it needs
+// are staged once in LDS as f64 (int16 converted on the way in); each thread then owns R consecutive
+// outputs and slides a register window over the taps, so one LDS read feeds R fmas.  The LDS image
+// carries one spare double after every 8 so that lane t's window starts 9 doubles after lane t-1's
+// (18 dwords: conflict-free for ds_read_b64).  Results go back through the same LDS image so that
+// the global stores are coalesced (lane-contiguous 8 B).
+#include "pm_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxTaps = 8192;
+
+// one spare double after every R: lane t's window (R consecutive outputs) starts R+1 doubles after lane t-1's,
+// an odd number of 8-byte bank pairs, so the 32 lanes of a ds_read_b64 group hit 32 different pairs
+template <int R>
+__host__ __device__ __forceinline__ int slot(int p) { return p + p / R; }
+
+template <typename InT, int R, bool NEG>
+__global__ __launch_bounds__(kThreads) void fir_valid_kernel(const InT *__restrict__ x, int64_t n,
+                                                             const double *__restrict__ h, int m,
+                                                             double *__restrict__ y, int64_t nout)
+{
+    extern __shared__ double xs[];
+    constexpr int T = kThreads * R;
+    const int64_t tile0 = (int64_t)blockIdx.x * T;
+    const int t = threadIdx.x;
+    const int span = T + m - 1;
+    for (int idx = t; idx < span; idx += kThreads) {
+        int64_t gi = tile0 + idx;
+        xs[slot<R>(idx)] = gi < n ? (double)x[gi] : 0.0;
+    }
+    __syncthreads();
+
+    double acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+    double w[R + 7];
+    const int base = t * R;
+#pragma unroll
+    for (int j = 0; j < R - 1; ++j) w[j] = xs[slot<R>(base + j)];
+    int i0 = 0;
+    for (; i0 + 8 <= m; i0 += 8) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) w[R - 1 + b] = xs[slot<R>(base + i0 + R - 1 + b)];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const double g = h[m - 1 - (i0 + b)];
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = __builtin_fma(g, w[r + b], acc[r]);
+        }
+#pragma unroll
+        for (int j = 0; j < R - 1; ++j) w[j] = w[j + 8];
+    }
+    for (; i0 < m; ++i0) {       // m % 8 leftover taps, straight from LDS
+        const double g = h[m - 1 - i0];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = __builtin_fma(g, xs[slot<R>(base + i0 + r)], acc[r]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) xs[slot<R>(base + r)] = NEG ? -acc[r] : acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int idx = r * kThreads + t;
+        const int64_t go = tile0 + idx;
+        if (go < nout) y[go] = xs[slot<R>(idx)];
+    }
+}
+
+// Four correlators over one staged window; R outputs x 4 filters = 4R accumulators per thread.
+template <int R>
+__global__ __launch_bounds__(kThreads) void afsk_correlate_kernel(const double *__restrict__ x, int64_t n,
+                                                                  const double *__restrict__ mi, const double *__restrict__ mq,
+                                                                  const double *__restrict__ si, const double *__restrict__ sq,
+                                                                  int m, double *__restrict__ y, int64_t nout)
+{
+    extern __shared__ double xs[];
+    constexpr int T = kThreads * R;
+    const int64_t tile0 = (int64_t)blockIdx.x * T;
+    const int t = threadIdx.x;
+    const int span = T + m - 1;
+    for (int idx = t; idx < span; idx += kThreads) {
+        int64_t gi = tile0 + idx;
+        xs[slot<R>(idx)] = gi < n ? x[gi] : 0.0;
+    }
+    __syncthreads();
+
+    double a[R], b[R], c[R], d[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) a[r] = b[r] = c[r] = d[r] = 0.0;
+    double w[R + 3];
+    const int base = t * R;
+#pragma unroll
+    for (int j = 0; j < R - 1; ++j) w[j] = xs[slot<R>(base + j)];
+    int i0 = 0;
+    for (; i0 + 4 <= m; i0 += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[R - 1 + q] = xs[slot<R>(base + i0 + R - 1 + q)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = m - 1 - (i0 + q);
+            const double ga = mi[k], gb = mq[k], gc = si[k], gd = sq[k];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double v = w[r + q];
+                a[r] = __builtin_fma(ga, v, a[r]);
+                b[r] = __builtin_fma(gb, v, b[r]);
+                c[r] = __builtin_fma(gc, v, c[r]);
+                d[r] = __builtin_fma(gd, v, d[r]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < R - 1; ++j) w[j] = w[j + 4];
+    }
+    for (; i0 < m; ++i0) {
+        const int k = m - 1 - i0;
+        const double ga = mi[k], gb = mq[k], gc = si[k], gd = sq[k];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double v = xs[slot<R>(base + i0 + r)];
+            a[r] = __builtin_fma(ga, v, a[r]);
+            b[r] = __builtin_fma(gb, v, b[r]);
+            c[r] = __builtin_fma(gc, v, c[r]);
+            d[r] = __builtin_fma(gd, v, d[r]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        // afsk.py:153-162: sqrt(i**2 + q**2) with separately rounded squares and sum, then mark - space
+        const double mark = __builtin_sqrt(a[r] * a[r] + b[r] * b[r]);
+        const double space = __builtin_sqrt(c[r] * c[r] + d[r] * d[r]);
+        xs[slot<R>(base + r)] = mark - space;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int idx = r * kThreads + t;
+        const int64_t go = tile0 + idx;
+        if (go < nout) y[go] = xs[slot<R>(idx)];
+    }
+}
+
+// One 64-bit word per wave per step: lane l tests sample 64*w + l, the ballot is the word.
+__global__ __launch_bounds__(kThreads) void signs_kernel(const double *__restrict__ x, int64_t n,
+                                                         uint64_t *__restrict__ bits, int64_t nwords)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t w = wave; w < nwords; w += nwaves) {
+        const int64_t k = w * 64 + lane;
+        const bool p = (k < n) && (x[k] >= 0.0);
+        const uint64_t mask = __ballot(p);
+        if (lane == 0) bits[w] = mask;
+    }
+}
+
+template <int R>
+size_t lds_bytes(int m) { return (size_t)(slot<R>(kThreads * R + m - 1) + 2) * sizeof(double); }
+
+template <typename K>
+int allow_lds(K kernel, size_t bytes)
+{
+    if (bytes > 64 * 1024)
+        PM_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return PM_OK;
+}
+
+template <typename InT>
+int fir_launch(pm_ctx *ctx, const InT *d_x, int64_t n, const double *d_taps, int m, double *d_y, int flags)
+{
+    PM_ARG(ctx && d_x && d_taps && d_y);
+    PM_ARG(m >= 1 && m <= kMaxTaps);
+    PM_ARG(n >= m);
+    constexpr int R = 8;
+    const int64_t nout = n - m + 1;
+    const int64_t grid = pm_cdiv(nout, (int64_t)kThreads * R);
+    PM_ARG(grid < (1LL << 31));
+    const size_t lds = lds_bytes<R>(m);
+    if (flags & PM_FIR_NEGATE) {
+        if (int rc = allow_lds(fir_valid_kernel<InT, R, true>, lds)) return rc;
+        hipLaunchKernelGGL((fir_valid_kernel<InT, R, true>), dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream,
+                           d_x, n, d_taps, m, d_y, nout);
+    } else {
+        if (int rc = allow_lds(fir_valid_kernel<InT, R, false>, lds)) return rc;
+        hipLaunchKernelGGL((fir_valid_kernel<InT, R, false>), dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream,
+                           d_x, n, d_taps, m, d_y, nout);
+    }
+    PM_HIP(hipGetLastError());
+    return PM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pm_fir_valid_i16(pm_ctx *ctx, const int16_t *d_x, int64_t n, const double *d_taps, int m, double *d_y, int flags)
+{
+    return fir_launch<int16_t>(ctx, d_x, n, d_taps, m, d_y, flags);
+}
+
+int pm_fir_valid_f64(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_taps, int m, double *d_y, int flags)
+{
+    return fir_launch<double>(ctx, d_x, n, d_taps, m, d_y, flags);
+}
+
+int pm_afsk_correlate(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_mark_i, const double *d_mark_q,
+                      const double *d_space_i, const double *d_space_q, int m, double *d_y)
+{
+    PM_ARG(ctx && d_x && d_mark_i && d_mark_q && d_space_i && d_space_q && d_y);
+    PM_ARG(m >= 1 && m <= kMaxTaps);
+    PM_ARG(n >= m);
+    constexpr int R = 4;
+    const int64_t nout = n - m + 1;
+    const int64_t grid = pm_cdiv(nout, (int64_t)kThreads * R);
+    PM_ARG(grid < (1LL << 31));
+    const size_t lds = lds_bytes<R>(m);
+    if (int rc = allow_lds(afsk_correlate_kernel<R>, lds)) return rc;
+    hipLaunchKernelGGL((afsk_correlate_kernel<R>), dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream,
+                       d_x, n, d_mark_i, d_mark_q, d_space_i, d_space_q, m, d_y, nout);
+    PM_HIP(hipGetLastError());
+    return PM_OK;
+}
+
+int pm_signs_f64(pm_ctx *ctx, const double *d_x, int64_t n, uint64_t *d_bits)
+{
+    PM_ARG(ctx && d_bits && n >= 0);
+    if (n == 0) return PM_OK;
+    PM_ARG(d_x != nullptr);
+    const int64_t nwords = pm_cdiv(n, 64);
+    int64_t grid = pm_cdiv(nwords, kThreads / 64);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(signs_kernel, dim3((unsigned)grid), dim3(kThreads), 0, ctx->stream, d_x, n, d_bits, nwords);
+    PM_HIP(hipGetLastError());
+    return PM_OK;
+}
+
+}  // extern "C"

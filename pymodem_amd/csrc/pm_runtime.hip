@@ -1,0 +1,145 @@
+// Context, memory, error and timer entry points of the C ABI (include/pymodem_amd.h).
+#include "pm_common.h"
+#include <cstring>
+
+static thread_local char g_err[512] = "";
+
+int pm_set_error(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" {
+
+int pm_version(void) { return PM_VERSION; }
+
+int pm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pm_last_error(char *buf, size_t cap)
+{
+    if (!buf || cap == 0) return PM_ERR_ARG;
+    strncpy(buf, g_err, cap - 1);
+    buf[cap - 1] = 0;
+    return PM_OK;
+}
+
+int pm_ctx_create(int device, pm_ctx **out)
+{
+    PM_ARG(out != nullptr);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return pm_set_error(PM_ERR_NODEV, "no HIP device visible: the HIP path cannot run (there is no CPU fallback)");
+    PM_ARG(device >= 0 && device < n);
+    PM_HIP(hipSetDevice(device));
+    pm_ctx *c = new pm_ctx();
+    c->device = device;
+    PM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    PM_HIP(hipEventCreate(&c->ev0));
+    PM_HIP(hipEventCreate(&c->ev1));
+    PM_HIP(hipHostMalloc(&c->h_pinned, 4096, hipHostMallocDefault));
+    *out = c;
+    return PM_OK;
+}
+
+int pm_ctx_destroy(pm_ctx *c)
+{
+    if (!c) return PM_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    if (c->d_scratch) hipFree(c->d_scratch);
+    if (c->h_pinned) hipHostFree(c->h_pinned);
+    hipEventDestroy(c->ev0);
+    hipEventDestroy(c->ev1);
+    hipStreamDestroy(c->stream);
+    delete c;
+    return PM_OK;
+}
+
+int pm_ctx_sync(pm_ctx *c)
+{
+    PM_ARG(c != nullptr);
+    PM_HIP(hipStreamSynchronize(c->stream));
+    return PM_OK;
+}
+
+void *pm_ctx_stream(pm_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int pm_malloc(pm_ctx *c, size_t bytes, void **d_out)
+{
+    PM_ARG(c != nullptr && d_out != nullptr);
+    PM_HIP(hipSetDevice(c->device));
+    PM_HIP(hipMalloc(d_out, bytes ? bytes : 8));
+    return PM_OK;
+}
+
+int pm_free(pm_ctx *c, void *p)
+{
+    PM_ARG(c != nullptr);
+    if (!p) return PM_OK;
+    PM_HIP(hipStreamSynchronize(c->stream));
+    PM_HIP(hipFree(p));
+    return PM_OK;
+}
+
+int pm_h2d(pm_ctx *c, void *d_dst, const void *h_src, size_t bytes)
+{
+    PM_ARG(c != nullptr && (bytes == 0 || (d_dst && h_src)));
+    if (bytes) PM_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+    // pageable source: the runtime has staged the bytes when the call returns, the caller may reuse h_src
+    return PM_OK;
+}
+
+int pm_d2h(pm_ctx *c, void *h_dst, const void *d_src, size_t bytes)
+{
+    PM_ARG(c != nullptr && (bytes == 0 || (h_dst && d_src)));
+    if (bytes) PM_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    PM_HIP(hipStreamSynchronize(c->stream));
+    return PM_OK;
+}
+
+int pm_memset(pm_ctx *c, void *d_dst, int value, size_t bytes)
+{
+    PM_ARG(c != nullptr && (bytes == 0 || d_dst));
+    if (bytes) PM_HIP(hipMemsetAsync(d_dst, value, bytes, c->stream));
+    return PM_OK;
+}
+
+int pm_timer_start(pm_ctx *c)
+{
+    PM_ARG(c != nullptr);
+    PM_HIP(hipEventRecord(c->ev0, c->stream));
+    return PM_OK;
+}
+
+int pm_timer_stop(pm_ctx *c, float *ms)
+{
+    PM_ARG(c != nullptr && ms != nullptr);
+    PM_HIP(hipEventRecord(c->ev1, c->stream));
+    PM_HIP(hipEventSynchronize(c->ev1));
+    PM_HIP(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return PM_OK;
+}
+
+}  // extern "C"
+
+int pm_scratch_reserve(pm_ctx *c, size_t bytes)
+{
+    if (bytes <= c->scratch_bytes) return PM_OK;
+    PM_HIP(hipStreamSynchronize(c->stream));
+    if (c->d_scratch) PM_HIP(hipFree(c->d_scratch));
+    c->d_scratch = nullptr;
+    c->scratch_bytes = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    PM_HIP(hipMalloc(&c->d_scratch, want));
+    c->scratch_bytes = want;
+    return PM_OK;
+}

@@ -1,0 +1,53 @@
+"""Boundary types of the chain (data_classes.py:7-17 of the reference) plus their device/array forms."""
+import numpy as np
+
+
+class AddressedData:
+    """One sliced byte and the 1-based stream address of the sample that completed it."""
+    __slots__ = ("data", "address")
+
+    def __init__(self, data, address, *args):
+        self.data = data
+        self.address = address
+
+
+class IQData:
+    def __init__(self):
+        self.i_data = []
+        self.q_data = []
+
+
+class DeviceIQ:
+    """IQData whose two streams are DeviceBuffers in HBM (MPSKModem.demod(device_out=True))."""
+    def __init__(self, i_data, q_data):
+        self.i_data = i_data
+        self.q_data = q_data
+
+
+class AddressedArray:
+    """list[AddressedData] stored as two NumPy arrays.  Behaves like the reference's list for len(), indexing and
+    iteration (items are materialised on demand), while the native stages read `.data` / `.address` directly."""
+
+    def __init__(self, data, address):
+        self.data = np.ascontiguousarray(data, dtype=np.uint8)
+        self.address = np.ascontiguousarray(address, dtype=np.int64)
+        assert self.data.shape == self.address.shape
+
+    @classmethod
+    def coerce(cls, seq):
+        if isinstance(seq, cls):
+            return seq
+        return cls(np.fromiter((int(s.data) for s in seq), dtype=np.uint8, count=len(seq)),
+                   np.fromiter((int(s.address) for s in seq), dtype=np.int64, count=len(seq)))
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return AddressedArray(self.data[k], self.address[k])
+        return AddressedData(int(self.data[k]), int(self.address[k]))
+
+    def __iter__(self):
+        for d, a in zip(self.data.tolist(), self.address.tolist()):
+            yield AddressedData(d, a)

@@ -1,0 +1,121 @@
+"""Device context and buffers on top of the C ABI (pm_ctx_*, pm_malloc, pm_h2d, pm_d2h)."""
+import ctypes
+
+import numpy as np
+
+from ._native import NativeError, check, lib
+
+
+class Context:
+    """One HIP stream on one GPU.  Created lazily by the stage objects inside demod()/slice(), i.e. in the
+    process that runs the chain (fork-safe, see pymodem.py:144-151)."""
+    _default = {}
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        self.device = device
+        check(lib().pm_ctx_create(device, ctypes.byref(self._h)))
+
+    @classmethod
+    def default(cls, device=None):
+        import os
+        if device is None:
+            device = int(os.environ.get("PYMODEM_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            n = lib().pm_device_count()
+            if n > 0:
+                device %= n
+        key = (os.getpid(), device)
+        if key not in cls._default:
+            cls._default[key] = cls(device)
+        return cls._default[key]
+
+    @property
+    def handle(self):
+        return self._h
+
+    def sync(self):
+        check(lib().pm_ctx_sync(self._h))
+
+    def empty(self, n, dtype):
+        return DeviceBuffer(self, int(n), np.dtype(dtype))
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host)
+        buf = DeviceBuffer(self, host.size, host.dtype)
+        check(lib().pm_h2d(self._h, buf.ptr, host.ctypes.data_as(ctypes.c_void_p), host.nbytes))
+        return buf
+
+    def scratch(self, tag, n, dtype):
+        """A persistent work buffer of at least n elements for `tag`; contents are undefined and the same
+        storage is handed out again on the next call with the same tag (no hipMalloc in steady state)."""
+        dtype = np.dtype(dtype)
+        pool = self.__dict__.setdefault("_pool", {})
+        need = max(int(n), 1) * dtype.itemsize
+        raw = pool.get(tag)
+        if raw is None or raw.n < need:
+            if raw is not None:
+                raw.free()
+            raw = DeviceBuffer(self, need + need // 8 + 256, np.uint8)
+            pool[tag] = raw
+        out = DeviceBuffer(self, int(n), dtype, ptr=raw.ptr.value)
+        out._parent = raw
+        return out
+
+    def timer_start(self):
+        check(lib().pm_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = ctypes.c_float()
+        check(lib().pm_timer_stop(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self._h:
+            lib().pm_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+
+class DeviceBuffer:
+    """A typed device allocation (or a borrowed device pointer, e.g. torch.Tensor.data_ptr())."""
+
+    def __init__(self, ctx, n, dtype, ptr=None):
+        self.ctx, self.n, self.dtype = ctx, int(n), np.dtype(dtype)
+        self._owned = ptr is None
+        if ptr is None:
+            p = ctypes.c_void_p()
+            check(lib().pm_malloc(ctx.handle, self.n * self.dtype.itemsize, ctypes.byref(p)))
+            self.ptr = p
+        else:
+            self.ptr = ctypes.c_void_p(int(ptr))
+
+    @classmethod
+    def borrow(cls, ctx, ptr, n, dtype):
+        return cls(ctx, n, dtype, ptr=ptr)
+
+    def view(self, offset, n):
+        """Sub-range [offset, offset+n) as a borrowed buffer."""
+        assert 0 <= offset and offset + n <= self.n
+        out = DeviceBuffer(self.ctx, n, self.dtype, ptr=(self.ptr.value or 0) + offset * self.dtype.itemsize)
+        out._parent = self
+        return out
+
+    def download(self, n=None):
+        n = self.n if n is None else int(n)
+        out = np.empty(n, dtype=self.dtype)
+        if n:
+            check(lib().pm_d2h(self.ctx.handle, out.ctypes.data_as(ctypes.c_void_p), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self._owned and self.ptr:
+            lib().pm_free(self.ctx.handle, self.ptr)
+            self.ptr = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+__all__ = ["Context", "DeviceBuffer", "NativeError"]

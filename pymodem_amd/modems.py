@@ -1,0 +1,421 @@
+"""Modem stage objects: same constructor kwargs, `StringOptionsRetune`, `retune`, `tune`, `demod` and
+attribute names as the reference's classes, so they drop in under chain_builder / chain_execute.
+`demod()` runs entirely on the GPU through the C ABI (pm_fir_valid_*, pm_afsk_correlate, pm_agc_apply,
+pm_costas_bpsk, pm_mpsk_loop, pm_pll_afsk); there is no CPU path.
+
+Reference: AFSKModem afsk.py:13-167, FSKModem fsk.py:15-159, BPSKModem psk.py:20-195,
+MPSKModem psk.py:479-773, AFSKPLLModem afsk_pll.py:16-170.  QPSKModem (psk.py:197-476) is not provided:
+no bundled config uses type "qpsk" (SURVEY 2).
+
+Inputs: a host ndarray (int16 as scipy.io.wavfile returns it, or float64) or a DeviceBuffer already in HBM.
+Outputs: host float64 ndarray / IQData by default (the reference's contract); with `device_out=True`
+the result stays in HBM as DeviceBuffer / DeviceIQ for the slicer.
+"""
+import ctypes
+import math
+
+import numpy as np
+
+from . import taps as T
+from ._native import AGCParams, Loop, check, lib
+from .data_classes import DeviceIQ, IQData
+from .device import Context, DeviceBuffer
+from .string_ops import check_boolean
+
+
+class _DeviceStage:
+    """Lazy device state: nothing touches HIP until demod() runs (the reference forks after construction)."""
+    _ctx = None
+
+    def _context(self):
+        if self._ctx is None:
+            self._ctx = Context.default()
+            self._dev = {}
+        return self._ctx
+
+    def _const(self, name, host, dtype=np.float64):
+        """Upload a constant array once per (name, contents)."""
+        host = np.ascontiguousarray(host, dtype=dtype)
+        key = (name, host.tobytes())
+        hit = self._dev.get(name)
+        if hit is None or hit[0] != key[1]:
+            self._dev[name] = (key[1], self._ctx.upload(host))
+        return self._dev[name][1]
+
+    def _input(self, audio):
+        """-> (DeviceBuffer, is_int16).  Host arrays are uploaded; anything not int16 is taken as float64,
+        which is what numpy.convolve's type promotion does to it."""
+        ctx = self._context()
+        if isinstance(audio, DeviceBuffer):
+            assert audio.dtype in (np.dtype(np.int16), np.dtype(np.float64))
+            return audio, audio.dtype == np.dtype(np.int16)
+        a = np.asarray(audio)
+        if a.ndim != 1:
+            raise ValueError("demod expects a 1-D mono sample array")
+        if a.dtype == np.int16:
+            return ctx.upload(a), True
+        return ctx.upload(np.ascontiguousarray(a, dtype=np.float64)), False
+
+    def _fir(self, x, is_i16, taps_name, taps, flags=0, tag=None):
+        ctx = self._ctx
+        m = len(taps)
+        if x.n < m:
+            raise ValueError(f"input of {x.n} samples is shorter than the {m}-tap filter {taps_name}")
+        y = ctx.scratch((id(self), tag or taps_name), x.n - m + 1, np.float64)
+        fn = lib().pm_fir_valid_i16 if is_i16 else lib().pm_fir_valid_f64
+        check(fn(ctx.handle, x.ptr, x.n, self._const(taps_name, taps).ptr, m, y.ptr, flags))
+        return y
+
+    def _agc(self, buf):
+        if not hasattr(self, "_agc_state"):
+            self._agc_state = (ctypes.c_double * 2)(0.0, 0.0)
+        a = self.AGC
+        p = AGCParams(a.attack_rate, a.decay_rate, a.sustain_time, a.sample_rate, a.target_amplitude)
+        check(lib().pm_agc_apply(self._ctx.handle, buf.ptr, buf.n, ctypes.byref(p), self._agc_state))
+
+    def _finish(self, y, device_out):
+        return y if device_out else y.download()
+
+
+class _AGCSettings:
+    """The parameters of agc.py:7-24 (the envelope state lives with the modem that applies it)."""
+    def __init__(self, sample_rate, attack_rate, sustain_time, decay_rate, target_amplitude):
+        self.sample_rate, self.attack_rate, self.sustain_time = sample_rate, attack_rate, sustain_time
+        self.decay_rate, self.target_amplitude = decay_rate, target_amplitude
+
+
+class _LoopFilterSettings:
+    """IIR_1 coefficients (iir.py:15-29), fixed at construction with the constructor's sample rate."""
+    def __init__(self, sample_rate, cutoff, gain):
+        self.sample_rate, self.cutoff_freq, self.gain = sample_rate, cutoff, gain
+        b0, b1, a1 = T.one_pole_lowpass(sample_rate, cutoff, gain)
+        self.b_coefs, self.a_coefs = [b0, b1], [0.0, a1]
+
+
+class _PISettings:
+    """PI_control parameters and integral (pi_control.py:8-13)."""
+    def __init__(self, p, i, i_limit, gain):
+        self.p_rate, self.i_rate, self.i_limit, self.gain = p, i, i_limit, gain
+        self.integral = 0.0
+        self.proportional = 0.0
+
+
+def _make_loop(sample_rate, carrier, lpf, pi):
+    L = Loop()
+    L.phase_scaling = 2.0 * math.pi / sample_rate          # nco.py:31
+    L.index_scaling = 256 / (2.0 * math.pi)                # nco.py:27
+    L.set_frequency = carrier
+    L.b0, L.b1, L.a1 = lpf.b_coefs[0], lpf.b_coefs[1], lpf.a_coefs[1]
+    L.p_rate, L.i_rate, L.i_limit, L.gain = pi.p_rate, pi.i_rate, pi.i_limit, pi.gain
+    L.integral, L.proportional = pi.integral, pi.proportional
+    return L
+
+
+# =============================================================================================
+class AFSKModem(_DeviceStage):
+    def __init__(self, **kwargs):
+        self.definition = kwargs.get('config', '1200')
+        self.sample_rate = kwargs.get('sample_rate', 8000)
+        if self.definition == '300':          # afsk.py:19-42
+            self.symbol_rate = 300.0
+            self.input_bpf_low_cutoff = 1500.0
+            self.input_bpf_high_cutoff = 1900.0
+            self.input_bpf_span = 7
+            self.mark_freq = 1695.0
+            self.space_freq = 1705.0
+            self.space_gain = 1.0
+            self.output_lpf_cutoff = 240.0
+            self.output_lpf_span = 2.5
+            self.correlator_span = 0.3
+            self.correlator_offset = 0.0
+        else:                                 # afsk.py:43-66
+            self.symbol_rate = 1200.0
+            self.input_bpf_low_cutoff = 900.0
+            self.input_bpf_high_cutoff = 2500.0
+            self.input_bpf_span = 3.7
+            self.mark_freq = 1200.0
+            self.space_freq = 2200.0
+            self.space_gain = 1.0
+            self.output_lpf_cutoff = 1400.0
+            self.output_lpf_span = 2.5
+            self.correlator_span = 1.0
+            self.correlator_offset = 0.0
+        self.output_oversample = 1.0
+        self.tune()
+
+    _KEYS = ('symbol_rate', 'input_bpf_low_cutoff', 'input_bpf_high_cutoff', 'input_bpf_span', 'mark_freq', 'space_freq',
+             'space_gain', 'output_lpf_cutoff', 'output_lpf_span', 'correlator_span', 'correlator_offset', 'sample_rate')
+
+    def retune(self, **kwargs):
+        for k in self._KEYS:
+            setattr(self, k, kwargs.get(k, getattr(self, k)))
+        self.tune()
+
+    def StringOptionsRetune(self, options):   # afsk.py:87-100; unknown keys are ignored like there
+        for k in self._KEYS:
+            setattr(self, k, float(options.get(k, getattr(self, k))))
+        self.tune()
+
+    def tune(self):                           # afsk.py:102-146
+        self.input_bpf_tap_count = round(self.sample_rate * self.input_bpf_span / self.symbol_rate)
+        self.output_lpf_tap_count = round(self.sample_rate * self.output_lpf_span / self.symbol_rate)
+        self.input_bpf = T.windowed_sinc(self.input_bpf_tap_count, [self.input_bpf_low_cutoff, self.input_bpf_high_cutoff],
+                                         self.sample_rate, pass_zero=False)
+        self.output_lpf = T.windowed_sinc(self.output_lpf_tap_count, self.output_lpf_cutoff, self.sample_rate, pass_zero=True)
+        (self.mark_correlator_i, self.mark_correlator_q, self.space_correlator_i, self.space_correlator_q) = \
+            T.afsk_tone_correlators(self.sample_rate, self.symbol_rate, self.mark_freq, self.space_freq, self.space_gain,
+                                    self.correlator_span, self.correlator_offset)
+        self.output_sample_rate = self.output_oversample * self.sample_rate
+
+    def demod(self, input_audio, device_out=False):   # afsk.py:148-167
+        x, is_i16 = self._input(input_audio)
+        ctx = self._ctx
+        a = self._fir(x, is_i16, "input_bpf", self.input_bpf)
+        m = len(self.mark_correlator_i)
+        if a.n < m:
+            raise ValueError("input shorter than the correlators")
+        c = ctx.scratch((id(self), "corr"), a.n - m + 1, np.float64)
+        check(lib().pm_afsk_correlate(ctx.handle, a.ptr, a.n, self._const("mi", self.mark_correlator_i).ptr,
+                                      self._const("mq", self.mark_correlator_q).ptr, self._const("si", self.space_correlator_i).ptr,
+                                      self._const("sq", self.space_correlator_q).ptr, m, c.ptr))
+        y = self._fir(c, False, "output_lpf", self.output_lpf)
+        return self._finish(y, device_out)
+
+
+# =============================================================================================
+class FSKModem(_DeviceStage):
+    """One FIR (+ optional negate).  The reference builds an AGC but never applies it, and has no
+    `output_sample_rate` attribute (the runner falls back to the input rate, pymodem.py:87-90)."""
+    _PRESETS = {   # fsk.py:25-103: (symbol_rate, filter type, cutoff, span, rolloff, agc attack/sustain/decay)
+        '9600': (9600.0, 'lpf', 6000.0, 1.5, False, (1, 0.1, 1)),
+        '4800': (4800.0, 'lpf', 3000.0, 1.5, False, (1, 0.1, 1)),
+        '4800-rrc': (4800.0, 'rrc', None, 9, 0.2, (3, 0.1, 3)),
+        '9600-rrc': (9600.0, 'rrc', None, 9, 0.2, (50, 0.1, 3)),
+        '4800-gauss': (4800.0, 'lpf', 0.9 * 4800.0, 4, False, (50, 0.1, 3)),
+        '9600-gauss': (9600.0, 'lpf', 0.9 * 9600.0, 4, False, (50, 0.1, 3)),
+    }
+
+    def __init__(self, **kwargs):
+        self.definition = kwargs.get('config', '9600')
+        self.sample_rate = kwargs.get('sample_rate', 96000)
+        p = self._PRESETS.get(self.definition, self._PRESETS['9600'])
+        self.symbol_rate, self.input_filter_type, cutoff, self.input_lpf_span, self.rrc_rolloff_rate, agc = p
+        if cutoff is not None:
+            self.input_lpf_cutoff = cutoff
+        self.agc_attack_rate, self.agc_sustain_time, self.agc_decay_rate = agc
+        self.invert = False
+        self.tune()
+
+    def StringOptionsRetune(self, options):   # fsk.py:110-113
+        self.invert = check_boolean(options.get('invert', "false"))
+        self.tune()
+
+    def tune(self):                           # fsk.py:115-147
+        self.input_lpf_tap_count = round(self.sample_rate * self.input_lpf_span / self.symbol_rate)
+        if self.input_filter_type == 'rrc':
+            self.input_lpf = T.root_raised_cosine(self.sample_rate, self.symbol_rate, self.input_lpf_span, self.rrc_rolloff_rate)
+        else:
+            self.input_lpf = T.windowed_sinc(self.input_lpf_tap_count, [self.input_lpf_cutoff], self.sample_rate, pass_zero=True)
+
+    def demod(self, input_audio, device_out=False):   # fsk.py:149-159
+        x, is_i16 = self._input(input_audio)
+        y = self._fir(x, is_i16, "input_lpf", self.input_lpf, flags=1 if self.invert else 0)
+        return self._finish(y, device_out)
+
+
+# =============================================================================================
+class BPSKModem(_DeviceStage):
+    def __init__(self, **kwargs):
+        self.definition = kwargs.get('config', '300')
+        self.sample_rate = kwargs.get('sample_rate', 8000.0)
+        if self.definition == '300':          # psk.py:26-55
+            agc, self.symbol_rate = (500.0, 1.0, 50.0), 300.0
+            self.input_bpf_low_cutoff, self.input_bpf_high_cutoff, self.input_bpf_span = 1200.0, 1800.0, 1.5
+            self.carrier_freq, self.rrc_rolloff_rate, self.rrc_span = 1500.0, 0.6, 6
+            self.max_freq_offset = 25 * 1.25
+            lpf, pi_p, pi_gain = (250.0, 1.0), 0.06, 7200
+        elif self.definition == '1200':       # psk.py:56-85
+            agc, self.symbol_rate = (500.0, 1.0, 50.0), 1200.0
+            self.input_bpf_low_cutoff, self.input_bpf_high_cutoff, self.input_bpf_span = 200.0, 2800.0, 4.80
+            self.carrier_freq, self.rrc_rolloff_rate, self.rrc_span = 1500.0, 0.9, 6
+            self.max_freq_offset = 50 * 1.25
+            lpf, pi_p, pi_gain = (250.0, 1.0), 0.4, 1800
+        else:
+            raise AttributeError(f"BPSKModem has no preset {self.definition!r}")   # the reference fails on a missing attribute
+        self.agc_attack_rate, self.agc_sustain_time, self.agc_decay_rate = agc
+        self.Loop_LPF = _LoopFilterSettings(self.sample_rate, lpf[0], lpf[1])
+        self.FeedbackController = _PISettings(pi_p, pi_p / 1000, self.max_freq_offset, pi_gain)
+        self.oscillator_amplitude = 1.0
+        self.tune()
+
+    _KEYS = ('symbol_rate', 'input_bpf_low_cutoff', 'input_bpf_high_cutoff', 'input_bpf_span', 'sample_rate', 'carrier_freq')
+
+    def retune(self, **kwargs):
+        for k in self._KEYS:
+            setattr(self, k, kwargs.get(k, getattr(self, k)))
+        self.tune()
+
+    def StringOptionsRetune(self, options):   # psk.py:102-109
+        for k in self._KEYS:
+            setattr(self, k, float(options.get(k, getattr(self, k))))
+        self.tune()
+
+    def tune(self):                           # psk.py:111-160
+        self.input_bpf_tap_count = round(self.sample_rate * self.input_bpf_span / self.symbol_rate)
+        self.input_bpf = T.windowed_sinc(self.input_bpf_tap_count, [self.input_bpf_low_cutoff, self.input_bpf_high_cutoff],
+                                         self.sample_rate, pass_zero=False)
+        self.AGC = _AGCSettings(self.sample_rate, self.agc_attack_rate, self.agc_sustain_time, self.agc_decay_rate, self.oscillator_amplitude)
+        self.wavetable = T.sine_wavetable(self.oscillator_amplitude, 256)
+        self.rrc_taps = T.root_raised_cosine(self.sample_rate, self.symbol_rate, self.rrc_span, self.rrc_rolloff_rate)
+        self._loop = _make_loop(self.sample_rate, self.carrier_freq, self.Loop_LPF, self.FeedbackController)
+        self.output_sample_rate = self.sample_rate
+
+    def demod(self, input_audio, device_out=False):   # psk.py:162-195
+        x, is_i16 = self._input(input_audio)
+        ctx = self._ctx
+        a = self._fir(x, is_i16, "input_bpf", self.input_bpf)
+        self._agc(a)
+        d = ctx.scratch((id(self), "loop"), a.n, np.float64)
+        check(lib().pm_costas_bpsk(ctx.handle, ctypes.byref(self._loop), 1, self._const("wavetable", self.wavetable).ptr,
+                                   a.ptr, 0, a.n, d.ptr, a.n))
+        y = self._fir(d, False, "rrc", self.rrc_taps)
+        return self._finish(y, device_out)
+
+
+# =============================================================================================
+class MPSKModem(_DeviceStage):
+    _PRESETS = {   # psk.py:485-628
+        'qpsk_3600': dict(const='qpsk', agc=(5000.0, 0.1, 50.0), symbol_rate=1800, lo=300.0, hi=3000.0, span=2, hilbert=4.5,
+                          carrier=1650.0, max_off=12.5 * 1.25, rolloff=0.3, lpf=(250.0, 1), p=0.15, i_div=1000, gain=(14400 / 65536)),
+        'qpsk_600': dict(const='qpsk', agc=(500.0, 1, 50.0), symbol_rate=300, lo=1200.0, hi=1800.0, span=4, hilbert=3.4,
+                         carrier=1500.0, max_off=25, rolloff=0.6, lpf=(150, 1), p=0.1, i_div=1000, gain=(7200 / 65536)),
+        'qpsk_2400': dict(const='qpsk', agc=(500.0, 1, 50.0), symbol_rate=1200, lo=200.0, hi=2800.0, span=2.7, hilbert=3.4,
+                          carrier=1500.0, max_off=25 * 1.25, rolloff=0.9, lpf=(250.0, 1), p=0.3, i_div=2000, gain=(14400 / 65536)),
+        'bpsk_300': dict(const='bpsk', agc=(500.0, 1, 50.0), symbol_rate=300, lo=1200.0, hi=1800.0, span=2.7, hilbert=2.7,
+                         carrier=1500.0, max_off=50, rolloff=0.6, lpf=(250.0, 1.0), p=0.15, i_div=1000, gain=1.5 * (500)),
+        'bpsk_1200': dict(const='bpsk', agc=(500.0, 1, 50.0), symbol_rate=1200, lo=200.0, hi=2800.0, span=4.8, hilbert=2,
+                          carrier=1500.0, max_off=87.5, rolloff=0.9, lpf=(200.0, 1.0), p=0.15, i_div=1000, gain=5),
+    }
+
+    def __init__(self, **kwargs):
+        self.definition = kwargs.get('config', 'qpsk_3600')
+        self.sample_rate = kwargs.get('sample_rate', 44100.0)
+        if self.definition not in self._PRESETS:
+            raise AttributeError(f"MPSKModem has no preset {self.definition!r}")
+        p = self._PRESETS[self.definition]
+        self.constellation_id = p['const']
+        self.agc_attack_rate, self.agc_sustain_time, self.agc_decay_rate = p['agc']
+        self.symbol_rate = p['symbol_rate']
+        self.input_bpf_low_cutoff, self.input_bpf_high_cutoff = p['lo'], p['hi']
+        self.input_bpf_span, self.hilbert_span = p['span'], p['hilbert']      # milliseconds
+        self.carrier_freq, self.max_freq_offset = p['carrier'], p['max_off']
+        self.rrc_rolloff_rate, self.rrc_span = p['rolloff'], 6
+        self.Loop_LPF = _LoopFilterSettings(self.sample_rate, p['lpf'][0], p['lpf'][1])
+        self.FeedbackController = _PISettings(p['p'], p['p'] / p['i_div'], self.max_freq_offset, p['gain'])
+        self.oscillator_amplitude = 1.0
+        self.pd_gain = 32
+        self.tune()
+
+    def StringOptionsRetune(self, options):   # psk.py:633-637
+        self.symbol_rate = float(options.get('symbol_rate', self.symbol_rate))
+        self.sample_rate = float(options.get('sample_rate', self.sample_rate))
+        self.carrier_freq = float(options.get('carrier_freq', self.carrier_freq))
+        self.tune()
+
+    def tune(self):                           # psk.py:639-703
+        self.input_bpf_tap_count = round(self.sample_rate * self.input_bpf_span / 1000)
+        self.hilbert_tap_count = round(self.sample_rate * self.hilbert_span / 1000)
+        self.input_bpf = T.windowed_sinc(self.input_bpf_tap_count, [self.input_bpf_low_cutoff, self.input_bpf_high_cutoff],
+                                         self.sample_rate, pass_zero=False)
+        if self.hilbert_tap_count % 2 == 0:
+            self.hilbert_tap_count += 1
+        self.hilbert_taps, self.hilbert_delay = T.hilbert_transformer(self.hilbert_tap_count)
+        self.AGC = _AGCSettings(self.sample_rate, self.agc_attack_rate, self.agc_sustain_time, self.agc_decay_rate, self.oscillator_amplitude)
+        self.wavetable = T.sine_wavetable(self.oscillator_amplitude, 256)
+        self.rrc_taps = T.root_raised_cosine(self.sample_rate, self.symbol_rate, self.rrc_span, self.rrc_rolloff_rate)
+        self.output_sample_rate = self.sample_rate
+        self.FeedbackController.integral = -self.max_freq_offset      # psk.py:703: start at the maximum offset
+        self._loop = _make_loop(self.sample_rate, self.carrier_freq, self.Loop_LPF, self.FeedbackController)
+        self.phase_error_table = T.qpsk_error_table(64, self.pd_gain)
+
+    def front_end(self, input_audio):
+        """BPF -> AGC -> Hilbert pair (psk.py:710-716): (real, imag) DeviceBuffers of equal length.  Chains that differ
+        only in carrier_freq (configs/qpsk_2400.json) share this part; see chain_execute.run_mpsk_group."""
+        x, is_i16 = self._input(input_audio)
+        a = self._fir(x, is_i16, "input_bpf", self.input_bpf)
+        self._agc(a)
+        imag = self._fir(a, False, "hilbert", self.hilbert_taps)
+        # the delay FIR [1,0,...,0] followed by [:-delay] is a pure shift: real[k] = a[k + delay]
+        real = a.view(self.hilbert_delay, imag.n)
+        return real, imag
+
+    def demod(self, input_audio, device_out=False):   # psk.py:705-773
+        real, imag = self.front_end(input_audio)
+        ctx = self._ctx
+        n = imag.n
+        i_mix = ctx.scratch((id(self), "i_mix"), n, np.float64)
+        q_mix = ctx.scratch((id(self), "q_mix"), n, np.float64)
+        check(lib().pm_mpsk_loop(ctx.handle, ctypes.byref(self._loop), 1, self._const("wavetable", self.wavetable).ptr,
+                                 self._const("pd", self.phase_error_table.reshape(-1), np.int32).ptr,
+                                 real.ptr, imag.ptr, 0, n, i_mix.ptr, q_mix.ptr, n))
+        i_out = self._fir(i_mix, False, "rrc", self.rrc_taps, tag="i_out")
+        q_out = self._fir(q_mix, False, "rrc", self.rrc_taps, tag="q_out")
+        if device_out:
+            return DeviceIQ(i_out, q_out)
+        out = IQData()
+        out.i_data, out.q_data = i_out.download(), q_out.download()
+        return out
+
+
+# =============================================================================================
+class AFSKPLLModem(_DeviceStage):
+    def __init__(self, **kwargs):
+        self.definition = kwargs.get('config', '300')
+        self.sample_rate = kwargs.get('sample_rate', 8000.0)
+        if self.definition != '300':          # afsk_pll.py:22-54 defines this preset only
+            raise AttributeError(f"AFSKPLLModem has no preset {self.definition!r}")
+        self.agc_attack_rate, self.agc_sustain_time, self.agc_decay_rate = 500.0, 1.0, 50.0
+        self.symbol_rate = 300.0
+        self.input_bpf_low_cutoff, self.input_bpf_high_cutoff, self.input_bpf_span = 1500.0, 1900.0, 7.0
+        self.carrier_freq = 1700.0
+        self.output_lpf_cutoff, self.output_lpf_span = 240.0, 5
+        self.max_freq_offset = 50
+        self.LoopFilter = _LoopFilterSettings(self.sample_rate, 150.0, 1.0)
+        self.FeedbackController = _PISettings(0.6, 0.6 / 6000, self.max_freq_offset, 900)
+        self.oscillator_amplitude = 1.0
+        self.tune()
+
+    _KEYS = ('symbol_rate', 'input_bpf_low_cutoff', 'input_bpf_high_cutoff', 'input_bpf_span', 'output_lpf_cutoff',
+             'output_lpf_span', 'sample_rate', 'carrier_freq')
+
+    def retune(self, **kwargs):
+        for k in self._KEYS:
+            setattr(self, k, kwargs.get(k, getattr(self, k)))
+        self.tune()
+
+    def StringOptionsRetune(self, options):   # afsk_pll.py:73-82
+        for k in self._KEYS:
+            setattr(self, k, float(options.get(k, getattr(self, k))))
+        self.tune()
+
+    def tune(self):                           # afsk_pll.py:84-138
+        self.input_bpf_tap_count = round(self.sample_rate * self.input_bpf_span / self.symbol_rate)
+        self.output_lpf_tap_count = round(self.sample_rate * self.output_lpf_span / self.symbol_rate)
+        self.input_bpf = T.windowed_sinc(self.input_bpf_tap_count, [self.input_bpf_low_cutoff, self.input_bpf_high_cutoff],
+                                         self.sample_rate, pass_zero=False)
+        self.output_lpf = T.windowed_sinc(self.output_lpf_tap_count, self.output_lpf_cutoff, self.sample_rate, pass_zero=True)
+        self.AGC = _AGCSettings(self.sample_rate, self.agc_attack_rate, self.agc_sustain_time, self.agc_decay_rate, self.oscillator_amplitude)
+        self.wavetable = T.sine_wavetable(self.oscillator_amplitude, 256)
+        self._loop = _make_loop(self.sample_rate, self.carrier_freq, self.LoopFilter, self.FeedbackController)
+        self.output_sample_rate = self.sample_rate
+
+    def demod(self, input_audio, device_out=False):   # afsk_pll.py:140-170
+        x, is_i16 = self._input(input_audio)
+        ctx = self._ctx
+        a = self._fir(x, is_i16, "input_bpf", self.input_bpf)
+        self._agc(a)
+        d = ctx.scratch((id(self), "loop"), a.n, np.float64)
+        check(lib().pm_pll_afsk(ctx.handle, ctypes.byref(self._loop), 1, self._const("wavetable", self.wavetable).ptr,
+                                a.ptr, 0, a.n, d.ptr, a.n))
+        y = self._fir(d, False, "output_lpf", self.output_lpf)
+        return self._finish(y, device_out)

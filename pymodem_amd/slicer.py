@@ -1,0 +1,114 @@
+"""Slicer stage objects (BinarySlicer slicer.py:9-107, QuadratureSlicer slicer.py:109-242 of the reference).
+`slice()` runs on the GPU: sign bitmap (pm_signs_f64) -> chunk-parallel timing recovery (pm_slice_*).
+FourLevelSlicer is not provided: it raises NameError in the reference (slicer.py:312,432)."""
+import ctypes
+
+import numpy as np
+
+from ._native import SlicerParams, check, lib
+from .data_classes import AddressedArray, DeviceIQ, IQData
+from .device import Context, DeviceBuffer
+
+
+class _SlicerBase:
+    _ctx = None
+    last_stats = None
+
+    def retune(self, **kwargs):
+        self.symbol_rate = kwargs.get('symbol_rate', self.symbol_rate)
+        self.lock_rate = kwargs.get('lock_rate', self.lock_rate)
+        self.sample_rate = kwargs.get('sample_rate', self.sample_rate)
+        self.tune()
+
+    def StringOptionsRetune(self, options):   # slicer.py:43-47,187-191
+        self.symbol_rate = float(options.get('symbol_rate', self.symbol_rate))
+        self.sample_rate = float(options.get('sample_rate', self.sample_rate))
+        self.lock_rate = float(options.get('lock_rate', self.lock_rate))
+        self.tune()
+
+    def tune(self):                           # slicer.py:49-56,193-202
+        self.phase_clock = 0.0
+        self.samples_per_symbol = self.sample_rate / self.symbol_rate
+        self.rollover_threshold = (self.samples_per_symbol / 2.0) - 0.5
+        self.streamaddress = 0
+
+    def _params(self):
+        p = SlicerParams()
+        p.samples_per_symbol = self.samples_per_symbol
+        p.lock_rate = self.lock_rate
+        p.bits_per_symbol = self.bits_per_symbol
+        p.state_mask = self.state_mask
+        for k, v in enumerate(self.demap):
+            p.demap[k] = v
+        return p
+
+    def _bits(self, ctx, x, tag):
+        if not isinstance(x, DeviceBuffer):
+            x = ctx.upload(np.ascontiguousarray(x, dtype=np.float64))
+        assert x.dtype == np.dtype(np.float64)
+        bits = ctx.scratch((id(self), tag), (x.n + 63) // 64 + 1, np.uint64)
+        check(lib().pm_signs_f64(ctx.handle, x.ptr, x.n, bits.ptr))
+        return bits, x.n
+
+    def _run(self, ctx, bits_i, bits_q, n):
+        cap = n * self.bits_per_symbol // 8 + 4            # at most one symbol per sample
+        data = ctx.scratch((id(self), "bytes"), cap + 4, np.uint8)
+        addr = ctx.scratch((id(self), "addr"), cap, np.int64)
+        count = ctypes.c_int64()
+        p = self._params()
+        if bits_q is None:
+            check(lib().pm_slice_binary(ctx.handle, bits_i.ptr, n, ctypes.byref(p), data.ptr, addr.ptr, cap, ctypes.byref(count)))
+        else:
+            check(lib().pm_slice_quadrature(ctx.handle, bits_i.ptr, bits_q.ptr, n, ctypes.byref(p), data.ptr, addr.ptr, cap,
+                                            ctypes.byref(count)))
+        it, cl, nc = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
+        lib().pm_slicer_stats(ctx.handle, ctypes.byref(it), ctypes.byref(cl), ctypes.byref(nc))
+        self.last_stats = {"iterations": it.value, "chunk_len": cl.value, "chunks": nc.value}
+        return AddressedArray(data.download(count.value), addr.download(count.value))
+
+
+class BinarySlicer(_SlicerBase):
+    bits_per_symbol, state_mask, demap = 1, 0x3, [0, 0, 1, 1]
+
+    def __init__(self, **kwargs):
+        self.definition = kwargs.get('config', '1200')
+        self.sample_rate = kwargs.get('sample_rate', '8000')
+        self.symbol_rate, self.lock_rate = {'300': (300, 0.75), '9600': (9600, 0.88), '4800': (4800, 0.88)}.get(
+            self.definition, (1200, 0.75))        # slicer.py:22-33
+        self.tune()
+
+    def slice(self, samples):
+        """-> AddressedArray (list[AddressedData]-compatible).  `samples`: host float64 sequence or DeviceBuffer."""
+        ctx = self._ctx = self._ctx or Context.default()
+        n = samples.n if isinstance(samples, DeviceBuffer) else len(samples)
+        if n == 0:
+            return AddressedArray(np.zeros(0, np.uint8), np.zeros(0, np.int64))
+        bits, n = self._bits(ctx, samples, "bits_i")
+        return self._run(ctx, bits, None, n)
+
+
+class QuadratureSlicer(_SlicerBase):
+    _QPSK = [3, 1, 2, 0, 2, 3, 0, 1, 1, 0, 3, 2, 0, 2, 1, 3]
+    _PRESETS = {   # slicer.py:124-165: (state_mask, bits_per_symbol, demap, symbol_rate, lock_rate)
+        'qpsk_600': (0xF, 2, _QPSK, 300, 0.815), 'bpsk_300': (0x3, 1, [0, 0, 1, 1], 300, 0.815),
+        'bpsk_1200': (0x3, 1, [0, 0, 1, 1], 1200, 0.9), 'qpsk_2400': (0xF, 2, _QPSK, 1200, 0.9),
+        'qpsk_4800': (0xF, 2, _QPSK, 2400, 0.99), 'qpsk_3600': (0xF, 2, _QPSK, 1800, 0.99),
+    }
+
+    def __init__(self, **kwargs):
+        self.sample_rate = kwargs.get('sample_rate', '8000')
+        self.definition = kwargs.get('config', '600')
+        self.state_mask, self.bits_per_symbol, self.demap, self.symbol_rate, self.lock_rate = self._PRESETS.get(
+            self.definition, (0xF, 2, self._QPSK, 1200, 0.9))
+        self.tune()
+
+    def slice(self, iq_samples):
+        ctx = self._ctx = self._ctx or Context.default()
+        i, q = iq_samples.i_data, iq_samples.q_data
+        n = i.n if isinstance(i, DeviceBuffer) else len(i)
+        if n == 0:
+            return AddressedArray(np.zeros(0, np.uint8), np.zeros(0, np.int64))
+        bi, n = self._bits(ctx, i, "bits_i")
+        bq, nq = self._bits(ctx, q, "bits_q")
+        assert n == nq
+        return self._run(ctx, bi, bq, n)

@@ -1,0 +1,224 @@
+"""GPU parity: every HIP kernel, through the C ABI, against the oracle on the same seeded inputs.
+Bar: bit-exact (the oracle's *_canon FIRs use the kernels' summation order; the loops and slicers are
+sequential restatements), so np.array_equal on float64 arrays, bytes and addresses."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import pymodem_amd
+    if pymodem_amd.lib().pm_device_count() < 1:
+        pytest.fail("no GPU visible: -m gpu tests need an MI355X")
+    return pymodem_amd.Context.default()
+
+
+def L():
+    import pymodem_amd
+    return pymodem_amd.lib()
+
+
+def chk(rc):
+    from pymodem_amd._native import check
+    check(rc)
+
+
+def fir_gpu(ctx, x, h, flags=0):
+    dx = ctx.upload(x)
+    dh = ctx.upload(np.ascontiguousarray(h, dtype=np.float64))
+    y = ctx.empty(len(x) - len(h) + 1, np.float64)
+    fn = L().pm_fir_valid_i16 if x.dtype == np.int16 else L().pm_fir_valid_f64
+    chk(fn(ctx.handle, dx.ptr, len(x), dh.ptr, len(h), y.ptr, flags))
+    return y.download()
+
+
+@pytest.mark.parametrize("m", [1, 2, 7, 8, 9, 40, 60, 100, 148, 241, 961, 1120])
+def test_fir_bit_exact(ctx, m):
+    rng = np.random.default_rng(m)
+    h = rng.standard_normal(m)
+    for n in sorted({m, m + 1, m + 2047, m + 2048, m + 2049, 5000 + m, 70001}):
+        if n < m:
+            continue
+        xi = np.clip(np.rint(rng.standard_normal(n) * 8000), -32768, 32767).astype(np.int16)
+        assert np.array_equal(fir_gpu(ctx, xi, h), O.fir_canon(xi, h)), (m, n, "i16")
+        xf = rng.standard_normal(n) * 100.0
+        assert np.array_equal(fir_gpu(ctx, xf, h), O.fir_canon(xf, h)), (m, n, "f64")
+    xf = rng.standard_normal(4096 + m)
+    assert np.array_equal(fir_gpu(ctx, xf, h, flags=1), -O.fir_canon(xf, h))
+    # and the reference's own summation order agrees to rounding
+    ref = np.convolve(xf, h, "valid")
+    assert np.abs(fir_gpu(ctx, xf, h) - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-300)
+
+
+def test_fir_rejects_bad_arguments(ctx):
+    from pymodem_amd import NativeError
+    x = ctx.upload(np.zeros(4))
+    h = ctx.upload(np.ones(8))
+    y = ctx.empty(8, np.float64)
+    with pytest.raises(NativeError):
+        chk(L().pm_fir_valid_f64(ctx.handle, x.ptr, 4, h.ptr, 8, y.ptr, 0))     # n < m
+    with pytest.raises(NativeError):
+        chk(L().pm_fir_valid_f64(ctx.handle, None, 16, h.ptr, 8, y.ptr, 0))
+
+
+@pytest.mark.parametrize("m", [3, 4, 8, 14, 40, 60, 61])
+def test_afsk_correlate_bit_exact(ctx, m):
+    rng = np.random.default_rng(100 + m)
+    taps = [rng.standard_normal(m) for _ in range(4)]
+    for n in [m, m + 1023, m + 1024, m + 1025, 50000]:
+        x = rng.standard_normal(n) * 300.0
+        dx = ctx.upload(x)
+        dt = [ctx.upload(t) for t in taps]
+        y = ctx.empty(n - m + 1, np.float64)
+        chk(L().pm_afsk_correlate(ctx.handle, dx.ptr, n, dt[0].ptr, dt[1].ptr, dt[2].ptr, dt[3].ptr, m, y.ptr))
+        assert np.array_equal(y.download(), O.afsk_correlate_canon(x, *taps)), (m, n)
+
+
+def test_sqrt_is_correctly_rounded(ctx):
+    """The correlator magnitude relies on the device sqrt being IEEE: one tap turns the kernel into sqrt(a*a + 0)."""
+    rng = np.random.default_rng(5)
+    x = np.abs(rng.standard_normal(200000)) * 10.0 ** rng.integers(-150, 150, 200000)
+    one, zero = ctx.upload(np.ones(1)), ctx.upload(np.zeros(1))
+    dx = ctx.upload(x)
+    y = ctx.empty(len(x), np.float64)
+    chk(L().pm_afsk_correlate(ctx.handle, dx.ptr, len(x), one.ptr, zero.ptr, zero.ptr, zero.ptr, 1, y.ptr))
+    assert np.array_equal(y.download(), np.sqrt(x * x + 0.0 * 0.0) - np.sqrt(0.0))
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 65536, 100003])
+def test_signs(ctx, n):
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n)
+    x[::7] = 0.0
+    x[3::11] = -0.0
+    dx = ctx.upload(x)
+    bits = ctx.empty((n + 63) // 64, np.uint64)
+    chk(L().pm_signs_f64(ctx.handle, dx.ptr, n, bits.ptr))
+    got = np.unpackbits(bits.download().view(np.uint8), bitorder="little")[:n].astype(bool)
+    assert np.array_equal(got, x >= 0)
+
+
+def slicer_input(n, seed, kind):
+    rng = np.random.default_rng(seed)
+    if kind == "noise":
+        return rng.standard_normal(n)
+    if kind == "smooth":          # band-limited: few crossings per symbol, like a real demodulated stream
+        return np.convolve(rng.standard_normal(n + 63), np.hanning(64), "valid")
+    if kind == "silence":         # exact zeros: no crossing ever, the fixed point needs one iteration per chunk
+        return np.zeros(n)
+    if kind == "alternating":     # a crossing at every sample
+        return np.where(np.arange(n) % 2 == 0, 1.0, -1.0)
+    raise ValueError(kind)
+
+
+BIN = [(48000, "1200", "0.77"), (8000, "300", "0.90"), (44100, "1200", "0.75"), (48000, "9600", "0.88"), (48000, "300", "0.99")]
+
+
+@pytest.mark.parametrize("kind", ["noise", "smooth", "silence", "alternating"])
+@pytest.mark.parametrize("rate,cfg,lock", BIN)
+def test_binary_slicer_bit_exact(ctx, rate, cfg, lock, kind):
+    from pymodem_amd.slicer import BinarySlicer
+    for n in [1, 100, 1023, 1024, 1025, 40000, 300001]:
+        if kind == "silence" and n > 40000:
+            continue
+        x = slicer_input(n, n + rate, kind)
+        s = BinarySlicer(sample_rate=rate, config=cfg)
+        s.StringOptionsRetune({"lock_rate": lock})
+        got = s.slice(x)
+        d, a = O.BinarySlicer(rate, cfg, {"lock_rate": lock}).slice(x)
+        assert np.array_equal(got.data, d) and np.array_equal(got.address, a), (n, kind, s.last_stats)
+
+
+QUAD = [(48000, "qpsk_2400", "0.98"), (8000, "qpsk_600", "0.815"), (48000, "bpsk_1200", "0.9"), (44100, "qpsk_3600", "0.985"),
+        (48000, "bpsk_300", "0.815")]
+
+
+@pytest.mark.parametrize("kind", ["noise", "smooth", "alternating"])
+@pytest.mark.parametrize("rate,cfg,lock", QUAD)
+def test_quadrature_slicer_bit_exact(ctx, rate, cfg, lock, kind):
+    from pymodem_amd.data_classes import IQData
+    from pymodem_amd.slicer import QuadratureSlicer
+    for n in [1, 777, 4096, 50001, 300000]:
+        iq = IQData()
+        iq.i_data = slicer_input(n, n + rate, kind)
+        iq.q_data = slicer_input(n, n + rate + 1, "smooth" if kind == "alternating" else kind)
+        s = QuadratureSlicer(sample_rate=rate, config=cfg)
+        s.StringOptionsRetune({"lock_rate": lock})
+        got = s.slice(iq)
+        d, a = O.QuadratureSlicer(rate, cfg, {"lock_rate": lock}).slice((iq.i_data, iq.q_data))
+        assert np.array_equal(got.data, d) and np.array_equal(got.address, a), (n, kind, s.last_stats)
+
+
+def test_agc_bit_exact(ctx, golden):
+    from pymodem_amd._native import AGCParams
+    g = golden("primitives")
+    cases = [("agc_8k_in", 8000.0, 0.5), ("agc_48k_in", 48000.0, 0.5), ("agc_neg_in", 8000.0, 0.01), ("agc_zero_in", 8000.0, 0.01)]
+    for key, rate, sustain in cases:
+        x = g[key].copy()
+        d = ctx.upload(x)
+        st = (ctypes.c_double * 2)(0.0, 0.0)
+        p = AGCParams(500.0, 50.0, sustain, rate, 1.0)
+        chk(L().pm_agc_apply(ctx.handle, d.ptr, len(x), ctypes.byref(p), st))
+        want = x.copy()
+        ost = np.zeros(2)
+        O.agc_apply(want, rate, 500.0, sustain, 50.0, 1.0, state=ost)
+        assert np.array_equal(d.download(), want), key
+        assert np.array_equal(d.download(), g[key.replace("_in", "_out")]), key      # and the reference itself
+        assert st[0] == ost[0] and st[1] == ost[1]
+
+
+def loops_pair(rate, carrier, cutoff, p, i, lim, gain, integral0=0.0):
+    from pymodem_amd._native import Loop
+    a = O.make_loop(rate, carrier, cutoff, 1.0, p, i, lim, gain, integral0)
+    b = Loop()
+    for f, _ in Loop._fields_:
+        setattr(b, f, getattr(a, f))
+    return a, b
+
+
+def agc_like(n, seed):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n)
+    return np.sin(2 * np.pi * 1503.7 * t / 48000 + 0.4) * (0.6 + 0.3 * np.sin(t / 5000.0)) + 0.2 * rng.standard_normal(n)
+
+
+@pytest.mark.parametrize("n", [1, 255, 256, 257, 20000])
+def test_costas_and_pll_bit_exact(ctx, n):
+    tab = O.nco_table()
+    dt = ctx.upload(tab)
+    x = agc_like(n, n)
+    dx = ctx.upload(x)
+    for fn, ofn, args in [(L().pm_costas_bpsk, O.costas_bpsk, (48000.0, 1500.0, 250.0, 0.06, 0.06 / 1000, 31.25, 7200)),
+                          (L().pm_pll_afsk, O.pll_afsk, (8000.0, 1700.0, 150.0, 0.6, 0.6 / 6000, 50, 900))]:
+        a, b = loops_pair(*args)
+        out = ctx.empty(n, np.float64)
+        chk(fn(ctx.handle, ctypes.byref(b), 1, dt.ptr, dx.ptr, 0, n, out.ptr, n))
+        want = ofn(a, x, tab)
+        assert np.array_equal(out.download(), want)
+        for f, _ in a._fields_:
+            assert getattr(a, f) == getattr(b, f), f           # end state identical too
+
+
+def test_mpsk_loop_batch_bit_exact(ctx):
+    """Eleven loops at swept carriers over one shared input (the qpsk_2400.json arrangement), one launch."""
+    from pymodem_amd._native import Loop
+    n = 30000
+    tab, pdt = O.nco_table(), O.pd_table()
+    re, im = agc_like(n, 1), agc_like(n, 2)
+    carriers = [1450.0 + 10 * k for k in range(11)]
+    pairs = [loops_pair(48000.0, c, 250.0, 0.3, 0.3 / 2000, 31.25, 14400 / 65536, -31.25) for c in carriers]
+    arr = (Loop * len(pairs))(*[b for _, b in pairs])
+    io, qo = ctx.empty(n * len(pairs), np.float64), ctx.empty(n * len(pairs), np.float64)
+    chk(L().pm_mpsk_loop(ctx.handle, arr, len(pairs), ctx.upload(tab).ptr, ctx.upload(pdt.reshape(-1)).ptr,
+                         ctx.upload(re).ptr, ctx.upload(im).ptr, 0, n, io.ptr, qo.ptr, n))
+    gi, gq = io.download().reshape(len(pairs), n), qo.download().reshape(len(pairs), n)
+    for k, (a, _) in enumerate(pairs):
+        wi, wq = O.mpsk_loop(a, re, im, tab, pdt)
+        assert np.array_equal(gi[k], wi) and np.array_equal(gq[k], wq), k
+        assert a.phase == arr[k].phase and a.integral == arr[k].integral and a.control == arr[k].control
