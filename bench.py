@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s through demod_chain on MI355X (BASELINE.json metric), one process per GPU.
+
+A step = one pass of the rank's demod_chains (modem -> slicer on the GPU, LFSR -> codec native on the host, packet
+gather + de-dup) over one synthetic recording that is already resident in HBM.  Weak scaling: every rank runs
+--chains-per-gpu chains, chains are independent (no data-path collective); the only exchange is the packet gather.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--samples S] [--chains-per-gpu C]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant GPU kernel, HIP-event time measured inside the timed region
+through pm_prof_*) and `cpu_baseline` (the oracle -- the CPU restatement of the reference -- on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
+
+
+# ---- workloads: BASELINE.json configs as lists of 'demod_chain' lines --------------------------------------------
+def _afsk_line(name, space_gain, mark, space, span, codec="ax25"):
+    opts = {"space_gain": str(space_gain), "mark_freq": str(mark), "space_freq": str(space)}
+    if span is not None:
+        opts["correlator_span"] = str(span)
+    if codec == "ax25":
+        stream, cdc = {"type": "lfsr", "options": {"poly": "0x3", "invert": "True"}}, {"type": "ax25"}
+    else:
+        stream = {"type": "lfsr", "options": {"poly": "0x1", "invert": "False"}}
+        cdc = {"type": "il2p", "options": {"crc": "yes", "disable_rs": "no", "min_dist": "0", "sync_tol": "0"}}
+    return {"object_name": name, "object_type": "demod_chain", "modem": {"type": "afsk", "config": "1200", "options": opts},
+            "slicer": {"type": "binary", "config": "1200", "options": {"lock_rate": "0.77"}}, "stream": stream, "codec": cdc}
+
+
+def wl_afsk_super_opt(j):
+    """configs/afsk_1200_ax25_super_opt.json: chain 0 = 1600/1800 span 1.0; chains 1..7 = 1300/2100 span 1.5 with
+    space_gain 1.25..2.75.  Beyond 8 chains (more GPUs) the space_gain sweep continues in finer steps."""
+    k, rep = j % 8, j // 8
+    if k == 0:
+        return _afsk_line(f"AFSK 1200 AX.25 1600/1800 sg 1.0 #{rep}", 1.0 + 0.05 * rep, 1600.0, 1800.0, None)
+    sg = 1.0 + 0.25 * k + 0.03 * rep
+    return _afsk_line(f"AFSK 1200 AX.25 1300/2100 sg {sg:.2f}", sg, 1300.0, 2100.0, 1.5)
+
+
+def wl_fsk_9600(j):
+    """configs/fsk_9600.json: 3 chains sharing one 8-tap LPF (IL2P, IL2P inverted, G3RUH AX.25)."""
+    k = j % 3
+    il2p = {"type": "il2p", "options": {"crc": "yes", "disable_rs": "no", "min_dist": "0", "sync_tol": "2"}}
+    stream = [{"poly": "0x1", "invert": "no"}, {"poly": "0x1", "invert": "yes"}, {"poly": "0x63003", "invert": "yes"}][k]
+    return {"object_name": f"FSK 9600 #{j}", "object_type": "demod_chain", "modem": {"type": "fsk", "config": "9600", "options": {}},
+            "slicer": {"type": "binary", "config": "9600", "options": {"lock_rate": "0.88"}},
+            "stream": {"type": "lfsr", "options": stream}, "codec": il2p if k < 2 else {"type": "ax25"}}
+
+
+def wl_bpsk_300(j):
+    """configs/bpsk_300.json (single chain); replicas sweep the carrier."""
+    return {"object_name": f"BPSK 300 IL2P+CRC {1500 + 5 * j}Hz", "object_type": "demod_chain",
+            "modem": {"type": "bpsk", "config": "300", "options": {"carrier_freq": str(1500 + 5 * j)}},
+            "slicer": {"type": "binary", "config": "300", "options": {"lock_rate": "0.90"}},
+            "stream": {"type": "lfsr", "options": {"poly": "0x3", "invert": "True"}},
+            "codec": {"type": "il2p", "options": {"crc": "yes", "disable_rs": "no", "min_dist": "0", "sync_tol": "2"}}}
+
+
+def wl_qpsk_2400(j):
+    """BASELINE configs[4]: replicated qpsk_2400 chains at swept tuning offsets (the bundled file sweeps 1475/1500/1525)."""
+    f = 1500.0 + 3.125 * (j - 32)
+    return {"object_name": f"QPSK 2400 IL2P+CRC {f:g}", "object_type": "demod_chain",
+            "modem": {"type": "mpsk", "config": "qpsk_2400", "options": {"carrier_freq": str(f)}},
+            "slicer": {"type": "quadrature", "config": "qpsk_2400", "options": {"lock_rate": "0.98"}},
+            "stream": {"type": "lfsr", "options": {"poly": "0x1", "invert": "False"}},
+            "codec": {"type": "il2p", "options": {"crc": "yes", "disable_rs": "no", "min_dist": "0", "sync_tol": "2"}}}
+
+
+WORKLOADS = {
+    # name: (line factory, default chains/GPU, description)
+    "afsk_1200_super_opt": (wl_afsk_super_opt, 8, "configs/afsk_1200_ax25_super_opt.json (BASELINE configs[3]): AFSK-1200 AX.25 chains, "
+                            "BPF 148 + 4 correlators 40/60 + LPF 100 taps @48 kHz, binary slicer, NRZI, AX.25"),
+    "fsk_9600": (wl_fsk_9600, 3, "configs/fsk_9600.json (BASELINE configs[2]): 8-tap LPF, binary slicer, IL2P / G3RUH AX.25"),
+    "bpsk_300": (wl_bpsk_300, 1, "configs/bpsk_300.json (BASELINE configs[1]): BPF 240, AGC, Costas loop, RRC 961, binary slicer, IL2P"),
+    "qpsk_2400": (wl_qpsk_2400, 8, "BASELINE configs[4]: qpsk_2400 MPSK chains at swept carriers (BPF 130, AGC, Hilbert 163, "
+                  "carrier loop, 2x RRC 241, quadrature slicer, IL2P)"),
+}
+
+# ALGORITHMIC bytes per input sample and launch for each kernel class: read + write of the stage, taps excluded
+ALG_BYTES = {"fir_i16": 10.0, "fir_f64": 16.0, "afsk_correlate": 16.0, "signs": 8.0 + 1.0 / 8, "slice_iter": 1.0 / 8,
+             "slice_emit": 1.0 / 8, "agc": 16.0, "loop": 16.0}
+
+
+def synth_buffer(n, seed=1234):
+    """BASELINE.md throughput buffer: default_rng(1234).standard_normal(n)*8000 -> int16."""
+    x = np.random.default_rng(seed).standard_normal(n) * 8000.0
+    return np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="afsk_1200_super_opt", choices=sorted(WORKLOADS))
+    ap.add_argument("--samples", type=int, default=28_800_000, help="samples per recording (10 min @ 48 kHz)")
+    ap.add_argument("--chains-per-gpu", type=int, default=0)
+    ap.add_argument("--rate", type=int, default=48000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="samples for the CPU baseline leg (0 = auto)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+
+    import torch
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import pymodem_amd
+    from pymodem_amd import chain_builder as cb, chain_execute as ce, dist as pdist
+    ctx = pymodem_amd.Context(local)
+
+    factory, default_cpg, desc = WORKLOADS[args.workload]
+    cpg = args.chains_per_gpu or default_cpg
+    nchains = cpg * world
+    my = [c for c in range(nchains) if c // cpg == rank]          # contiguous blocks: chains sharing a front end stay together
+    lines = {c: factory(c) for c in range(nchains)}
+    names = [lines[c]["object_name"] for c in range(nchains)]
+
+    audio = synth_buffer(args.samples)
+    d_audio = ctx.upload(audio)                                   # resident in HBM before the timed region
+    ctx.sync()
+    modems = {c: cb.ModemConfigurator(args.rate, lines[c]["modem"]) for c in my}     # tap design once (host)
+
+    def step():
+        pk = {}
+        for c in my:
+            line = lines[c]
+            modem = modems[c]
+            if hasattr(modem, "reset"):
+                modem.reset()
+            srate = getattr(modem, "output_sample_rate", args.rate)
+            chain = [line["object_name"], modem, cb.SlicerConfigurator(srate, line["slicer"]),
+                     cb.StreamConfigurator(line["stream"]), cb.CodecConfigurator(line["codec"], line["object_name"])]
+            pk[c] = ce.process_chain_device(chain, d_audio)
+        gathered = pdist.gather_packets(pk, names, device=f"cuda:{local}" if world > 1 else None)
+        if gathered is not None:
+            return pdist.correlate(gathered, nchains, args.rate / 40)
+        return None
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    result = None
+    for _ in range(args.steps):
+        result = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_samples = float(args.samples) * nchains * args.steps
+        value = total_samples / elapsed / 1e6
+        # dominant GPU kernel of this rank inside the timed region
+        dom = max(prof, key=lambda k: prof[k][0])
+        dom_ms, dom_n = prof[dom]
+        avg_ms = dom_ms / max(dom_n, 1)
+        alg_bytes = ALG_BYTES[dom] * args.samples
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "Msamples/s through demod_chain", "value": round(value, 3), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}", "chains_per_gpu": cpg, "chains_total": nchains,
+                       "samples_per_recording": args.samples, "sample_rate": args.rate,
+                       "buffer": "default_rng(1234).standard_normal(n)*8000 -> int16, resident in HBM",
+                       "parallelism": f"chains sharded {cpg}/GPU x {world} GPU, packet gather to rank 0"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "avg_kernel_ms": round(avg_ms, 5), "launches": dom_n, "algorithmic_bytes_per_launch": alg_bytes},
+            "gpu_kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]},
+            "packets": {"unique_good": result.CountGood() if result is not None else None,
+                        "bad": result.CountBad() if result is not None else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, [lines[c] for c in my])
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def cpu_baseline(args, lines):
+    """The oracle (CPU restatement of the reference: numpy.convolve FIRs + C loops) on a bounded sample of the same
+    workload, one core.  A reported baseline, not the optimisation target."""
+    from oracle import oracle as O
+    n = args.cpu_sample or min(args.samples, 2_400_000)
+    audio = synth_buffer(args.samples if args.samples <= n else n)
+    t0 = time.perf_counter()
+    done = 0
+    for line in lines:
+        O.run_chain(O.build_chain(args.rate, line), audio, canon=False)
+        done += 1
+        if time.perf_counter() - t0 > 30.0:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(len(audio) * done / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": f"{done} of {len(lines)} chains x {len(audio)} samples of the same buffer, oracle (numpy.convolve FIRs + C loops), {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -59,6 +59,13 @@ int pm_memset(pm_ctx *ctx, void *d_dst, int value, size_t bytes);
 int pm_timer_start(pm_ctx *ctx);
 int pm_timer_stop(pm_ctx *ctx, float *ms);
 
+/* Per-kernel-class timing with HIP events on the ctx stream, for bench.py's roofline line.  While enabled, every
+ * launch of a tracked kernel class is bracketed by an event pair; pm_prof_read sums the elapsed times. */
+enum { PM_K_FIR_I16 = 0, PM_K_FIR_F64 = 1, PM_K_AFSK_CORR = 2, PM_K_SIGNS = 3, PM_K_SLICE_ITER = 4, PM_K_SLICE_EMIT = 5,
+       PM_K_AGC = 6, PM_K_LOOP = 7, PM_K_COUNT = 8 };
+int pm_prof_enable(pm_ctx *ctx, int on);                 /* also resets the accumulators */
+int pm_prof_read(pm_ctx *ctx, int kernel_class, double *total_ms, int64_t *launches);
+
 /* ---- FIR stages -------------------------------------------------------------------------------
  * numpy.convolve(x, h, 'valid'): y[k] = sum_j h[j] * x[k+m-1-j], k = 0 .. n-m.  Replaces the 19
  * numpy.convolve call sites (afsk.py:151-166, fsk.py:151, psk.py:165,193,710-751, afsk_pll.py:143,168).

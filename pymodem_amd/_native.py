@@ -35,6 +35,7 @@ class SlicerParams(ctypes.Structure):
                 ("bits_per_symbol", ctypes.c_int32), ("state_mask", ctypes.c_int32), ("demap", ctypes.c_int32 * 16)]
 
 
+KERNEL_CLASSES = ("fir_i16", "fir_f64", "afsk_correlate", "signs", "slice_iter", "slice_emit", "agc", "loop")
 PKT_MAX = 1280
 
 
@@ -62,6 +63,8 @@ _SIGS = {
     "pm_memset": ([_vp, _vp, _int, ctypes.c_size_t], _int),
     "pm_timer_start": ([_vp], _int),
     "pm_timer_stop": ([_vp, ctypes.POINTER(ctypes.c_float)], _int),
+    "pm_prof_enable": ([_vp, _int], _int),
+    "pm_prof_read": ([_vp, _int, ctypes.POINTER(_dbl), ctypes.POINTER(_i64)], _int),
     "pm_fir_valid_i16": ([_vp, _vp, _i64, _vp, _int, _vp, _int], _int),
     "pm_fir_valid_f64": ([_vp, _vp, _i64, _vp, _int, _vp, _int], _int),
     "pm_afsk_correlate": ([_vp, _vp, _i64, _vp, _vp, _vp, _vp, _int, _vp], _int),

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <vector>
 #include "../../include/pymodem_amd.h"
 
 struct pm_ctx {
@@ -14,6 +15,13 @@ struct pm_ctx {
     void *h_pinned = nullptr;       // 4 KiB
     void *d_scratch = nullptr;      // grows on demand
     size_t scratch_bytes = 0;
+    // optional per-kernel-class timing (pm_prof_*)
+    bool prof_on = false;
+    struct ProfPair { hipEvent_t a, b; int cls; };
+    std::vector<ProfPair> prof_pending;
+    std::vector<hipEvent_t> prof_free;
+    double prof_ms[PM_K_COUNT] = {0};
+    int64_t prof_n[PM_K_COUNT] = {0};
     // slicer diagnostics
     int32_t sl_iterations = 0, sl_chunk_len = 0;
     int64_t sl_chunks = 0;
@@ -35,5 +43,13 @@ int pm_scratch_reserve(pm_ctx *ctx, size_t bytes);     // ensures ctx->d_scratch
         if (!(cond)) return pm_set_error(PM_ERR_ARG, "bad argument: %s (%s:%d)", #cond, \
                                          __FILE__, __LINE__);                           \
     } while (0)
+
+// Bracket a launch: `PmProf p(ctx, PM_K_X); launch...; ` (destructor records the end event).
+struct PmProf {
+    pm_ctx *c; hipEvent_t a = nullptr, b = nullptr; int cls;
+    PmProf(pm_ctx *ctx, int k);
+    ~PmProf();
+};
+int pm_prof_fold(pm_ctx *ctx);      // sync + accumulate pending pairs
 
 static inline int64_t pm_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

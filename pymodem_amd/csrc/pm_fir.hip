@@ -190,6 +190,7 @@ int fir_launch(pm_ctx *ctx, const InT *d_x, int64_t n, const double *d_taps, int
     const int64_t grid = pm_cdiv(nout, (int64_t)kThreads * R);
     PM_ARG(grid < (1LL << 31));
     const size_t lds = lds_bytes<R>(m);
+    PmProf prof(ctx, sizeof(InT) == 2 ? PM_K_FIR_I16 : PM_K_FIR_F64);
     if (flags & PM_FIR_NEGATE) {
         if (int rc = allow_lds(fir_valid_kernel<InT, R, true>, lds)) return rc;
         hipLaunchKernelGGL((fir_valid_kernel<InT, R, true>), dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream,
@@ -229,6 +230,7 @@ int pm_afsk_correlate(pm_ctx *ctx, const double *d_x, int64_t n, const double *d
     PM_ARG(grid < (1LL << 31));
     const size_t lds = lds_bytes<R>(m);
     if (int rc = allow_lds(afsk_correlate_kernel<R>, lds)) return rc;
+    PmProf prof(ctx, PM_K_AFSK_CORR);
     hipLaunchKernelGGL((afsk_correlate_kernel<R>), dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream,
                        d_x, n, d_mark_i, d_mark_q, d_space_i, d_space_q, m, d_y, nout);
     PM_HIP(hipGetLastError());
@@ -243,6 +245,7 @@ int pm_signs_f64(pm_ctx *ctx, const double *d_x, int64_t n, uint64_t *d_bits)
     const int64_t nwords = pm_cdiv(n, 64);
     int64_t grid = pm_cdiv(nwords, kThreads / 64);
     if (grid > 8192) grid = 8192;
+    PmProf prof(ctx, PM_K_SIGNS);
     hipLaunchKernelGGL(signs_kernel, dim3((unsigned)grid), dim3(kThreads), 0, ctx->stream, d_x, n, d_bits, nwords);
     PM_HIP(hipGetLastError());
     return PM_OK;

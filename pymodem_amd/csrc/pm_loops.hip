@@ -197,8 +197,11 @@ int loop_launch(pm_ctx *ctx, pm_loop *h_loops, int nloops, const double *d_table
     const size_t lds = loop_lds_bytes(MODE, x_stride == 0);
     if (lds > 64 * 1024)
         PM_HIP(hipFuncSetAttribute((const void *)loop_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((loop_kernel<MODE>), dim3((unsigned)pm_cdiv(nloops, kG)), dim3(64), lds, ctx->stream,
-                       d_loops, nloops, d_table, d_pd, d_x0, d_x1, x_stride, n, d_o0, d_o1, out_stride);
+    {
+        PmProf prof(ctx, PM_K_LOOP);
+        hipLaunchKernelGGL((loop_kernel<MODE>), dim3((unsigned)pm_cdiv(nloops, kG)), dim3(64), lds, ctx->stream,
+                           d_loops, nloops, d_table, d_pd, d_x0, d_x1, x_stride, n, d_o0, d_o1, out_stride);
+    }
     PM_HIP(hipGetLastError());
     PM_HIP(hipMemcpyAsync(h_loops, d_loops, bytes, hipMemcpyDeviceToHost, ctx->stream));
     PM_HIP(hipStreamSynchronize(ctx->stream));
@@ -323,8 +326,11 @@ int pm_agc_apply(pm_ctx *ctx, double *d_buf, int64_t n, const pm_agc_params *hp,
     P.sustain_inc = 1 / hp->sample_rate;                            // agc.py:17
     P.target = hp->target_amplitude;
     P.att = P.dec = 0;
-    hipLaunchKernelGGL(agc_kernel, dim3(1), dim3(64), 0, ctx->stream, d_buf, n, d_partial, npartial,
-                       hp->attack_rate / hp->sample_rate, hp->decay_rate / hp->sample_rate, P, d_state);   // agc.py:15-16
+    {
+        PmProf prof(ctx, PM_K_AGC);
+        hipLaunchKernelGGL(agc_kernel, dim3(1), dim3(64), 0, ctx->stream, d_buf, n, d_partial, npartial,
+                           hp->attack_rate / hp->sample_rate, hp->decay_rate / hp->sample_rate, P, d_state);   // agc.py:15-16
+    }
     PM_HIP(hipGetLastError());
     PM_HIP(hipMemcpyAsync(h_state, d_state, 16, hipMemcpyDeviceToHost, ctx->stream));
     PM_HIP(hipStreamSynchronize(ctx->stream));

@@ -53,13 +53,15 @@ int pm_ctx_create(int device, pm_ctx **out)
 int pm_ctx_destroy(pm_ctx *c)
 {
     if (!c) return PM_OK;
-    hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
-    if (c->d_scratch) hipFree(c->d_scratch);
-    if (c->h_pinned) hipHostFree(c->h_pinned);
-    hipEventDestroy(c->ev0);
-    hipEventDestroy(c->ev1);
-    hipStreamDestroy(c->stream);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    pm_prof_fold(c);
+    for (hipEvent_t e : c->prof_free) (void)hipEventDestroy(e);
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    (void)hipEventDestroy(c->ev0);
+    (void)hipEventDestroy(c->ev1);
+    (void)hipStreamDestroy(c->stream);
     delete c;
     return PM_OK;
 }
@@ -130,6 +132,63 @@ int pm_timer_stop(pm_ctx *c, float *ms)
 }
 
 }  // extern "C"
+
+PmProf::PmProf(pm_ctx *ctx, int k) : c(ctx), cls(k)
+{
+    if (!c->prof_on) return;
+    auto grab = [&]() {
+        hipEvent_t e = nullptr;
+        if (!c->prof_free.empty()) { e = c->prof_free.back(); c->prof_free.pop_back(); }
+        else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+        return e;
+    };
+    a = grab();
+    b = grab();
+    if (a && b) (void)hipEventRecord(a, c->stream);
+}
+
+PmProf::~PmProf()
+{
+    if (!c->prof_on || !a || !b) return;
+    (void)hipEventRecord(b, c->stream);
+    c->prof_pending.push_back({a, b, cls});
+    if (c->prof_pending.size() >= 2048) pm_prof_fold(c);
+}
+
+int pm_prof_fold(pm_ctx *c)
+{
+    if (c->prof_pending.empty()) return PM_OK;
+    PM_HIP(hipStreamSynchronize(c->stream));
+    for (auto &p : c->prof_pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            c->prof_ms[p.cls] += ms;
+            c->prof_n[p.cls] += 1;
+        }
+        c->prof_free.push_back(p.a);
+        c->prof_free.push_back(p.b);
+    }
+    c->prof_pending.clear();
+    return PM_OK;
+}
+
+extern "C" int pm_prof_enable(pm_ctx *c, int on)
+{
+    PM_ARG(c != nullptr);
+    if (int rc = pm_prof_fold(c)) return rc;
+    for (int k = 0; k < PM_K_COUNT; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
+    c->prof_on = on != 0;
+    return PM_OK;
+}
+
+extern "C" int pm_prof_read(pm_ctx *c, int cls, double *total_ms, int64_t *launches)
+{
+    PM_ARG(c != nullptr && cls >= 0 && cls < PM_K_COUNT);
+    if (int rc = pm_prof_fold(c)) return rc;
+    if (total_ms) *total_ms = c->prof_ms[cls];
+    if (launches) *launches = c->prof_n[cls];
+    return PM_OK;
+}
 
 int pm_scratch_reserve(pm_ctx *c, size_t bytes)
 {

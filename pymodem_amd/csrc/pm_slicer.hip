@@ -32,17 +32,6 @@ struct SlicerDev {
 __device__ __forceinline__ uint64_t dbits(double v) { return (uint64_t)__double_as_longlong(v); }
 __device__ __forceinline__ double bitsd(uint64_t v) { return __longlong_as_double((long long)v); }
 
-// Per-chunk bookkeeping.  start[c] = phase_clock at the first sample of chunk c (as raw bits).
-struct ChunkArrays {
-    uint64_t *start_a, *start_b;     // ping-pong, nchunks+1 entries each
-    uint8_t *dirty_a, *dirty_b;      // ping-pong, nchunks+1 entries each
-    uint32_t *count;                 // symbols taken in chunk c at its last run
-    uint8_t *lastsym;                // (i<<1|q) of the last symbol taken in chunk c, 0xFF if none
-    uint64_t *offset;                // exclusive scan of count, nchunks+1 entries
-    uint8_t *prevsym;                // last symbol before chunk c (initial state_register bits if none)
-    int *changed;
-};
-
 template <bool QUAD>
 __global__ __launch_bounds__(64) void slice_iter_kernel(const uint64_t *__restrict__ bi, const uint64_t *__restrict__ bq,
                                                         int64_t n, int lc_words, int64_t nchunks,
@@ -287,6 +276,7 @@ int slice_run(pm_ctx *ctx, const uint64_t *d_bi, const uint64_t *d_bq, int64_t n
         // a short burst of iterations between host checks keeps the launch queue full
         const int burst = iters < 2 ? 2 : 4;
         for (int b = 0; b < burst; ++b) {
+            PmProf prof(ctx, PM_K_SLICE_ITER);
             hipLaunchKernelGGL((slice_iter_kernel<QUAD>), dim3(grid), dim3(64), 0, ctx->stream, d_bi, d_bq, n, (int)lc_words,
                                nchunks, sa, sb, da, db, cnt, ls, changed, iters, P);
             std::swap(sa, sb);
@@ -306,6 +296,7 @@ int slice_run(pm_ctx *ctx, const uint64_t *d_bi, const uint64_t *d_bq, int64_t n
     hipLaunchKernelGGL(slice_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, cnt, ls, nchunks, offs, ps, QUAD ? 1 : 0, 0);
     if (cap > 0) {
         PM_HIP(hipMemsetAsync(d_data, 0, align_up((size_t)cap, 4), ctx->stream));
+        PmProf prof(ctx, PM_K_SLICE_EMIT);
         hipLaunchKernelGGL((slice_emit_kernel<QUAD>), dim3(grid), dim3(64), 0, ctx->stream, d_bi, d_bq, n, (int)lc_words, nchunks,
                            sa, offs, ps, (uint32_t *)d_data, d_addr, cap, P);
     }

@@ -61,6 +61,19 @@ class Context:
         out._parent = raw
         return out
 
+    def profile(self, on=True):
+        check(lib().pm_prof_enable(self._h, int(bool(on))))
+
+    def profile_read(self):
+        """{kernel class: (total_ms, launches)} accumulated since profile(True)."""
+        from ._native import KERNEL_CLASSES
+        out = {}
+        for k, name in enumerate(KERNEL_CLASSES):
+            ms, n = ctypes.c_double(), ctypes.c_int64()
+            check(lib().pm_prof_read(self._h, k, ctypes.byref(ms), ctypes.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
+
     def timer_start(self):
         check(lib().pm_timer_start(self._h))
 

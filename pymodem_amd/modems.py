@@ -73,6 +73,14 @@ class _DeviceStage:
         p = AGCParams(a.attack_rate, a.decay_rate, a.sustain_time, a.sample_rate, a.target_amplitude)
         check(lib().pm_agc_apply(self._ctx.handle, buf.ptr, buf.n, ctypes.byref(p), self._agc_state))
 
+    def reset(self):
+        """Back to the just-constructed state (AGC envelope, loop phase/filter/integral) without redesigning taps, so one
+        object can process another recording.  The reference's objects are single-use; this is what bench.py uses."""
+        if hasattr(self, "_agc_state"):
+            self._agc_state[0] = self._agc_state[1] = 0.0
+        if hasattr(self, "_loop0"):
+            ctypes.memmove(ctypes.byref(self._loop), self._loop0, ctypes.sizeof(Loop))
+
     def _finish(self, y, device_out):
         return y if device_out else y.download()
 
@@ -109,6 +117,10 @@ def _make_loop(sample_rate, carrier, lpf, pi):
     L.p_rate, L.i_rate, L.i_limit, L.gain = pi.p_rate, pi.i_rate, pi.i_limit, pi.gain
     L.integral, L.proportional = pi.integral, pi.proportional
     return L
+
+
+def _snapshot(loop):
+    return ctypes.string_at(ctypes.byref(loop), ctypes.sizeof(Loop))
 
 
 # =============================================================================================
@@ -268,6 +280,7 @@ class BPSKModem(_DeviceStage):
         self.wavetable = T.sine_wavetable(self.oscillator_amplitude, 256)
         self.rrc_taps = T.root_raised_cosine(self.sample_rate, self.symbol_rate, self.rrc_span, self.rrc_rolloff_rate)
         self._loop = _make_loop(self.sample_rate, self.carrier_freq, self.Loop_LPF, self.FeedbackController)
+        self._loop0 = _snapshot(self._loop)
         self.output_sample_rate = self.sample_rate
 
     def demod(self, input_audio, device_out=False):   # psk.py:162-195
@@ -336,6 +349,7 @@ class MPSKModem(_DeviceStage):
         self.output_sample_rate = self.sample_rate
         self.FeedbackController.integral = -self.max_freq_offset      # psk.py:703: start at the maximum offset
         self._loop = _make_loop(self.sample_rate, self.carrier_freq, self.Loop_LPF, self.FeedbackController)
+        self._loop0 = _snapshot(self._loop)
         self.phase_error_table = T.qpsk_error_table(64, self.pd_gain)
 
     def front_end(self, input_audio):
@@ -407,6 +421,7 @@ class AFSKPLLModem(_DeviceStage):
         self.AGC = _AGCSettings(self.sample_rate, self.agc_attack_rate, self.agc_sustain_time, self.agc_decay_rate, self.oscillator_amplitude)
         self.wavetable = T.sine_wavetable(self.oscillator_amplitude, 256)
         self._loop = _make_loop(self.sample_rate, self.carrier_freq, self.LoopFilter, self.FeedbackController)
+        self._loop0 = _snapshot(self._loop)
         self.output_sample_rate = self.sample_rate
 
     def demod(self, input_audio, device_out=False):   # afsk_pll.py:140-170

@@ -215,8 +215,8 @@ def test_mpsk_loop_batch_bit_exact(ctx):
     pairs = [loops_pair(48000.0, c, 250.0, 0.3, 0.3 / 2000, 31.25, 14400 / 65536, -31.25) for c in carriers]
     arr = (Loop * len(pairs))(*[b for _, b in pairs])
     io, qo = ctx.empty(n * len(pairs), np.float64), ctx.empty(n * len(pairs), np.float64)
-    chk(L().pm_mpsk_loop(ctx.handle, arr, len(pairs), ctx.upload(tab).ptr, ctx.upload(pdt.reshape(-1)).ptr,
-                         ctx.upload(re).ptr, ctx.upload(im).ptr, 0, n, io.ptr, qo.ptr, n))
+    dtab, dpd, dre, dim = ctx.upload(tab), ctx.upload(np.ascontiguousarray(pdt.reshape(-1), dtype=np.int32)), ctx.upload(re), ctx.upload(im)
+    chk(L().pm_mpsk_loop(ctx.handle, arr, len(pairs), dtab.ptr, dpd.ptr, dre.ptr, dim.ptr, 0, n, io.ptr, qo.ptr, n))
     gi, gq = io.download().reshape(len(pairs), n), qo.download().reshape(len(pairs), n)
     for k, (a, _) in enumerate(pairs):
         wi, wq = O.mpsk_loop(a, re, im, tab, pdt)
