@@ -129,7 +129,7 @@ def main():
 
     import pymodem_amd
     from pymodem_amd import chain_builder as cb, chain_execute as ce, dist as pdist
-    ctx = pymodem_amd.Context(local)
+    ctx = pymodem_amd.Context.default(local)      # the stage objects use the same per-process default context
 
     factory, default_cpg, desc = WORKLOADS[args.workload]
     cpg = args.chains_per_gpu or default_cpg
@@ -144,16 +144,15 @@ def main():
     modems = {c: cb.ModemConfigurator(args.rate, lines[c]["modem"]) for c in my}     # tap design once (host)
 
     def step():
-        pk = {}
+        chains = []
         for c in my:
             line = lines[c]
             modem = modems[c]
-            if hasattr(modem, "reset"):
-                modem.reset()
+            modem.reset()
             srate = getattr(modem, "output_sample_rate", args.rate)
-            chain = [line["object_name"], modem, cb.SlicerConfigurator(srate, line["slicer"]),
-                     cb.StreamConfigurator(line["stream"]), cb.CodecConfigurator(line["codec"], line["object_name"])]
-            pk[c] = ce.process_chain_device(chain, d_audio)
+            chains.append([line["object_name"], modem, cb.SlicerConfigurator(srate, line["slicer"]),
+                           cb.StreamConfigurator(line["stream"]), cb.CodecConfigurator(line["codec"], line["object_name"])])
+        pk = dict(zip(my, ce.process_chains_device(chains, d_audio)))
         gathered = pdist.gather_packets(pk, names, device=f"cuda:{local}" if world > 1 else None)
         if gathered is not None:
             return pdist.correlate(gathered, nchains, args.rate / 40)

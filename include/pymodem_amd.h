@@ -135,6 +135,19 @@ int pm_slice_binary(pm_ctx *ctx, const uint64_t *d_bits, int64_t n, const pm_sli
 int pm_slice_quadrature(pm_ctx *ctx, const uint64_t *d_bits_i, const uint64_t *d_bits_q, int64_t n,
                         const pm_slicer_params *h_params, uint8_t *d_data, int64_t *d_addr, int64_t cap,
                         int64_t *h_count);                                                                  /* slicer.py:193-242 */
+/* Many streams in one launch sequence (chains are independent; batching them shares the iteration launches and the
+ * host checks).  d_bits_q == NULL selects the binary slicer for that stream.  `count` is written per job. */
+typedef struct pm_slice_job {
+    const uint64_t *d_bits_i;
+    const uint64_t *d_bits_q;
+    int64_t n;
+    pm_slicer_params params;
+    uint8_t *d_data;
+    int64_t *d_addr;
+    int64_t cap;
+    int64_t count;                   /* out */
+} pm_slice_job;
+int pm_slice_batch(pm_ctx *ctx, pm_slice_job *h_jobs, int njobs);           /* njobs <= 64 */
 /* Diagnostics of the last slicer call on this ctx: fixed-point iterations used, chunk length, chunks. */
 int pm_slicer_stats(pm_ctx *ctx, int32_t *iterations, int32_t *chunk_len, int64_t *chunks);
 
@@ -160,10 +173,11 @@ typedef struct pm_codec pm_codec;
 /* kind 0 = AX25Codec (ax25.py:11-93), 1 = IL2PCodec (il2p.py:110-519). */
 int pm_codec_create(int kind, int crc, int disable_rs, int min_dist, int sync_tol, int source_decoder, pm_codec **out);
 int pm_codec_destroy(pm_codec *c);
-/* Feed n descrambled bytes with their stream addresses; appends decoded packets to h_out (cap entries).
- * *h_count = packets produced by this call.  CRC and header validity are filled (packet_meta.py:197-208). */
-int pm_codec_decode(pm_codec *c, const uint8_t *h_data, const int64_t *h_addr, int64_t n,
-                    pm_packet *h_out, int64_t cap, int64_t *h_count);
+/* Feed n descrambled bytes with their stream addresses (state carries over between calls, like the reference's
+ * codec objects); decoded packets queue inside the codec, *h_pending = packets waiting.  pm_codec_fetch moves up to
+ * cap of them out, oldest first, with CRC and header validity filled (packet_meta.py:197-208). */
+int pm_codec_decode(pm_codec *c, const uint8_t *h_data, const int64_t *h_addr, int64_t n, int64_t *h_pending);
+int pm_codec_fetch(pm_codec *c, pm_packet *h_out, int64_t cap, int64_t *h_count);
 int pm_crc16_ccitt(const uint8_t *h_data, int64_t n);                    /* crc_functions.py:44-55 */
 
 /* PacketMetaArray.Correlate (packet_meta.py:230-271): h_pkts hold all chains' packets in config order

@@ -35,6 +35,12 @@ class SlicerParams(ctypes.Structure):
                 ("bits_per_symbol", ctypes.c_int32), ("state_mask", ctypes.c_int32), ("demap", ctypes.c_int32 * 16)]
 
 
+class SliceJob(ctypes.Structure):
+    """pm_slice_job"""
+    _fields_ = [("d_bits_i", ctypes.c_void_p), ("d_bits_q", ctypes.c_void_p), ("n", ctypes.c_int64), ("params", SlicerParams),
+                ("d_data", ctypes.c_void_p), ("d_addr", ctypes.c_void_p), ("cap", ctypes.c_int64), ("count", ctypes.c_int64)]
+
+
 KERNEL_CLASSES = ("fir_i16", "fir_f64", "afsk_correlate", "signs", "slice_iter", "slice_emit", "agc", "loop")
 PKT_MAX = 1280
 
@@ -75,11 +81,13 @@ _SIGS = {
     "pm_mpsk_loop": ([_vp, ctypes.POINTER(Loop), _int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64], _int),
     "pm_slice_binary": ([_vp, _vp, _i64, ctypes.POINTER(SlicerParams), _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
     "pm_slice_quadrature": ([_vp, _vp, _vp, _i64, ctypes.POINTER(SlicerParams), _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
+    "pm_slice_batch": ([_vp, ctypes.POINTER(SliceJob), _int], _int),
     "pm_slicer_stats": ([_vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_i64)], _int),
     "pm_lfsr_unscramble": ([_vp, _i64, ctypes.c_uint64, _int, ctypes.POINTER(ctypes.c_uint64), _vp], _int),
     "pm_codec_create": ([_int, _int, _int, _int, _int, _int, ctypes.POINTER(_vp)], _int),
     "pm_codec_destroy": ([_vp], _int),
-    "pm_codec_decode": ([_vp, _vp, _vp, _i64, ctypes.POINTER(Packet), _i64, ctypes.POINTER(_i64)], _int),
+    "pm_codec_decode": ([_vp, _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
+    "pm_codec_fetch": ([_vp, ctypes.POINTER(Packet), _i64, ctypes.POINTER(_i64)], _int),
     "pm_crc16_ccitt": ([_vp, _i64], _int),
     "pm_correlate": ([ctypes.POINTER(Packet), ctypes.POINTER(_i64), _int, _dbl, ctypes.POINTER(_i64),
                       ctypes.POINTER(ctypes.c_int32), _i64], _i64),

@@ -1,7 +1,22 @@
 """Chain execution (chain_execute.py:6-52 of the reference): demod -> slice -> stream -> codec.
-`process_chain` has the reference's signature and stage-by-stage host hand-offs; `process_chain_device`
-keeps the demodulated stream in HBM between modem and slicer (only the sliced bytes come back)."""
+
+`process_chain` / `multiprocess_chain` keep the reference's signatures and stage-by-stage hand-offs.
+`process_chain_device` keeps the demodulated stream in HBM between modem and slicer.
+`process_chains_device` runs a whole group of independent chains over one recording the way the hardware wants it:
+chains with the same front end share it (every chain of afsk_1200_ax25_super_opt.json has the same input band-pass;
+the qpsk_2400.json chains share band-pass, AGC and Hilbert pair), MPSK carrier loops of such a group run in one
+launch (one lane each), all slicers run in one pm_slice_batch call, and the host-integer stages (LFSR, codec) of the
+chains run concurrently in a small thread pool (the native calls release the GIL).
+"""
+import ctypes
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from ._native import Loop, check, lib
 from .device import Context, DeviceBuffer
+from .modems import AFSKModem, MPSKModem
+from .slicer import slice_batch
 
 
 def process_chain(chain, input_audio):
@@ -24,3 +39,88 @@ def process_chain_device(chain, input_audio, stages=None):
     if stages is not None:
         stages["sliced"], stages["descrambled"] = sliced_data, descrambled_data
     return chain[4].decode(descrambled_data)
+
+
+def _host_stages(chain, sliced):
+    return chain[4].decode(chain[3].stream_unscramble_8bit(sliced))
+
+
+_POOL = None
+
+
+def _pool():
+    global _POOL
+    if _POOL is None:
+        import os
+        _POOL = ThreadPoolExecutor(max_workers=max(2, min(8, (os.cpu_count() or 4) // 2)))
+    return _POOL
+
+
+def process_chains_device(chains, input_audio, stages=None):
+    """[chain, ...] -> [packets of chain 0, packets of chain 1, ...] (config order), identical to running
+    process_chain on each.  See the module docstring for what is shared and batched."""
+    ctx = Context.default()
+    audio = input_audio
+    if not isinstance(audio, DeviceBuffer):
+        a = np.asarray(audio)
+        audio = ctx.upload(a if a.dtype == np.int16 else np.ascontiguousarray(a, dtype=np.float64))
+    n_chains = len(chains)
+    bitmaps = [None] * n_chains
+    group_key = "chain-group"          # work buffers are reused from one group run to the next
+
+    # ---- shared front ends ------------------------------------------------------------------------------------
+    front = {}
+
+    def shared_front(modem):
+        key = modem.front_end_key()
+        if key not in front:
+            modem.scratch_key = (group_key, "front", len(front))
+            front[key] = modem.front_end(audio)
+        return front[key]
+
+    # ---- MPSK groups: one carrier-loop launch per shared front end ----------------------------------------------
+    mpsk_groups = {}
+    for k, ch in enumerate(chains):
+        if isinstance(ch[1], MPSKModem):
+            mpsk_groups.setdefault(ch[1].front_end_key(), []).append(k)
+    for gi, (key, members) in enumerate(mpsk_groups.items()):
+        lead = chains[members[0]][1]
+        real, imag = shared_front(lead)
+        n = imag.n
+        g = len(members)
+        loops = (Loop * g)()
+        for j, k in enumerate(members):
+            ctypes.memmove(ctypes.byref(loops[j]), ctypes.byref(chains[k][1]._loop), ctypes.sizeof(Loop))
+        i_mix = ctx.scratch((group_key, "i_mix", gi), n * g, np.float64)
+        q_mix = ctx.scratch((group_key, "q_mix", gi), n * g, np.float64)
+        check(lib().pm_mpsk_loop(ctx.handle, loops, g, lead._const("wavetable", lead.wavetable).ptr,
+                                 lead._const("pd", lead.phase_error_table.reshape(-1), np.int32).ptr,
+                                 real.ptr, imag.ptr, 0, n, i_mix.ptr, q_mix.ptr, n))
+        for j, k in enumerate(members):
+            modem = chains[k][1]
+            ctypes.memmove(ctypes.byref(modem._loop), ctypes.byref(loops[j]), ctypes.sizeof(Loop))
+            modem.scratch_key = (group_key, "mpsk_back")
+            out = modem.back_end(i_mix.view(j * n, n), q_mix.view(j * n, n), device_out=True)
+            bitmaps[k] = chains[k][2].sign_bitmaps(out)
+
+    # ---- everything else, chain by chain (work buffers shared across the group) ----------------------------------
+    for k, ch in enumerate(chains):
+        if bitmaps[k] is not None:
+            continue
+        modem = ch[1]
+        if isinstance(modem, AFSKModem):
+            bpf = shared_front(modem)
+            modem.scratch_key = (group_key, "afsk_back")
+            out = modem.back_end(bpf, device_out=True)
+        else:
+            modem.scratch_key = (group_key, type(modem).__name__)
+            out = modem.demod(audio, device_out=True)
+        bitmaps[k] = ch[2].sign_bitmaps(out)
+
+    # ---- all slicers in one batch, host stages in parallel ---------------------------------------------------------
+    sliced = slice_batch([ch[2] for ch in chains], bitmaps)
+    futures = [_pool().submit(_host_stages, ch, sl) for ch, sl in zip(chains, sliced)]
+    packets = [f.result() for f in futures]
+    if stages is not None:
+        stages["sliced"] = sliced
+    return packets

@@ -23,19 +23,18 @@ class _NativeCodec:
     def decode(self, data):
         """list[AddressedData] | AddressedArray -> list[PacketMeta] (data, streamaddress, SourceDecoder, BytesCorrected)."""
         src = AddressedArray.coerce(data)
-        cap = max(64, len(src) // 16 + 16)
-        while True:
-            out = (Packet * cap)()
-            count = ctypes.c_int64()
-            if self._h is not None and getattr(self, "_retry_state", None):
-                pass
-            rc = lib().pm_codec_decode(self._handle(), src.data.ctypes.data_as(ctypes.c_void_p),
-                                       src.address.ctypes.data_as(ctypes.c_void_p), len(src), out, cap, ctypes.byref(count))
-            if rc == -4:                      # PM_ERR_CAPACITY cannot happen with this bound: a packet needs >= 17 bytes of stream
-                raise RuntimeError("codec output bound exceeded")
-            check(rc)
-            break
-        return [PacketMeta.from_native(out[k], self.identifier) for k in range(count.value)]
+        pending = ctypes.c_int64()
+        check(lib().pm_codec_decode(self._handle(), src.data.ctypes.data_as(ctypes.c_void_p),
+                                    src.address.ctypes.data_as(ctypes.c_void_p), len(src), ctypes.byref(pending)))
+        out = []
+        while pending.value > 0:
+            n = min(pending.value, 256)
+            recs = (Packet * n)()
+            got = ctypes.c_int64()
+            check(lib().pm_codec_fetch(self._handle(), recs, n, ctypes.byref(got)))
+            out.extend(PacketMeta.from_native(recs[k], self.identifier) for k in range(got.value))
+            pending.value -= got.value
+        return out
 
     def __del__(self):
         try:

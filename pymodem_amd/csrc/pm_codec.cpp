@@ -55,21 +55,17 @@ void finalize(pm_packet &p)
     p.correlated_count = 0;
 }
 
+struct Queued {
+    int64_t addr;
+    int corrected;
+    std::vector<uint8_t> data;
+};
+
 struct Sink {
-    pm_packet *out;
-    int64_t cap, n;
-    void push(const std::vector<uint8_t> &data, int64_t addr, int corrected, int source)
+    std::vector<Queued> q;
+    void push(const std::vector<uint8_t> &data, int64_t addr, int corrected, int /*source*/)
     {
-        if (n < cap) {
-            pm_packet &p = out[n];
-            p.streamaddress = addr;
-            p.len = (int32_t)std::min<size_t>(data.size(), PM_PKT_MAX);
-            p.bytes_corrected = corrected;
-            p.source_decoder = source;
-            memcpy(p.data, data.data(), (size_t)p.len);
-            finalize(p);
-        }
-        ++n;
+        q.push_back(Queued{addr, corrected, data});
     }
 };
 
@@ -198,19 +194,86 @@ int rs_decode(int num_roots, uint8_t *buf, int n, int min_distance)
 
 // ---- codecs ------------------------------------------------------------------------------------------
 struct pm_codec {
+    Sink sink;
+    int source = 0;
     virtual ~pm_codec() {}
     virtual void feed(uint8_t byte, int64_t addr, Sink &sink) = 0;
+    virtual void feed_many(const uint8_t *d, const int64_t *a, int64_t n)
+    {
+        for (int64_t k = 0; k < n; ++k) feed(d[k], a[k], sink);
+    }
 };
 
 namespace {
 
+// Per (consecutive-ones count on entry, input byte): the de-stuffed bits this byte appends, provided no flag or abort
+// can occur inside it (the count never reaches 6 before a bit is examined).  Everything else takes the bit-serial path.
+struct Ax25Fast {
+    uint8_t fast, nout, outbits, ones_out;
+};
+
+const Ax25Fast *ax25_table()
+{
+    static Ax25Fast t[6][256];
+    static bool built = false;
+    if (!built) {
+        for (int ones0 = 0; ones0 < 6; ++ones0)
+            for (int byte = 0; byte < 256; ++byte) {
+                Ax25Fast e{1, 0, 0, 0};
+                int ones = ones0;
+                for (int i = 0; i < 8 && e.fast; ++i) {
+                    const int bit = (byte >> (7 - i)) & 1;
+                    if (ones >= 6) { e.fast = 0; break; }            // next bit decides flag / abort: slow path
+                    if (bit) {
+                        e.outbits |= (uint8_t)(1u << e.nout);
+                        ++e.nout;
+                        ++ones;
+                    } else {
+                        if (ones < 5) ++e.nout;                      // a data zero (bit already 0 in outbits)
+                        ones = 0;                                    // ones == 5: stuffed zero, dropped
+                    }
+                }
+                e.ones_out = (uint8_t)ones;
+                t[ones0][byte] = e;
+            }
+        built = true;
+    }
+    return &t[0][0];
+}
+
 struct Ax25 : pm_codec {
-    int source;
     unsigned wb = 0;
     int nbytes = 0, ones = 0, nbits = 0;
     std::vector<uint8_t> data;
     static constexpr int kMin = 18, kMax = 1023;           // ax25.py:14-15
-    explicit Ax25(int src) : source(src) {}
+    const Ax25Fast *table = ax25_table();
+    explicit Ax25(int src) { source = src; }
+
+    void feed_many(const uint8_t *d, const int64_t *a, int64_t n) override
+    {
+        for (int64_t k = 0; k < n; ++k) {
+            const uint8_t byte = d[k];
+            if (ones < 6 && nbytes < kMax - 2) {
+                const Ax25Fast e = table[ones * 256 + byte];
+                if (e.fast) {
+                    // wb holds the last 7 appended bits in bits 6..0 (newest at 6); X extends it with this byte's bits
+                    const unsigned x = (wb & 0x7F) | ((unsigned)e.outbits << 7);
+                    const int need = 8 - nbits;
+                    if (e.nout >= need) {
+                        data.push_back((uint8_t)((x >> (need - 1)) & 0xFF));
+                        ++nbytes;                                    // cannot pass kMax here (guard above)
+                        nbits = e.nout - need;
+                    } else {
+                        nbits += e.nout;
+                    }
+                    wb = (x >> e.nout) & 0x7F;
+                    ones = e.ones_out;
+                    continue;
+                }
+            }
+            feed(byte, a[k], sink);
+        }
+    }
 
     void byte_done(bool from_one)
     {
@@ -262,7 +325,6 @@ const uint8_t kHamming74[128] = {   // il2p.py:23-40
 
 struct Il2p : pm_codec {
     enum State { kSync, kHeader, kBig, kSmall, kCrc };
-    int source;
     bool want_crc, disable_rs;
     int min_dist, sync_tol;
     State state = kSync;
@@ -273,9 +335,42 @@ struct Il2p : pm_codec {
     bool fail = false;
     std::vector<uint8_t> data;
 
-    Il2p(int src, bool crc, bool norx, int md, int tol) : source(src), want_crc(crc), disable_rs(norx), min_dist(md), sync_tol(tol)
+    Il2p(int src, bool crc, bool norx, int md, int tol) : want_crc(crc), disable_rs(norx), min_dist(md), sync_tol(tol)
     {
+        source = src;
         memset(buf, 0, sizeof(buf));
+    }
+
+    void feed_many(const uint8_t *d, const int64_t *a, int64_t n) override
+    {
+        for (int64_t k = 0; k < n; ++k) {
+            if (state != kSync) {
+                feed(d[k], a[k], sink);
+                continue;
+            }
+            // sync search (il2p.py:367-376), tight loop; the rest of the byte goes through the state machine
+            unsigned b = d[k];
+            uint32_t w = word;
+            int i = 0;
+            bool hit = false;
+            for (; i < 8; ++i, b <<= 1) {
+                w = (w << 1) | ((b & 0x80) ? 1u : 0u);
+                if (__builtin_popcount((w & 0xFFFFFF) ^ 0xF15E48) <= sync_tol || __builtin_popcount(w ^ 0x5D57DF7Fu) <= sync_tol) {
+                    hit = true;
+                    ++i;
+                    b <<= 1;
+                    break;
+                }
+            }
+            word = w;
+            if (!hit) {
+                nbits += 8;
+                continue;
+            }
+            nbits = 0;
+            state = kHeader;
+            feed_bits(b, 8 - i, a[k], sink);
+        }
     }
 
     static void descramble(uint8_t *p, int n)
@@ -366,10 +461,12 @@ struct Il2p : pm_codec {
         return count;
     }
 
-    void feed(uint8_t byte, int64_t addr, Sink &sink) override
+    void feed(uint8_t byte, int64_t addr, Sink &sink) override { feed_bits(byte, 8, addr, sink); }
+
+    // `count` bits of b, most significant first (b is pre-shifted so that the next bit is 0x80)
+    void feed_bits(unsigned b, int count, int64_t addr, Sink &sink)
     {
-        unsigned b = byte;
-        for (int i = 0; i < 8; ++i, b <<= 1) {
+        for (int i = 0; i < count; ++i, b <<= 1) {
             const uint32_t mask = state == kSync ? 0xFFFFFFFFu : 0xFFu;
             word = ((word << 1) & mask) | ((b & 0x80) ? 1u : 0u);      // il2p.py:146-152
             ++nbits;
@@ -459,19 +556,44 @@ extern "C" {
 int pm_lfsr_unscramble(const uint8_t *h_in, int64_t n, uint64_t poly, int invert, uint64_t *h_sr, uint8_t *h_out)
 {
     if (n < 0 || (n > 0 && (!h_in || !h_out)) || !h_sr) return pm_set_error(PM_ERR_ARG, "pm_lfsr_unscramble: bad argument");
-    uint64_t reg = *h_sr;
-    unsigned w = 0;
-    for (int64_t k = 0; k < n; ++k) {
-        unsigned b = h_in[k];
-        for (int i = 0; i < 8; ++i) {
-            w = (w << 1) & 0xFE;
-            if (b & 0x80) reg ^= poly;
-            w |= (unsigned)(reg & 1);
-            b <<= 1;
-            reg >>= 1;
+    // The Galois register of lfsr.py:30-51 is a feed-forward filter over GF(2): with stream bit t (MSB of byte 0 first),
+    //     out[t] = XOR over set bits j of poly of in[t - j]   (+ bit t of the incoming register for t < 64)
+    // so the stream is processed as big-endian 64-bit words XORed with copies of itself delayed by each tap.
+    const uint64_t reg0 = *h_sr;
+    if (n == 0) return PM_OK;
+    const int64_t nwords = (n + 7) / 8;
+    auto load = [&](int64_t w) -> uint64_t {
+        if (w < 0) return 0;
+        uint64_t v = 0;
+        const int64_t base = w * 8;
+        const int take = (int)std::min<int64_t>(8, n - base);
+        for (int i = 0; i < take; ++i) v |= (uint64_t)h_in[base + i] << (56 - 8 * i);
+        return v;
+    };
+    uint64_t prev = 0, cur = load(0);
+    for (int64_t w = 0; w < nwords; ++w) {
+        uint64_t o = 0;
+        for (uint64_t p = poly; p; p &= p - 1) {
+            const int j = __builtin_ctzll(p);
+            o ^= j == 0 ? cur : ((cur >> j) | (prev << (64 - j)));
         }
-        h_out[k] = (uint8_t)(invert ? (0xFF ^ w) : w);
+        if (w == 0) {                       // pending contributions of the incoming register: bit t -> stream bit t
+            uint64_t r = reg0, rev = 0;
+            for (int i = 0; i < 64; ++i, r >>= 1) rev = (rev << 1) | (r & 1);
+            o ^= rev;
+        }
+        if (invert) o = ~o;
+        const int64_t base = w * 8;
+        const int take = (int)std::min<int64_t>(8, n - base);
+        for (int i = 0; i < take; ++i) h_out[base + i] = (uint8_t)(o >> (56 - 8 * i));
+        prev = cur;
+        cur = load(w + 1);
     }
+    // outgoing register after T = 8n bits: reg0 >> T, plus poly >> (T - t) for every set input bit t among the last 63
+    const int64_t T = n * 8;
+    uint64_t reg = T < 64 ? (reg0 >> T) : 0;
+    for (int64_t t = std::max<int64_t>(0, T - 63); t < T; ++t)
+        if ((h_in[t >> 3] >> (7 - (t & 7))) & 1) reg ^= poly >> (T - t);
     *h_sr = reg;
     return PM_OK;
 }
@@ -490,14 +612,31 @@ int pm_codec_destroy(pm_codec *c)
     return PM_OK;
 }
 
-int pm_codec_decode(pm_codec *c, const uint8_t *h_data, const int64_t *h_addr, int64_t n, pm_packet *h_out, int64_t cap, int64_t *h_count)
+int pm_codec_decode(pm_codec *c, const uint8_t *h_data, const int64_t *h_addr, int64_t n, int64_t *h_pending)
 {
-    if (!c || n < 0 || (n > 0 && (!h_data || !h_addr)) || !h_count || cap < 0 || (cap > 0 && !h_out))
+    if (!c || n < 0 || (n > 0 && (!h_data || !h_addr)) || !h_pending)
         return pm_set_error(PM_ERR_ARG, "pm_codec_decode: bad argument");
-    Sink sink{h_out, cap, 0};
-    for (int64_t k = 0; k < n; ++k) c->feed(h_data[k], h_addr[k], sink);
-    *h_count = sink.n;
-    if (sink.n > cap) return pm_set_error(PM_ERR_CAPACITY, "pm_codec_decode: %lld packets, capacity %lld", (long long)sink.n, (long long)cap);
+    c->feed_many(h_data, h_addr, n);
+    *h_pending = (int64_t)c->sink.q.size();
+    return PM_OK;
+}
+
+int pm_codec_fetch(pm_codec *c, pm_packet *h_out, int64_t cap, int64_t *h_count)
+{
+    if (!c || cap < 0 || (cap > 0 && !h_out) || !h_count) return pm_set_error(PM_ERR_ARG, "pm_codec_fetch: bad argument");
+    const int64_t take = std::min<int64_t>(cap, (int64_t)c->sink.q.size());
+    for (int64_t k = 0; k < take; ++k) {
+        const Queued &src = c->sink.q[(size_t)k];
+        pm_packet &p = h_out[k];
+        p.streamaddress = src.addr;
+        p.len = (int32_t)std::min<size_t>(src.data.size(), PM_PKT_MAX);
+        p.bytes_corrected = src.corrected;
+        p.source_decoder = c->source;
+        memcpy(p.data, src.data.data(), (size_t)p.len);
+        finalize(p);
+    }
+    c->sink.q.erase(c->sink.q.begin(), c->sink.q.begin() + take);
+    *h_count = take;
     return PM_OK;
 }
 

@@ -1,284 +1,377 @@
 // Symbol-timing slicers (BinarySlicer.slice slicer.py:59-107, QuadratureSlicer.slice slicer.py:193-242)
-// evaluated chunk-parallel on the sign bitmap of the demodulated stream.
+// evaluated chunk-parallel on the sign bitmap(s) of the demodulated stream(s), many streams per launch.
 //
 // The reference recurrence, per sample k (1-based address k+1):
 //     clk += 1.0;  if (clk >= sps/2 - 0.5) { clk -= sps;  take a symbol from sign(x[k]) }
 //     if sign(x[k]) != sign(x[k-1]):  clk *= lock_rate
-// is sequential in `clk` only.  The stream is cut into chunks of L samples, one lane per chunk.
+// is sequential in `clk` only.  Every stream is cut into chunks of L samples, one lane per chunk.
 // Iteration r runs every chunk from the start state handed to it and hands its end state to the next
-// chunk; chunk 0 always starts from the true state.  A chunk whose start state did not change is not
-// re-run.  When an iteration changes no start state, every chunk started from the end state of its
-// predecessor, so by induction from chunk 0 the per-chunk runs ARE the sequential run, bit for bit
-// (each lane executes the reference's operations in the reference's order; only the starting value is
-// guessed).  Two trajectories that see the same zero crossings contract by lock_rate per crossing, so a
-// few iterations suffice on real signals; the worst case (no crossings at all) degrades to nchunks
-// iterations, i.e. sequential cost, never to a wrong answer.
+// chunk; chunk 0 of a stream always starts from the true state.  A chunk whose start state did not
+// change is not re-run.  When an iteration changes no start state, every chunk started from the end
+// state of its predecessor, so by induction from chunk 0 the per-chunk runs ARE the sequential run, bit
+// for bit: each lane executes the reference's operations in the reference's order, only the starting
+// value is guessed.  Two trajectories that see the same zero crossings contract by lock_rate per
+// crossing, so a few iterations suffice on real signals; the worst case (no crossings at all) degrades
+// to nchunks iterations, i.e. sequential cost, never to a wrong answer.
 //
-// After the fixed point: an exclusive scan of per-chunk symbol counts gives every chunk its global
-// symbol index (hence byte index and bit phase), and an emit pass re-runs the chunks writing bytes
-// (atomicOr of bit fields into a zeroed buffer) and the address of each byte's last symbol.
+// A lone wave is instruction-issue bound (~5 cycles per VALU instruction), so the sample step is kept to
+// about ten instructions: the symbol decision and the crossing enter as multiplicands (x - sps*{0,1}
+// through one fma, x*{1,lock}), which is bitwise the reference's `clk -= sps` / `clk *= lock_rate`, and each
+// run leaves a bitmap of the samples at which it took a symbol.  After the fixed point a count/scan/pack
+// pipeline turns symbol bitmap + sign bitmap(s) into bytes and the 1-based address of each byte's last symbol.
 #include "pm_common.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <vector>
 
 namespace {
 
-struct SlicerDev {
-    double sps, thr, lock;
-    int bps, mask;
+constexpr int kMaxJobs = 64;
+
+struct JobDev {
+    const uint64_t *bi, *bq;       // sign bitmaps (bq null for binary)
+    int64_t n, nwords;
+    int64_t chunk0, nchunks;       // global chunk range of this stream
+    int64_t word0;                 // offset of this stream in the global symbol bitmap
+    double thr, sps, lock;
+    int bps, mask, quad, pad;
     int demap[16];
+    uint32_t *data32;
+    int64_t *addr;
+    int64_t cap;
 };
 
 __device__ __forceinline__ uint64_t dbits(double v) { return (uint64_t)__double_as_longlong(v); }
 __device__ __forceinline__ double bitsd(uint64_t v) { return __longlong_as_double((long long)v); }
+__device__ __forceinline__ double mkdouble(uint32_t hi, uint32_t lo) { return __hiloint2double((int)hi, (int)lo); }
 
-template <bool QUAD>
-__global__ __launch_bounds__(64) void slice_iter_kernel(const uint64_t *__restrict__ bi, const uint64_t *__restrict__ bq,
-                                                        int64_t n, int lc_words, int64_t nchunks,
+__device__ __forceinline__ int find_job(const JobDev *jobs, int njobs, int64_t gc)
+{
+    int j = 0;
+    while (j + 1 < njobs && gc >= jobs[j + 1].chunk0) ++j;
+    return j;
+}
+
+// 32 samples, most significant bit first: zc = crossing flags (bit 31 = first sample).  Returns the symbol flags in
+// the same orientation.  clk is updated in place.
+__device__ __forceinline__ uint32_t step32(double &clk, uint32_t zc, double thr, double neg_sps, uint32_t lock_hi, uint32_t lock_lo)
+{
+    uint32_t sym = 0;
+#pragma unroll
+    for (int b = 0; b < 32; ++b) {
+        const double a = clk + 1.0;                                         // slicer.py:77
+        const bool s = a >= thr;                                            // slicer.py:79
+        const double c = __builtin_fma(mkdouble(s ? 0x3FF00000u : 0u, 0u), neg_sps, a);   // a - sps (one rounding) or a
+        sym = (sym << 1) | (s ? 1u : 0u);
+        const bool x = (int)zc < 0;                                         // crossing at this sample (slicer.py:99-102)
+        zc <<= 1;
+        clk = c * mkdouble(x ? lock_hi : 0x3FF00000u, x ? lock_lo : 0u);    // c * lock_rate, or c * 1.0 == c
+    }
+    return sym;
+}
+
+// One fixed-point iteration over all chunks of all streams.
+__global__ __launch_bounds__(64) void slice_iter_kernel(const JobDev *__restrict__ jobs, int njobs, int lc_words, int64_t total_chunks,
                                                         const uint64_t *__restrict__ s_in, uint64_t *__restrict__ s_out,
                                                         const uint8_t *__restrict__ d_in, uint8_t *__restrict__ d_out,
-                                                        uint32_t *__restrict__ count, uint8_t *__restrict__ lastsym,
-                                                        int *__restrict__ changed, int iter, SlicerDev P)
+                                                        uint64_t *__restrict__ symmap, int *__restrict__ changed, int iter)
 {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nchunks) return;
-    // chunk 0 starts from the true state: it runs once.  Nobody writes d_in[0], so it is not consulted.
-    const bool dirty = c == 0 ? (iter == 0) : (d_in[c] != 0);
-    if (!dirty) {                        // start state unchanged: end state and counts stand
-        s_out[c + 1] = s_in[c + 1];
-        d_out[c + 1] = 0;
+    const int64_t gc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gc >= total_chunks) return;
+    const int j = find_job(jobs, njobs, gc);
+    const JobDev &J = jobs[j];
+    const int64_t c = gc - J.chunk0;
+    const int64_t so = gc + j;                       // state arrays hold nchunks+1 entries per stream
+    // chunk 0 starts from the true state: it runs once.  Nobody writes d_in[so] for c == 0, so it is not consulted.
+    const bool dirty = c == 0 ? (iter == 0) : (d_in[so] != 0);
+    if (!dirty) {                                    // start state unchanged: end state and symbol bitmap stand
+        s_out[so + 1] = s_in[so + 1];
+        d_out[so + 1] = 0;
         return;
     }
-    double clk = bitsd(s_in[c]);
-    const int64_t nwords = (n + 63) >> 6;
+    double clk = bitsd(s_in[so]);
     const int64_t w0 = c * lc_words;
-    const int64_t w1 = min(w0 + (int64_t)lc_words, nwords);
+    const int64_t w1 = min(w0 + (int64_t)lc_words, J.nwords);
     // last_sample starts at 0.0, i.e. ">= 0" (slicer.py:55,164-165)
-    uint64_t li = w0 == 0 ? 1ull : (bi[w0 - 1] >> 63);
+    uint64_t li = w0 == 0 ? 1ull : (J.bi[w0 - 1] >> 63);
     uint64_t lq = 1ull;
-    if (QUAD) lq = w0 == 0 ? 1ull : (bq[w0 - 1] >> 63);
-    uint32_t cnt = 0;
-    uint32_t ls = 0xFF;
+    if (J.quad) lq = w0 == 0 ? 1ull : (J.bq[w0 - 1] >> 63);
+    const double thr = J.thr, neg_sps = -J.sps;
+    const uint32_t lock_hi = (uint32_t)(dbits(J.lock) >> 32), lock_lo = (uint32_t)dbits(J.lock);
+    uint64_t *sm = symmap + J.word0;
     for (int64_t w = w0; w < w1; ++w) {
-        const uint64_t si = bi[w];
+        const uint64_t si = J.bi[w];
         uint64_t zc = si ^ ((si << 1) | li);
         li = si >> 63;
-        uint64_t sq = 0;
-        if (QUAD) {
-            sq = bq[w];
+        if (J.quad) {
+            const uint64_t sq = J.bq[w];
             zc |= sq ^ ((sq << 1) | lq);
             lq = sq >> 63;
         }
-        const int64_t left = n - (w << 6);
-        const int nb = left < 64 ? (int)left : 64;
-        for (int b = 0; b < nb; ++b) {
-            clk += 1.0;
-            if (clk >= P.thr) {
-                clk -= P.sps;
-                cnt++;
-                if (QUAD) ls = (uint32_t)((((si >> b) & 1) << 1) | ((sq >> b) & 1));
+        const int64_t left = J.n - (w << 6);
+        uint64_t sym;
+        if (left >= 64) {
+            const uint32_t lo = step32(clk, __brev((uint32_t)zc), thr, neg_sps, lock_hi, lock_lo);
+            const uint32_t hi = step32(clk, __brev((uint32_t)(zc >> 32)), thr, neg_sps, lock_hi, lock_lo);
+            sym = ((uint64_t)__brev(hi) << 32) | (uint64_t)__brev(lo);
+        } else {                                     // the stream's last, partial word
+            sym = 0;
+            for (int b = 0; b < (int)left; ++b) {
+                clk += 1.0;
+                if (clk >= thr) {
+                    clk -= J.sps;
+                    sym |= 1ull << b;
+                }
+                if ((zc >> b) & 1) clk = clk * J.lock;
             }
-            if ((zc >> b) & 1) clk = clk * P.lock;
         }
+        sm[w] = sym;
     }
     const uint64_t e = dbits(clk);
-    const bool ch = e != s_in[c + 1];
-    s_out[c + 1] = e;
-    d_out[c + 1] = ch ? 1 : 0;
-    count[c] = cnt;
-    if (QUAD) lastsym[c] = (uint8_t)ls;
-    if (ch && c + 1 < nchunks) atomicOr(changed, 1);
+    const bool ch = e != s_in[so + 1];
+    s_out[so + 1] = e;
+    d_out[so + 1] = ch ? 1 : 0;
+    if (ch && c + 1 < J.nchunks) atomicOr(changed, 1);
 }
 
-// Exclusive scan of symbol counts + "last symbol before this chunk" carry.  One workgroup.
-__global__ __launch_bounds__(1024) void slice_scan_kernel(const uint32_t *__restrict__ count, const uint8_t *__restrict__ lastsym,
-                                                          int64_t nchunks, uint64_t *__restrict__ offset,
-                                                          uint8_t *__restrict__ prevsym, int quad, int init_sym)
+// Symbols per chunk and the (i<<1|q) bits of its last symbol (0xFF if it took none).
+__global__ __launch_bounds__(64) void slice_count_kernel(const JobDev *__restrict__ jobs, int njobs, int lc_words, int64_t total_chunks,
+                                                         const uint64_t *__restrict__ symmap, uint32_t *__restrict__ count,
+                                                         uint8_t *__restrict__ lastsym)
+{
+    const int64_t gc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gc >= total_chunks) return;
+    const int j = find_job(jobs, njobs, gc);
+    const JobDev &J = jobs[j];
+    const int64_t c = gc - J.chunk0;
+    const int64_t w0 = c * lc_words, w1 = min(w0 + (int64_t)lc_words, J.nwords);
+    const uint64_t *sm = symmap + J.word0;
+    uint32_t cnt = 0;
+    uint32_t ls = 0xFF;
+    for (int64_t w = w0; w < w1; ++w) {
+        const uint64_t s = sm[w];
+        cnt += (uint32_t)__popcll(s);
+        if (J.quad && s) {
+            const int b = 63 - __clzll((long long)s);
+            ls = (uint32_t)((((J.bi[w] >> b) & 1) << 1) | ((J.bq[w] >> b) & 1));
+        }
+    }
+    count[gc] = cnt;
+    lastsym[gc] = (uint8_t)ls;
+}
+
+// Per stream: exclusive scan of symbol counts and the "last symbol before this chunk" carry.  One workgroup per stream.
+__global__ __launch_bounds__(1024) void slice_scan_kernel(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ count,
+                                                          const uint8_t *__restrict__ lastsym, uint64_t *__restrict__ offset,
+                                                          uint8_t *__restrict__ prevsym, uint64_t *__restrict__ totals)
 {
     __shared__ uint64_t sums[1024];
     __shared__ int lasts[1024];
+    const JobDev &J = jobs[blockIdx.x];
+    const uint32_t *cnt = count + J.chunk0;
+    const uint8_t *lsym = lastsym + J.chunk0;
+    uint64_t *off = offset + J.chunk0 + blockIdx.x;        // nchunks+1 entries per stream
+    uint8_t *psym = prevsym + J.chunk0;
     const int t = threadIdx.x;
-    const int64_t per = (nchunks + 1023) / 1024;
-    const int64_t c0 = min((int64_t)t * per, nchunks), c1 = min(c0 + per, nchunks);
+    const int64_t per = (J.nchunks + 1023) / 1024;
+    const int64_t c0 = min((int64_t)t * per, J.nchunks), c1 = min(c0 + per, J.nchunks);
     uint64_t s = 0;
     int l = -1;
     for (int64_t c = c0; c < c1; ++c) {
-        s += count[c];
-        if (quad && lastsym[c] != 0xFF) l = lastsym[c];
+        s += cnt[c];
+        if (lsym[c] != 0xFF) l = lsym[c];
     }
     sums[t] = s;
     lasts[t] = l;
     __syncthreads();
-    if (t == 0) {                       // 1024 partials: a serial pass is ~microseconds
+    if (t == 0) {
         uint64_t run = 0;
-        int carry = init_sym;
+        int carry = 0;                                     // state_register starts at 0 (slicer.py:202)
         for (int i = 0; i < 1024; ++i) {
-            uint64_t v = sums[i];
-            int lv = lasts[i];
+            const uint64_t v = sums[i];
+            const int lv = lasts[i];
             sums[i] = run;
             lasts[i] = carry;
             run += v;
             if (lv >= 0) carry = lv;
         }
-        offset[nchunks] = run;
+        off[J.nchunks] = run;
+        totals[blockIdx.x] = run;
     }
     __syncthreads();
     uint64_t run = sums[t];
     int carry = lasts[t];
     for (int64_t c = c0; c < c1; ++c) {
-        offset[c] = run;
-        if (quad) prevsym[c] = (uint8_t)carry;
-        run += count[c];
-        if (quad && lastsym[c] != 0xFF) carry = lastsym[c];
+        off[c] = run;
+        psym[c] = (uint8_t)carry;
+        run += cnt[c];
+        if (lsym[c] != 0xFF) carry = lsym[c];
     }
 }
 
-template <bool QUAD>
-__global__ __launch_bounds__(64) void slice_emit_kernel(const uint64_t *__restrict__ bi, const uint64_t *__restrict__ bq,
-                                                        int64_t n, int lc_words, int64_t nchunks,
-                                                        const uint64_t *__restrict__ start, const uint64_t *__restrict__ offset,
-                                                        const uint8_t *__restrict__ prevsym, uint32_t *__restrict__ data32,
-                                                        int64_t *__restrict__ addr, int64_t cap, SlicerDev P)
+// Symbol bitmap + sign bitmap(s) -> packed bytes (MSB first) and the address of each byte's last symbol.
+__global__ __launch_bounds__(64) void slice_pack_kernel(const JobDev *__restrict__ jobs, int njobs, int lc_words, int64_t total_chunks,
+                                                        const uint64_t *__restrict__ symmap, const uint64_t *__restrict__ offset,
+                                                        const uint8_t *__restrict__ prevsym)
 {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nchunks) return;
-    double clk = bitsd(start[c]);
-    uint64_t g = offset[c];
-    const uint64_t total = offset[nchunks];
-    const int spb = 8 / P.bps;                       // symbols per byte
-    const uint64_t nbytes = total / (uint64_t)spb;   // a trailing partial byte is never emitted (slicer.py:94-96)
-    uint32_t prev = QUAD ? prevsym[c] : 0;
-    const int64_t nwords = (n + 63) >> 6;
-    const int64_t w0 = c * lc_words;
-    const int64_t w1 = min(w0 + (int64_t)lc_words, nwords);
-    uint64_t li = w0 == 0 ? 1ull : (bi[w0 - 1] >> 63);
-    uint64_t lq = 1ull;
-    if (QUAD) lq = w0 == 0 ? 1ull : (bq[w0 - 1] >> 63);
+    const int64_t gc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gc >= total_chunks) return;
+    const int j = find_job(jobs, njobs, gc);
+    const JobDev &J = jobs[j];
+    const int64_t c = gc - J.chunk0;
+    const uint64_t *off = offset + J.chunk0 + j;
+    uint64_t g = off[c];
+    const uint64_t total = off[J.nchunks];
+    const int bps = J.bps, spb = 8 / bps;                  // symbols per byte
+    const uint64_t nbytes = total / (uint64_t)spb;         // a trailing partial byte is never emitted (slicer.py:94-96)
+    uint32_t prev = prevsym[gc];
+    const int64_t w0 = c * lc_words, w1 = min(w0 + (int64_t)lc_words, J.nwords);
+    const uint64_t *sm = symmap + J.word0;
     uint32_t acc = 0;
     bool pending = false;
     for (int64_t w = w0; w < w1; ++w) {
-        const uint64_t si = bi[w];
-        uint64_t zc = si ^ ((si << 1) | li);
-        li = si >> 63;
-        uint64_t sq = 0;
-        if (QUAD) {
-            sq = bq[w];
-            zc |= sq ^ ((sq << 1) | lq);
-            lq = sq >> 63;
-        }
-        const int64_t left = n - (w << 6);
-        const int nb = left < 64 ? (int)left : 64;
-        for (int b = 0; b < nb; ++b) {
-            clk += 1.0;
-            if (clk >= P.thr) {
-                clk -= P.sps;
-                uint32_t v;
-                if (QUAD) {
-                    const uint32_t cur = (uint32_t)((((si >> b) & 1) << 1) | ((sq >> b) & 1));
-                    const uint32_t sreg = ((prev << 2) | cur) & (uint32_t)P.mask;     // slicer.py:210-214
-                    v = (uint32_t)P.demap[sreg];
-                    prev = cur;
-                } else {
-                    v = (uint32_t)((si >> b) & 1);                                     // slicer.py:85-90
-                }
-                const int j = (int)(g % (uint64_t)spb);
-                acc |= v << (8 - P.bps * (j + 1));            // MSB-first packing
-                pending = true;
-                if (j == spb - 1) {
-                    const uint64_t idx = g / (uint64_t)spb;
-                    if (idx < (uint64_t)cap) {
-                        atomicOr(&data32[idx >> 2], (acc & 0xFF) << ((idx & 3) * 8));
-                        addr[idx] = (w << 6) + b + 1;          // streamaddress, 1-based
-                    }
-                    acc = 0;
-                    pending = false;
-                }
-                g++;
+        uint64_t s = sm[w];
+        if (!s) continue;
+        const uint64_t si = J.bi[w];
+        const uint64_t sq = J.quad ? J.bq[w] : 0;
+        while (s) {
+            const int b = __ffsll((long long)s) - 1;
+            s &= s - 1;
+            uint32_t v;
+            if (J.quad) {
+                const uint32_t cur = (uint32_t)((((si >> b) & 1) << 1) | ((sq >> b) & 1));
+                v = (uint32_t)J.demap[((prev << 2) | cur) & (uint32_t)J.mask];        // slicer.py:210-217
+                prev = cur;
+            } else {
+                v = (uint32_t)((si >> b) & 1);                                         // slicer.py:85-90
             }
-            if ((zc >> b) & 1) clk = clk * P.lock;
+            const int k = (int)(g % (uint64_t)spb);
+            acc |= v << (8 - bps * (k + 1));
+            pending = true;
+            if (k == spb - 1) {
+                const uint64_t idx = g / (uint64_t)spb;
+                if (idx < (uint64_t)J.cap) {
+                    atomicOr(&J.data32[idx >> 2], (acc & 0xFF) << ((idx & 3) * 8));
+                    J.addr[idx] = (w << 6) + b + 1;        // streamaddress, 1-based
+                }
+                acc = 0;
+                pending = false;
+            }
+            ++g;
         }
     }
-    if (pending) {                     // head of a byte that a later chunk completes
+    if (pending) {                                         // head of a byte that a later chunk completes
         const uint64_t idx = g / (uint64_t)spb;
-        if (idx < nbytes && idx < (uint64_t)cap) atomicOr(&data32[idx >> 2], (acc & 0xFF) << ((idx & 3) * 8));
+        if (idx < nbytes && idx < (uint64_t)J.cap) atomicOr(&J.data32[idx >> 2], (acc & 0xFF) << ((idx & 3) * 8));
     }
 }
 
-__global__ void slice_init_kernel(uint64_t *sa, uint64_t *sb, uint8_t *da, uint8_t *db, int64_t nchunks, uint64_t init_clk, int *changed)
+__global__ void slice_init_kernel(const JobDev *__restrict__ jobs, int njobs, int64_t total_chunks, uint64_t *sa, uint64_t *sb,
+                                  uint8_t *da, uint8_t *db, int *changed)
 {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0) *changed = 0;
-    if (c > nchunks) return;
-    sa[c] = c == 0 ? init_clk : 0ull;      // cold start: phase_clock = 0.0
-    sb[c] = c == 0 ? init_clk : 0ull;
-    da[c] = c < nchunks ? 1 : 0;
-    db[c] = 0;
+    const int64_t gc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gc == 0) *changed = 0;
+    if (gc >= total_chunks) return;
+    const int j = find_job(jobs, njobs, gc);
+    const int64_t so = gc + j;
+    // cold start everywhere: phase_clock = 0.0, which for chunk 0 is the true initial state (slicer.py:50)
+    sa[so] = 0ull; sb[so] = 0ull; da[so] = 1; db[so] = 0;
+    if (gc - jobs[j].chunk0 == jobs[j].nchunks - 1) { sa[so + 1] = 0ull; sb[so + 1] = 0ull; da[so + 1] = 0; db[so + 1] = 0; }
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-template <bool QUAD>
-int slice_run(pm_ctx *ctx, const uint64_t *d_bi, const uint64_t *d_bq, int64_t n, const pm_slicer_params *hp,
-              uint8_t *d_data, int64_t *d_addr, int64_t cap, int64_t *h_count)
+}  // namespace
+
+extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
 {
-    PM_ARG(ctx && hp && h_count && n >= 0 && cap >= 0);
-    PM_ARG(hp->bits_per_symbol == 1 || hp->bits_per_symbol == 2);
-    PM_ARG(hp->samples_per_symbol > 0.0 && hp->lock_rate == hp->lock_rate);
-    *h_count = 0;
+    PM_ARG(ctx && jobs && njobs >= 1 && njobs <= kMaxJobs);
     ctx->sl_iterations = 0;
-    if (n == 0) return PM_OK;
-    PM_ARG(d_bi && (!QUAD || d_bq) && (cap == 0 || (d_data && d_addr)));
-    PM_ARG(((uintptr_t)d_data & 3) == 0);
+    int64_t max_n = 0;
+    for (int j = 0; j < njobs; ++j) {
+        pm_slice_job &q = jobs[j];
+        q.count = 0;
+        PM_ARG(q.n >= 0 && q.cap >= 0);
+        PM_ARG(q.params.bits_per_symbol == 1 || q.params.bits_per_symbol == 2);
+        PM_ARG(q.params.samples_per_symbol > 0.0 && q.params.lock_rate == q.params.lock_rate);
+        PM_ARG(q.n == 0 || (q.d_bits_i && (q.cap == 0 || (q.d_data && q.d_addr))));
+        PM_ARG(((uintptr_t)q.d_data & 3) == 0);
+        max_n = std::max(max_n, q.n);
+    }
+    if (max_n == 0) return PM_OK;
 
-    SlicerDev P;
-    P.sps = hp->samples_per_symbol;
-    P.thr = (hp->samples_per_symbol / 2.0) - 0.5;      // slicer.py:52
-    P.lock = hp->lock_rate;
-    P.bps = hp->bits_per_symbol;
-    P.mask = hp->state_mask;
-    for (int i = 0; i < 16; ++i) P.demap[i] = hp->demap[i];
-
-    // chunk length: multiple of 64 samples, ~8192 chunks on long streams, never shorter than 1024 samples
-    const int64_t nwords = pm_cdiv(n, 64);
-    int64_t lc_words = pm_cdiv(nwords, 8192);
-    lc_words = std::max<int64_t>(16, std::min<int64_t>(lc_words, 128));
-    const int64_t nchunks = pm_cdiv(nwords, lc_words);
+    // chunk length: a multiple of 64 samples; PM_SLICER_CHUNK_WORDS overrides (tuning)
+    int64_t lc_words = 32;
+    if (const char *e = getenv("PM_SLICER_CHUNK_WORDS")) lc_words = std::max(1, atoi(e));
+    std::vector<JobDev> jd;
+    jd.reserve(njobs);
+    std::vector<int> live;
+    int64_t total_chunks = 0, total_words = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const pm_slice_job &q = jobs[j];
+        if (q.n == 0) continue;
+        JobDev d;
+        memset(&d, 0, sizeof(d));
+        d.bi = q.d_bits_i;
+        d.bq = q.d_bits_q;
+        d.quad = q.d_bits_q != nullptr;
+        d.n = q.n;
+        d.nwords = pm_cdiv(q.n, 64);
+        d.chunk0 = total_chunks;
+        d.nchunks = pm_cdiv(d.nwords, lc_words);
+        d.word0 = total_words;
+        d.sps = q.params.samples_per_symbol;
+        d.thr = (q.params.samples_per_symbol / 2.0) - 0.5;          // slicer.py:52
+        d.lock = q.params.lock_rate;
+        d.bps = q.params.bits_per_symbol;
+        d.mask = q.params.state_mask;
+        for (int i = 0; i < 16; ++i) d.demap[i] = q.params.demap[i];
+        d.data32 = (uint32_t *)q.d_data;
+        d.addr = q.d_addr;
+        d.cap = q.cap;
+        total_chunks += d.nchunks;
+        total_words += d.nwords;
+        jd.push_back(d);
+        live.push_back(j);
+    }
+    const int nj = (int)jd.size();
     ctx->sl_chunk_len = (int32_t)(lc_words * 64);
-    ctx->sl_chunks = nchunks;
+    ctx->sl_chunks = total_chunks;
 
-    // carve the scratch
-    const size_t e = (size_t)nchunks + 1;
+    const size_t e = (size_t)total_chunks + nj;             // nchunks+1 state entries per stream
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    const size_t o_sa = carve(e * 8), o_sb = carve(e * 8), o_da = carve(e), o_db = carve(e), o_cnt = carve(e * 4),
-                 o_ls = carve(e), o_off = carve(e * 8), o_ps = carve(e), o_ch = carve(256);
+    const size_t o_jobs = carve(sizeof(JobDev) * nj), o_sa = carve(e * 8), o_sb = carve(e * 8), o_da = carve(e), o_db = carve(e),
+                 o_cnt = carve((size_t)total_chunks * 4), o_ls = carve(total_chunks), o_off = carve(e * 8), o_ps = carve(total_chunks),
+                 o_sym = carve((size_t)total_words * 8), o_tot = carve((size_t)nj * 8), o_ch = carve(256);
     if (int rc = pm_scratch_reserve(ctx, off)) return rc;
     char *base = (char *)ctx->d_scratch;
+    JobDev *d_jobs = (JobDev *)(base + o_jobs);
     uint64_t *sa = (uint64_t *)(base + o_sa), *sb = (uint64_t *)(base + o_sb);
     uint8_t *da = (uint8_t *)(base + o_da), *db = (uint8_t *)(base + o_db);
     uint32_t *cnt = (uint32_t *)(base + o_cnt);
     uint8_t *ls = (uint8_t *)(base + o_ls), *ps = (uint8_t *)(base + o_ps);
-    uint64_t *offs = (uint64_t *)(base + o_off);
+    uint64_t *offs = (uint64_t *)(base + o_off), *symmap = (uint64_t *)(base + o_sym), *totals = (uint64_t *)(base + o_tot);
     int *changed = (int *)(base + o_ch);
 
-    const unsigned grid = (unsigned)pm_cdiv(nchunks, 64);
-    const double init_clk = 0.0;
-    uint64_t init_bits;
-    memcpy(&init_bits, &init_clk, 8);
-    hipLaunchKernelGGL(slice_init_kernel, dim3((unsigned)pm_cdiv((int64_t)e, 256)), dim3(256), 0, ctx->stream,
-                       sa, sb, da, db, nchunks, init_bits, changed);
+    PM_HIP(hipMemcpyAsync(d_jobs, jd.data(), sizeof(JobDev) * nj, hipMemcpyHostToDevice, ctx->stream));
+    const unsigned grid = (unsigned)pm_cdiv(total_chunks, 64);
+    hipLaunchKernelGGL(slice_init_kernel, dim3(grid), dim3(64), 0, ctx->stream, d_jobs, nj, total_chunks, sa, sb, da, db, changed);
 
     int *h_flag = (int *)ctx->h_pinned;
     int iters = 0;
-    const int64_t max_iters = nchunks + 2;
+    int64_t most_chunks = 0;
+    for (const JobDev &d : jd) most_chunks = std::max(most_chunks, d.nchunks);
+    const int64_t max_iters = most_chunks + 2;
     bool converged = false;
     while (!converged) {
-        // a short burst of iterations between host checks keeps the launch queue full
-        const int burst = iters < 2 ? 2 : 4;
+        // a burst of iterations between host checks keeps the launch queue full
+        const int burst = 4;
         for (int b = 0; b < burst; ++b) {
             PmProf prof(ctx, PM_K_SLICE_ITER);
-            hipLaunchKernelGGL((slice_iter_kernel<QUAD>), dim3(grid), dim3(64), 0, ctx->stream, d_bi, d_bq, n, (int)lc_words,
-                               nchunks, sa, sb, da, db, cnt, ls, changed, iters, P);
+            hipLaunchKernelGGL(slice_iter_kernel, dim3(grid), dim3(64), 0, ctx->stream, d_jobs, nj, (int)lc_words, total_chunks,
+                               sa, sb, da, db, symmap, changed, iters);
             std::swap(sa, sb);
             std::swap(da, db);
             ++iters;
@@ -286,46 +379,70 @@ int slice_run(pm_ctx *ctx, const uint64_t *d_bi, const uint64_t *d_bq, int64_t n
         PM_HIP(hipMemcpyAsync(h_flag, changed, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         PM_HIP(hipMemsetAsync(changed, 0, sizeof(int), ctx->stream));
         PM_HIP(hipStreamSynchronize(ctx->stream));
-        // `changed` accumulates over the burst; a burst with no change at all means the LAST state is a fixed point
+        // `changed` accumulates over the burst: a burst with no change at all ends on a fixed point
         converged = (*h_flag == 0);
         if (!converged && iters > max_iters + 8)
-            return pm_set_error(PM_ERR_NOCONVERGE, "slicer fixed point not reached after %d iterations (%lld chunks)", iters, (long long)nchunks);
+            return pm_set_error(PM_ERR_NOCONVERGE, "slicer fixed point not reached after %d iterations (%lld chunks)", iters, (long long)most_chunks);
     }
     ctx->sl_iterations = iters;
 
-    hipLaunchKernelGGL(slice_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, cnt, ls, nchunks, offs, ps, QUAD ? 1 : 0, 0);
-    if (cap > 0) {
-        PM_HIP(hipMemsetAsync(d_data, 0, align_up((size_t)cap, 4), ctx->stream));
+    {
         PmProf prof(ctx, PM_K_SLICE_EMIT);
-        hipLaunchKernelGGL((slice_emit_kernel<QUAD>), dim3(grid), dim3(64), 0, ctx->stream, d_bi, d_bq, n, (int)lc_words, nchunks,
-                           sa, offs, ps, (uint32_t *)d_data, d_addr, cap, P);
+        hipLaunchKernelGGL(slice_count_kernel, dim3(grid), dim3(64), 0, ctx->stream, d_jobs, nj, (int)lc_words, total_chunks, symmap, cnt, ls);
+        hipLaunchKernelGGL(slice_scan_kernel, dim3(nj), dim3(1024), 0, ctx->stream, d_jobs, cnt, ls, offs, ps, totals);
+        for (const JobDev &d : jd)
+            if (d.cap > 0) PM_HIP(hipMemsetAsync(d.data32, 0, align_up((size_t)d.cap, 4), ctx->stream));
+        hipLaunchKernelGGL(slice_pack_kernel, dim3(grid), dim3(64), 0, ctx->stream, d_jobs, nj, (int)lc_words, total_chunks, symmap, offs, ps);
     }
-    uint64_t *h_total = (uint64_t *)ctx->h_pinned;
-    PM_HIP(hipMemcpyAsync(h_total, offs + nchunks, 8, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<uint64_t> h_tot(nj);
+    PM_HIP(hipMemcpyAsync(h_tot.data(), totals, (size_t)nj * 8, hipMemcpyDeviceToHost, ctx->stream));
     PM_HIP(hipStreamSynchronize(ctx->stream));
     PM_HIP(hipGetLastError());
-    const int64_t nbytes = (int64_t)(*h_total / (uint64_t)(8 / P.bps));
-    *h_count = nbytes;
-    if (nbytes > cap)
-        return pm_set_error(PM_ERR_CAPACITY, "slicer produced %lld bytes, capacity %lld", (long long)nbytes, (long long)cap);
-    return PM_OK;
+    int rc = PM_OK;
+    for (int k = 0; k < nj; ++k) {
+        pm_slice_job &q = jobs[live[k]];
+        q.count = (int64_t)(h_tot[k] / (uint64_t)(8 / jd[k].bps));
+        if (q.count > q.cap)
+            rc = pm_set_error(PM_ERR_CAPACITY, "slicer stream %d produced %lld bytes, capacity %lld", live[k], (long long)q.count, (long long)q.cap);
+    }
+    return rc;
 }
-
-}  // namespace
 
 extern "C" {
 
 int pm_slice_binary(pm_ctx *ctx, const uint64_t *d_bits, int64_t n, const pm_slicer_params *h_params,
                     uint8_t *d_data, int64_t *d_addr, int64_t cap, int64_t *h_count)
 {
-    PM_ARG(h_params && h_params->bits_per_symbol == 1);
-    return slice_run<false>(ctx, d_bits, nullptr, n, h_params, d_data, d_addr, cap, h_count);
+    PM_ARG(h_params && h_count && h_params->bits_per_symbol == 1);
+    pm_slice_job job;
+    memset(&job, 0, sizeof(job));
+    job.d_bits_i = d_bits;
+    job.n = n;
+    job.params = *h_params;
+    job.d_data = d_data;
+    job.d_addr = d_addr;
+    job.cap = cap;
+    const int rc = pm_slice_batch(ctx, &job, 1);
+    *h_count = job.count;
+    return rc;
 }
 
 int pm_slice_quadrature(pm_ctx *ctx, const uint64_t *d_bits_i, const uint64_t *d_bits_q, int64_t n,
                         const pm_slicer_params *h_params, uint8_t *d_data, int64_t *d_addr, int64_t cap, int64_t *h_count)
 {
-    return slice_run<true>(ctx, d_bits_i, d_bits_q, n, h_params, d_data, d_addr, cap, h_count);
+    PM_ARG(h_params && h_count && (n == 0 || d_bits_q));
+    pm_slice_job job;
+    memset(&job, 0, sizeof(job));
+    job.d_bits_i = d_bits_i;
+    job.d_bits_q = d_bits_q;
+    job.n = n;
+    job.params = *h_params;
+    job.d_data = d_data;
+    job.d_addr = d_addr;
+    job.cap = cap;
+    const int rc = pm_slice_batch(ctx, &job, 1);
+    *h_count = job.count;
+    return rc;
 }
 
 int pm_slicer_stats(pm_ctx *ctx, int32_t *iterations, int32_t *chunk_len, int64_t *chunks)

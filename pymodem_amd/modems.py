@@ -26,6 +26,10 @@ from .string_ops import check_boolean
 class _DeviceStage:
     """Lazy device state: nothing touches HIP until demod() runs (the reference forks after construction)."""
     _ctx = None
+    scratch_key = None      # chains run one after another on one stream may share work buffers: same key, same storage
+
+    def _key(self):
+        return self.scratch_key if self.scratch_key is not None else id(self)
 
     def _context(self):
         if self._ctx is None:
@@ -61,7 +65,7 @@ class _DeviceStage:
         m = len(taps)
         if x.n < m:
             raise ValueError(f"input of {x.n} samples is shorter than the {m}-tap filter {taps_name}")
-        y = ctx.scratch((id(self), tag or taps_name), x.n - m + 1, np.float64)
+        y = ctx.scratch((self._key(), tag or taps_name), x.n - m + 1, np.float64)
         fn = lib().pm_fir_valid_i16 if is_i16 else lib().pm_fir_valid_f64
         check(fn(ctx.handle, x.ptr, x.n, self._const(taps_name, taps).ptr, m, y.ptr, flags))
         return y
@@ -179,14 +183,25 @@ class AFSKModem(_DeviceStage):
                                     self.correlator_span, self.correlator_offset)
         self.output_sample_rate = self.output_oversample * self.sample_rate
 
-    def demod(self, input_audio, device_out=False):   # afsk.py:148-167
+    def front_end(self, input_audio):
+        """Input band-pass only (afsk.py:151).  Chains with the same BPF (every chain of afsk_1200_ax25_super_opt.json)
+        can share its output: chain_execute.process_chains_device does."""
         x, is_i16 = self._input(input_audio)
-        ctx = self._ctx
-        a = self._fir(x, is_i16, "input_bpf", self.input_bpf)
+        return self._fir(x, is_i16, "input_bpf", self.input_bpf)
+
+    def front_end_key(self):
+        return ("afsk", float(self.sample_rate), self.input_bpf.tobytes())
+
+    def demod(self, input_audio, device_out=False):   # afsk.py:148-167
+        return self.back_end(self.front_end(input_audio), device_out)
+
+    def back_end(self, a, device_out=False):
+        """Correlators + output low-pass on an already band-passed stream (afsk.py:153-166)."""
+        ctx = self._context()
         m = len(self.mark_correlator_i)
         if a.n < m:
             raise ValueError("input shorter than the correlators")
-        c = ctx.scratch((id(self), "corr"), a.n - m + 1, np.float64)
+        c = ctx.scratch((self._key(), "corr"), a.n - m + 1, np.float64)
         check(lib().pm_afsk_correlate(ctx.handle, a.ptr, a.n, self._const("mi", self.mark_correlator_i).ptr,
                                       self._const("mq", self.mark_correlator_q).ptr, self._const("si", self.space_correlator_i).ptr,
                                       self._const("sq", self.space_correlator_q).ptr, m, c.ptr))
@@ -288,7 +303,7 @@ class BPSKModem(_DeviceStage):
         ctx = self._ctx
         a = self._fir(x, is_i16, "input_bpf", self.input_bpf)
         self._agc(a)
-        d = ctx.scratch((id(self), "loop"), a.n, np.float64)
+        d = ctx.scratch((self._key(), "loop"), a.n, np.float64)
         check(lib().pm_costas_bpsk(ctx.handle, ctypes.byref(self._loop), 1, self._const("wavetable", self.wavetable).ptr,
                                    a.ptr, 0, a.n, d.ptr, a.n))
         y = self._fir(d, False, "rrc", self.rrc_taps)
@@ -363,15 +378,25 @@ class MPSKModem(_DeviceStage):
         real = a.view(self.hilbert_delay, imag.n)
         return real, imag
 
+    def front_end_key(self):
+        a = self.AGC
+        return ("mpsk", float(self.sample_rate), self.input_bpf.tobytes(), self.hilbert_taps.tobytes(),
+                (a.attack_rate, a.decay_rate, a.sustain_time, a.target_amplitude))
+
     def demod(self, input_audio, device_out=False):   # psk.py:705-773
         real, imag = self.front_end(input_audio)
         ctx = self._ctx
         n = imag.n
-        i_mix = ctx.scratch((id(self), "i_mix"), n, np.float64)
-        q_mix = ctx.scratch((id(self), "q_mix"), n, np.float64)
+        i_mix = ctx.scratch((self._key(), "i_mix"), n, np.float64)
+        q_mix = ctx.scratch((self._key(), "q_mix"), n, np.float64)
         check(lib().pm_mpsk_loop(ctx.handle, ctypes.byref(self._loop), 1, self._const("wavetable", self.wavetable).ptr,
                                  self._const("pd", self.phase_error_table.reshape(-1), np.int32).ptr,
                                  real.ptr, imag.ptr, 0, n, i_mix.ptr, q_mix.ptr, n))
+        return self.back_end(i_mix, q_mix, device_out)
+
+    def back_end(self, i_mix, q_mix, device_out=False):
+        """Matched filter on both arms of the carrier-loop output (psk.py:750-751)."""
+        self._context()
         i_out = self._fir(i_mix, False, "rrc", self.rrc_taps, tag="i_out")
         q_out = self._fir(q_mix, False, "rrc", self.rrc_taps, tag="q_out")
         if device_out:
@@ -429,7 +454,7 @@ class AFSKPLLModem(_DeviceStage):
         ctx = self._ctx
         a = self._fir(x, is_i16, "input_bpf", self.input_bpf)
         self._agc(a)
-        d = ctx.scratch((id(self), "loop"), a.n, np.float64)
+        d = ctx.scratch((self._key(), "loop"), a.n, np.float64)
         check(lib().pm_pll_afsk(ctx.handle, ctypes.byref(self._loop), 1, self._const("wavetable", self.wavetable).ptr,
                                 a.ptr, 0, a.n, d.ptr, a.n))
         y = self._fir(d, False, "output_lpf", self.output_lpf)

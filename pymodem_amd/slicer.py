@@ -5,7 +5,7 @@ import ctypes
 
 import numpy as np
 
-from ._native import SlicerParams, check, lib
+from ._native import SliceJob, SlicerParams, check, lib
 from .data_classes import AddressedArray, DeviceIQ, IQData
 from .device import Context, DeviceBuffer
 
@@ -50,21 +50,48 @@ class _SlicerBase:
         check(lib().pm_signs_f64(ctx.handle, x.ptr, x.n, bits.ptr))
         return bits, x.n
 
+    def sign_bitmaps(self, samples):
+        """Stage 1 of slice(): the (x >= 0) bitmap(s) of the demodulated stream -> (bits_i, bits_q | None, n)."""
+        ctx = self._ctx = self._ctx or Context.default()
+        if isinstance(samples, (IQData, DeviceIQ)):
+            bi, n = self._bits(ctx, samples.i_data, "bits_i")
+            bq, nq = self._bits(ctx, samples.q_data, "bits_q")
+            assert n == nq
+            return bi, bq, n
+        bi, n = self._bits(ctx, samples, "bits_i")
+        return bi, None, n
+
     def _run(self, ctx, bits_i, bits_q, n):
-        cap = n * self.bits_per_symbol // 8 + 4            # at most one symbol per sample
-        data = ctx.scratch((id(self), "bytes"), cap + 4, np.uint8)
-        addr = ctx.scratch((id(self), "addr"), cap, np.int64)
-        count = ctypes.c_int64()
-        p = self._params()
-        if bits_q is None:
-            check(lib().pm_slice_binary(ctx.handle, bits_i.ptr, n, ctypes.byref(p), data.ptr, addr.ptr, cap, ctypes.byref(count)))
-        else:
-            check(lib().pm_slice_quadrature(ctx.handle, bits_i.ptr, bits_q.ptr, n, ctypes.byref(p), data.ptr, addr.ptr, cap,
-                                            ctypes.byref(count)))
+        return slice_batch([self], [(bits_i, bits_q, n)])[0]
+
+
+def slice_batch(slicers, bitmaps):
+    """Stage 2 of slice() for many independent streams in ONE pm_slice_batch call (shared iteration launches).
+    bitmaps[k] = (bits_i, bits_q | None, n) from slicers[k].sign_bitmaps().  Returns one AddressedArray per stream."""
+    ctx = slicers[0]._ctx or Context.default()
+    out = [None] * len(slicers)
+    for base in range(0, len(slicers), 64):
+        group = list(range(base, min(base + 64, len(slicers))))
+        jobs = (SliceJob * len(group))()
+        bufs = []
+        for j, k in enumerate(group):
+            sl, (bi, bq, n) = slicers[k], bitmaps[k]
+            cap = n * sl.bits_per_symbol // 8 + 4          # at most one symbol per sample
+            data = ctx.scratch((id(sl), "bytes"), cap + 4, np.uint8)
+            addr = ctx.scratch((id(sl), "addr"), cap, np.int64)
+            bufs.append((data, addr))
+            jobs[j].d_bits_i = bi.ptr if bi is not None else None
+            jobs[j].d_bits_q = bq.ptr if bq is not None else None
+            jobs[j].n = n
+            jobs[j].params = sl._params()
+            jobs[j].d_data, jobs[j].d_addr, jobs[j].cap = data.ptr, addr.ptr, cap
+        check(lib().pm_slice_batch(ctx.handle, jobs, len(group)))
         it, cl, nc = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
         lib().pm_slicer_stats(ctx.handle, ctypes.byref(it), ctypes.byref(cl), ctypes.byref(nc))
-        self.last_stats = {"iterations": it.value, "chunk_len": cl.value, "chunks": nc.value}
-        return AddressedArray(data.download(count.value), addr.download(count.value))
+        for j, k in enumerate(group):
+            slicers[k].last_stats = {"iterations": it.value, "chunk_len": cl.value, "chunks": nc.value}
+            out[k] = AddressedArray(bufs[j][0].download(jobs[j].count), bufs[j][1].download(jobs[j].count))
+    return out
 
 
 class BinarySlicer(_SlicerBase):
