@@ -301,8 +301,12 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
     }
     if (max_n == 0) return PM_OK;
 
-    // chunk length: a multiple of 64 samples; PM_SLICER_CHUNK_WORDS overrides (tuning)
-    int64_t lc_words = 32;
+    // Chunk length (a multiple of 64 samples).  A lone wave is issue bound, so an iteration costs (waves per SIMD) x L x
+    // t_step while the number of iterations falls as 1/L: the best L puts about one wave on each of the 1024 SIMDs
+    // (65536 lanes), but never below 1024 samples.  PM_SLICER_CHUNK_WORDS overrides (tuning).
+    int64_t all_words = 0;
+    for (int j = 0; j < njobs; ++j) all_words += pm_cdiv(jobs[j].n, 64);
+    int64_t lc_words = std::max<int64_t>(16, std::min<int64_t>(pm_cdiv(all_words, 65536), 1024));
     if (const char *e = getenv("PM_SLICER_CHUNK_WORDS")) lc_words = std::max(1, atoi(e));
     std::vector<JobDev> jd;
     jd.reserve(njobs);

@@ -1,0 +1,94 @@
+"""Multi-GPU layer on CPU: world size 2, gloo.  Chains are sharded over ranks, every rank contributes its packets, rank 0
+de-dups in config order.  Uses the reference's packets of the bundled recording (afsk_300.json: 49 good / 6 bad)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+WORKER = r'''
+import json, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from pymodem_amd import dist as pdist
+from pymodem_amd.packet_meta import PacketMeta
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+g = np.load(os.path.join(sys.argv[1], "tests", "golden", "wav_chains.npz"))
+names = json.load(open(os.path.join(sys.argv[1], "tests", "golden", "wav_chains_summary.json")))["afsk_300"]["chains"]
+mine = pdist.shard_chains(len(names), rank, world)
+pk = {}
+for c in mine:
+    lens, data, addr, corr = g[f"afsk_300__c{c}_pkt_len"], g[f"afsk_300__c{c}_pkt_data"], g[f"afsk_300__c{c}_pkt_addr"], g[f"afsk_300__c{c}_pkt_corrected"]
+    pos, lst = 0, []
+    for k in range(len(lens)):
+        p = PacketMeta(); p.data = data[pos:pos + lens[k]].tolist(); pos += int(lens[k])
+        p.streamaddress, p.BytesCorrected, p.SourceDecoder = int(addr[k]), int(corr[k]), names[c]
+        lst.append(p)
+    pk[c] = lst
+for _ in range(2):                       # twice: the exchange must be repeatable
+    got = pdist.gather_packets(pk, names)
+if rank == 0:
+    arr = pdist.correlate(got, len(names), 8000 / 40)
+    u = arr.unique_packet_array
+    print("RESULT " + json.dumps({"good": arr.CountGood(), "bad": arr.CountBad(), "addr": [p.streamaddress for p in u],
+          "dec": [list(p.CorrelatedDecoders) for p in u], "per_chain": {str(c): len(v) for c, v in got.items()}}))
+else:
+    assert got is None
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_shard_chains_partitions():
+    from pymodem_amd.dist import shard_chains
+    for n in [1, 5, 8, 64]:
+        for w in [1, 2, 3, 8]:
+            parts = [shard_chains(n, r, w) for r in range(w)]
+            assert sorted(c for p in parts for c in p) == list(range(n))
+
+
+def test_record_round_trip(golden):
+    from pymodem_amd import dist as pdist
+    from pymodem_amd.packet_meta import PacketMeta
+    rng = np.random.default_rng(3)
+    pk = {}
+    for c in [4, 0, 2]:
+        lst = []
+        for _ in range(int(rng.integers(0, 5))):
+            p = PacketMeta()
+            p.data = rng.integers(0, 256, int(rng.integers(2, 1100))).tolist()
+            p.streamaddress, p.BytesCorrected = int(rng.integers(0, 2 ** 40)), int(rng.integers(0, 9))
+            lst.append(p)
+        pk[c] = lst
+    back = pdist.unpack_packets(pdist.pack_packets(pk), [f"chain{c}" for c in range(5)])
+    for c, lst in pk.items():
+        assert [(p.streamaddress, p.data, p.BytesCorrected) for p in lst] == \
+               [(p.streamaddress, p.data, p.BytesCorrected) for p in back.get(c, [])]
+        assert all(p.SourceDecoder == f"chain{c}" for p in back.get(c, []))
+
+
+def test_two_rank_gather_and_dedup(tmp_path, golden):
+    g = golden("wav_chains")
+    summ = json.load(open(os.path.join(GOLDEN, "wav_chains_summary.json")))["afsk_300"]
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = 29500 + os.getpid() % 2000
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+    line = [l for l in outs[0][0].splitlines() if l.startswith("RESULT ")][0]
+    res = json.loads(line[7:])
+    assert res["good"] == summ["good"] == 49 and res["bad"] == summ["bad"] == 6
+    assert res["addr"] == g["afsk_300__uniq_addr"].tolist()
+    assert res["dec"] == summ["uniq_decoders"]           # config order, although ranks 0 and 1 interleave the chains
+    assert res["per_chain"] == {"0": 5, "2": 48, "3": 47}
