@@ -45,23 +45,38 @@ __global__ __launch_bounds__(kThreads) void fir_valid_kernel(const InT *__restri
     double acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.0;
-    double w[R + 7];
     const int base = t * R;
+    // Window registers: two sets of R that alternate between "carry" (last R-1 values of the previous block) and "new".
+    // With base = t*R the padded LDS index of input p = base + k is t*(R+1) + k + k/R: the lane part is constant and the
+    // tap part is the same for every lane, so each read is lane_base + compile-time offset and only lp advances per block.
+    static_assert(R == 8, "the block schedule below is written for 8 outputs per thread and 8 taps per block");
+    double s0[R], s1[R];
+    const double *lp = xs + t * (R + 1);
 #pragma unroll
-    for (int j = 0; j < R - 1; ++j) w[j] = xs[slot<R>(base + j)];
+    for (int j = 0; j < R - 1; ++j) s1[j + 1] = lp[j];
+    const double *hp = h + (m - 8);          // hp[7 - b] = h[m - 1 - (i0 + b)]: eight contiguous taps per block
     int i0 = 0;
-    for (; i0 + 8 <= m; i0 += 8) {
-#pragma unroll
-        for (int b = 0; b < 8; ++b) w[R - 1 + b] = xs[slot<R>(base + i0 + R - 1 + b)];
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const double g = h[m - 1 - (i0 + b)];
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = __builtin_fma(g, w[r + b], acc[r]);
-        }
-#pragma unroll
-        for (int j = 0; j < R - 1; ++j) w[j] = w[j + 8];
+#define PM_FIR_BLOCK(CARRY, NEW)                                                                   \
+    {                                                                                              \
+        NEW[0] = lp[7];                                                                            \
+        _Pragma("unroll") for (int b = 1; b < 8; ++b) NEW[b] = lp[8 + b];                          \
+        _Pragma("unroll") for (int b = 0; b < 8; ++b) {                                            \
+            const double g = hp[7 - b];                                                            \
+            _Pragma("unroll") for (int r = 0; r < R; ++r)                                          \
+                acc[r] = __builtin_fma(g, (r + b < 7) ? CARRY[r + b + 1] : NEW[r + b - 7], acc[r]); \
+        }                                                                                          \
+        lp += R + 1;                                                                               \
+        hp -= 8;                                                                                   \
     }
+    for (; i0 + 16 <= m; i0 += 16) {
+        PM_FIR_BLOCK(s1, s0)
+        PM_FIR_BLOCK(s0, s1)
+    }
+    if (i0 + 8 <= m) {
+        PM_FIR_BLOCK(s1, s0)
+        i0 += 8;
+    }
+#undef PM_FIR_BLOCK
     for (; i0 < m; ++i0) {       // m % 8 leftover taps, straight from LDS
         const double g = h[m - 1 - i0];
 #pragma unroll
@@ -100,30 +115,40 @@ __global__ __launch_bounds__(kThreads) void afsk_correlate_kernel(const double *
     double a[R], b[R], c[R], d[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) a[r] = b[r] = c[r] = d[r] = 0.0;
-    double w[R + 3];
     const int base = t * R;
+    static_assert(R == 4, "the block schedule below is written for 4 outputs per thread and 4 taps per block");
+    double s0[R], s1[R];                     // alternating carry / new window sets, as in fir_valid_kernel
+    const double *lp = xs + t * (R + 1);
 #pragma unroll
-    for (int j = 0; j < R - 1; ++j) w[j] = xs[slot<R>(base + j)];
+    for (int j = 0; j < R - 1; ++j) s1[j + 1] = lp[j];
+    const double *pa = mi + (m - 4), *pb = mq + (m - 4), *pc = si + (m - 4), *pd = sq + (m - 4);
     int i0 = 0;
-    for (; i0 + 4 <= m; i0 += 4) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) w[R - 1 + q] = xs[slot<R>(base + i0 + R - 1 + q)];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = m - 1 - (i0 + q);
-            const double ga = mi[k], gb = mq[k], gc = si[k], gd = sq[k];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const double v = w[r + q];
-                a[r] = __builtin_fma(ga, v, a[r]);
-                b[r] = __builtin_fma(gb, v, b[r]);
-                c[r] = __builtin_fma(gc, v, c[r]);
-                d[r] = __builtin_fma(gd, v, d[r]);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < R - 1; ++j) w[j] = w[j + 4];
+#define PM_CORR_BLOCK(CARRY, NEW)                                                                  \
+    {                                                                                              \
+        NEW[0] = lp[3];                                                                            \
+        _Pragma("unroll") for (int q = 1; q < 4; ++q) NEW[q] = lp[4 + q];                          \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                            \
+            const double ga = pa[3 - q], gb = pb[3 - q], gc = pc[3 - q], gd = pd[3 - q];           \
+            _Pragma("unroll") for (int r = 0; r < R; ++r) {                                        \
+                const double v = (r + q < 3) ? CARRY[r + q + 1] : NEW[r + q - 3];                  \
+                a[r] = __builtin_fma(ga, v, a[r]);                                                 \
+                b[r] = __builtin_fma(gb, v, b[r]);                                                 \
+                c[r] = __builtin_fma(gc, v, c[r]);                                                 \
+                d[r] = __builtin_fma(gd, v, d[r]);                                                 \
+            }                                                                                      \
+        }                                                                                          \
+        lp += R + 1;                                                                               \
+        pa -= 4; pb -= 4; pc -= 4; pd -= 4;                                                        \
     }
+    for (; i0 + 8 <= m; i0 += 8) {
+        PM_CORR_BLOCK(s1, s0)
+        PM_CORR_BLOCK(s0, s1)
+    }
+    if (i0 + 4 <= m) {
+        PM_CORR_BLOCK(s1, s0)
+        i0 += 4;
+    }
+#undef PM_CORR_BLOCK
     for (; i0 < m; ++i0) {
         const int k = m - 1 - i0;
         const double ga = mi[k], gb = mq[k], gc = si[k], gd = sq[k];

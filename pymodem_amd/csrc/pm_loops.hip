@@ -26,17 +26,25 @@ struct LoopRegs {
     double phase, control, sine, cosine, x0, x1, y0, integral, proportional;
 };
 
+// The bodies below are written branch-free: a lone wave pays ~5 cycles per instruction and far more per taken branch, and
+// every statement is on the loop-carried path.  Each select reproduces the reference's `if`/`while` exactly:
+//   while (p >= 2pi) p -= 2pi  ==  one conditional subtract, then (never in practice) the loop for what is left.
 __device__ __forceinline__ void nco_update(LoopRegs &L, const double *tab)
 {
-    L.phase += L.phase_scaling * (L.set_frequency + L.control);          // nco.py:35
-    while (L.phase >= kTwoPi) L.phase = L.phase - kTwoPi;                // nco.py:36-37
-    while (L.phase < 0) L.phase = L.phase + kTwoPi;                      // nco.py:38-39
-    const int idx = (int)(L.phase * L.index_scaling);                    // nco.py:40, int() truncates
-    if (idx >= 0 && idx < 256) L.sine = tab[idx];                        // nco.py:41-45 (IndexError keeps the old value)
-    int cidx = idx + 64;                                                 // nco.py:46-50
-    while (cidx >= 256) cidx -= 256;
-    while (cidx < 0) cidx += 256;
-    L.cosine = tab[cidx];
+    double ph = L.phase + L.phase_scaling * (L.set_frequency + L.control);   // nco.py:35
+    const double down = ph - kTwoPi;
+    ph = ph >= kTwoPi ? down : ph;                                          // nco.py:36-37, first trip
+    const double up = ph + kTwoPi;
+    ph = ph < 0 ? up : ph;                                                  // nco.py:38-39, first trip
+    if (__builtin_expect(!(ph >= 0 && ph < kTwoPi), 0)) {                   // |control| beyond one turn per sample
+        while (ph >= kTwoPi) ph = ph - kTwoPi;
+        while (ph < 0) ph = ph + kTwoPi;
+    }
+    L.phase = ph;
+    const int idx = (int)(ph * L.index_scaling);                            // nco.py:40, int() truncates; 0..256
+    const double s_new = tab[min(idx, 255) & 255];
+    L.sine = idx < 256 ? s_new : L.sine;                                    // nco.py:41-45: index 256 keeps the old value
+    L.cosine = tab[(idx + 64) & 255];                                       // nco.py:46-51
 }
 
 __device__ __forceinline__ double iir_update(LoopRegs &L, double sample)
@@ -53,26 +61,28 @@ __device__ __forceinline__ double iir_update(LoopRegs &L, double sample)
 
 __device__ __forceinline__ double pi_update(LoopRegs &L, double sample)
 {
-    L.proportional = L.gain * L.p_rate * sample;                         // pi_control.py:26
-    L.integral += L.gain * (L.i_rate * sample);                          // pi_control.py:27
-    if (L.integral > L.i_limit) L.integral = L.i_limit;
-    if (L.integral < -L.i_limit) L.integral = -L.i_limit;
-    return L.proportional + L.integral;                                  // pi_control.py:32
+    L.proportional = L.gain * L.p_rate * sample;                         // pi_control.py:26, (gain*p_rate)*sample
+    double in = L.integral + L.gain * (L.i_rate * sample);               // pi_control.py:27
+    in = in > L.i_limit ? L.i_limit : in;                                // pi_control.py:28-31
+    in = in < -L.i_limit ? -L.i_limit : in;
+    L.integral = in;
+    return L.proportional + in;                                          // pi_control.py:32
 }
 
 __device__ __forceinline__ int pd_lookup(const int32_t *tbl, double re, double im)
 {
     // phase_detector.py:124-149, granularity 64: floor(x*64*0.5), clip to +-63, quadrant fold
     double fr = floor(re * 64 * 0.5), fi = floor(im * 64 * 0.5);
-    fr = fr > 1e9 ? 1e9 : (fr < -1e9 ? -1e9 : fr);
-    fi = fi > 1e9 ? 1e9 : (fi < -1e9 ? -1e9 : fi);
+    fr = fmin(fmax(fr, -1e9), 1e9);
+    fi = fmin(fmax(fi, -1e9), 1e9);
     int r = (int)fr, i = (int)fi;
-    if (r >= 64) r = 63;
-    if (i >= 64) i = 63;
-    if (r <= -64) r = -63;
-    if (i <= -64) i = -63;
-    if (r >= 0) return i >= 0 ? tbl[r * 64 + i] : tbl[(-i) * 64 + r];
-    return i >= 0 ? tbl[i * 64 + (-r)] : tbl[(-r) * 64 + (-i)];
+    r = min(max(r, -63), 63);                       // >= 64 -> 63, <= -64 -> -63
+    i = min(max(i, -63), 63);
+    const int ar = abs(r), ai = abs(i);
+    // Q1 T[r][i] | Q4 T[-i][r] | Q2 T[i][-r] | Q3 T[-r][-i]
+    const bool swap = (r >= 0) != (i >= 0);
+    const int row = swap ? ai : ar, col = swap ? ar : ai;
+    return tbl[row * 64 + col];
 }
 
 enum { kCostas = 0, kPll = 1, kMpsk = 2 };
@@ -261,16 +271,14 @@ __global__ __launch_bounds__(64) void agc_kernel(double *__restrict__ buf, int64
         if (lane == 0) {
             for (int k = 0; k < len; ++k) {
                 const double cmp = fabs(xs[k]);
-                if (cmp > env) {                        // agc.py:28-32
-                    env += att;
-                    if (env > cmp) env = cmp;
-                    sustain = 0.0;
-                }
-                if (sustain >= P.sustain_time) {        // agc.py:33-36
-                    env -= dec;
-                    if (env < 0) env = 0;
-                }
-                sustain += P.sustain_inc;               // agc.py:37
+                const bool attack = cmp > env;                          // agc.py:28-32
+                const double up = fmin(env + att, cmp);                 // env += att; if env > cmp: env = cmp
+                env = attack ? up : env;
+                sustain = attack ? 0.0 : sustain;
+                const bool decay = sustain >= P.sustain_time;           // agc.py:33-36
+                const double dn = env - dec;
+                env = decay ? (dn < 0 ? 0.0 : dn) : env;
+                sustain += P.sustain_inc;                               // agc.py:37
                 es[k] = env;
             }
         }
