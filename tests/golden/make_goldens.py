@@ -424,6 +424,59 @@ def gen_wav_chains():
     print("wav_chains.npz:", len(d), "arrays;", {k: (v["good"], v["bad"]) for k, v in summary.items() if isinstance(v, dict)})
 
 
+SIGNAL_CASES = [   # (siggen mode, config, rate, packets, noise sigma, seed)
+    ("afsk1200_ax25", "afsk_1200.json", 48000, 5, 2500.0, 11),
+    ("afsk1200_il2p", "afsk_1200.json", 48000, 5, 9000.0, 12),       # RS corrections happen at this noise level
+    ("afsk1200_ax25", "afsk_1200_ax25_super_opt.json", 44100, 4, 2000.0, 13),
+    ("fsk9600_ax25", "fsk_9600.json", 48000, 5, 1500.0, 14),
+    ("fsk9600_il2p", "fsk_9600.json", 48000, 5, 5500.0, 12),
+    ("bpsk300_il2p", "bpsk_300.json", 48000, 2, 3000.0, 16),
+    ("bpsk1200_il2p", "bpsk_1200.json", 48000, 5, 11000.0, 12),      # one packet fails its CRC here
+    ("qpsk2400_il2p", "qpsk_2400.json", 48000, 4, 6500.0, 18),
+    ("qpsk600_il2p", "qpsk_600.json", 48000, 2, 1500.0, 19),
+    ("qpsk3600_il2p", "qpsk_3600.json", 48000, 4, 800.0, 20),
+]
+
+
+def gen_signal_chains():
+    """Packet-bearing recordings from the build's own generator (pymodem_amd/siggen.py; the reference has no modulator
+    and 11 of its 12 recordings are missing), decoded by the REFERENCE: audio and every stage output are stored."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from pymodem_amd import siggen
+    d = {}
+    summary = {}
+    for mode, cfgname, rate, npk, sigma, seed in SIGNAL_CASES:
+        audio, frames = siggen.recording(mode, rate, packets=npk, seed=seed, noise_sigma=sigma, payload_len=(16, 70))
+        case = f"{mode}__{cfgname[:-5]}__{rate}"
+        d[case + "__audio"] = audio
+        lines = [l for l in load_config(cfgname) if l.get("object_type") == "demod_chain"]
+        results = PacketMetaArray()
+        info = {"sent": len(frames), "chains": []}
+        for ci, line in enumerate(lines):
+            chain = build_chain(rate, line)
+            pkts = run_chain(chain, audio, d, f"{case}__c{ci}", keep_demod=True, decim=97)
+            results.add(pkts)
+            for p in pkts:
+                p.CalcCRC()
+                p.Validate()
+            good = [p for p in pkts if p.ValidCRC and p.ValidHeader]
+            info["chains"].append({"packets": len(pkts), "good": len(good),
+                                   "match": sum(1 for p in good if [int(b) for b in p.data[:-2]] in frames),
+                                   "corrected": int(sum(p.BytesCorrected for p in pkts))})
+        results.CalcCRCs()
+        results.Correlate(address_distance=rate / 40)
+        u = results.unique_packet_array
+        d[case + "__uniq_addr"] = np.array([p.streamaddress for p in u], dtype=np.int64)
+        d[case + "__uniq_crc"] = np.array([p.CalculatedCRC for p in u], dtype=np.int64)
+        info["good"], info["bad"] = int(results.CountGood()), int(results.CountBad())
+        info["uniq_decoders"] = [list(p.CorrelatedDecoders) for p in u]
+        summary[case] = info
+        print(case, info["good"], info["bad"], [(c["packets"], c["good"], c["match"], c["corrected"]) for c in info["chains"]], flush=True)
+    np.savez_compressed(os.path.join(OUT, "signal_chains.npz"), **d)
+    with open(os.path.join(OUT, "signal_chains_summary.json"), "w") as f:
+        json.dump({"cases": [list(c) for c in SIGNAL_CASES], "results": summary}, f, indent=1)
+
+
 def copy_data_files():
     """Data files (not source): the bundled recording and the JSON-lines configs.  MIT, see the
     reference's LICENSE.  They are inputs of the parity tests; the GPU box only has /root/repo."""
@@ -434,7 +487,7 @@ def copy_data_files():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["taps", "prims", "synth", "wav", "copy"]
+    which = sys.argv[1:] or ["taps", "prims", "synth", "wav", "signal", "copy"]
     if "taps" in which:
         gen_taps()
     if "prims" in which:
@@ -443,5 +496,7 @@ if __name__ == "__main__":
         gen_synth_chains()
     if "wav" in which:
         gen_wav_chains()
+    if "signal" in which:
+        gen_signal_chains()
     if "copy" in which:
         copy_data_files()
