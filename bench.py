@@ -93,6 +93,32 @@ ALG_BYTES = {"fir_i16": 10.0, "fir_f64": 16.0, "afsk_correlate": 16.0, "signs": 
              "slice_emit": 1.0 / 8, "agc": 16.0, "loop": 16.0}
 
 
+SIGNAL_MODE = {"afsk_1200_super_opt": "afsk1200_ax25", "fsk_9600": "fsk9600_il2p", "bpsk_300": "bpsk300_il2p", "qpsk_2400": "qpsk2400_il2p"}
+BUFFER_DESC = {"noise": "default_rng(1234).standard_normal(n)*8000 -> int16",
+               "signal": "pymodem_amd.siggen packets of the workload's mode (seed 1234, amplitude 8000) + AWGN sigma 2000, one minute tiled to the recording length"}
+
+
+def make_buffer(args, n=None):
+    """The recording every chain of every rank processes (same seed on every rank)."""
+    n = args.samples if n is None else n
+    if args.buffer == "noise":
+        return synth_buffer(n)
+    from pymodem_amd import siggen
+    minute = min(n, 60 * args.rate)
+    mode = SIGNAL_MODE[args.workload]
+    per_packet = {"afsk1200_ax25": 0.60, "fsk9600_il2p": 0.28, "bpsk300_il2p": 2.5, "qpsk2400_il2p": 0.45}[mode]   # lower bound, seconds incl. gap
+    audio = np.zeros(0, np.int16)
+    seed = 1234
+    while len(audio) < minute:                    # noise everywhere, no digital silence: generate past the minute, then cut
+        part, _ = siggen.recording(mode, args.rate, packets=max(1, int(minute / args.rate / per_packet)), seed=seed, noise_sigma=2000.0,
+                                   payload_len=(20, 80))
+        audio = np.concatenate([audio, part])
+        seed += 1
+    audio = audio[:minute]
+    reps = -(-n // len(audio))
+    return np.tile(audio, reps)[:n]
+
+
 def synth_buffer(n, seed=1234):
     """BASELINE.md throughput buffer: default_rng(1234).standard_normal(n)*8000 -> int16."""
     x = np.random.default_rng(seed).standard_normal(n) * 8000.0
@@ -109,6 +135,10 @@ def main():
     ap.add_argument("--chains-per-gpu", type=int, default=0)
     ap.add_argument("--rate", type=int, default=48000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
+    ap.add_argument("--buffer", default="signal", choices=["signal", "noise"],
+                    help="signal: seeded packet-bearing recording of the workload's mode + AWGN (pymodem_amd.siggen), tiled to --samples; "
+                         "noise: BASELINE.md's default_rng(1234) noise buffer")
     ap.add_argument("--cpu-sample", type=int, default=0, help="samples for the CPU baseline leg (0 = auto)")
     args = ap.parse_args()
 
@@ -121,15 +151,23 @@ def main():
         args.gpus = world
 
     import torch
-    torch.cuda.set_device(local)
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        sys.exit("bench.py needs a GPU")
+    dev_index = local % ndev                      # more ranks than GPUs only happens in the gloo rehearsal
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
+    coll_device = f"cuda:{dev_index}" if (world > 1 and args.backend == "nccl") else None
 
     import pymodem_amd
     from pymodem_amd import chain_builder as cb, chain_execute as ce, dist as pdist
-    ctx = pymodem_amd.Context.default(local)      # the stage objects use the same per-process default context
+    ctx = pymodem_amd.Context.default(dev_index)  # the stage objects use the same per-process default context
 
     factory, default_cpg, desc = WORKLOADS[args.workload]
     cpg = args.chains_per_gpu or default_cpg
@@ -138,10 +176,12 @@ def main():
     lines = {c: factory(c) for c in range(nchains)}
     names = [lines[c]["object_name"] for c in range(nchains)]
 
-    audio = synth_buffer(args.samples)
+    audio = make_buffer(args)
     d_audio = ctx.upload(audio)                                   # resident in HBM before the timed region
     ctx.sync()
     modems = {c: cb.ModemConfigurator(args.rate, lines[c]["modem"]) for c in my}     # tap design once (host)
+
+    chains_ref = []
 
     def step():
         chains = []
@@ -152,11 +192,10 @@ def main():
             srate = getattr(modem, "output_sample_rate", args.rate)
             chains.append([line["object_name"], modem, cb.SlicerConfigurator(srate, line["slicer"]),
                            cb.StreamConfigurator(line["stream"]), cb.CodecConfigurator(line["codec"], line["object_name"])])
-        pk = dict(zip(my, ce.process_chains_device(chains, d_audio)))
-        gathered = pdist.gather_packets(pk, names, device=f"cuda:{local}" if world > 1 else None)
-        if gathered is not None:
-            return pdist.correlate(gathered, nchains, args.rate / 40)
-        return None
+        rows = ce.process_chains_table(chains, d_audio, chain_ids=my)
+        chains_ref[:] = chains
+        table = pdist.gather_rows(rows, nchains, names, device=coll_device)           # the one exchange step
+        return table.correlate(args.rate / 40) if table is not None else None         # rank 0: cross-chain de-dup
 
     def fence():
         ctx.sync()
@@ -177,7 +216,7 @@ def main():
     prof = ctx.profile_read()
     ctx.profile(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device or "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -196,12 +235,13 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "chains_per_gpu": cpg, "chains_total": nchains,
                        "samples_per_recording": args.samples, "sample_rate": args.rate,
-                       "buffer": "default_rng(1234).standard_normal(n)*8000 -> int16, resident in HBM",
+                       "buffer": BUFFER_DESC[args.buffer] + ", resident in HBM",
                        "parallelism": f"chains sharded {cpg}/GPU x {world} GPU, packet gather to rank 0"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "avg_kernel_ms": round(avg_ms, 5), "launches": dom_n, "algorithmic_bytes_per_launch": alg_bytes},
             "gpu_kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]},
+            "slicer": chains_ref[0][2].last_stats if chains_ref else None,
             "packets": {"unique_good": result.CountGood() if result is not None else None,
                         "bad": result.CountBad() if result is not None else None},
         }
@@ -218,7 +258,7 @@ def cpu_baseline(args, lines):
     workload, one core.  A reported baseline, not the optimisation target."""
     from oracle import oracle as O
     n = args.cpu_sample or min(args.samples, 9_600_000)          # 200 s of audio per chain keeps numpy's buffers modest
-    audio = synth_buffer(args.samples)[:n]
+    audio = make_buffer(args)[:n]
     t0 = time.perf_counter()
     done = 0
     while True:                                                  # whole chains until ~12 s of CPU work are spent

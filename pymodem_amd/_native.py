@@ -53,6 +53,16 @@ class Packet(ctypes.Structure):
                 ("data", ctypes.c_uint8 * PKT_MAX)]
 
 
+def packet_dtype():
+    """NumPy view of pm_packet (same layout as the ctypes Packet: 40-byte header + PKT_MAX data bytes)."""
+    import numpy as np
+    dt = np.dtype([("streamaddress", "<i8"), ("len", "<i4"), ("bytes_corrected", "<i4"), ("calculated_crc", "<i4"), ("carried_crc", "<i4"),
+                   ("valid_crc", "<i4"), ("valid_header", "<i4"), ("source_decoder", "<i4"), ("correlated_count", "<i4"),
+                   ("data", "u1", (PKT_MAX,))])
+    assert dt.itemsize == ctypes.sizeof(Packet)
+    return dt
+
+
 _vp, _i64, _int, _dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double
 _SIGS = {
     "pm_version": ([], _int),
@@ -87,10 +97,9 @@ _SIGS = {
     "pm_codec_create": ([_int, _int, _int, _int, _int, _int, ctypes.POINTER(_vp)], _int),
     "pm_codec_destroy": ([_vp], _int),
     "pm_codec_decode": ([_vp, _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
-    "pm_codec_fetch": ([_vp, ctypes.POINTER(Packet), _i64, ctypes.POINTER(_i64)], _int),
+    "pm_codec_fetch": ([_vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
     "pm_crc16_ccitt": ([_vp, _i64], _int),
-    "pm_correlate": ([ctypes.POINTER(Packet), ctypes.POINTER(_i64), _int, _dbl, ctypes.POINTER(_i64),
-                      ctypes.POINTER(ctypes.c_int32), _i64], _i64),
+    "pm_correlate": ([_vp, ctypes.POINTER(_i64), _int, _dbl, _vp, _vp, _i64], _i64),
 }
 EXPORTS = tuple(_SIGS)
 

@@ -45,6 +45,10 @@ def _host_stages(chain, sliced):
     return chain[4].decode(chain[3].stream_unscramble_8bit(sliced))
 
 
+def _host_stages_rows(chain, sliced):
+    return chain[4].decode_rows(chain[3].stream_unscramble_8bit(sliced))
+
+
 _POOL = None
 
 
@@ -56,7 +60,15 @@ def _pool():
     return _POOL
 
 
-def process_chains_device(chains, input_audio, stages=None):
+def process_chains_table(chains, input_audio, chain_ids=None, names=None):
+    """Same work as process_chains_device, but the packets come back as pm_packet rows keyed by (global) chain index:
+    {chain id: rows}.  Feed them to PacketTable / dist.gather_rows; no per-packet Python objects are made."""
+    rows = process_chains_device(chains, input_audio, _rows=True)
+    ids = list(range(len(chains))) if chain_ids is None else list(chain_ids)
+    return dict(zip(ids, rows))
+
+
+def process_chains_device(chains, input_audio, stages=None, _rows=False):
     """[chain, ...] -> [packets of chain 0, packets of chain 1, ...] (config order), identical to running
     process_chain on each.  See the module docstring for what is shared and batched."""
     ctx = Context.default()
@@ -119,7 +131,7 @@ def process_chains_device(chains, input_audio, stages=None):
 
     # ---- all slicers in one batch, host stages in parallel ---------------------------------------------------------
     sliced = slice_batch([ch[2] for ch in chains], bitmaps)
-    futures = [_pool().submit(_host_stages, ch, sl) for ch, sl in zip(chains, sliced)]
+    futures = [_pool().submit(_host_stages_rows if _rows else _host_stages, ch, sl) for ch, sl in zip(chains, sliced)]
     packets = [f.result() for f in futures]
     if stages is not None:
         stages["sliced"] = sliced

@@ -2,9 +2,11 @@
 gf_functions.py, lfsr.py:54-92) of the reference, as native C++ state machines behind pm_codec_*."""
 import ctypes
 
-from ._native import Packet, check, lib
+import numpy as np
+
+from ._native import check, lib, packet_dtype
 from .data_classes import AddressedArray
-from .packet_meta import PacketMeta
+from .packet_meta import rows_to_packets
 from .string_ops import check_boolean
 
 
@@ -20,21 +22,23 @@ class _NativeCodec:
             self._h = h
         return self._h
 
-    def decode(self, data):
-        """list[AddressedData] | AddressedArray -> list[PacketMeta] (data, streamaddress, SourceDecoder, BytesCorrected)."""
+    def decode_rows(self, data):
+        """Like decode(), but the packets stay rows of a NumPy structured array with the pm_packet layout
+        (pymodem_amd._native.packet_dtype): CRC and header validity already filled by the native codec."""
         src = AddressedArray.coerce(data)
         pending = ctypes.c_int64()
         check(lib().pm_codec_decode(self._handle(), src.data.ctypes.data_as(ctypes.c_void_p),
                                     src.address.ctypes.data_as(ctypes.c_void_p), len(src), ctypes.byref(pending)))
-        out = []
-        while pending.value > 0:
-            n = min(pending.value, 256)
-            recs = (Packet * n)()
+        rows = np.zeros(pending.value, dtype=packet_dtype())
+        if pending.value:
             got = ctypes.c_int64()
-            check(lib().pm_codec_fetch(self._handle(), recs, n, ctypes.byref(got)))
-            out.extend(PacketMeta.from_native(recs[k], self.identifier) for k in range(got.value))
-            pending.value -= got.value
-        return out
+            check(lib().pm_codec_fetch(self._handle(), rows.ctypes.data_as(ctypes.c_void_p), pending.value, ctypes.byref(got)))
+            assert got.value == pending.value
+        return rows
+
+    def decode(self, data):
+        """list[AddressedData] | AddressedArray -> list[PacketMeta] (data, streamaddress, SourceDecoder, BytesCorrected)."""
+        return rows_to_packets(self.decode_rows(data), self.identifier)
 
     def __del__(self):
         try:

@@ -348,25 +348,28 @@ struct Il2p : pm_codec {
                 feed(d[k], a[k], sink);
                 continue;
             }
-            // sync search (il2p.py:367-376), tight loop; the rest of the byte goes through the state machine
-            unsigned b = d[k];
-            uint32_t w = word;
+            // sync search (il2p.py:367-376): the last 32 bits before each of the byte's 8 bit positions, tested without a
+            // per-bit loop; a hit (rare) hands the rest of the byte to the state machine
+            const uint64_t win = ((uint64_t)word << 8) | d[k];
             int i = 0;
             bool hit = false;
-            for (; i < 8; ++i, b <<= 1) {
-                w = (w << 1) | ((b & 0x80) ? 1u : 0u);
-                if (__builtin_popcount((w & 0xFFFFFF) ^ 0xF15E48) <= sync_tol || __builtin_popcount(w ^ 0x5D57DF7Fu) <= sync_tol) {
-                    hit = true;
-                    ++i;
-                    b <<= 1;
-                    break;
-                }
+#define PM_SYNC_AT(S)                                                                                                   \
+            if (!hit) {                                                                                                 \
+                const uint32_t w = (uint32_t)(win >> (7 - (S)));                                                        \
+                if (__builtin_popcount((w & 0xFFFFFF) ^ 0xF15E48) <= sync_tol || __builtin_popcount(w ^ 0x5D57DF7Fu) <= sync_tol) { \
+                    hit = true;                                                                                         \
+                    i = (S) + 1;                                                                                        \
+                    word = w;                                                                                           \
+                }                                                                                                       \
             }
-            word = w;
+            PM_SYNC_AT(0) PM_SYNC_AT(1) PM_SYNC_AT(2) PM_SYNC_AT(3) PM_SYNC_AT(4) PM_SYNC_AT(5) PM_SYNC_AT(6) PM_SYNC_AT(7)
+#undef PM_SYNC_AT
             if (!hit) {
+                word = (uint32_t)win;
                 nbits += 8;
                 continue;
             }
+            const unsigned b = ((unsigned)d[k] << i) & 0xFF;
             nbits = 0;
             state = kHeader;
             feed_bits(b, 8 - i, a[k], sink);

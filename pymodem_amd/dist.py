@@ -25,7 +25,7 @@ def pack_packets(packets_by_chain):
     k = 0
     for chain in sorted(packets_by_chain):
         for p in packets_by_chain[chain]:
-            d = bytes(bytearray(int(b) & 0xFF for b in p.data[:PKT_BYTES]))
+            d = p.raw()[:PKT_BYTES]
             rec[k]["streamaddress"], rec[k]["chain"], rec[k]["len"] = p.streamaddress, chain, len(d)
             rec[k]["bytes_corrected"] = p.BytesCorrected
             rec[k]["data"][:len(d)] = np.frombuffer(d, dtype=np.uint8)
@@ -36,13 +36,11 @@ def pack_packets(packets_by_chain):
 def unpack_packets(rec, chain_names):
     """records -> {chain index: list[PacketMeta]} (decode order within a chain is preserved)."""
     out = {}
-    for r in rec:
-        p = PacketMeta()
-        p.data = r["data"][:int(r["len"])].tolist()
-        p.streamaddress = int(r["streamaddress"])
-        p.BytesCorrected = int(r["bytes_corrected"])
-        p.SourceDecoder = chain_names[int(r["chain"])]
-        out.setdefault(int(r["chain"]), []).append(p)
+    chains, lens, addrs, corr = rec["chain"].tolist(), rec["len"].tolist(), rec["streamaddress"].tolist(), rec["bytes_corrected"].tolist()
+    data = rec["data"]
+    for k in range(len(rec)):
+        p = PacketMeta.from_bytes(data[k, :lens[k]].tobytes(), addrs[k], chain_names[chains[k]], corr[k])
+        out.setdefault(chains[k], []).append(p)
     return out
 
 
@@ -51,9 +49,9 @@ def gather_packets(packets_by_chain, chain_names, device=None):
     Two collectives: all_gather of record counts, then all_gather of the padded record blocks."""
     import torch
     import torch.distributed as dist
-    rec = pack_packets(packets_by_chain)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return unpack_packets(rec, chain_names)
+        return {c: list(v) for c, v in packets_by_chain.items()}        # single rank: nothing to exchange
+    rec = pack_packets(packets_by_chain)
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = torch.device(device) if device is not None else torch.device("cpu")
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
@@ -70,6 +68,51 @@ def gather_packets(packets_by_chain, chain_names, device=None):
         return None
     parts = [b.cpu().numpy().view(RECORD)[:int(c.item())] for b, c in zip(blocks, counts)]
     return unpack_packets(np.concatenate(parts), chain_names)
+
+
+def gather_rows(rows_by_chain, nchains, names, device=None):
+    """Table form of gather_packets: pm_packet rows in, PacketTable (all chains, config order) on rank 0, None elsewhere.
+    The rows travel as they are (header + the longest packet's bytes), no per-packet Python work."""
+    import torch
+    import torch.distributed as dist
+    from ._native import packet_dtype
+    from .packet_meta import PacketTable
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return PacketTable(rows_by_chain, names)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    dt = packet_dtype()
+    mine = []
+    for c in sorted(rows_by_chain):
+        r = rows_by_chain[c].copy()
+        r["source_decoder"] = c
+        mine.append(r)
+    mine = np.concatenate(mine) if mine else np.zeros(0, dtype=dt)
+    width = 40 + (int(mine["len"].max()) if len(mine) else 0)               # header + longest payload
+    meta = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(meta, torch.tensor([len(mine), width], dtype=torch.int64, device=dev))
+    most, wide = max(int(m[0]) for m in meta), max(int(m[1]) for m in meta)
+    if most == 0:
+        return PacketTable({}, names) if rank == 0 else None
+    block = np.zeros((most, wide), dtype=np.uint8)
+    if len(mine):
+        block[:len(mine)] = mine.view(np.uint8).reshape(len(mine), dt.itemsize)[:, :wide]
+    t = torch.from_numpy(block.reshape(-1)).to(dev)
+    blocks = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(blocks, t)
+    if rank != 0:
+        return None
+    by_chain = {}
+    for b, m in zip(blocks, meta):
+        k = int(m[0])
+        if not k:
+            continue
+        full = np.zeros((k, dt.itemsize), dtype=np.uint8)
+        full[:, :wide] = b.cpu().numpy().reshape(most, wide)[:k]
+        rows = full.reshape(-1).view(dt)
+        for c in np.unique(rows["source_decoder"]):
+            by_chain[int(c)] = rows[rows["source_decoder"] == c]
+    return PacketTable(by_chain, names)
 
 
 def correlate(packets_by_chain, nchains, address_distance):

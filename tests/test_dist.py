@@ -31,6 +31,23 @@ for c in mine:
         p.streamaddress, p.BytesCorrected, p.SourceDecoder = int(addr[k]), int(corr[k]), names[c]
         lst.append(p)
     pk[c] = lst
+from pymodem_amd._native import packet_dtype
+rows = {}
+for c, lst in pk.items():                # the same packets as pm_packet rows (what the native codecs hand out)
+    r = np.zeros(len(lst), dtype=packet_dtype())
+    for k, p in enumerate(lst):
+        p.CalcCRC(); p.Validate()
+        r[k]["streamaddress"], r[k]["len"], r[k]["bytes_corrected"] = p.streamaddress, len(p.data), p.BytesCorrected
+        r[k]["calculated_crc"], r[k]["carried_crc"], r[k]["valid_crc"], r[k]["valid_header"] = p.CalculatedCRC, p.CarriedCRC, p.ValidCRC, p.ValidHeader
+        r[k]["data"][:len(p.data)] = p.data
+    rows[c] = r
+table = pdist.gather_rows(rows, len(names), names)
+if rank == 0:
+    table.correlate(8000 / 40)
+    print("TABLE " + json.dumps({"good": table.CountGood(), "bad": table.CountBad(), "addr": table.rows["streamaddress"][table.unique_idx].tolist(),
+          "dec": table.unique_decoders}))
+else:
+    assert table is None
 for _ in range(2):                       # twice: the exchange must be repeatable
     got = pdist.gather_packets(pk, names)
 if rank == 0:
@@ -92,3 +109,5 @@ def test_two_rank_gather_and_dedup(tmp_path, golden):
     assert res["addr"] == g["afsk_300__uniq_addr"].tolist()
     assert res["dec"] == summ["uniq_decoders"]           # config order, although ranks 0 and 1 interleave the chains
     assert res["per_chain"] == {"0": 5, "2": 48, "3": 47}
+    tab = json.loads([l for l in outs[0][0].splitlines() if l.startswith("TABLE ")][0][6:])
+    assert tab["good"] == 49 and tab["bad"] == 6 and tab["addr"] == res["addr"] and tab["dec"] == res["dec"]

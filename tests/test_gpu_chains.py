@@ -142,3 +142,18 @@ def test_group_executor_on_bundled_recording(golden, config_lines):
         arr = pdist.correlate(dict(enumerate(pkts)), len(lines), rate / 40)
         assert arr.CountGood() == 49 and arr.CountBad() == 6
         assert np.array_equal(np.array([p.streamaddress for p in arr.unique_packet_array], dtype=np.int64), g["afsk_300__uniq_addr"])
+
+
+def test_table_path_on_bundled_recording(golden, config_lines):
+    """process_chains_table -> PacketTable.correlate: same 49 / 6 and the same unique packets, without PacketMeta objects."""
+    from pymodem_amd import chain_builder as cb, chain_execute as ce, dist as pdist
+    g = golden("wav_chains")
+    rate, audio = read_wav_pcm16(os.path.join(GOLDEN, "afsk_300_il2pc_noise.wav"))
+    lines = config_lines("afsk_300.json")
+    chains = [cb.build_chain(rate, line) for line in lines]
+    rows = ce.process_chains_table(chains, audio)
+    table = pdist.gather_rows(rows, len(lines), [l["object_name"] for l in lines]).correlate(rate / 40)
+    assert table.CountGood() == 49 and table.CountBad() == 6
+    assert np.array_equal(table.rows["streamaddress"][table.unique_idx], g["afsk_300__uniq_addr"])
+    for ci in range(len(lines)):
+        assert np.array_equal(rows[ci]["streamaddress"], g[f"afsk_300__c{ci}_pkt_addr"])

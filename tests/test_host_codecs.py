@@ -112,3 +112,31 @@ def test_codecs_reproduce_reference_packets_on_bundled_recording(golden, config_
         assert np.array_equal(np.array([p.streamaddress for p in u], dtype=np.int64), g[k + "__uniq_addr"])
         assert [list(p.CorrelatedDecoders) for p in u] == summ[k]["uniq_decoders"]
         assert dict(res.DecoderHistogram) == summ[k]["hist"] and dict(res.DecoderUniqueHistogram) == summ[k]["uniq_hist"]
+
+
+def test_packet_table_path_matches_the_object_path(golden, config_lines):
+    """decode_rows -> PacketTable.correlate (all native, no PacketMeta objects) == decode -> CalcCRCs -> Correlate."""
+    from pymodem_amd import chain_builder as cb
+    from pymodem_amd.data_classes import AddressedArray
+    from pymodem_amd.packet_meta import PacketTable
+    g = golden("wav_chains")
+    summ = json.load(open(os.path.join(GOLDEN, "wav_chains_summary.json")))
+    for cfg in ["afsk_300.json", "afsk_300_ax25.json"]:
+        k = cfg[:-5]
+        lines = config_lines(cfg)
+        rows = {}
+        for ci, line in enumerate(lines):
+            lf = cb.StreamConfigurator(line["stream"]).stream_unscramble_8bit(
+                AddressedArray(g[f"{k}__c{ci}_slice_data"], g[f"{k}__c{ci}_slice_addr"]))
+            rows[ci] = cb.CodecConfigurator(line["codec"], line["object_name"]).decode_rows(lf)
+        t = PacketTable(rows, [l["object_name"] for l in lines]).correlate(8000 / 40)
+        assert t.CountGood() == summ[k]["good"] and t.CountBad() == summ[k]["bad"]
+        assert np.array_equal(t.rows["streamaddress"][t.unique_idx], g[k + "__uniq_addr"])
+        assert np.array_equal(t.rows["calculated_crc"][t.unique_idx], g[k + "__uniq_crc"])
+        assert t.unique_decoders == summ[k]["uniq_decoders"]
+        flat = np.stack([t.rows["valid_crc"], t.rows["valid_header"], t.rows["calculated_crc"], t.rows["carried_crc"]], axis=1)
+        assert np.array_equal(flat.astype(np.int64), g[k + "__raw_valid"])
+        u = t.unique_packets()
+        assert [p.streamaddress for p in u] == g[k + "__uniq_addr"].tolist() and all(p.ValidCRC for p in u)
+        for ci in range(len(lines)):
+            assert [p.streamaddress for p in t.packets(ci)] == g[f"{k}__c{ci}_pkt_addr"].tolist()
