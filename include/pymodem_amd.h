@@ -74,6 +74,12 @@ int pm_prof_read(pm_ctx *ctx, int kernel_class, double *total_ms, int64_t *launc
 int pm_fir_valid_i16(pm_ctx *ctx, const int16_t *d_x, int64_t n, const double *d_taps, int m, double *d_y, int flags);
 int pm_fir_valid_f64(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_taps, int m, double *d_y, int flags);
 
+/* The same FIRs fused with the slicer's sign test: only the (y >= 0) bitmap of the n-m+1 outputs is written (bit k of the
+ * little-endian uint64 array; (n-m+1+63)/64 words), not the float64 stream.  For the last FIR of a chain, whose output
+ * feeds slicer.slice() and nothing else (afsk.py:166, fsk.py:151, psk.py:193,750-751, afsk_pll.py:168). */
+int pm_fir_signs_i16(pm_ctx *ctx, const int16_t *d_x, int64_t n, const double *d_taps, int m, uint64_t *d_bits, int flags);
+int pm_fir_signs_f64(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_taps, int m, uint64_t *d_bits, int flags);
+
 /* AFSK mark/space quadrature correlators fused with magnitude and difference (afsk.py:153-162):
  * y[k] = sqrt(mi*x ^2 + mq*x ^2) - sqrt(si*x ^2 + sq*x ^2), each product a 'valid' convolution. */
 int pm_afsk_correlate(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_mark_i, const double *d_mark_q,

@@ -33,7 +33,7 @@ def multiprocess_chain(chain, input_audio, queue):
 def process_chain_device(chain, input_audio, stages=None):
     """Same result as process_chain; `input_audio` may already be a DeviceBuffer.  If `stages` is a dict it
     receives the slicer output and the descrambled stream (for parity checks)."""
-    demod_audio = chain[1].demod(input_audio, device_out=True)
+    demod_audio = chain[1].demod_signs(input_audio)          # last FIR writes the sign bitmap only
     sliced_data = chain[2].slice(demod_audio)
     descrambled_data = chain[3].stream_unscramble_8bit(sliced_data)
     if stages is not None:
@@ -112,7 +112,7 @@ def process_chains_device(chains, input_audio, stages=None, _rows=False):
             modem = chains[k][1]
             ctypes.memmove(ctypes.byref(modem._loop), ctypes.byref(loops[j]), ctypes.sizeof(Loop))
             modem.scratch_key = (group_key, "mpsk_back")
-            out = modem.back_end(i_mix.view(j * n, n), q_mix.view(j * n, n), device_out=True)
+            out = modem.back_end(i_mix.view(j * n, n), q_mix.view(j * n, n), signs=True)
             bitmaps[k] = chains[k][2].sign_bitmaps(out)
 
     # ---- everything else, chain by chain (work buffers shared across the group) ----------------------------------
@@ -123,10 +123,10 @@ def process_chains_device(chains, input_audio, stages=None, _rows=False):
         if isinstance(modem, AFSKModem):
             bpf = shared_front(modem)
             modem.scratch_key = (group_key, "afsk_back")
-            out = modem.back_end(bpf, device_out=True)
+            out = modem.back_end(bpf, signs=True)
         else:
             modem.scratch_key = (group_key, type(modem).__name__)
-            out = modem.demod(audio, device_out=True)
+            out = modem.demod_signs(audio)
         bitmaps[k] = ch[2].sign_bitmaps(out)
 
     # ---- all slicers in one batch, host stages in parallel ---------------------------------------------------------

@@ -15,6 +15,8 @@
 // (18 dwords: conflict-free for ds_read_b64).  Results go back through the same LDS image so that
 // the global stores are coalesced (lane-contiguous 8 B).
 #include "pm_common.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -26,21 +28,68 @@ constexpr int kMaxTaps = 8192;
 template <int R>
 __host__ __device__ __forceinline__ int slot(int p) { return p + p / R; }
 
-template <typename InT, int R, bool NEG>
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0), which would drain the
+// next tile's prefetch and this tile's global stores at every barrier; the barriers in these kernels protect nothing
+// but the LDS image.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+typedef double double2v __attribute__((ext_vector_type(2)));
+typedef short short8v __attribute__((ext_vector_type(8)));
+
+// Stage inputs [tile0, tile0 + span) of x into the padded LDS image, 16 bytes per global load.  Input pairs (f64) / octets
+// (int16) start at even / multiple-of-8 positions, so they never straddle a pad slot: their LDS slots are consecutive.
+template <int R>
+__device__ __forceinline__ void stage_vec(const double *__restrict__ x, int64_t n, int64_t tile0, int span, int t, double *xs)
+{
+    for (int p = 2 * t; p < span; p += 2 * kThreads) {
+        const int64_t gi = tile0 + p;
+        double2v v = {0.0, 0.0};
+        if (gi + 1 < n) v = *reinterpret_cast<const double2v *>(x + gi);
+        else if (gi < n) v.x = x[gi];
+        const int s0 = slot<R>(p);
+        xs[s0] = v.x;
+        xs[s0 + 1] = v.y;
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void stage_vec(const int16_t *__restrict__ x, int64_t n, int64_t tile0, int span, int t, double *xs)
+{
+    for (int p = 8 * t; p < span; p += 8 * kThreads) {
+        const int64_t gi = tile0 + p;
+        short8v v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (gi + 7 < n) v = *reinterpret_cast<const short8v *>(x + gi);
+        else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (gi + k < n) v[k] = x[gi + k];
+        }
+        const int s0 = slot<R>(p);                 // p % 8 == 0 (R == 8): the eight slots are consecutive
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xs[s0 + k] = (double)v[k];
+    }
+}
+
+// SIGNS: instead of the float64 outputs, write only their (y >= 0) bitmap -- all a slicer reads of them.
+template <typename InT, int R, bool NEG, bool VEC, bool SIGNS>
 __global__ __launch_bounds__(kThreads) void fir_valid_kernel(const InT *__restrict__ x, int64_t n,
                                                              const double *__restrict__ h, int m,
-                                                             double *__restrict__ y, int64_t nout)
+                                                             double *__restrict__ y, int64_t nout, uint64_t *__restrict__ bits)
 {
     extern __shared__ double xs[];
     constexpr int T = kThreads * R;
-    const int64_t tile0 = (int64_t)blockIdx.x * T;
     const int t = threadIdx.x;
     const int span = T + m - 1;
-    for (int idx = t; idx < span; idx += kThreads) {
-        int64_t gi = tile0 + idx;
-        xs[slot<R>(idx)] = gi < n ? (double)x[gi] : 0.0;
+    const int64_t tile0 = (int64_t)blockIdx.x * T;
+    if (VEC) {
+        stage_vec<R>(x, n, tile0, span, t, xs);
+    } else {
+        for (int idx = t; idx < span; idx += kThreads) {
+            int64_t gi = tile0 + idx;
+            xs[slot<R>(idx)] = gi < n ? (double)x[gi] : 0.0;
+        }
     }
-    __syncthreads();
+    lds_barrier();
 
     double acc[R];
 #pragma unroll
@@ -77,25 +126,68 @@ __global__ __launch_bounds__(kThreads) void fir_valid_kernel(const InT *__restri
         i0 += 8;
     }
 #undef PM_FIR_BLOCK
-    for (; i0 < m; ++i0) {       // m % 8 leftover taps, straight from LDS
-        const double g = h[m - 1 - i0];
+    // m % 8 leftover taps: same register-window block with a compile-time tap count (carry is in s0 after an odd number
+    // of blocks, else in s1; both cases are handled by copying the carry into s1 first -- seven moves, once per tile)
+    if (i0 < m) {
+        if ((i0 >> 3) & 1) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = __builtin_fma(g, xs[slot<R>(base + i0 + r)], acc[r]);
+            for (int j = 1; j < R; ++j) s1[j] = s0[j];
+        }
+        const int left = m - i0;
+#define PM_FIR_TAIL(K)                                                                             \
+        case K: {                                                                                  \
+            s0[0] = lp[7];                                                                         \
+            _Pragma("unroll") for (int b = 1; b < K; ++b) s0[b] = lp[8 + b];                       \
+            _Pragma("unroll") for (int b = 0; b < K; ++b) {                                        \
+                const double g = h[left - 1 - b];                                                  \
+                _Pragma("unroll") for (int r = 0; r < R; ++r)                                      \
+                    acc[r] = __builtin_fma(g, (r + b < 7) ? s1[r + b + 1] : s0[r + b - 7], acc[r]); \
+            }                                                                                      \
+        } break;
+        switch (left) {
+            PM_FIR_TAIL(1) PM_FIR_TAIL(2) PM_FIR_TAIL(3) PM_FIR_TAIL(4) PM_FIR_TAIL(5) PM_FIR_TAIL(6) PM_FIR_TAIL(7)
+        default: break;
+        }
+#undef PM_FIR_TAIL
     }
-    __syncthreads();
+    lds_barrier();
+    {
+        double *op = xs + t * (R + 1);     // this thread's R outputs occupy R consecutive slots
 #pragma unroll
-    for (int r = 0; r < R; ++r) xs[slot<R>(base + r)] = NEG ? -acc[r] : acc[r];
-    __syncthreads();
+        for (int r = 0; r < R; ++r) op[r] = NEG ? -acc[r] : acc[r];
+    }
+    lds_barrier();
+    if (SIGNS) {
+        // tile0 is a multiple of 2048, so every wave's 64 consecutive outputs are exactly one bitmap word
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int idx = r * kThreads + t;
-        const int64_t go = tile0 + idx;
-        if (go < nout) y[go] = xs[slot<R>(idx)];
+        for (int r = 0; r < R; ++r) {
+            const int idx = r * kThreads + t;
+            const int64_t go = tile0 + idx;
+            const uint64_t word = __ballot(go < nout && xs[slot<R>(idx)] >= 0.0);
+            if ((t & 63) == 0 && go < nout) bits[go >> 6] = word;
+        }
+    } else if (VEC) {
+#pragma unroll
+        for (int r = 0; r < R / 2; ++r) {
+            const int idx = 2 * (r * kThreads + t);            // even: idx and idx+1 sit in adjacent slots
+            const int64_t go = tile0 + idx;
+            const int s0i = slot<R>(idx);
+            const double2v v = {xs[s0i], xs[s0i + 1]};
+            if (go + 1 < nout) *reinterpret_cast<double2v *>(y + go) = v;
+            else if (go < nout) y[go] = v.x;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int idx = r * kThreads + t;
+            const int64_t go = tile0 + idx;
+            if (go < nout) y[go] = xs[slot<R>(idx)];
+        }
     }
 }
 
 // Four correlators over one staged window; R outputs x 4 filters = 4R accumulators per thread.
-template <int R>
+template <int R, bool VEC>
 __global__ __launch_bounds__(kThreads) void afsk_correlate_kernel(const double *__restrict__ x, int64_t n,
                                                                   const double *__restrict__ mi, const double *__restrict__ mq,
                                                                   const double *__restrict__ si, const double *__restrict__ sq,
@@ -103,14 +195,18 @@ __global__ __launch_bounds__(kThreads) void afsk_correlate_kernel(const double *
 {
     extern __shared__ double xs[];
     constexpr int T = kThreads * R;
-    const int64_t tile0 = (int64_t)blockIdx.x * T;
     const int t = threadIdx.x;
     const int span = T + m - 1;
-    for (int idx = t; idx < span; idx += kThreads) {
-        int64_t gi = tile0 + idx;
-        xs[slot<R>(idx)] = gi < n ? x[gi] : 0.0;
+    const int64_t tile0 = (int64_t)blockIdx.x * T;
+    if (VEC) {
+        stage_vec<R>(x, n, tile0, span, t, xs);
+    } else {
+        for (int idx = t; idx < span; idx += kThreads) {
+            int64_t gi = tile0 + idx;
+            xs[slot<R>(idx)] = gi < n ? x[gi] : 0.0;
+        }
     }
-    __syncthreads();
+    lds_barrier();
 
     double a[R], b[R], c[R], d[R];
 #pragma unroll
@@ -149,32 +245,60 @@ __global__ __launch_bounds__(kThreads) void afsk_correlate_kernel(const double *
         i0 += 4;
     }
 #undef PM_CORR_BLOCK
-    for (; i0 < m; ++i0) {
-        const int k = m - 1 - i0;
-        const double ga = mi[k], gb = mq[k], gc = si[k], gd = sq[k];
+    if (i0 < m) {                            // m % 4 leftover taps, compile-time count, carry moved into s1
+        if ((i0 >> 2) & 1) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const double v = xs[slot<R>(base + i0 + r)];
-            a[r] = __builtin_fma(ga, v, a[r]);
-            b[r] = __builtin_fma(gb, v, b[r]);
-            c[r] = __builtin_fma(gc, v, c[r]);
-            d[r] = __builtin_fma(gd, v, d[r]);
+            for (int j = 1; j < R; ++j) s1[j] = s0[j];
         }
+        const int left = m - i0;
+#define PM_CORR_TAIL(K)                                                                            \
+        case K: {                                                                                  \
+            s0[0] = lp[3];                                                                         \
+            _Pragma("unroll") for (int q = 1; q < K; ++q) s0[q] = lp[4 + q];                       \
+            _Pragma("unroll") for (int q = 0; q < K; ++q) {                                        \
+                const int k = left - 1 - q;                                                        \
+                const double ga = mi[k], gb = mq[k], gc = si[k], gd = sq[k];                       \
+                _Pragma("unroll") for (int r = 0; r < R; ++r) {                                    \
+                    const double v = (r + q < 3) ? s1[r + q + 1] : s0[r + q - 3];                  \
+                    a[r] = __builtin_fma(ga, v, a[r]);                                             \
+                    b[r] = __builtin_fma(gb, v, b[r]);                                             \
+                    c[r] = __builtin_fma(gc, v, c[r]);                                             \
+                    d[r] = __builtin_fma(gd, v, d[r]);                                             \
+                }                                                                                  \
+            }                                                                                      \
+        } break;
+        switch (left) {
+            PM_CORR_TAIL(1) PM_CORR_TAIL(2) PM_CORR_TAIL(3)
+        default: break;
+        }
+#undef PM_CORR_TAIL
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         // afsk.py:153-162: sqrt(i**2 + q**2) with separately rounded squares and sum, then mark - space
         const double mark = __builtin_sqrt(a[r] * a[r] + b[r] * b[r]);
         const double space = __builtin_sqrt(c[r] * c[r] + d[r] * d[r]);
-        xs[slot<R>(base + r)] = mark - space;
+        xs[t * (R + 1) + r] = mark - space;
     }
-    __syncthreads();
+    lds_barrier();
+    if (VEC) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int idx = r * kThreads + t;
-        const int64_t go = tile0 + idx;
-        if (go < nout) y[go] = xs[slot<R>(idx)];
+        for (int r = 0; r < R / 2; ++r) {
+            const int idx = 2 * (r * kThreads + t);
+            const int64_t go = tile0 + idx;
+            const int s0i = slot<R>(idx);
+            const double2v v = {xs[s0i], xs[s0i + 1]};
+            if (go + 1 < nout) *reinterpret_cast<double2v *>(y + go) = v;
+            else if (go < nout) y[go] = v.x;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int idx = r * kThreads + t;
+            const int64_t go = tile0 + idx;
+            if (go < nout) y[go] = xs[slot<R>(idx)];
+        }
     }
 }
 
@@ -204,29 +328,40 @@ int allow_lds(K kernel, size_t bytes)
     return PM_OK;
 }
 
-template <typename InT>
-int fir_launch(pm_ctx *ctx, const InT *d_x, int64_t n, const double *d_taps, int m, double *d_y, int flags)
+template <typename InT, bool NEG>
+int fir_launch2(pm_ctx *ctx, const InT *d_x, int64_t n, const double *d_taps, int m, double *d_y, uint64_t *d_bits)
 {
-    PM_ARG(ctx && d_x && d_taps && d_y);
-    PM_ARG(m >= 1 && m <= kMaxTaps);
-    PM_ARG(n >= m);
     constexpr int R = 8;
     const int64_t nout = n - m + 1;
-    const int64_t grid = pm_cdiv(nout, (int64_t)kThreads * R);
-    PM_ARG(grid < (1LL << 31));
+    const int64_t ntiles = pm_cdiv(nout, (int64_t)kThreads * R);
+    PM_ARG(ntiles < (1LL << 31));
     const size_t lds = lds_bytes<R>(m);
     PmProf prof(ctx, sizeof(InT) == 2 ? PM_K_FIR_I16 : PM_K_FIR_F64);
-    if (flags & PM_FIR_NEGATE) {
-        if (int rc = allow_lds(fir_valid_kernel<InT, R, true>, lds)) return rc;
-        hipLaunchKernelGGL((fir_valid_kernel<InT, R, true>), dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream,
-                           d_x, n, d_taps, m, d_y, nout);
-    } else {
-        if (int rc = allow_lds(fir_valid_kernel<InT, R, false>, lds)) return rc;
-        hipLaunchKernelGGL((fir_valid_kernel<InT, R, false>), dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream,
-                           d_x, n, d_taps, m, d_y, nout);
+    const bool vec = (((uintptr_t)d_x | (uintptr_t)d_y) & 15) == 0;          // 16-byte loads and stores
+#define PM_FIR_GO(VECF, SIGNF)                                                                                              \
+    {                                                                                                                       \
+        if (int rc = allow_lds(fir_valid_kernel<InT, R, NEG, VECF, SIGNF>, lds)) return rc;                                  \
+        hipLaunchKernelGGL((fir_valid_kernel<InT, R, NEG, VECF, SIGNF>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, \
+                           d_x, n, d_taps, m, d_y, nout, d_bits);                                                           \
     }
+    if (d_bits) {
+        if (vec) PM_FIR_GO(true, true) else PM_FIR_GO(false, true)
+    } else {
+        if (vec) PM_FIR_GO(true, false) else PM_FIR_GO(false, false)
+    }
+#undef PM_FIR_GO
     PM_HIP(hipGetLastError());
     return PM_OK;
+}
+
+template <typename InT>
+int fir_launch(pm_ctx *ctx, const InT *d_x, int64_t n, const double *d_taps, int m, double *d_y, uint64_t *d_bits, int flags)
+{
+    PM_ARG(ctx && d_x && d_taps && (d_y || d_bits));
+    PM_ARG(m >= 1 && m <= kMaxTaps);
+    PM_ARG(n >= m);
+    return (flags & PM_FIR_NEGATE) ? fir_launch2<InT, true>(ctx, d_x, n, d_taps, m, d_y, d_bits)
+                                   : fir_launch2<InT, false>(ctx, d_x, n, d_taps, m, d_y, d_bits);
 }
 
 }  // namespace
@@ -235,12 +370,22 @@ extern "C" {
 
 int pm_fir_valid_i16(pm_ctx *ctx, const int16_t *d_x, int64_t n, const double *d_taps, int m, double *d_y, int flags)
 {
-    return fir_launch<int16_t>(ctx, d_x, n, d_taps, m, d_y, flags);
+    return fir_launch<int16_t>(ctx, d_x, n, d_taps, m, d_y, nullptr, flags);
+}
+
+int pm_fir_signs_i16(pm_ctx *ctx, const int16_t *d_x, int64_t n, const double *d_taps, int m, uint64_t *d_bits, int flags)
+{
+    return fir_launch<int16_t>(ctx, d_x, n, d_taps, m, nullptr, d_bits, flags);
+}
+
+int pm_fir_signs_f64(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_taps, int m, uint64_t *d_bits, int flags)
+{
+    return fir_launch<double>(ctx, d_x, n, d_taps, m, nullptr, d_bits, flags);
 }
 
 int pm_fir_valid_f64(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_taps, int m, double *d_y, int flags)
 {
-    return fir_launch<double>(ctx, d_x, n, d_taps, m, d_y, flags);
+    return fir_launch<double>(ctx, d_x, n, d_taps, m, d_y, nullptr, flags);
 }
 
 int pm_afsk_correlate(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_mark_i, const double *d_mark_q,
@@ -251,13 +396,20 @@ int pm_afsk_correlate(pm_ctx *ctx, const double *d_x, int64_t n, const double *d
     PM_ARG(n >= m);
     constexpr int R = 4;
     const int64_t nout = n - m + 1;
-    const int64_t grid = pm_cdiv(nout, (int64_t)kThreads * R);
-    PM_ARG(grid < (1LL << 31));
+    const int64_t ntiles = pm_cdiv(nout, (int64_t)kThreads * R);
+    PM_ARG(ntiles < (1LL << 31));
     const size_t lds = lds_bytes<R>(m);
-    if (int rc = allow_lds(afsk_correlate_kernel<R>, lds)) return rc;
     PmProf prof(ctx, PM_K_AFSK_CORR);
-    hipLaunchKernelGGL((afsk_correlate_kernel<R>), dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream,
-                       d_x, n, d_mark_i, d_mark_q, d_space_i, d_space_q, m, d_y, nout);
+    const bool vec = (((uintptr_t)d_x | (uintptr_t)d_y) & 15) == 0;
+    if (vec) {
+        if (int rc = allow_lds(afsk_correlate_kernel<R, true>, lds)) return rc;
+        hipLaunchKernelGGL((afsk_correlate_kernel<R, true>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream,
+                           d_x, n, d_mark_i, d_mark_q, d_space_i, d_space_q, m, d_y, nout);
+    } else {
+        if (int rc = allow_lds(afsk_correlate_kernel<R, false>, lds)) return rc;
+        hipLaunchKernelGGL((afsk_correlate_kernel<R, false>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream,
+                           d_x, n, d_mark_i, d_mark_q, d_space_i, d_space_q, m, d_y, nout);
+    }
     PM_HIP(hipGetLastError());
     return PM_OK;
 }

@@ -28,6 +28,7 @@
 namespace {
 
 constexpr int kMaxJobs = 64;
+constexpr int kBlock = 256;     // four waves: one per SIMD when the grid is one workgroup per CU
 
 struct JobDev {
     const uint64_t *bi, *bq;       // sign bitmaps (bq null for binary)
@@ -55,24 +56,29 @@ __device__ __forceinline__ int find_job(const JobDev *jobs, int njobs, int64_t g
 
 // 32 samples, most significant bit first: zc = crossing flags (bit 31 = first sample).  Returns the symbol flags in
 // the same orientation.  clk is updated in place.
-__device__ __forceinline__ uint32_t step32(double &clk, uint32_t zc, double thr, double neg_sps, uint32_t lock_hi, uint32_t lock_lo)
+//
+// A lone wave is bound by the dependent-issue latency of this loop-carried chain (~15 cycles per level), so the step
+// is arranged in four levels: a = clk + 1.0 | b = a - sps speculatively, beside the compare a >= thr | c = select(b, a) |
+// clk = c * m, where m = {lock, 1.0} is picked from the crossing flag off the chain (c * 1.0 == c exactly).  Every
+// arithmetic operation is the reference's own: clk + 1.0, clk >= thr, clk - sps, clk * lock_rate.
+__device__ __forceinline__ uint32_t step32(double &clk, uint32_t zc, double thr, double neg_sps, double lock)
 {
     uint32_t sym = 0;
 #pragma unroll
-    for (int b = 0; b < 32; ++b) {
-        const double a = clk + 1.0;                                         // slicer.py:77
-        const bool s = a >= thr;                                            // slicer.py:79
-        const double c = __builtin_fma(mkdouble(s ? 0x3FF00000u : 0u, 0u), neg_sps, a);   // a - sps (one rounding) or a
-        sym = (sym << 1) | (s ? 1u : 0u);
-        const bool x = (int)zc < 0;                                         // crossing at this sample (slicer.py:99-102)
+    for (int k = 0; k < 32; ++k) {
+        const double m = (int)zc < 0 ? lock : 1.0;          // crossing at this sample (slicer.py:99-104)
         zc <<= 1;
-        clk = c * mkdouble(x ? lock_hi : 0x3FF00000u, x ? lock_lo : 0u);    // c * lock_rate, or c * 1.0 == c
+        const double a = clk + 1.0;                         // slicer.py:77
+        const double b = a + neg_sps;                       // slicer.py:81, used only if the symbol is taken
+        const bool s = a >= thr;                            // slicer.py:79
+        sym = (sym << 1) | (s ? 1u : 0u);
+        clk = (s ? b : a) * m;
     }
     return sym;
 }
 
 // One fixed-point iteration over all chunks of all streams.
-__global__ __launch_bounds__(64) void slice_iter_kernel(const JobDev *__restrict__ jobs, int njobs, int lc_words, int64_t total_chunks,
+__global__ __launch_bounds__(kBlock) void slice_iter_kernel(const JobDev *__restrict__ jobs, int njobs, int lc_words, int64_t total_chunks,
                                                         const uint64_t *__restrict__ s_in, uint64_t *__restrict__ s_out,
                                                         const uint8_t *__restrict__ d_in, uint8_t *__restrict__ d_out,
                                                         uint64_t *__restrict__ symmap, int *__restrict__ changed, int iter)
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(64) void slice_iter_kernel(const JobDev *__restrict
     uint64_t lq = 1ull;
     if (J.quad) lq = w0 == 0 ? 1ull : (J.bq[w0 - 1] >> 63);
     const double thr = J.thr, neg_sps = -J.sps;
-    const uint32_t lock_hi = (uint32_t)(dbits(J.lock) >> 32), lock_lo = (uint32_t)dbits(J.lock);
+    const double lock = J.lock;
     uint64_t *sm = symmap + J.word0;
     for (int64_t w = w0; w < w1; ++w) {
         const uint64_t si = J.bi[w];
@@ -112,8 +118,8 @@ __global__ __launch_bounds__(64) void slice_iter_kernel(const JobDev *__restrict
         const int64_t left = J.n - (w << 6);
         uint64_t sym;
         if (left >= 64) {
-            const uint32_t lo = step32(clk, __brev((uint32_t)zc), thr, neg_sps, lock_hi, lock_lo);
-            const uint32_t hi = step32(clk, __brev((uint32_t)(zc >> 32)), thr, neg_sps, lock_hi, lock_lo);
+            const uint32_t lo = step32(clk, __brev((uint32_t)zc), thr, neg_sps, lock);
+            const uint32_t hi = step32(clk, __brev((uint32_t)(zc >> 32)), thr, neg_sps, lock);
             sym = ((uint64_t)__brev(hi) << 32) | (uint64_t)__brev(lo);
         } else {                                     // the stream's last, partial word
             sym = 0;
@@ -132,11 +138,11 @@ __global__ __launch_bounds__(64) void slice_iter_kernel(const JobDev *__restrict
     const bool ch = e != s_in[so + 1];
     s_out[so + 1] = e;
     d_out[so + 1] = ch ? 1 : 0;
-    if (ch && c + 1 < J.nchunks) atomicOr(changed, 1);
+    if (ch && c + 1 < J.nchunks) atomicAdd(changed, 1);
 }
 
 // Symbols per chunk and the (i<<1|q) bits of its last symbol (0xFF if it took none).
-__global__ __launch_bounds__(64) void slice_count_kernel(const JobDev *__restrict__ jobs, int njobs, int lc_words, int64_t total_chunks,
+__global__ __launch_bounds__(kBlock) void slice_count_kernel(const JobDev *__restrict__ jobs, int njobs, int lc_words, int64_t total_chunks,
                                                          const uint64_t *__restrict__ symmap, uint32_t *__restrict__ count,
                                                          uint8_t *__restrict__ lastsym)
 {
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(1024) void slice_scan_kernel(const JobDev *__restri
 }
 
 // Symbol bitmap + sign bitmap(s) -> packed bytes (MSB first) and the address of each byte's last symbol.
-__global__ __launch_bounds__(64) void slice_pack_kernel(const JobDev *__restrict__ jobs, int njobs, int lc_words, int64_t total_chunks,
+__global__ __launch_bounds__(kBlock) void slice_pack_kernel(const JobDev *__restrict__ jobs, int njobs, int lc_words, int64_t total_chunks,
                                                         const uint64_t *__restrict__ symmap, const uint64_t *__restrict__ offset,
                                                         const uint8_t *__restrict__ prevsym)
 {
@@ -307,7 +313,7 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
     int64_t all_words = 0;
     for (int j = 0; j < njobs; ++j) all_words += pm_cdiv(jobs[j].n, 64);
     int64_t lc_words = std::max<int64_t>(16, std::min<int64_t>(pm_cdiv(all_words, 65536), 1024));
-    if (const char *e = getenv("PM_SLICER_CHUNK_WORDS")) lc_words = std::max(1, atoi(e));
+    if (const char *e = getenv("PM_SLICER_CHUNK_WORDS")) { if (atoi(e) > 0) lc_words = atoi(e); }
     std::vector<JobDev> jd;
     jd.reserve(njobs);
     std::vector<int> live;
@@ -360,8 +366,8 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
     int *changed = (int *)(base + o_ch);
 
     PM_HIP(hipMemcpyAsync(d_jobs, jd.data(), sizeof(JobDev) * nj, hipMemcpyHostToDevice, ctx->stream));
-    const unsigned grid = (unsigned)pm_cdiv(total_chunks, 64);
-    hipLaunchKernelGGL(slice_init_kernel, dim3(grid), dim3(64), 0, ctx->stream, d_jobs, nj, total_chunks, sa, sb, da, db, changed);
+    const unsigned grid = (unsigned)pm_cdiv(total_chunks, kBlock);
+    hipLaunchKernelGGL(slice_init_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_jobs, nj, total_chunks, sa, sb, da, db, changed);
 
     int *h_flag = (int *)ctx->h_pinned;
     int iters = 0;
@@ -374,7 +380,7 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
         const int burst = 4;
         for (int b = 0; b < burst; ++b) {
             PmProf prof(ctx, PM_K_SLICE_ITER);
-            hipLaunchKernelGGL(slice_iter_kernel, dim3(grid), dim3(64), 0, ctx->stream, d_jobs, nj, (int)lc_words, total_chunks,
+            hipLaunchKernelGGL(slice_iter_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_jobs, nj, (int)lc_words, total_chunks,
                                sa, sb, da, db, symmap, changed, iters);
             std::swap(sa, sb);
             std::swap(da, db);
@@ -385,6 +391,7 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
         PM_HIP(hipStreamSynchronize(ctx->stream));
         // `changed` accumulates over the burst: a burst with no change at all ends on a fixed point
         converged = (*h_flag == 0);
+        if (getenv("PM_SLICER_TRACE")) fprintf(stderr, "[slicer] after %d iterations: %d start states changed in the last burst\n", iters, *h_flag);
         if (!converged && iters > max_iters + 8)
             return pm_set_error(PM_ERR_NOCONVERGE, "slicer fixed point not reached after %d iterations (%lld chunks)", iters, (long long)most_chunks);
     }
@@ -392,11 +399,11 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
 
     {
         PmProf prof(ctx, PM_K_SLICE_EMIT);
-        hipLaunchKernelGGL(slice_count_kernel, dim3(grid), dim3(64), 0, ctx->stream, d_jobs, nj, (int)lc_words, total_chunks, symmap, cnt, ls);
+        hipLaunchKernelGGL(slice_count_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_jobs, nj, (int)lc_words, total_chunks, symmap, cnt, ls);
         hipLaunchKernelGGL(slice_scan_kernel, dim3(nj), dim3(1024), 0, ctx->stream, d_jobs, cnt, ls, offs, ps, totals);
         for (const JobDev &d : jd)
             if (d.cap > 0) PM_HIP(hipMemsetAsync(d.data32, 0, align_up((size_t)d.cap, 4), ctx->stream));
-        hipLaunchKernelGGL(slice_pack_kernel, dim3(grid), dim3(64), 0, ctx->stream, d_jobs, nj, (int)lc_words, total_chunks, symmap, offs, ps);
+        hipLaunchKernelGGL(slice_pack_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_jobs, nj, (int)lc_words, total_chunks, symmap, offs, ps);
     }
     std::vector<uint64_t> h_tot(nj);
     PM_HIP(hipMemcpyAsync(h_tot.data(), totals, (size_t)nj * 8, hipMemcpyDeviceToHost, ctx->stream));

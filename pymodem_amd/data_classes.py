@@ -24,6 +24,13 @@ class DeviceIQ:
         self.q_data = q_data
 
 
+class SignBits:
+    """What a slicer needs of a demodulated stream: the (x >= 0) bitmap(s) in HBM and the sample count.  Produced by
+    modem.demod_signs(), where the chain's last FIR writes the bitmap instead of the float64 stream."""
+    def __init__(self, bits_i, bits_q, n):
+        self.bits_i, self.bits_q, self.n = bits_i, bits_q, int(n)
+
+
 class AddressedArray:
     """list[AddressedData] stored as two NumPy arrays.  Behaves like the reference's list for len(), indexing and
     iteration (items are materialised on demand), while the native stages read `.data` / `.address` directly."""

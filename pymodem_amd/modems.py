@@ -18,7 +18,7 @@ import numpy as np
 
 from . import taps as T
 from ._native import AGCParams, Loop, check, lib
-from .data_classes import DeviceIQ, IQData
+from .data_classes import DeviceIQ, IQData, SignBits
 from .device import Context, DeviceBuffer
 from .string_ops import check_boolean
 
@@ -69,6 +69,18 @@ class _DeviceStage:
         fn = lib().pm_fir_valid_i16 if is_i16 else lib().pm_fir_valid_f64
         check(fn(ctx.handle, x.ptr, x.n, self._const(taps_name, taps).ptr, m, y.ptr, flags))
         return y
+
+    def _fir_signs(self, x, is_i16, taps_name, taps, flags=0, tag=None):
+        """The chain's last FIR, writing only the sign bitmap of its output (pm_fir_signs_*)."""
+        ctx = self._ctx
+        m = len(taps)
+        if x.n < m:
+            raise ValueError(f"input of {x.n} samples is shorter than the {m}-tap filter {taps_name}")
+        nout = x.n - m + 1
+        bits = ctx.scratch((id(self), "signs", tag or taps_name), (nout + 63) // 64 + 1, np.uint64)
+        fn = lib().pm_fir_signs_i16 if is_i16 else lib().pm_fir_signs_f64
+        check(fn(ctx.handle, x.ptr, x.n, self._const(taps_name, taps).ptr, m, bits.ptr, flags))
+        return bits, nout
 
     def _agc(self, buf):
         if not hasattr(self, "_agc_state"):
@@ -195,7 +207,11 @@ class AFSKModem(_DeviceStage):
     def demod(self, input_audio, device_out=False):   # afsk.py:148-167
         return self.back_end(self.front_end(input_audio), device_out)
 
-    def back_end(self, a, device_out=False):
+    def demod_signs(self, input_audio):
+        """demod() for a slicer: the output low-pass writes only the sign bitmap.  -> SignBits"""
+        return self.back_end(self.front_end(input_audio), signs=True)
+
+    def back_end(self, a, device_out=False, signs=False):
         """Correlators + output low-pass on an already band-passed stream (afsk.py:153-166)."""
         ctx = self._context()
         m = len(self.mark_correlator_i)
@@ -205,6 +221,9 @@ class AFSKModem(_DeviceStage):
         check(lib().pm_afsk_correlate(ctx.handle, a.ptr, a.n, self._const("mi", self.mark_correlator_i).ptr,
                                       self._const("mq", self.mark_correlator_q).ptr, self._const("si", self.space_correlator_i).ptr,
                                       self._const("sq", self.space_correlator_q).ptr, m, c.ptr))
+        if signs:
+            bits, nout = self._fir_signs(c, False, "output_lpf", self.output_lpf)
+            return SignBits(bits, None, nout)
         y = self._fir(c, False, "output_lpf", self.output_lpf)
         return self._finish(y, device_out)
 
@@ -248,6 +267,11 @@ class FSKModem(_DeviceStage):
         x, is_i16 = self._input(input_audio)
         y = self._fir(x, is_i16, "input_lpf", self.input_lpf, flags=1 if self.invert else 0)
         return self._finish(y, device_out)
+
+    def demod_signs(self, input_audio):
+        x, is_i16 = self._input(input_audio)
+        bits, nout = self._fir_signs(x, is_i16, "input_lpf", self.input_lpf, flags=1 if self.invert else 0)
+        return SignBits(bits, None, nout)
 
 
 # =============================================================================================
@@ -298,7 +322,7 @@ class BPSKModem(_DeviceStage):
         self._loop0 = _snapshot(self._loop)
         self.output_sample_rate = self.sample_rate
 
-    def demod(self, input_audio, device_out=False):   # psk.py:162-195
+    def demod(self, input_audio, device_out=False, signs=False):   # psk.py:162-195
         x, is_i16 = self._input(input_audio)
         ctx = self._ctx
         a = self._fir(x, is_i16, "input_bpf", self.input_bpf)
@@ -306,8 +330,14 @@ class BPSKModem(_DeviceStage):
         d = ctx.scratch((self._key(), "loop"), a.n, np.float64)
         check(lib().pm_costas_bpsk(ctx.handle, ctypes.byref(self._loop), 1, self._const("wavetable", self.wavetable).ptr,
                                    a.ptr, 0, a.n, d.ptr, a.n))
+        if signs:
+            bits, nout = self._fir_signs(d, False, "rrc", self.rrc_taps)
+            return SignBits(bits, None, nout)
         y = self._fir(d, False, "rrc", self.rrc_taps)
         return self._finish(y, device_out)
+
+    def demod_signs(self, input_audio):
+        return self.demod(input_audio, signs=True)
 
 
 # =============================================================================================
@@ -383,7 +413,7 @@ class MPSKModem(_DeviceStage):
         return ("mpsk", float(self.sample_rate), self.input_bpf.tobytes(), self.hilbert_taps.tobytes(),
                 (a.attack_rate, a.decay_rate, a.sustain_time, a.target_amplitude))
 
-    def demod(self, input_audio, device_out=False):   # psk.py:705-773
+    def demod(self, input_audio, device_out=False, signs=False):   # psk.py:705-773
         real, imag = self.front_end(input_audio)
         ctx = self._ctx
         n = imag.n
@@ -392,11 +422,18 @@ class MPSKModem(_DeviceStage):
         check(lib().pm_mpsk_loop(ctx.handle, ctypes.byref(self._loop), 1, self._const("wavetable", self.wavetable).ptr,
                                  self._const("pd", self.phase_error_table.reshape(-1), np.int32).ptr,
                                  real.ptr, imag.ptr, 0, n, i_mix.ptr, q_mix.ptr, n))
-        return self.back_end(i_mix, q_mix, device_out)
+        return self.back_end(i_mix, q_mix, device_out, signs)
 
-    def back_end(self, i_mix, q_mix, device_out=False):
+    def demod_signs(self, input_audio):
+        return self.demod(input_audio, signs=True)
+
+    def back_end(self, i_mix, q_mix, device_out=False, signs=False):
         """Matched filter on both arms of the carrier-loop output (psk.py:750-751)."""
         self._context()
+        if signs:
+            bi, nout = self._fir_signs(i_mix, False, "rrc", self.rrc_taps, tag="i")
+            bq, _ = self._fir_signs(q_mix, False, "rrc", self.rrc_taps, tag="q")
+            return SignBits(bi, bq, nout)
         i_out = self._fir(i_mix, False, "rrc", self.rrc_taps, tag="i_out")
         q_out = self._fir(q_mix, False, "rrc", self.rrc_taps, tag="q_out")
         if device_out:
@@ -449,7 +486,7 @@ class AFSKPLLModem(_DeviceStage):
         self._loop0 = _snapshot(self._loop)
         self.output_sample_rate = self.sample_rate
 
-    def demod(self, input_audio, device_out=False):   # afsk_pll.py:140-170
+    def demod(self, input_audio, device_out=False, signs=False):   # afsk_pll.py:140-170
         x, is_i16 = self._input(input_audio)
         ctx = self._ctx
         a = self._fir(x, is_i16, "input_bpf", self.input_bpf)
@@ -457,5 +494,11 @@ class AFSKPLLModem(_DeviceStage):
         d = ctx.scratch((self._key(), "loop"), a.n, np.float64)
         check(lib().pm_pll_afsk(ctx.handle, ctypes.byref(self._loop), 1, self._const("wavetable", self.wavetable).ptr,
                                 a.ptr, 0, a.n, d.ptr, a.n))
+        if signs:
+            bits, nout = self._fir_signs(d, False, "output_lpf", self.output_lpf)
+            return SignBits(bits, None, nout)
         y = self._fir(d, False, "output_lpf", self.output_lpf)
         return self._finish(y, device_out)
+
+    def demod_signs(self, input_audio):
+        return self.demod(input_audio, signs=True)

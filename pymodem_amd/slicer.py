@@ -6,7 +6,7 @@ import ctypes
 import numpy as np
 
 from ._native import SliceJob, SlicerParams, check, lib
-from .data_classes import AddressedArray, DeviceIQ, IQData
+from .data_classes import AddressedArray, DeviceIQ, IQData, SignBits
 from .device import Context, DeviceBuffer
 
 
@@ -53,6 +53,8 @@ class _SlicerBase:
     def sign_bitmaps(self, samples):
         """Stage 1 of slice(): the (x >= 0) bitmap(s) of the demodulated stream -> (bits_i, bits_q | None, n)."""
         ctx = self._ctx = self._ctx or Context.default()
+        if isinstance(samples, SignBits):
+            return samples.bits_i, samples.bits_q, samples.n
         if isinstance(samples, (IQData, DeviceIQ)):
             bi, n = self._bits(ctx, samples.i_data, "bits_i")
             bq, nq = self._bits(ctx, samples.q_data, "bits_q")
@@ -107,10 +109,10 @@ class BinarySlicer(_SlicerBase):
     def slice(self, samples):
         """-> AddressedArray (list[AddressedData]-compatible).  `samples`: host float64 sequence or DeviceBuffer."""
         ctx = self._ctx = self._ctx or Context.default()
-        n = samples.n if isinstance(samples, DeviceBuffer) else len(samples)
+        n = samples.n if isinstance(samples, (DeviceBuffer, SignBits)) else len(samples)
         if n == 0:
             return AddressedArray(np.zeros(0, np.uint8), np.zeros(0, np.int64))
-        bits, n = self._bits(ctx, samples, "bits_i")
+        bits, _, n = self.sign_bitmaps(samples)
         return self._run(ctx, bits, None, n)
 
 
@@ -131,11 +133,11 @@ class QuadratureSlicer(_SlicerBase):
 
     def slice(self, iq_samples):
         ctx = self._ctx = self._ctx or Context.default()
-        i, q = iq_samples.i_data, iq_samples.q_data
-        n = i.n if isinstance(i, DeviceBuffer) else len(i)
+        if isinstance(iq_samples, SignBits):
+            n = iq_samples.n
+        else:
+            n = iq_samples.i_data.n if isinstance(iq_samples.i_data, DeviceBuffer) else len(iq_samples.i_data)
         if n == 0:
             return AddressedArray(np.zeros(0, np.uint8), np.zeros(0, np.int64))
-        bi, n = self._bits(ctx, i, "bits_i")
-        bq, nq = self._bits(ctx, q, "bits_q")
-        assert n == nq
+        bi, bq, n = self.sign_bitmaps(iq_samples)
         return self._run(ctx, bi, bq, n)

@@ -222,3 +222,25 @@ def test_mpsk_loop_batch_bit_exact(ctx):
         wi, wq = O.mpsk_loop(a, re, im, tab, pdt)
         assert np.array_equal(gi[k], wi) and np.array_equal(gq[k], wq), k
         assert a.phase == arr[k].phase and a.integral == arr[k].integral and a.control == arr[k].control
+
+
+@pytest.mark.parametrize("m", [1, 8, 13, 100, 241])
+def test_fir_signs_fused(ctx, m):
+    """pm_fir_signs_*: the bitmap equals (FIR output >= 0) of the unfused kernel / the oracle, for both input types and NEGATE."""
+    rng = np.random.default_rng(300 + m)
+    h = rng.standard_normal(m)
+    dh = ctx.upload(h)
+    for n in [m, m + 63, m + 64, m + 2047, m + 2048, 70003]:
+        xi = np.clip(np.rint(rng.standard_normal(n) * 8000), -32768, 32767).astype(np.int16)
+        xf = rng.standard_normal(n)
+        xf[::5] = 0.0                                   # exact zeros in the output are ">= 0"
+        for x, fn in [(xi, L().pm_fir_signs_i16), (xf, L().pm_fir_signs_f64)]:
+            for flags in (0, 1):
+                nout = n - m + 1
+                bits = ctx.empty((nout + 63) // 64 + 1, np.uint64)
+                dx = ctx.upload(x)
+                chk(fn(ctx.handle, dx.ptr, n, dh.ptr, m, bits.ptr, flags))
+                got = np.unpackbits(bits.download().view(np.uint8), bitorder="little")[:nout].astype(bool)
+                y = O.fir_canon(x, h)
+                want = (-y if flags else y) >= 0
+                assert np.array_equal(got, want), (m, n, x.dtype, flags)
