@@ -11,6 +11,8 @@
 //
 // Built with -ffp-contract=off; no fma is used here because the reference has none.
 #include "pm_common.h"
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -244,54 +246,98 @@ struct AgcDev {
     double att, dec, sustain_time, sustain_inc, target;
 };
 
-// One wave.  Lane 0 runs the envelope follower over the LDS tile (agc.py:26-37); all lanes then scale the
-// tile (agc.py:75-76) and stream it back.  state = {envelope, sustain_count}.
-__global__ __launch_bounds__(64) void agc_kernel(double *__restrict__ buf, int64_t n, const double *__restrict__ partial, int npartial,
-                                                 double scaled_attack, double scaled_decay, AgcDev P, double *__restrict__ state)
+// ---- AGC as a chunk-parallel fixed point -------------------------------------------------------------------------------
+// The envelope follower (agc.py:26-37) carries two doubles, (envelope, sustain_count).  Whenever a sample exceeds the
+// envelope by less than one attack step the envelope is clamped to |s| and sustain_count restarts, which erases the
+// history: two runs that both clamp at the same sample are bit-identical from there on.  So, as in the slicer, the buffer
+// is cut into chunks (one lane each), every chunk is run from the end state of its predecessor's previous run, and the
+// iteration stops when no start state changes -- at which point the chunk runs are the sequential run.  Worst case (no
+// common clamp for a long stretch) degrades to sequential cost.  The converged pass writes the envelope, and the division
+// buf[i] = target*s/env (agc.py:75-76), which is not part of the recurrence, runs fully parallel.
+__device__ __forceinline__ void agc_step(double s, double &env, double &sustain, const AgcDev &P)
 {
-    __shared__ double xs[kAgcTile];
-    __shared__ double es[kAgcTile];
-    __shared__ double s_normal;
-    const int lane = threadIdx.x;
-    if (lane == 0) {
-        double m = partial[0];
-        for (int i = 1; i < npartial; ++i)
-            if (partial[i] > m) m = partial[i];
-        s_normal = m;                                   // agc.py:67 normal = max(buffer)
-    }
-    __syncthreads();
-    const double normal = s_normal;
-    const double att = scaled_attack * normal;          // agc.py:29 scaled_attack_rate * normal
-    const double dec = scaled_decay * normal;           // agc.py:34
-    double env = state[0], sustain = state[1];
-    for (int64_t tile0 = 0; tile0 < n; tile0 += kAgcTile) {
-        const int len = (int)min((int64_t)kAgcTile, n - tile0);
-        for (int k = lane; k < len; k += 64) xs[k] = buf[tile0 + k];
-        __syncthreads();
-        if (lane == 0) {
-            for (int k = 0; k < len; ++k) {
-                const double cmp = fabs(xs[k]);
-                const bool attack = cmp > env;                          // agc.py:28-32
-                const double up = fmin(env + att, cmp);                 // env += att; if env > cmp: env = cmp
-                env = attack ? up : env;
-                sustain = attack ? 0.0 : sustain;
-                const bool decay = sustain >= P.sustain_time;           // agc.py:33-36
-                const double dn = env - dec;
-                env = decay ? (dn < 0 ? 0.0 : dn) : env;
-                sustain += P.sustain_inc;                               // agc.py:37
-                es[k] = env;
-            }
+    const double cmp = fabs(s);
+    const bool attack = cmp > env;                          // agc.py:28-32
+    const double up = fmin(env + P.att, cmp);               // env += att; if env > cmp: env = cmp
+    env = attack ? up : env;
+    sustain = attack ? 0.0 : sustain;
+    const bool decay = sustain >= P.sustain_time;           // agc.py:33-36
+    const double dn = env - P.dec;
+    env = decay ? (dn < 0 ? 0.0 : dn) : env;
+    sustain += P.sustain_inc;                               // agc.py:37
+}
+
+struct AgcScale {
+    double scaled_attack, scaled_decay;
+};
+
+// partial[] -> normal, att, dec (agc.py:29,34,67); one thread
+__global__ void agc_prepare_kernel(const double *__restrict__ partial, int npartial, AgcScale sc, double *__restrict__ consts)
+{
+    double m = partial[0];
+    for (int i = 1; i < npartial; ++i)
+        if (partial[i] > m) m = partial[i];
+    consts[0] = m;
+    consts[1] = sc.scaled_attack * m;
+    consts[2] = sc.scaled_decay * m;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(256) void agc_iter_kernel(const double *__restrict__ buf, int64_t n, int lc, int64_t nchunks,
+                                                       const double *__restrict__ consts, AgcDev P,
+                                                       const double2 *__restrict__ s_in, double2 *__restrict__ s_out,
+                                                       const uint8_t *__restrict__ d_in, uint8_t *__restrict__ d_out,
+                                                       double *__restrict__ env_out, int *__restrict__ changed, int iter)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    if (!EMIT) {
+        const bool dirty = c == 0 ? (iter == 0) : (d_in[c] != 0);
+        if (!dirty) {
+            s_out[c + 1] = s_in[c + 1];
+            d_out[c + 1] = 0;
+            return;
         }
-        __syncthreads();
-        for (int k = lane; k < len; k += 64) {
-            const double e = es[k], s = xs[k];
-            buf[tile0 + k] = e != 0 ? P.target * s / e : s;      // agc.py:75-76
-        }
-        __syncthreads();
     }
-    if (lane == 0) {
-        state[0] = env;
-        state[1] = sustain;
+    P.att = consts[1];
+    P.dec = consts[2];
+    double env = s_in[c].x, sustain = s_in[c].y;
+    const int64_t k0 = c * lc, k1 = min(k0 + (int64_t)lc, n);
+    for (int64_t k = k0; k < k1; ++k) {
+        agc_step(buf[k], env, sustain, P);
+        if (EMIT) env_out[k] = env;
+    }
+    if (!EMIT) {
+        const double2 prev = s_in[c + 1];
+        const bool ch = __double_as_longlong(prev.x) != __double_as_longlong(env) ||
+                        __double_as_longlong(prev.y) != __double_as_longlong(sustain);
+        s_out[c + 1] = make_double2(env, sustain);
+        d_out[c + 1] = ch ? 1 : 0;
+        if (ch && c + 1 < nchunks) atomicAdd(changed, 1);
+    } else if (c == nchunks - 1) {
+        s_out[nchunks] = make_double2(env, sustain);        // final state, handed back to the caller
+    }
+}
+
+__global__ void agc_init_kernel(double2 *sa, double2 *sb, uint8_t *da, uint8_t *db, int64_t nchunks, double env0, double sus0, int *changed)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0) *changed = 0;
+    if (c > nchunks) return;
+    // chunk 0 starts from the caller's state (the true one); every other chunk is guessed "fresh" (0, 0)
+    const double2 v = c == 0 ? make_double2(env0, sus0) : make_double2(0.0, 0.0);
+    sa[c] = v;
+    sb[c] = v;
+    da[c] = c < nchunks ? 1 : 0;
+    db[c] = 0;
+}
+
+__global__ __launch_bounds__(256) void agc_scale_kernel(double *__restrict__ buf, const double *__restrict__ env, int64_t n, double target)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double e = env[i], s = buf[i];
+        buf[i] = e != 0 ? target * s / e : s;               // agc.py:75-76
     }
 }
 
@@ -324,24 +370,67 @@ int pm_agc_apply(pm_ctx *ctx, double *d_buf, int64_t n, const pm_agc_params *hp,
     if (n == 0) return PM_OK;
     PM_ARG(d_buf != nullptr && hp->sample_rate > 0);
     const int npartial = (int)std::min<int64_t>(1024, pm_cdiv(n, 256));
-    if (int rc = pm_scratch_reserve(ctx, (size_t)(npartial + 2) * 8)) return rc;
-    double *d_partial = (double *)ctx->d_scratch;
-    double *d_state = d_partial + npartial;
-    PM_HIP(hipMemcpyAsync(d_state, h_state, 16, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(max_partial_kernel, dim3(npartial), dim3(256), 0, ctx->stream, d_buf, n, d_partial);
+    // chunk length: ~64 K lanes at most, never shorter than 2048 samples
+    const int lc = (int)std::max<int64_t>(2048, pm_cdiv(n, 65536));
+    const int64_t nchunks = pm_cdiv(n, lc);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) / 256 * 256; return o; };
+    const size_t e = (size_t)nchunks + 1;
+    const size_t o_part = carve((size_t)npartial * 8), o_const = carve(64), o_sa = carve(e * 16), o_sb = carve(e * 16), o_da = carve(e),
+                 o_db = carve(e), o_ch = carve(256), o_env = carve((size_t)n * 8);
+    if (int rc = pm_scratch_reserve(ctx, off)) return rc;
+    char *base = (char *)ctx->d_scratch;
+    double *d_partial = (double *)(base + o_part), *d_const = (double *)(base + o_const), *d_env = (double *)(base + o_env);
+    double2 *sa = (double2 *)(base + o_sa), *sb = (double2 *)(base + o_sb);
+    uint8_t *da = (uint8_t *)(base + o_da), *db = (uint8_t *)(base + o_db);
+    int *changed = (int *)(base + o_ch);
+
     AgcDev P;
     P.sustain_time = hp->sustain_time;
     P.sustain_inc = 1 / hp->sample_rate;                            // agc.py:17
     P.target = hp->target_amplitude;
     P.att = P.dec = 0;
-    {
-        PmProf prof(ctx, PM_K_AGC);
-        hipLaunchKernelGGL(agc_kernel, dim3(1), dim3(64), 0, ctx->stream, d_buf, n, d_partial, npartial,
-                           hp->attack_rate / hp->sample_rate, hp->decay_rate / hp->sample_rate, P, d_state);   // agc.py:15-16
+    AgcScale sc{hp->attack_rate / hp->sample_rate, hp->decay_rate / hp->sample_rate};      // agc.py:15-16
+
+    PmProf prof(ctx, PM_K_AGC);
+    hipLaunchKernelGGL(max_partial_kernel, dim3(npartial), dim3(256), 0, ctx->stream, d_buf, n, d_partial);
+    hipLaunchKernelGGL(agc_prepare_kernel, dim3(1), dim3(1), 0, ctx->stream, d_partial, npartial, sc, d_const);
+    const unsigned grid = (unsigned)pm_cdiv(nchunks, 256);
+    hipLaunchKernelGGL(agc_init_kernel, dim3((unsigned)pm_cdiv((int64_t)e, 256)), dim3(256), 0, ctx->stream, sa, sb, da, db, nchunks,
+                       h_state[0], h_state[1], changed);
+    int *h_flag = (int *)ctx->h_pinned;
+    int iters = 0;
+    bool converged = nchunks == 1;
+    if (converged) {           // one chunk: its start state is the caller's, nothing to iterate
+        iters = 0;
     }
+    while (!converged) {
+        for (int b = 0; b < 4; ++b) {
+            hipLaunchKernelGGL((agc_iter_kernel<false>), dim3(grid), dim3(256), 0, ctx->stream, d_buf, n, lc, nchunks, d_const, P,
+                               sa, sb, da, db, nullptr, changed, iters);
+            std::swap(sa, sb);
+            std::swap(da, db);
+            ++iters;
+        }
+        PM_HIP(hipMemcpyAsync(h_flag, changed, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        PM_HIP(hipMemsetAsync(changed, 0, sizeof(int), ctx->stream));
+        PM_HIP(hipStreamSynchronize(ctx->stream));
+        converged = (*h_flag == 0);
+        if (getenv("PM_AGC_TRACE")) fprintf(stderr, "[agc] after %d iterations: %d start states changed (chunks %lld x %d)\n", iters, *h_flag, (long long)nchunks, lc);
+        if (!converged && iters > nchunks + 10)
+            return pm_set_error(PM_ERR_NOCONVERGE, "AGC fixed point not reached after %d iterations", iters);
+    }
+    // converged start states are in sa: emit the envelope, then scale in parallel
+    hipLaunchKernelGGL((agc_iter_kernel<true>), dim3(grid), dim3(256), 0, ctx->stream, d_buf, n, lc, nchunks, d_const, P,
+                       sa, sb, da, db, d_env, changed, iters);
+    hipLaunchKernelGGL(agc_scale_kernel, dim3(2048), dim3(256), 0, ctx->stream, d_buf, d_env, n, hp->target_amplitude);
     PM_HIP(hipGetLastError());
-    PM_HIP(hipMemcpyAsync(h_state, d_state, 16, hipMemcpyDeviceToHost, ctx->stream));
+    double2 fin;
+    PM_HIP(hipMemcpyAsync(&fin, sb + nchunks, sizeof(fin), hipMemcpyDeviceToHost, ctx->stream));
     PM_HIP(hipStreamSynchronize(ctx->stream));
+    h_state[0] = fin.x;
+    h_state[1] = fin.y;
+    ctx->sl_iterations = iters;
     return PM_OK;
 }
 
