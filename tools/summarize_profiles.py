@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""gpurun_out/{prof_stats,pmc_fetch,pmc_write,kernel_bench.jsonl,bench_default.json} -> profiles/<tag>_* (committed)."""
+import collections
+import csv
+import glob
+import json
+import re
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+workload, samples = "afsk_1200_super_opt", 28_800_000
+
+
+def short(n):
+    m = re.search(r"(\w+_kernel)(<[^>]*>)?", n)
+    return (m.group(1) + (m.group(2) or "")) if m else n[:40]
+
+
+stats = sorted(glob.glob("gpurun_out/prof_stats/*/*_kernel_stats.csv"))[-1]
+shutil.copyfile(stats, f"profiles/{tag}_{workload}_kernel_stats.csv")
+res = {}
+for name, ctr in [("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")]:
+    f = sorted(glob.glob(f"gpurun_out/{name}/*/*_counter_collection.csv"))[-1]
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(f)):
+        agg[short(r["Kernel_Name"])][0] += 1
+        agg[short(r["Kernel_Name"])][1] += float(r["Counter_Value"])
+    for k, (n, v) in agg.items():
+        res.setdefault(k, {})[ctr + "_KB_avg_per_launch"] = round(v / n, 1)
+        res[k][ctr + "_launches"] = n
+alg = {"afsk_correlate_kernel": 16.0, "fir_valid_kernel<double": 16.0, "fir_valid_kernel<short": 10.0, "signs_kernel": 8.125}
+out = {"workload": workload, "samples": samples,
+       "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (two separate passes) --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+       "corrections": "bytes = counter * 1024; FETCH_SIZE doubled (gfx950 reports half the bytes of a coalesced streaming read, MI355X_MICROARCH.md "
+                      "HBM section; calibrated in round 1 on signs_kernel: 230.4 MB read, 115.2 MB reported). Kernels that write only a sign bitmap "
+                      "(SIGNS variants) have ~N/8 bytes of writes.",
+       "kernels": {}}
+for k, v in sorted(res.items()):
+    f = v.get("FETCH_SIZE_KB_avg_per_launch", 0) * 1024 * 2
+    w = v.get("WRITE_SIZE_KB_avg_per_launch", 0) * 1024
+    v["hbm_read_bytes_corrected"], v["hbm_write_bytes"], v["traffic_bytes_per_launch"] = round(f), round(w), round(f + w)
+    for key, per in alg.items():
+        if k.startswith(key):
+            v["algorithmic_bytes_per_launch_full_output"] = per * samples
+    out["kernels"][k] = v
+json.dump(out, open(f"profiles/{tag}_{workload}_pmc.json", "w"), indent=1)
+shutil.copyfile("gpurun_out/kernel_bench.jsonl", f"profiles/{tag}_kernel_bench.jsonl")
+shutil.copyfile("gpurun_out/bench_default.json", f"profiles/{tag}_bench_default.json")
+for k, v in out["kernels"].items():
+    print(f"{k:45s} traffic {v['traffic_bytes_per_launch'] / 1e6:9.1f} MB/launch")
+print(open(f"profiles/{tag}_{workload}_kernel_stats.csv").read()[:1500])
