@@ -477,6 +477,32 @@ def gen_signal_chains():
         json.dump({"cases": [list(c) for c in SIGNAL_CASES], "results": summary}, f, indent=1)
 
 
+def gen_reports():
+    """Report text of the reference (packet_meta.py:283-370) for the bundled recording and two generated ones, chains added
+    in config order (the reference CLI's own order depends on process completion)."""
+    from modems_codecs.packet_meta import ReportStyle
+    out = {}
+    g = np.load(os.path.join(OUT, "signal_chains.npz"))
+    rate_w, audio_w = readwav(WAV)
+    cases = [("afsk_300.json", rate_w, audio_w), ("afsk_300_ax25.json", rate_w, audio_w),
+             ("afsk_1200.json", 48000, g["afsk1200_ax25__afsk_1200__48000__audio"]),
+             ("qpsk_2400.json", 48000, g["qpsk2400_il2p__qpsk_2400__48000__audio"])]
+    for cfgname, rate, audio in cases:
+        lines = [l for l in load_config(cfgname) if l.get("object_type") == "demod_chain"]
+        results = PacketMetaArray()
+        with quiet():
+            for line in lines:
+                chain = build_chain(rate, line)
+                results.add(chain[4].decode(chain[3].stream_unscramble_8bit(chain[2].slice(chain[1].demod(audio)))))
+            results.CalcCRCs()
+            results.Correlate(address_distance=rate / 40)
+            style = ReportStyle({"style": "decoded_headers", "destination": "std_out"})
+            out[cfgname] = {"rate": int(rate), "raw_bad": results.PrintRawBad(), "report": results.Report(style)}
+    with open(os.path.join(OUT, "reports.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("reports.json:", {k: (len(v["raw_bad"]), len(v["report"])) for k, v in out.items()})
+
+
 def copy_data_files():
     """Data files (not source): the bundled recording and the JSON-lines configs.  MIT, see the
     reference's LICENSE.  They are inputs of the parity tests; the GPU box only has /root/repo."""
@@ -487,7 +513,7 @@ def copy_data_files():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["taps", "prims", "synth", "wav", "signal", "copy"]
+    which = sys.argv[1:] or ["taps", "prims", "synth", "wav", "signal", "reports", "copy"]
     if "taps" in which:
         gen_taps()
     if "prims" in which:
@@ -498,5 +524,7 @@ if __name__ == "__main__":
         gen_wav_chains()
     if "signal" in which:
         gen_signal_chains()
+    if "reports" in which:
+        gen_reports()
     if "copy" in which:
         copy_data_files()
