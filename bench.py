@@ -135,6 +135,9 @@ def main():
     ap.add_argument("--chains-per-gpu", type=int, default=0)
     ap.add_argument("--rate", type=int, default=48000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", type=int, default=1,
+                    help="1: the host half of step k (LFSR, codec, packet gather, de-dup) runs in a worker thread while the GPU half of "
+                         "step k+1 (demod, slice) runs, as a service decoding successive recordings would; 0: strictly one after the other")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--buffer", default="signal", choices=["signal", "noise"],
                     help="signal: seeded packet-bearing recording of the workload's mode + AWGN (pymodem_amd.siggen), tiled to --samples; "
@@ -183,7 +186,7 @@ def main():
 
     chains_ref = []
 
-    def step():
+    def build_chains():
         chains = []
         for c in my:
             line = lines[c]
@@ -192,10 +195,32 @@ def main():
             srate = getattr(modem, "output_sample_rate", args.rate)
             chains.append([line["object_name"], modem, cb.SlicerConfigurator(srate, line["slicer"]),
                            cb.StreamConfigurator(line["stream"]), cb.CodecConfigurator(line["codec"], line["object_name"])])
-        rows = ce.process_chains_table(chains, d_audio, chain_ids=my)
         chains_ref[:] = chains
-        table = pdist.gather_rows(rows, nchains, names, device=coll_device)           # the one exchange step
-        return table.correlate(args.rate / 40) if table is not None else None         # rank 0: cross-chain de-dup
+        return chains
+
+    def finish(rows_list):
+        table = pdist.gather_rows(dict(zip(my, rows_list)), nchains, names, device=coll_device)    # the one exchange step
+        return table.correlate(args.rate / 40) if table is not None else None                      # rank 0: cross-chain de-dup
+
+    def step():
+        return finish(ce.process_chains_split(build_chains(), d_audio)())
+
+    def run_steps(k):
+        """k steps; with --overlap the host half of each step runs behind the GPU half of the next one."""
+        if not args.overlap:
+            res = None
+            for _ in range(k):
+                res = step()
+            return res
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=1) as worker:       # one worker: host halves (and their collectives) stay in step order
+            pending = None
+            for _ in range(k):
+                host_half = ce.process_chains_split(build_chains(), d_audio)
+                if pending is not None:
+                    pending.result()
+                pending = worker.submit(lambda h=host_half: finish(h()))
+            return pending.result() if pending is not None else None
 
     def fence():
         ctx.sync()
@@ -203,14 +228,11 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     fence()
     ctx.profile(True)
     t0 = time.perf_counter()
-    result = None
-    for _ in range(args.steps):
-        result = step()
+    result = run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_read()
@@ -241,7 +263,8 @@ def main():
             "config": {"workload": f"{args.workload}: {desc}", "chains_per_gpu": cpg, "chains_total": nchains,
                        "samples_per_recording": args.samples, "sample_rate": args.rate,
                        "buffer": BUFFER_DESC[args.buffer] + ", resident in HBM",
-                       "parallelism": f"chains sharded {cpg}/GPU x {world} GPU, packet gather to rank 0"},
+                       "parallelism": f"chains sharded {cpg}/GPU x {world} GPU, packet gather to rank 0",
+                       "overlap": "host half of step k behind GPU half of step k+1" if args.overlap else "none"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "avg_kernel_ms": round(avg_ms, 5), "launches": dom_n, "algorithmic_bytes_per_launch": alg_bytes,

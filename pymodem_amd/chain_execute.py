@@ -68,7 +68,19 @@ def process_chains_table(chains, input_audio, chain_ids=None, names=None):
     return dict(zip(ids, rows))
 
 
-def process_chains_device(chains, input_audio, stages=None, _rows=False):
+def process_chains_split(chains, input_audio):
+    """The GPU half of process_chains_table, returning a zero-argument callable for the host half: demod + slice run (and
+    finish) now; calling the result runs LFSR + codec for every chain and returns their pm_packet rows.  Lets the host half
+    of one recording overlap the GPU half of the next (bench.py --overlap)."""
+    sliced = process_chains_device(chains, input_audio, _sliced_only=True)
+
+    def host_half():
+        futures = [_pool().submit(_host_stages_rows, ch, sl) for ch, sl in zip(chains, sliced)]
+        return [f.result() for f in futures]
+    return host_half
+
+
+def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced_only=False):
     """[chain, ...] -> [packets of chain 0, packets of chain 1, ...] (config order), identical to running
     process_chain on each.  See the module docstring for what is shared and batched."""
     ctx = Context.default()
@@ -79,6 +91,9 @@ def process_chains_device(chains, input_audio, stages=None, _rows=False):
     n_chains = len(chains)
     bitmaps = [None] * n_chains
     group_key = "chain-group"          # work buffers are reused from one group run to the next
+    for k, ch in enumerate(chains):    # stable per-chain keys: a new set of stage objects reuses the previous run's buffers
+        ch[1].own_key = (group_key, "modem", k)
+        ch[2].own_key = (group_key, "slicer", k)
 
     # ---- shared front ends ------------------------------------------------------------------------------------
     front = {}
@@ -131,6 +146,8 @@ def process_chains_device(chains, input_audio, stages=None, _rows=False):
 
     # ---- all slicers in one batch, host stages in parallel ---------------------------------------------------------
     sliced = slice_batch([ch[2] for ch in chains], bitmaps)
+    if _sliced_only:
+        return sliced
     futures = [_pool().submit(_host_stages_rows if _rows else _host_stages, ch, sl) for ch, sl in zip(chains, sliced)]
     packets = [f.result() for f in futures]
     if stages is not None:

@@ -98,11 +98,18 @@ struct GF256 {
         while (r > 254) r -= 255;
         return table[r];
     }
+    // row[i][v] = v * table[i] for the 16 generator roots table[0..15]: one lookup per byte in the Horner syndromes
+    uint8_t row[16][256];
+    void build_rows()
+    {
+        for (int i = 0; i < 16; ++i)
+            for (int v = 0; v < 256; ++v) row[i][v] = (uint8_t)mul(v, table[i]);
+    }
 };
 
 const GF256 &gf()
 {
-    static const GF256 g;
+    static const GF256 g = [] { GF256 t; t.build_rows(); return t; }();
     return g;
 }
 
@@ -120,13 +127,20 @@ int rs_decode(int num_roots, uint8_t *buf, int n, int min_distance)
     int syn[16];
     auto syndromes = [&]() {
         for (int i = 0; i < num_roots; ++i) {
-            const int x = g.table[first_root + i];
-            int v = 0;
-            for (int j = 0; j < n - 1; ++j) v = g.mul(v ^ buf[j], x);
-            syn[i] = v ^ buf[n - 1];
+            const uint8_t *row = g.row[first_root + i];            // multiplication by the i-th root
+            unsigned v = 0;
+            for (int j = 0; j < n - 1; ++j) v = row[v ^ buf[j]];
+            syn[i] = (int)(v ^ buf[n - 1]);
         }
     };
     syndromes();
+    {
+        // All syndromes zero: the locator stays {1}, the Chien search finds no root (x = loc[0] = 1), nothing is corrected and
+        // the closing check passes -- the reference's algorithm returns 0 with the data untouched.  Skip straight there.
+        bool clean = true;
+        for (int i = 0; i < num_roots; ++i) clean &= syn[i] == 0;
+        if (clean) return 0;
+    }
     int loc[17] = {0}, nxt[17] = {0}, corr[18] = {0}, where[17] = {0};
     loc[0] = 1;
     corr[1] = 1;

@@ -45,6 +45,26 @@ class Context:
         check(lib().pm_h2d(self._h, buf.ptr, host.ctypes.data_as(ctypes.c_void_p), host.nbytes))
         return buf
 
+    def owner_key(self, obj):
+        """A pool key tied to `obj`'s lifetime: its work buffers are released when the object is garbage collected
+        (stage objects are single-use per recording; without this every new object would leave its buffers behind)."""
+        import weakref
+        key = ("obj", id(obj))
+        owned = self.__dict__.setdefault("_owned", set())
+        if key not in owned:
+            owned.add(key)
+            weakref.finalize(obj, self._release, key)
+        return key
+
+    def _release(self, key):
+        pool = self.__dict__.get("_pool", {})
+        for tag in [t for t in pool if isinstance(t, tuple) and t and t[0] == key]:
+            try:
+                pool.pop(tag).free()
+            except Exception:
+                pass
+        self.__dict__.get("_owned", set()).discard(key)
+
     def scratch(self, tag, n, dtype):
         """A persistent work buffer of at least n elements for `tag`; contents are undefined and the same
         storage is handed out again on the next call with the same tag (no hipMalloc in steady state)."""

@@ -27,9 +27,14 @@ class _DeviceStage:
     """Lazy device state: nothing touches HIP until demod() runs (the reference forks after construction)."""
     _ctx = None
     scratch_key = None      # chains run one after another on one stream may share work buffers: same key, same storage
+    own_key = None          # stable per-chain key given by the group executor (else tied to this object's lifetime)
 
     def _key(self):
-        return self.scratch_key if self.scratch_key is not None else id(self)
+        return self.scratch_key if self.scratch_key is not None else self._ctx.owner_key(self)
+
+    def _own_key(self):
+        """Key for buffers that must stay distinct per chain inside a group (the sign bitmaps the batched slicer reads)."""
+        return self.own_key if self.own_key is not None else self._ctx.owner_key(self)
 
     def _context(self):
         if self._ctx is None:
@@ -77,7 +82,7 @@ class _DeviceStage:
         if x.n < m:
             raise ValueError(f"input of {x.n} samples is shorter than the {m}-tap filter {taps_name}")
         nout = x.n - m + 1
-        bits = ctx.scratch((id(self), "signs", tag or taps_name), (nout + 63) // 64 + 1, np.uint64)
+        bits = ctx.scratch((self._own_key(), "signs", tag or taps_name), (nout + 63) // 64 + 1, np.uint64)
         fn = lib().pm_fir_signs_i16 if is_i16 else lib().pm_fir_signs_f64
         check(fn(ctx.handle, x.ptr, x.n, self._const(taps_name, taps).ptr, m, bits.ptr, flags))
         return bits, nout

@@ -13,6 +13,10 @@ from .device import Context, DeviceBuffer
 class _SlicerBase:
     _ctx = None
     last_stats = None
+    own_key = None          # stable key given by the group executor (else tied to this object's lifetime)
+
+    def _own_key(self):
+        return self.own_key if self.own_key is not None else self._ctx.owner_key(self)
 
     def retune(self, **kwargs):
         self.symbol_rate = kwargs.get('symbol_rate', self.symbol_rate)
@@ -46,7 +50,7 @@ class _SlicerBase:
         if not isinstance(x, DeviceBuffer):
             x = ctx.upload(np.ascontiguousarray(x, dtype=np.float64))
         assert x.dtype == np.dtype(np.float64)
-        bits = ctx.scratch((id(self), tag), (x.n + 63) // 64 + 1, np.uint64)
+        bits = ctx.scratch((self._own_key(), tag), (x.n + 63) // 64 + 1, np.uint64)
         check(lib().pm_signs_f64(ctx.handle, x.ptr, x.n, bits.ptr))
         return bits, x.n
 
@@ -79,8 +83,9 @@ def slice_batch(slicers, bitmaps):
         for j, k in enumerate(group):
             sl, (bi, bq, n) = slicers[k], bitmaps[k]
             cap = n * sl.bits_per_symbol // 8 + 4          # at most one symbol per sample
-            data = ctx.scratch((id(sl), "bytes"), cap + 4, np.uint8)
-            addr = ctx.scratch((id(sl), "addr"), cap, np.int64)
+            sl._ctx = sl._ctx or ctx
+            data = ctx.scratch((sl._own_key(), "bytes"), cap + 4, np.uint8)
+            addr = ctx.scratch((sl._own_key(), "addr"), cap, np.int64)
             bufs.append((data, addr))
             jobs[j].d_bits_i = bi.ptr if bi is not None else None
             jobs[j].d_bits_q = bq.ptr if bq is not None else None

@@ -157,3 +157,22 @@ def test_table_path_on_bundled_recording(golden, config_lines):
     assert np.array_equal(table.rows["streamaddress"][table.unique_idx], g["afsk_300__uniq_addr"])
     for ci in range(len(lines)):
         assert np.array_equal(rows[ci]["streamaddress"], g[f"afsk_300__c{ci}_pkt_addr"])
+
+
+def test_work_buffers_do_not_accumulate(config_lines):
+    """Stage objects are single-use; their pooled work buffers must go with them (stand-alone use) or be reused (group runs)."""
+    import gc
+    import pymodem_amd
+    from pymodem_amd import chain_builder as cb, chain_execute as ce
+    ctx = pymodem_amd.Context.default()
+    audio = noise_i16(60000)
+    lines = config_lines("afsk_1200.json")
+    sizes = []
+    for _ in range(4):
+        chain = cb.build_chain(48000, lines[0])
+        ce.process_chain(chain, audio)
+        ce.process_chains_device([cb.build_chain(48000, l) for l in lines], audio)
+        del chain
+        gc.collect()
+        sizes.append(len(ctx._pool))
+    assert sizes[1] == sizes[2] == sizes[3], sizes
