@@ -15,7 +15,7 @@ import numpy as np
 
 from ._native import Loop, check, lib
 from .device import Context, DeviceBuffer
-from .modems import AFSKModem, MPSKModem
+from .modems import AFSKModem, AFSKPLLModem, BPSKModem, MPSKModem
 from .slicer import slice_batch
 
 
@@ -129,6 +129,26 @@ def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced
             modem.scratch_key = (group_key, "mpsk_back")
             out = modem.back_end(i_mix.view(j * n, n), q_mix.view(j * n, n), signs=True)
             bitmaps[k] = chains[k][2].sign_bitmaps(out)
+
+    # ---- BPSK Costas / AFSK PLL groups: same idea, one real input stream -----------------------------------------------
+    loop_groups = {}
+    for k, ch in enumerate(chains):
+        if isinstance(ch[1], (BPSKModem, AFSKPLLModem)):
+            loop_groups.setdefault(ch[1].front_end_key(), []).append(k)
+    for gi, (key, members) in enumerate(loop_groups.items()):
+        lead = chains[members[0]][1]
+        x = shared_front(lead)
+        n, g = x.n, len(members)
+        loops = (Loop * g)()
+        for j, k in enumerate(members):
+            ctypes.memmove(ctypes.byref(loops[j]), ctypes.byref(chains[k][1]._loop), ctypes.sizeof(Loop))
+        mix = ctx.scratch((group_key, "loop_out", gi), n * g, np.float64)
+        check(getattr(lib(), lead.loop_entry)(ctx.handle, loops, g, lead._const("wavetable", lead.wavetable).ptr, x.ptr, 0, n, mix.ptr, n))
+        for j, k in enumerate(members):
+            modem = chains[k][1]
+            ctypes.memmove(ctypes.byref(modem._loop), ctypes.byref(loops[j]), ctypes.sizeof(Loop))
+            modem.scratch_key = (group_key, "loop_back")
+            bitmaps[k] = chains[k][2].sign_bitmaps(modem.back_end(mix.view(j * n, n), signs=True))
 
     # ---- everything else, chain by chain (work buffers shared across the group) ----------------------------------
     for k, ch in enumerate(chains):

@@ -327,14 +327,30 @@ class BPSKModem(_DeviceStage):
         self._loop0 = _snapshot(self._loop)
         self.output_sample_rate = self.sample_rate
 
-    def demod(self, input_audio, device_out=False, signs=False):   # psk.py:162-195
+    loop_entry = "pm_costas_bpsk"
+
+    def front_end(self, input_audio):
+        """Band-pass + AGC (psk.py:165-168): what chains that differ only in carrier_freq share."""
         x, is_i16 = self._input(input_audio)
-        ctx = self._ctx
         a = self._fir(x, is_i16, "input_bpf", self.input_bpf)
         self._agc(a)
+        return a
+
+    def front_end_key(self):
+        g = self.AGC
+        return ("bpsk", float(self.sample_rate), self.input_bpf.tobytes(), (g.attack_rate, g.decay_rate, g.sustain_time, g.target_amplitude))
+
+    def demod(self, input_audio, device_out=False, signs=False):   # psk.py:162-195
+        a = self.front_end(input_audio)
+        ctx = self._ctx
         d = ctx.scratch((self._key(), "loop"), a.n, np.float64)
         check(lib().pm_costas_bpsk(ctx.handle, ctypes.byref(self._loop), 1, self._const("wavetable", self.wavetable).ptr,
                                    a.ptr, 0, a.n, d.ptr, a.n))
+        return self.back_end(d, device_out, signs)
+
+    def back_end(self, d, device_out=False, signs=False):
+        """Matched filter on the loop output (psk.py:193)."""
+        self._context()
         if signs:
             bits, nout = self._fir_signs(d, False, "rrc", self.rrc_taps)
             return SignBits(bits, None, nout)
@@ -491,14 +507,30 @@ class AFSKPLLModem(_DeviceStage):
         self._loop0 = _snapshot(self._loop)
         self.output_sample_rate = self.sample_rate
 
-    def demod(self, input_audio, device_out=False, signs=False):   # afsk_pll.py:140-170
+    loop_entry = "pm_pll_afsk"
+
+    def front_end(self, input_audio):
+        """Band-pass + AGC (afsk_pll.py:143-146)."""
         x, is_i16 = self._input(input_audio)
-        ctx = self._ctx
         a = self._fir(x, is_i16, "input_bpf", self.input_bpf)
         self._agc(a)
+        return a
+
+    def front_end_key(self):
+        g = self.AGC
+        return ("pll", float(self.sample_rate), self.input_bpf.tobytes(), (g.attack_rate, g.decay_rate, g.sustain_time, g.target_amplitude))
+
+    def demod(self, input_audio, device_out=False, signs=False):   # afsk_pll.py:140-170
+        a = self.front_end(input_audio)
+        ctx = self._ctx
         d = ctx.scratch((self._key(), "loop"), a.n, np.float64)
         check(lib().pm_pll_afsk(ctx.handle, ctypes.byref(self._loop), 1, self._const("wavetable", self.wavetable).ptr,
                                 a.ptr, 0, a.n, d.ptr, a.n))
+        return self.back_end(d, device_out, signs)
+
+    def back_end(self, d, device_out=False, signs=False):
+        """Output low-pass on the loop's proportional term (afsk_pll.py:168)."""
+        self._context()
         if signs:
             bits, nout = self._fir_signs(d, False, "output_lpf", self.output_lpf)
             return SignBits(bits, None, nout)
