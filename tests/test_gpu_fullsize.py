@@ -1,0 +1,97 @@
+"""BASELINE.json's full size (10 min @ 48 kHz = 28.8 M samples) on the GPU, checked through size-independent properties:
+FIR-class kernels on random output windows against the oracle's exact dot products (same fma order -> bit-exact), the sign
+bitmap against a direct comparison, and the chunk-parallel slicer against the oracle's sequential C slicer over the WHOLE
+stream (bytes and addresses identical)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import noise_i16
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+N = 28_800_000
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import pymodem_amd
+    return pymodem_amd.Context.default()
+
+
+def windows(rng, nout, m, count=300):
+    ks = np.concatenate([[0, 1, 2047, 2048, 2049, nout - 1, nout - 2], rng.integers(0, nout, count)])
+    return np.unique(ks)
+
+
+def test_afsk_modem_stages_at_full_size(ctx, config_lines):
+    from pymodem_amd import chain_builder as cb
+    from pymodem_amd._native import check, lib
+    rng = np.random.default_rng(7)
+    audio = noise_i16(N)
+    modem = cb.ModemConfigurator(48000, config_lines("afsk_1200_ax25_super_opt.json")[1]["modem"])
+    d_audio = ctx.upload(audio)
+    bpf = modem.front_end(d_audio)
+    h_bpf = bpf.download()
+    m = len(modem.input_bpf)
+    assert len(h_bpf) == N - m + 1
+    for k in windows(rng, len(h_bpf), m):
+        assert h_bpf[k] == O.fir_canon(audio[k:k + m], modem.input_bpf)[0]
+    # correlators on the GPU's own band-passed stream
+    mc = len(modem.mark_correlator_i)
+    corr = ctx.empty(len(h_bpf) - mc + 1, np.float64)
+    t = [ctx.upload(v) for v in (modem.mark_correlator_i, modem.mark_correlator_q, modem.space_correlator_i, modem.space_correlator_q)]
+    check(lib().pm_afsk_correlate(ctx.handle, bpf.ptr, bpf.n, t[0].ptr, t[1].ptr, t[2].ptr, t[3].ptr, mc, corr.ptr))
+    h_corr = corr.download()
+    for k in windows(rng, len(h_corr), mc):
+        want = O.afsk_correlate_canon(h_bpf[k:k + mc], modem.mark_correlator_i, modem.mark_correlator_q,
+                                      modem.space_correlator_i, modem.space_correlator_q)[0]
+        assert h_corr[k] == want
+    # output low-pass, float64 out and fused sign bitmap
+    ml = len(modem.output_lpf)
+    taps = ctx.upload(modem.output_lpf)
+    lpf = ctx.empty(len(h_corr) - ml + 1, np.float64)
+    check(lib().pm_fir_valid_f64(ctx.handle, corr.ptr, corr.n, taps.ptr, ml, lpf.ptr, 0))
+    h_lpf = lpf.download()
+    for k in windows(rng, len(h_lpf), ml):
+        assert h_lpf[k] == O.fir_canon(h_corr[k:k + ml], modem.output_lpf)[0]
+    bits = ctx.empty((len(h_lpf) + 63) // 64 + 1, np.uint64)
+    check(lib().pm_fir_signs_f64(ctx.handle, corr.ptr, corr.n, taps.ptr, ml, bits.ptr, 0))
+    got = np.unpackbits(bits.download().view(np.uint8), bitorder="little")[:len(h_lpf)].astype(bool)
+    assert np.array_equal(got, h_lpf >= 0)
+    # whole-stream slicer: chunk-parallel fixed point vs the sequential oracle
+    from pymodem_amd.slicer import BinarySlicer
+    s = BinarySlicer(sample_rate=48000.0, config="1200")
+    s.StringOptionsRetune({"lock_rate": "0.77"})
+    out = s.slice(lpf)
+    d, a = O.BinarySlicer(48000.0, "1200", {"lock_rate": "0.77"}).slice(h_lpf)
+    assert np.array_equal(out.data, d) and np.array_equal(out.address, a)
+    assert len(d) > 80000 and s.last_stats["iterations"] < 200
+
+
+def test_quadrature_slicer_and_agc_at_full_size(ctx):
+    """QPSK-2400 slicer (lock 0.98, differential demap across chunk boundaries) and the chunk-parallel AGC over 28.8 M samples."""
+    from pymodem_amd._native import AGCParams, check, lib
+    from pymodem_amd.data_classes import DeviceIQ
+    from pymodem_amd.slicer import QuadratureSlicer
+    rng = np.random.default_rng(11)
+    xi = np.convolve(rng.standard_normal(N + 39), np.hanning(40), "valid")
+    xq = np.convolve(rng.standard_normal(N + 39), np.hanning(40), "valid")
+    s = QuadratureSlicer(sample_rate=48000.0, config="qpsk_2400")
+    s.StringOptionsRetune({"lock_rate": "0.98"})
+    out = s.slice(DeviceIQ(ctx.upload(xi), ctx.upload(xq)))
+    d, a = O.QuadratureSlicer(48000.0, "qpsk_2400", {"lock_rate": "0.98"}).slice((xi, xq))
+    assert np.array_equal(out.data, d) and np.array_equal(out.address, a)
+    # AGC: bursty envelope so that attack, sustain and decay all occur many times
+    env = 0.2 + np.abs(np.sin(np.arange(N) / 300000.0))
+    buf = xi * env * 100.0
+    want = buf.copy()
+    st_o = np.zeros(2)
+    O.agc_apply(want, 48000.0, 500.0, 1.0, 50.0, 1.0, state=st_o)
+    dbuf = ctx.upload(buf)
+    st = (ctypes.c_double * 2)(0.0, 0.0)
+    p = AGCParams(500.0, 50.0, 1.0, 48000.0, 1.0)
+    check(lib().pm_agc_apply(ctx.handle, dbuf.ptr, N, ctypes.byref(p), st))
+    assert np.array_equal(dbuf.download(), want)
+    assert st[0] == st_o[0] and st[1] == st_o[1]
