@@ -88,9 +88,7 @@ WORKLOADS = {
                   "carrier loop, 2x RRC 241, quadrature slicer, IL2P)"),
 }
 
-# ALGORITHMIC bytes per input sample and launch for each kernel class: read + write of the stage, taps excluded
-ALG_BYTES = {"fir_i16": 10.0, "fir_f64": 16.0, "afsk_correlate": 16.0, "signs": 8.0 + 1.0 / 8, "slice_iter": 1.0 / 8,
-             "slice_emit": 1.0 / 8, "agc": 16.0, "loop": 16.0}
+FP64_PEAK_TFLOPS = 78.6         # MI355X vector FP64 (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz); v_mfma_f64 has the same dense peak
 
 
 SIGNAL_MODE = {"afsk_1200_super_opt": "afsk1200_ax25", "fsk_9600": "fsk9600_il2p", "bpsk_300": "bpsk300_il2p", "qpsk_2400": "qpsk2400_il2p"}
@@ -128,16 +126,19 @@ def synth_buffer(n, seed=1234):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="afsk_1200_super_opt", choices=sorted(WORKLOADS))
     ap.add_argument("--samples", type=int, default=28_800_000, help="samples per recording (10 min @ 48 kHz)")
     ap.add_argument("--chains-per-gpu", type=int, default=0)
     ap.add_argument("--rate", type=int, default=48000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap", type=int, default=1,
-                    help="1: the host half of step k (LFSR, codec, packet gather, de-dup) runs in a worker thread while the GPU half of "
-                         "step k+1 (demod, slice) runs, as a service decoding successive recordings would; 0: strictly one after the other")
+    ap.add_argument("--overlap", type=int, default=2,
+                    help="how successive steps (recordings) overlap, as in a service decoding one recording after another. "
+                         "2: three-stage pipeline (chain_execute.RecordingPipeline): demod of step k+1 on the default stream, slicer of "
+                         "step k on a high-priority side stream, host half (LFSR, codec, packet gather, de-dup) of step k-1 in threads; "
+                         "1: only the host half runs behind the next step's GPU half; 0: strictly one after the other")
+    ap.add_argument("--slice-workers", type=int, default=3, help="--overlap 2: recordings whose slicers may be in flight at once")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--buffer", default="signal", choices=["signal", "noise"],
                     help="signal: seeded packet-bearing recording of the workload's mode + AWGN (pymodem_amd.siggen), tiled to --samples; "
@@ -205,12 +206,24 @@ def main():
     def step():
         return finish(ce.process_chains_split(build_chains(), d_audio)())
 
+    stage_ms = {}
+
     def run_steps(k):
         """k steps; with --overlap the host half of each step runs behind the GPU half of the next one."""
         if not args.overlap:
             res = None
             for _ in range(k):
                 res = step()
+            return res
+        if args.overlap >= 2:
+            pipe = ce.RecordingPipeline(slice_workers=args.slice_workers)
+            last = None
+            for _ in range(k):
+                last = pipe.submit(build_chains(), d_audio, finish)
+            res = last.result() if last is not None else None
+            pipe.close()
+            stage_ms.clear()
+            stage_ms.update({s: round(v / max(k, 1) * 1e3, 3) for s, v in pipe.stage_seconds.items()})
             return res
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=1) as worker:       # one worker: host halves (and their collectives) stay in step order
@@ -222,8 +235,12 @@ def main():
                 pending = worker.submit(lambda h=host_half: finish(h()))
             return pending.result() if pending is not None else None
 
+    sides = [pymodem_amd.Context.side(dev_index, i) for i in range(args.slice_workers)] if args.overlap >= 2 else []
+
     def fence():
         ctx.sync()
+        for sc in sides:
+            sc.sync()
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
@@ -231,12 +248,32 @@ def main():
     run_steps(args.warmup)
     fence()
     ctx.profile(True)
+    for sc in sides:
+        sc.profile(True)
     t0 = time.perf_counter()
     result = run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_read()
+    work = ctx.profile_work()
     ctx.profile(False)
+    for sc in sides:
+        for name, (ms, cnt) in sc.profile_read().items():
+            prof[name] = (prof[name][0] + ms, prof[name][1] + cnt)
+        for name, (by, fl) in sc.profile_work().items():
+            work[name] = (work[name][0] + by, work[name][1] + fl)
+        sc.profile(False)
+    # the same kernels with the GPU to themselves (one more step, strictly sequential, outside the timed region): in the pipelined
+    # run two or more streams share the CUs, which stretches every kernel's duration
+    alone = {}
+    if args.overlap:
+        saved, args.overlap = args.overlap, 0
+        ctx.profile(True)
+        run_steps(1)
+        fence()
+        alone = ctx.profile_read()
+        ctx.profile(False)
+        args.overlap = saved
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device or "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -245,17 +282,21 @@ def main():
     if rank == 0:
         total_samples = float(args.samples) * nchains * args.steps
         value = total_samples / elapsed / 1e6
-        # Roofline: the dominant kernel of the FIR/correlator stage (the stage north_star prices against HBM).  The slicer and
-        # the carrier loops are dependent-latency bound: a byte roofline says nothing about them, so they
-        # are listed with their time in `gpu_kernel_ms_per_step` and named in `dominant_by_time` when they lead.
+        # Roofline: the dominant kernel of the FIR/correlator stage (the stage north_star prices against HBM).  Algorithmic bytes
+        # and flops are what the library accounted for the very launches that were timed (pm_prof_work).  The slicer and the
+        # carrier loops are dependent-latency bound: neither roofline says anything about them, so they are
+        # listed with their time in `gpu_kernel_ms_per_step` and named in `dominant_by_time` when they lead.
         by_time = max(prof, key=lambda k: prof[k][0])
         stage = [k for k in ("fir_i16", "fir_f64", "afsk_correlate", "signs") if prof[k][1]]
         dom = max(stage, key=lambda k: prof[k][0])
         dom_ms, dom_n = prof[dom]
+        dom_bytes, dom_flops = work[dom]
         avg_ms = dom_ms / max(dom_n, 1)
-        alg_bytes = ALG_BYTES[dom] * args.samples
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        tflops = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         traffic = pmc_traffic(args, dom)
+        alone_ms = alone[dom][0] / max(alone[dom][1], 1) if alone.get(dom, (0, 0))[1] else None
+        per_launch_bytes, per_launch_flops = dom_bytes / max(dom_n, 1), dom_flops / max(dom_n, 1)
         out = {
             "metric": "Msamples/s through demod_chain", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -264,14 +305,25 @@ def main():
                        "samples_per_recording": args.samples, "sample_rate": args.rate,
                        "buffer": BUFFER_DESC[args.buffer] + ", resident in HBM",
                        "parallelism": f"chains sharded {cpg}/GPU x {world} GPU, packet gather to rank 0",
-                       "overlap": "host half of step k behind GPU half of step k+1" if args.overlap else "none"},
+                       "overlap": {0: "none", 1: "host half of step k behind GPU half of step k+1",
+                                   2: "3-stage pipeline: demod(k+1) | slice(k) on a side stream | host(k-1)"}[min(args.overlap, 2)]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "avg_kernel_ms": round(avg_ms, 5), "launches": dom_n, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_kernel_ms": round(avg_ms, 5), "launches": dom_n, "algorithmic_bytes_per_launch": round(per_launch_bytes),
                          "stage": "FIR/correlator", "dominant_by_time": by_time,
-                         "note": "achieved = algorithmic bytes / HIP-event time of this kernel inside the timed region; the kernel is "
-                                 "vector-f64-ALU bound above ~40 taps (DESIGN.md 4.1-4.2), so frac is a lower bound on its efficiency"},
+                         "alone": None if alone_ms is None else {
+                             "avg_kernel_ms": round(alone_ms, 5), "achieved": round(per_launch_bytes / (alone_ms * 1e-3) / 1e9, 2),
+                             "frac": round(per_launch_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                             "note": "same kernel class in one extra sequential step after the timed region, no other stream on the GPU"},
+                         "note": "achieved = algorithmic bytes of the timed launches / their HIP-event time inside the timed region (where "
+                                 "the slicer streams share the CUs).  Above ~40 taps the kernel is bound by the vector-f64 FMA pipe, not by "
+                                 "HBM: see roofline_fp64 for that fraction (DESIGN.md 4.1-4.2)"},
+            "roofline_fp64": {"bound": "valu_f64", "kernel": dom, "achieved": round(tflops, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(tflops / FP64_PEAK_TFLOPS, 5), "algorithmic_flops_per_launch": round(per_launch_flops),
+                              "alone_frac": None if alone_ms is None else round(per_launch_flops / (alone_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5),
+                              "note": "2 flops per fma of the FIR sums (epilogue sqrt / sign tests not counted) / the same HIP-event time"},
             "gpu_kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]},
+            "pipeline_stage_ms_per_step": stage_ms or None,
             "slicer": chains_ref[0][2].last_stats if chains_ref else None,
             "packets": {"unique_good": result.CountGood() if result is not None else None,
                         "bad": result.CountBad() if result is not None else None},
@@ -284,7 +336,6 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-PMC_KERNEL = {"fir_i16": "fir_valid_kernel<short", "fir_f64": "fir_valid_kernel<double", "afsk_correlate": "afsk_correlate_kernel", "signs": "signs_kernel"}
 
 
 def pmc_traffic(args, kernel_class):
@@ -299,9 +350,9 @@ def pmc_traffic(args, kernel_class):
             continue
         if d.get("workload") != args.workload or d.get("samples") != args.samples:
             continue
-        for name, v in d.get("kernels", {}).items():
-            if name.startswith(PMC_KERNEL[kernel_class]) and "traffic_bytes_per_launch" in v:
-                return v["traffic_bytes_per_launch"]
+        v = d.get("classes", {}).get(kernel_class)
+        if v and v.get("traffic_bytes_per_launch"):
+            return v["traffic_bytes_per_launch"]
     return None
 
 

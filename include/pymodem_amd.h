@@ -45,7 +45,16 @@ int pm_device_count(void);                               /* 0 when no GPU; never
 int pm_last_error(char *buf, size_t cap);                /* copies the calling thread's last message */
 
 int pm_ctx_create(int device, pm_ctx **out);
+/* Same, with the stream at the device's highest priority when high_priority != 0.  Several ctx may exist on one device: each has
+ * its own stream, scratch and profiler, device memory is shared.  The pipelined executor runs the slicer (a few resident waves,
+ * dependent-latency bound) on a high-priority ctx while the FIR/correlator kernels of the next recording fill the ALUs. */
+int pm_ctx_create_prio(int device, int high_priority, pm_ctx **out);
 int pm_ctx_destroy(pm_ctx *ctx);
+/* Cross-stream ordering without a host wait.  pm_event_record marks the point reached by ctx's stream (creating the event when
+ * *event is NULL); pm_event_wait makes everything submitted to ctx AFTER the call wait for that point.  Same device only. */
+int pm_event_record(pm_ctx *ctx, void **event);
+int pm_event_wait(pm_ctx *ctx, void *event);
+int pm_event_destroy(void *event);
 int pm_ctx_sync(pm_ctx *ctx);                            /* hipStreamSynchronize on the ctx stream */
 void *pm_ctx_stream(pm_ctx *ctx);                        /* the hipStream_t, for interop */
 
@@ -65,6 +74,10 @@ enum { PM_K_FIR_I16 = 0, PM_K_FIR_F64 = 1, PM_K_AFSK_CORR = 2, PM_K_SIGNS = 3, P
        PM_K_AGC = 6, PM_K_LOOP = 7, PM_K_COUNT = 8 };
 int pm_prof_enable(pm_ctx *ctx, int on);                 /* also resets the accumulators */
 int pm_prof_read(pm_ctx *ctx, int kernel_class, double *total_ms, int64_t *launches);
+/* Algorithmic work of the same launches, summed: compulsory HBM bytes (every input element read once, every output element
+ * written once, at their stored width) and f64 flops (2 per fused multiply-add of the FIR sums; epilogues not counted).
+ * Zero for the classes that are neither (slicer iterations, carrier loops, AGC). */
+int pm_prof_work(pm_ctx *ctx, int kernel_class, double *bytes, double *flops);
 
 /* ---- FIR stages -------------------------------------------------------------------------------
  * numpy.convolve(x, h, 'valid'): y[k] = sum_j h[j] * x[k+m-1-j], k = 0 .. n-m.  Replaces the 19
@@ -84,6 +97,14 @@ int pm_fir_signs_f64(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_
  * y[k] = sqrt(mi*x ^2 + mq*x ^2) - sqrt(si*x ^2 + sq*x ^2), each product a 'valid' convolution. */
 int pm_afsk_correlate(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_mark_i, const double *d_mark_q,
                       const double *d_space_i, const double *d_space_q, int m, double *d_y);
+
+/* `groups` AFSK modems over the same band-passed stream that share their MARK correlators and differ in the space correlators
+ * only (the chains of afsk_1200_ax25_super_opt.json: same tones and span, space_gain 1.25 ... 2.75, afsk.py:144-145): the mark
+ * sums and magnitude are computed once.  d_space = [groups][2][m] (space_i then space_q of modem g); output g is written at
+ * d_y + g*y_stride (n-m+1 values each).  Every output is bit-identical to pm_afsk_correlate with that modem's four filters. */
+#define PM_AFSK_GROUP_MAX 8
+int pm_afsk_correlate_group(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_mark_i, const double *d_mark_q,
+                            const double *d_space, int groups, int m, double *d_y, int64_t y_stride);
 
 /* Sign bitmap of a float64 stream: bit k of the little-endian uint64 array = (x[k] >= 0), the only
  * property of a sample the slicers read (slicer.py:85,99-102,210-232).  d_bits holds (n+63)/64 words. */

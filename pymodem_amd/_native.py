@@ -69,6 +69,10 @@ _SIGS = {
     "pm_device_count": ([], _int),
     "pm_last_error": ([ctypes.c_char_p, ctypes.c_size_t], _int),
     "pm_ctx_create": ([_int, ctypes.POINTER(_vp)], _int),
+    "pm_ctx_create_prio": ([_int, _int, ctypes.POINTER(_vp)], _int),
+    "pm_event_record": ([_vp, ctypes.POINTER(_vp)], _int),
+    "pm_event_wait": ([_vp, _vp], _int),
+    "pm_event_destroy": ([_vp], _int),
     "pm_ctx_destroy": ([_vp], _int),
     "pm_ctx_sync": ([_vp], _int),
     "pm_ctx_stream": ([_vp], _vp),
@@ -81,11 +85,13 @@ _SIGS = {
     "pm_timer_stop": ([_vp, ctypes.POINTER(ctypes.c_float)], _int),
     "pm_prof_enable": ([_vp, _int], _int),
     "pm_prof_read": ([_vp, _int, ctypes.POINTER(_dbl), ctypes.POINTER(_i64)], _int),
+    "pm_prof_work": ([_vp, _int, ctypes.POINTER(_dbl), ctypes.POINTER(_dbl)], _int),
     "pm_fir_valid_i16": ([_vp, _vp, _i64, _vp, _int, _vp, _int], _int),
     "pm_fir_valid_f64": ([_vp, _vp, _i64, _vp, _int, _vp, _int], _int),
     "pm_fir_signs_i16": ([_vp, _vp, _i64, _vp, _int, _vp, _int], _int),
     "pm_fir_signs_f64": ([_vp, _vp, _i64, _vp, _int, _vp, _int], _int),
     "pm_afsk_correlate": ([_vp, _vp, _i64, _vp, _vp, _vp, _vp, _int, _vp], _int),
+    "pm_afsk_correlate_group": ([_vp, _vp, _i64, _vp, _vp, _vp, _int, _int, _vp, _i64], _int),
     "pm_signs_f64": ([_vp, _vp, _i64, _vp], _int),
     "pm_agc_apply": ([_vp, _vp, _i64, ctypes.POINTER(AGCParams), ctypes.POINTER(_dbl)], _int),
     "pm_costas_bpsk": ([_vp, ctypes.POINTER(Loop), _int, _vp, _vp, _i64, _i64, _vp, _i64], _int),

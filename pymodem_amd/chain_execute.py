@@ -45,8 +45,24 @@ def _host_stages(chain, sliced):
     return chain[4].decode(chain[3].stream_unscramble_8bit(sliced))
 
 
-def _host_stages_rows(chain, sliced):
-    return chain[4].decode_rows(chain[3].stream_unscramble_8bit(sliced))
+def _host_pending(chain, sliced):
+    return chain[4].decode_pending(chain[3].stream_unscramble_8bit(sliced))
+
+
+def _host_rows(chains, sliced):
+    """LFSR + codec of every chain (thread pool; the native calls release the GIL) -> one pm_packet row block per chain, all of them
+    consecutive slices of ONE array the codecs wrote straight into (PacketTable then takes the whole array without a copy)."""
+    from ._native import packet_dtype
+    pool = _pool()
+    counts = [f.result() for f in [pool.submit(_host_pending, ch, sl) for ch, sl in zip(chains, sliced)]]
+    block = np.empty(sum(counts), dtype=packet_dtype())
+    views, at = [], 0
+    for n in counts:
+        views.append(block[at:at + n])
+        at += n
+    for f in [pool.submit(ch[4].fetch_into, v) for ch, v in zip(chains, views)]:
+        f.result()
+    return views
 
 
 _POOL = None
@@ -74,13 +90,76 @@ def process_chains_split(chains, input_audio):
     of one recording overlap the GPU half of the next (bench.py --overlap)."""
     sliced = process_chains_device(chains, input_audio, _sliced_only=True)
 
-    def host_half():
-        futures = [_pool().submit(_host_stages_rows, ch, sl) for ch, sl in zip(chains, sliced)]
-        return [f.result() for f in futures]
-    return host_half
+    return lambda: _host_rows(chains, sliced)
 
 
-def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced_only=False):
+class RecordingPipeline:
+    """Successive recordings through chain groups with the stages of the path overlapped, each on its own resource:
+
+      demod   FIR / correlator / loop kernels (vector-f64 ALU and HBM)                 default stream, caller's thread
+      slice   chunk-parallel timing recovery: ~1 resident wave per SIMD, dependent-     `slice_workers` high-priority side streams,
+              latency bound, so TWO recordings' slicers share the GPU almost for free    one thread each
+      host    LFSR + codec (native, GIL released)                                       same thread, fanned out to the pool
+      finish  the caller's `finish(rows per chain)`: gather / de-dup                    one thread, submission order (collectives)
+
+    While recordings k and k-1 are being sliced, recording k+1 is demodulated and k-2 finished.  The only GPU buffers that cross
+    stages are the sign bitmaps (one bit per sample), kept in slice_workers + 2 rotating slots (demod runs one recording ahead); a GPU event, not a host wait,
+    orders slicer after demod.  Results are identical to process_chains_table on each recording (tests/test_gpu_chains.py)."""
+
+    def __init__(self, slice_workers=2):
+        from collections import deque
+        self._workers = max(1, int(slice_workers))
+        self._slice = ThreadPoolExecutor(max_workers=self._workers)
+        self._finish = ThreadPoolExecutor(max_workers=1)
+        self._inflight = deque()
+        self._n = 0
+        self._slots = self._workers + 2                      # bitmaps: one set per slicer in flight, one being written, one ready
+        self._events = [None] * self._slots
+        self.stage_seconds = {"demod": 0.0, "slice": 0.0, "host": 0.0, "finish": 0.0}   # busy time per stage, summed over recordings
+
+    def submit(self, chains, input_audio, finish=None):
+        """Start one recording; returns a Future of finish(rows per chain) (rows per chain when finish is None)."""
+        import time
+        acc = self.stage_seconds
+        slots = self._slots
+        slot = self._n % slots
+        side = Context.side(index=self._n % self._workers)
+        self._n += 1
+        while len(self._inflight) >= slots - 1:               # the slicer that read this slot `slots` recordings ago is done
+            self._inflight.popleft().result()
+        t0 = time.perf_counter()
+        bitmaps = process_chains_device(chains, input_audio, _bitmaps_only=True, _slot=slot)
+        self._events[slot] = ready = Context.default().record_event(self._events[slot])   # bitmaps complete at this point of the stream
+        acc["demod"] += time.perf_counter() - t0
+
+        def slice_and_decode():
+            t = time.perf_counter()
+            side.wait_event(ready)
+            sliced = slice_batch([ch[2] for ch in chains], bitmaps, side)
+            t1 = time.perf_counter()
+            rows = _host_rows(chains, sliced)
+            acc["slice"] += t1 - t
+            acc["host"] += time.perf_counter() - t1
+            return rows
+        f_rows = self._slice.submit(slice_and_decode)
+        self._inflight.append(f_rows)
+
+        def finish_stage():
+            rows = f_rows.result()
+            if finish is None:
+                return rows
+            t = time.perf_counter()
+            out = finish(rows)
+            acc["finish"] += time.perf_counter() - t
+            return out
+        return self._finish.submit(finish_stage)
+
+    def close(self):
+        self._slice.shutdown(wait=True)
+        self._finish.shutdown(wait=True)
+
+
+def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced_only=False, _bitmaps_only=False, _slot=0):
     """[chain, ...] -> [packets of chain 0, packets of chain 1, ...] (config order), identical to running
     process_chain on each.  See the module docstring for what is shared and batched."""
     ctx = Context.default()
@@ -92,8 +171,8 @@ def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced
     bitmaps = [None] * n_chains
     group_key = "chain-group"          # work buffers are reused from one group run to the next
     for k, ch in enumerate(chains):    # stable per-chain keys: a new set of stage objects reuses the previous run's buffers
-        ch[1].own_key = (group_key, "modem", k)
-        ch[2].own_key = (group_key, "slicer", k)
+        ch[1].own_key = (group_key, "modem", _slot, k)      # the sign bitmaps: double-buffered by slot for RecordingPipeline
+        ch[2].own_key = (group_key, "slicer", _slot, k)
 
     # ---- shared front ends ------------------------------------------------------------------------------------
     front = {}
@@ -150,6 +229,27 @@ def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced
             modem.scratch_key = (group_key, "loop_back")
             bitmaps[k] = chains[k][2].sign_bitmaps(modem.back_end(mix.view(j * n, n), signs=True))
 
+    # ---- AFSK correlator banks that share their mark filters: one launch per group of up to 8 --------------------------
+    afsk_groups = {}
+    for k, ch in enumerate(chains):
+        if isinstance(ch[1], AFSKModem):
+            afsk_groups.setdefault(ch[1].mark_key(), []).append(k)
+    gi = 0
+    for key, members in afsk_groups.items():
+        for base in range(0, len(members), 8):
+            part = members[base:base + 8]
+            if len(part) < 2:
+                continue
+            mods = [chains[k][1] for k in part]
+            bpf = shared_front(mods[0])
+            for md in mods:
+                md._context()
+            streams = AFSKModem.correlate_group(mods, bpf, (group_key, "afsk_corr_group", gi))
+            gi += 1
+            for k, md, c in zip(part, mods, streams):
+                md.scratch_key = (group_key, "afsk_back")
+                bitmaps[k] = chains[k][2].sign_bitmaps(md.back_end(bpf, signs=True, correlated=c))
+
     # ---- everything else, chain by chain (work buffers shared across the group) ----------------------------------
     for k, ch in enumerate(chains):
         if bitmaps[k] is not None:
@@ -165,11 +265,15 @@ def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced
         bitmaps[k] = ch[2].sign_bitmaps(out)
 
     # ---- all slicers in one batch, host stages in parallel ---------------------------------------------------------
+    if _bitmaps_only:
+        return bitmaps
     sliced = slice_batch([ch[2] for ch in chains], bitmaps)
     if _sliced_only:
         return sliced
-    futures = [_pool().submit(_host_stages_rows if _rows else _host_stages, ch, sl) for ch, sl in zip(chains, sliced)]
-    packets = [f.result() for f in futures]
+    if _rows:
+        packets = _host_rows(chains, sliced)
+    else:
+        packets = [f.result() for f in [_pool().submit(_host_stages, ch, sl) for ch, sl in zip(chains, sliced)]]
     if stages is not None:
         stages["sliced"] = sliced
     return packets

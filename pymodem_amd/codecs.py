@@ -22,19 +22,27 @@ class _NativeCodec:
             self._h = h
         return self._h
 
-    def decode_rows(self, data):
-        """Like decode(), but the packets stay rows of a NumPy structured array with the pm_packet layout
-        (pymodem_amd._native.packet_dtype): CRC and header validity already filled by the native codec."""
+    def decode_pending(self, data):
+        """Run the decoder over `data`; the packets stay queued inside the native codec.  -> how many are waiting."""
         src = AddressedArray.coerce(data)
         pending = ctypes.c_int64()
         check(lib().pm_codec_decode(self._handle(), src.data.ctypes.data_as(ctypes.c_void_p),
                                     src.address.ctypes.data_as(ctypes.c_void_p), len(src), ctypes.byref(pending)))
-        rows = np.zeros(pending.value, dtype=packet_dtype())
-        if pending.value:
+        return pending.value
+
+    def fetch_into(self, rows):
+        """Move queued packets into `rows` (a C-contiguous pm_packet array, may be uninitialised: every byte is written)."""
+        if len(rows):
+            assert rows.flags.c_contiguous and rows.dtype == packet_dtype()
             got = ctypes.c_int64()
-            check(lib().pm_codec_fetch(self._handle(), rows.ctypes.data_as(ctypes.c_void_p), pending.value, ctypes.byref(got)))
-            assert got.value == pending.value
+            check(lib().pm_codec_fetch(self._handle(), rows.ctypes.data_as(ctypes.c_void_p), len(rows), ctypes.byref(got)))
+            assert got.value == len(rows)
         return rows
+
+    def decode_rows(self, data):
+        """Like decode(), but the packets stay rows of a NumPy structured array with the pm_packet layout
+        (pymodem_amd._native.packet_dtype): CRC and header validity already filled by the native codec."""
+        return self.fetch_into(np.empty(self.decode_pending(data), dtype=packet_dtype()))
 
     def decode(self, data):
         """list[AddressedData] | AddressedArray -> list[PacketMeta] (data, streamaddress, SourceDecoder, BytesCorrected)."""

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/pymodem_amd.h"
@@ -645,11 +646,13 @@ int pm_codec_fetch(pm_codec *c, pm_packet *h_out, int64_t cap, int64_t *h_count)
     for (int64_t k = 0; k < take; ++k) {
         const Queued &src = c->sink.q[(size_t)k];
         pm_packet &p = h_out[k];
+        memset(&p, 0, offsetof(pm_packet, data));            // h_out may be uninitialised memory: every byte of the row is written
         p.streamaddress = src.addr;
         p.len = (int32_t)std::min<size_t>(src.data.size(), PM_PKT_MAX);
         p.bytes_corrected = src.corrected;
         p.source_decoder = c->source;
         memcpy(p.data, src.data.data(), (size_t)p.len);
+        memset(p.data + p.len, 0, sizeof(p.data) - (size_t)p.len);
         finalize(p);
     }
     c->sink.q.erase(c->sink.q.begin(), c->sink.q.begin() + take);
@@ -666,27 +669,32 @@ int64_t pm_correlate(pm_packet *p, const int64_t *counts, int nchains, double ad
     // packet_meta.py:230-271.  Chains in config order; the first chain's valid packets are all unique; a later
     // packet is a duplicate of the FIRST unique packet (insertion order) from another decoder within
     // address_distance and with equal calculated CRC.
+    // The candidates for a packet are the unique packets with its CRC: one bucket per CRC value, each in insertion order,
+    // with address and decoder kept beside the index (rows are 1.3 KB apart; the scan must not touch them).
+    struct Cand { int64_t addr; uint32_t j; int32_t src; };
     std::vector<int64_t> u;
     std::vector<std::vector<int32_t>> decoders;
+    std::unordered_map<int32_t, std::vector<Cand>> by_crc;
     int64_t base = 0;
     for (int c = 0; c < nchains; ++c) {
         for (int64_t k = 0; k < counts[c]; ++k) {
             pm_packet &r = p[base + k];
             if (!(r.valid_crc && r.valid_header)) continue;
+            std::vector<Cand> &bucket = by_crc[r.calculated_crc];
             bool unique = true;
             if (c > 0) {
-                for (size_t j = 0; j < u.size(); ++j) {
-                    pm_packet &q = p[u[j]];
-                    if (q.source_decoder == r.source_decoder) continue;
-                    const int64_t d = r.streamaddress > q.streamaddress ? r.streamaddress - q.streamaddress : q.streamaddress - r.streamaddress;
-                    if ((double)d < address_distance && r.calculated_crc == q.calculated_crc) {
+                for (const Cand &q : bucket) {
+                    if (q.src == r.source_decoder) continue;
+                    const int64_t d = r.streamaddress > q.addr ? r.streamaddress - q.addr : q.addr - r.streamaddress;
+                    if ((double)d < address_distance) {
                         unique = false;
-                        decoders[j].push_back(r.source_decoder);
+                        decoders[q.j].push_back(r.source_decoder);
                         break;
                     }
                 }
             }
             if (unique) {
+                bucket.push_back(Cand{r.streamaddress, (uint32_t)u.size(), r.source_decoder});
                 u.push_back(base + k);
                 decoders.push_back({r.source_decoder});
             }

@@ -22,6 +22,7 @@ struct pm_ctx {
     std::vector<hipEvent_t> prof_free;
     double prof_ms[PM_K_COUNT] = {0};
     int64_t prof_n[PM_K_COUNT] = {0};
+    double prof_bytes[PM_K_COUNT] = {0}, prof_flops[PM_K_COUNT] = {0};   // algorithmic work of the tracked launches
     // slicer diagnostics
     int32_t sl_iterations = 0, sl_chunk_len = 0;
     int64_t sl_chunks = 0;
@@ -44,11 +45,21 @@ int pm_scratch_reserve(pm_ctx *ctx, size_t bytes);     // ensures ctx->d_scratch
                                          __FILE__, __LINE__);                           \
     } while (0)
 
+// First line of every entry point that takes a ctx: validate it and make its device current on the CALLING thread (the HIP
+// current device is per thread; a ctx may be driven from a worker thread, e.g. the slicer stage of the pipelined executor).
+#define PM_CTX(c)                                   \
+    do {                                            \
+        PM_ARG((c) != nullptr);                     \
+        PM_HIP(hipSetDevice((c)->device));          \
+    } while (0)
+
 // Bracket a launch: `PmProf p(ctx, PM_K_X); launch...; ` (destructor records the end event).
 struct PmProf {
     pm_ctx *c; hipEvent_t a = nullptr, b = nullptr; int cls;
     PmProf(pm_ctx *ctx, int k);
     ~PmProf();
+    // algorithmic (compulsory) HBM bytes and f64 flops of this launch: inputs read once, outputs written once, 2 flops per fma
+    void work(double bytes, double flops) { if (c->prof_on) { c->prof_bytes[cls] += bytes; c->prof_flops[cls] += flops; } }
 };
 int pm_prof_fold(pm_ctx *ctx);      // sync + accumulate pending pairs
 

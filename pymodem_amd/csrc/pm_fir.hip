@@ -302,6 +302,100 @@ __global__ __launch_bounds__(kThreads) void afsk_correlate_kernel(const double *
     }
 }
 
+// G correlator banks that share their mark filters (the chains of afsk_1200_ax25_super_opt.json differ in space gain only):
+// F = 2 + 2G filters over one staged window, the mark pair (and its square root) computed once.  w holds the filters interleaved
+// and reversed, w[i * F + f] = h_f[m - 1 - i], so that the F coefficients of one tap step are one contiguous scalar load.
+// R = 2 outputs per thread: F * R accumulators, one LDS read per F * R fmas, and each lane's results are 16 contiguous bytes,
+// so the G output streams are stored straight from registers.
+__global__ void pack_group_taps_kernel(const double *__restrict__ mi, const double *__restrict__ mq, const double *__restrict__ sp,
+                                       int m, int F, double *__restrict__ w)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m * F) return;
+    const int i = idx / F, f = idx % F, k = m - 1 - i;
+    w[idx] = f == 0 ? mi[k] : f == 1 ? mq[k] : sp[(size_t)(f - 2) * m + k];
+}
+
+template <int G, bool VEC>
+__global__ __launch_bounds__(kThreads) void afsk_group_kernel(const double *__restrict__ x, int64_t n, const double *__restrict__ w,
+                                                              int m, double *__restrict__ y, int64_t y_stride, int64_t nout)
+{
+    extern __shared__ double xs[];
+    constexpr int R = 2, F = 2 + 2 * G, T = kThreads * R;
+    const int t = threadIdx.x;
+    const int span = T + m - 1;
+    const int64_t tile0 = (int64_t)blockIdx.x * T;
+    if (VEC) {
+        stage_vec<R>(x, n, tile0, span, t, xs);
+    } else {
+        for (int idx = t; idx < span; idx += kThreads) {
+            int64_t gi = tile0 + idx;
+            xs[slot<R>(idx)] = gi < n ? x[gi] : 0.0;
+        }
+    }
+    lds_barrier();
+
+    double acc[F][R];
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[f][r] = 0.0;
+    const double *lp = xs + t * (R + 1);       // block b of this lane's window: lp[b * (R + 1) + 0 .. R-1]
+    double A[R], B[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) A[q] = lp[q];
+#define PM_GROUP_BLOCK(CUR, NXT, TAPS)                                                             \
+    {                                                                                              \
+        _Pragma("unroll") for (int q = 0; q < R; ++q) NXT[q] = lp[(R + 1) + q];                    \
+        _Pragma("unroll") for (int q = 0; q < TAPS; ++q) {                                         \
+            _Pragma("unroll") for (int f = 0; f < F; ++f) {                                        \
+                const double g = w[q * F + f];                                                     \
+                _Pragma("unroll") for (int r = 0; r < R; ++r) {                                    \
+                    const double v = (q + r < R) ? CUR[q + r] : NXT[q + r - R];                    \
+                    acc[f][r] = __builtin_fma(g, v, acc[f][r]);                                    \
+                }                                                                                  \
+            }                                                                                      \
+        }                                                                                          \
+        lp += R + 1;                                                                               \
+        w += TAPS * F;                                                                             \
+    }
+    int i0 = 0;
+    for (; i0 + 2 * R <= m; i0 += 2 * R) {
+        PM_GROUP_BLOCK(A, B, R)
+        PM_GROUP_BLOCK(B, A, R)
+    }
+    if (i0 + R <= m) {
+        PM_GROUP_BLOCK(A, B, R)
+        i0 += R;
+#pragma unroll
+        for (int q = 0; q < R; ++q) A[q] = B[q];
+    }
+    if (i0 < m) PM_GROUP_BLOCK(A, B, 1)       // R = 2: at most one tap left
+#undef PM_GROUP_BLOCK
+    static_assert(R == 2, "tail and stores are written for two outputs per thread");
+
+    const int64_t go = tile0 + (int64_t)t * R;
+    double mark[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) mark[r] = __builtin_sqrt(acc[0][r] * acc[0][r] + acc[1][r] * acc[1][r]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        double o[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double si = acc[2 + 2 * g][r], sq = acc[3 + 2 * g][r];
+            o[r] = mark[r] - __builtin_sqrt(si * si + sq * sq);          // afsk.py:153-162
+        }
+        double *yg = y + (size_t)g * y_stride;
+        if (VEC && go + 1 < nout) {
+            *reinterpret_cast<double2v *>(yg + go) = double2v{o[0], o[1]};
+        } else {
+            if (go < nout) yg[go] = o[0];
+            if (go + 1 < nout) yg[go + 1] = o[1];
+        }
+    }
+}
+
 // One 64-bit word per wave per step: lane l tests sample 64*w + l, the ballot is the word.
 __global__ __launch_bounds__(kThreads) void signs_kernel(const double *__restrict__ x, int64_t n,
                                                          uint64_t *__restrict__ bits, int64_t nwords)
@@ -337,6 +431,7 @@ int fir_launch2(pm_ctx *ctx, const InT *d_x, int64_t n, const double *d_taps, in
     PM_ARG(ntiles < (1LL << 31));
     const size_t lds = lds_bytes<R>(m);
     PmProf prof(ctx, sizeof(InT) == 2 ? PM_K_FIR_I16 : PM_K_FIR_F64);
+    prof.work((double)n * sizeof(InT) + (d_bits ? (double)nout / 8 : (double)nout * 8), 2.0 * m * (double)nout);
     const bool vec = (((uintptr_t)d_x | (uintptr_t)d_y) & 15) == 0;          // 16-byte loads and stores
 #define PM_FIR_GO(VECF, SIGNF)                                                                                              \
     {                                                                                                                       \
@@ -357,7 +452,8 @@ int fir_launch2(pm_ctx *ctx, const InT *d_x, int64_t n, const double *d_taps, in
 template <typename InT>
 int fir_launch(pm_ctx *ctx, const InT *d_x, int64_t n, const double *d_taps, int m, double *d_y, uint64_t *d_bits, int flags)
 {
-    PM_ARG(ctx && d_x && d_taps && (d_y || d_bits));
+    PM_CTX(ctx);
+    PM_ARG(d_x && d_taps && (d_y || d_bits));
     PM_ARG(m >= 1 && m <= kMaxTaps);
     PM_ARG(n >= m);
     return (flags & PM_FIR_NEGATE) ? fir_launch2<InT, true>(ctx, d_x, n, d_taps, m, d_y, d_bits)
@@ -365,6 +461,28 @@ int fir_launch(pm_ctx *ctx, const InT *d_x, int64_t n, const double *d_taps, int
 }
 
 }  // namespace
+
+template <int G>
+static int afsk_group_go(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_w, int m, double *d_y, int64_t y_stride, int64_t nout)
+{
+    constexpr int R = 2;
+    const int64_t ntiles = pm_cdiv(nout, (int64_t)kThreads * R);
+    PM_ARG(ntiles < (1LL << 31));
+    const size_t lds = lds_bytes<R>(m) + 4 * (R + 1) * sizeof(double);        // the last block's look-ahead load
+    const bool vec = ((((uintptr_t)d_x | (uintptr_t)d_y) & 15) == 0) && (y_stride % 2 == 0);
+    PmProf prof(ctx, PM_K_AFSK_CORR);
+    prof.work((double)n * 8 + (double)G * nout * 8, 2.0 * (2 + 2 * G) * m * (double)nout);
+    if (vec) {
+        if (int rc = allow_lds(afsk_group_kernel<G, true>, lds)) return rc;
+        hipLaunchKernelGGL((afsk_group_kernel<G, true>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, d_x, n, d_w, m, d_y, y_stride, nout);
+    } else {
+        if (int rc = allow_lds(afsk_group_kernel<G, false>, lds)) return rc;
+        hipLaunchKernelGGL((afsk_group_kernel<G, false>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, d_x, n, d_w, m, d_y, y_stride, nout);
+    }
+    PM_HIP(hipGetLastError());
+    return PM_OK;
+}
+
 
 extern "C" {
 
@@ -391,6 +509,7 @@ int pm_fir_valid_f64(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_
 int pm_afsk_correlate(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_mark_i, const double *d_mark_q,
                       const double *d_space_i, const double *d_space_q, int m, double *d_y)
 {
+    PM_CTX(ctx);
     PM_ARG(ctx && d_x && d_mark_i && d_mark_q && d_space_i && d_space_q && d_y);
     PM_ARG(m >= 1 && m <= kMaxTaps);
     PM_ARG(n >= m);
@@ -400,6 +519,7 @@ int pm_afsk_correlate(pm_ctx *ctx, const double *d_x, int64_t n, const double *d
     PM_ARG(ntiles < (1LL << 31));
     const size_t lds = lds_bytes<R>(m);
     PmProf prof(ctx, PM_K_AFSK_CORR);
+    prof.work((double)n * 8 + (double)nout * 8, 2.0 * 4 * m * (double)nout);
     const bool vec = (((uintptr_t)d_x | (uintptr_t)d_y) & 15) == 0;
     if (vec) {
         if (int rc = allow_lds(afsk_correlate_kernel<R, true>, lds)) return rc;
@@ -414,8 +534,37 @@ int pm_afsk_correlate(pm_ctx *ctx, const double *d_x, int64_t n, const double *d
     return PM_OK;
 }
 
+int pm_afsk_correlate_group(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_mark_i, const double *d_mark_q,
+                            const double *d_space, int groups, int m, double *d_y, int64_t y_stride)
+{
+    PM_CTX(ctx);
+    PM_ARG(d_x && d_mark_i && d_mark_q && d_space && d_y);
+    PM_ARG(groups >= 1 && groups <= PM_AFSK_GROUP_MAX);
+    PM_ARG(m >= 1 && m <= kMaxTaps);
+    PM_ARG(n >= m);
+    const int64_t nout = n - m + 1;
+    PM_ARG(groups == 1 || y_stride >= nout);
+    const int F = 2 + 2 * groups;
+    if (int rc = pm_scratch_reserve(ctx, (size_t)F * m * sizeof(double))) return rc;
+    double *d_w = (double *)ctx->d_scratch;
+    hipLaunchKernelGGL(pack_group_taps_kernel, dim3((unsigned)pm_cdiv((int64_t)F * m, 256)), dim3(256), 0, ctx->stream,
+                       d_mark_i, d_mark_q, d_space, m, F, d_w);
+    PM_HIP(hipGetLastError());
+    switch (groups) {
+    case 1: return afsk_group_go<1>(ctx, d_x, n, d_w, m, d_y, y_stride, nout);
+    case 2: return afsk_group_go<2>(ctx, d_x, n, d_w, m, d_y, y_stride, nout);
+    case 3: return afsk_group_go<3>(ctx, d_x, n, d_w, m, d_y, y_stride, nout);
+    case 4: return afsk_group_go<4>(ctx, d_x, n, d_w, m, d_y, y_stride, nout);
+    case 5: return afsk_group_go<5>(ctx, d_x, n, d_w, m, d_y, y_stride, nout);
+    case 6: return afsk_group_go<6>(ctx, d_x, n, d_w, m, d_y, y_stride, nout);
+    case 7: return afsk_group_go<7>(ctx, d_x, n, d_w, m, d_y, y_stride, nout);
+    default: return afsk_group_go<8>(ctx, d_x, n, d_w, m, d_y, y_stride, nout);
+    }
+}
+
 int pm_signs_f64(pm_ctx *ctx, const double *d_x, int64_t n, uint64_t *d_bits)
 {
+    PM_CTX(ctx);
     PM_ARG(ctx && d_bits && n >= 0);
     if (n == 0) return PM_OK;
     PM_ARG(d_x != nullptr);
@@ -423,6 +572,7 @@ int pm_signs_f64(pm_ctx *ctx, const double *d_x, int64_t n, uint64_t *d_bits)
     int64_t grid = pm_cdiv(nwords, kThreads / 64);
     if (grid > 8192) grid = 8192;
     PmProf prof(ctx, PM_K_SIGNS);
+    prof.work((double)n * 8 + (double)n / 8, 0.0);
     hipLaunchKernelGGL(signs_kernel, dim3((unsigned)grid), dim3(kThreads), 0, ctx->stream, d_x, n, d_bits, nwords);
     PM_HIP(hipGetLastError());
     return PM_OK;

@@ -198,7 +198,8 @@ int loop_launch(pm_ctx *ctx, pm_loop *h_loops, int nloops, const double *d_table
                 const double *d_x0, const double *d_x1, int64_t x_stride, int64_t n,
                 double *d_o0, double *d_o1, int64_t out_stride)
 {
-    PM_ARG(ctx && h_loops && nloops >= 1 && d_table && n >= 0);
+    PM_CTX(ctx);
+    PM_ARG(h_loops && nloops >= 1 && d_table && n >= 0);
     if (n == 0) return PM_OK;
     PM_ARG(d_x0 && d_o0 && (MODE != kMpsk || (d_x1 && d_o1 && d_pd)));
     PM_ARG(nloops == 1 || out_stride >= n);
@@ -366,6 +367,7 @@ int pm_mpsk_loop(pm_ctx *ctx, pm_loop *h_loops, int nloops, const double *d_tabl
 
 int pm_agc_apply(pm_ctx *ctx, double *d_buf, int64_t n, const pm_agc_params *hp, double *h_state)
 {
+    PM_CTX(ctx);
     PM_ARG(ctx && hp && h_state && n >= 0);
     if (n == 0) return PM_OK;
     PM_ARG(d_buf != nullptr && hp->sample_rate > 0);

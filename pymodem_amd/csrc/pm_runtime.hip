@@ -32,7 +32,9 @@ int pm_last_error(char *buf, size_t cap)
     return PM_OK;
 }
 
-int pm_ctx_create(int device, pm_ctx **out)
+int pm_ctx_create(int device, pm_ctx **out) { return pm_ctx_create_prio(device, 0, out); }
+
+int pm_ctx_create_prio(int device, int high_priority, pm_ctx **out)
 {
     PM_ARG(out != nullptr);
     int n = 0;
@@ -42,7 +44,13 @@ int pm_ctx_create(int device, pm_ctx **out)
     PM_HIP(hipSetDevice(device));
     pm_ctx *c = new pm_ctx();
     c->device = device;
-    PM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (high_priority) {
+        int lo = 0, hi = 0;                                   // numerically lower = higher priority
+        PM_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        PM_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
+    } else {
+        PM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    }
     PM_HIP(hipEventCreate(&c->ev0));
     PM_HIP(hipEventCreate(&c->ev1));
     PM_HIP(hipHostMalloc(&c->h_pinned, 4096, hipHostMallocDefault));
@@ -66,8 +74,36 @@ int pm_ctx_destroy(pm_ctx *c)
     return PM_OK;
 }
 
+int pm_event_record(pm_ctx *c, void **event)
+{
+    PM_CTX(c);
+    PM_ARG(event != nullptr);
+    if (*event == nullptr) {
+        hipEvent_t e;
+        PM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        *event = (void *)e;
+    }
+    PM_HIP(hipEventRecord((hipEvent_t)*event, c->stream));
+    return PM_OK;
+}
+
+int pm_event_wait(pm_ctx *c, void *event)
+{
+    PM_CTX(c);
+    PM_ARG(event != nullptr);
+    PM_HIP(hipStreamWaitEvent(c->stream, (hipEvent_t)event, 0));
+    return PM_OK;
+}
+
+int pm_event_destroy(void *event)
+{
+    if (event) PM_HIP(hipEventDestroy((hipEvent_t)event));
+    return PM_OK;
+}
+
 int pm_ctx_sync(pm_ctx *c)
 {
+    PM_CTX(c);
     PM_ARG(c != nullptr);
     PM_HIP(hipStreamSynchronize(c->stream));
     return PM_OK;
@@ -77,6 +113,7 @@ void *pm_ctx_stream(pm_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 int pm_malloc(pm_ctx *c, size_t bytes, void **d_out)
 {
+    PM_CTX(c);
     PM_ARG(c != nullptr && d_out != nullptr);
     PM_HIP(hipSetDevice(c->device));
     PM_HIP(hipMalloc(d_out, bytes ? bytes : 8));
@@ -85,6 +122,7 @@ int pm_malloc(pm_ctx *c, size_t bytes, void **d_out)
 
 int pm_free(pm_ctx *c, void *p)
 {
+    PM_CTX(c);
     PM_ARG(c != nullptr);
     if (!p) return PM_OK;
     PM_HIP(hipStreamSynchronize(c->stream));
@@ -94,6 +132,7 @@ int pm_free(pm_ctx *c, void *p)
 
 int pm_h2d(pm_ctx *c, void *d_dst, const void *h_src, size_t bytes)
 {
+    PM_CTX(c);
     PM_ARG(c != nullptr && (bytes == 0 || (d_dst && h_src)));
     if (bytes) PM_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
     // pageable source: the runtime has staged the bytes when the call returns, the caller may reuse h_src
@@ -102,6 +141,7 @@ int pm_h2d(pm_ctx *c, void *d_dst, const void *h_src, size_t bytes)
 
 int pm_d2h(pm_ctx *c, void *h_dst, const void *d_src, size_t bytes)
 {
+    PM_CTX(c);
     PM_ARG(c != nullptr && (bytes == 0 || (h_dst && d_src)));
     if (bytes) PM_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
     PM_HIP(hipStreamSynchronize(c->stream));
@@ -110,6 +150,7 @@ int pm_d2h(pm_ctx *c, void *h_dst, const void *d_src, size_t bytes)
 
 int pm_memset(pm_ctx *c, void *d_dst, int value, size_t bytes)
 {
+    PM_CTX(c);
     PM_ARG(c != nullptr && (bytes == 0 || d_dst));
     if (bytes) PM_HIP(hipMemsetAsync(d_dst, value, bytes, c->stream));
     return PM_OK;
@@ -117,6 +158,7 @@ int pm_memset(pm_ctx *c, void *d_dst, int value, size_t bytes)
 
 int pm_timer_start(pm_ctx *c)
 {
+    PM_CTX(c);
     PM_ARG(c != nullptr);
     PM_HIP(hipEventRecord(c->ev0, c->stream));
     return PM_OK;
@@ -124,6 +166,7 @@ int pm_timer_start(pm_ctx *c)
 
 int pm_timer_stop(pm_ctx *c, float *ms)
 {
+    PM_CTX(c);
     PM_ARG(c != nullptr && ms != nullptr);
     PM_HIP(hipEventRecord(c->ev1, c->stream));
     PM_HIP(hipEventSynchronize(c->ev1));
@@ -176,7 +219,7 @@ extern "C" int pm_prof_enable(pm_ctx *c, int on)
 {
     PM_ARG(c != nullptr);
     if (int rc = pm_prof_fold(c)) return rc;
-    for (int k = 0; k < PM_K_COUNT; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
+    for (int k = 0; k < PM_K_COUNT; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; c->prof_bytes[k] = 0; c->prof_flops[k] = 0; }
     c->prof_on = on != 0;
     return PM_OK;
 }
@@ -187,6 +230,14 @@ extern "C" int pm_prof_read(pm_ctx *c, int cls, double *total_ms, int64_t *launc
     if (int rc = pm_prof_fold(c)) return rc;
     if (total_ms) *total_ms = c->prof_ms[cls];
     if (launches) *launches = c->prof_n[cls];
+    return PM_OK;
+}
+
+extern "C" int pm_prof_work(pm_ctx *c, int cls, double *bytes, double *flops)
+{
+    PM_ARG(c != nullptr && cls >= 0 && cls < PM_K_COUNT);
+    if (bytes) *bytes = c->prof_bytes[cls];
+    if (flops) *flops = c->prof_flops[cls];
     return PM_OK;
 }
 

@@ -292,7 +292,8 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
 {
-    PM_ARG(ctx && jobs && njobs >= 1 && njobs <= kMaxJobs);
+    PM_CTX(ctx);
+    PM_ARG(jobs && njobs >= 1 && njobs <= kMaxJobs);
     ctx->sl_iterations = 0;
     int64_t max_n = 0;
     for (int j = 0; j < njobs; ++j) {

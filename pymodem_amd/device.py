@@ -10,11 +10,23 @@ class Context:
     """One HIP stream on one GPU.  Created lazily by the stage objects inside demod()/slice(), i.e. in the
     process that runs the chain (fork-safe, see pymodem.py:144-151)."""
     _default = {}
+    _side = {}
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, high_priority=False):
         self._h = ctypes.c_void_p()
         self.device = device
-        check(lib().pm_ctx_create(device, ctypes.byref(self._h)))
+        check(lib().pm_ctx_create_prio(device, int(bool(high_priority)), ctypes.byref(self._h)))
+
+    @classmethod
+    def side(cls, device=None, index=0):
+        """Additional high-priority streams on the default context's GPU (one per process, device and index): the pipelined
+        executor runs slicers there while the next recording's FIR/correlator kernels run on the default stream."""
+        import os
+        main = cls.default(device)
+        key = (os.getpid(), main.device, int(index))
+        if key not in cls._side:
+            cls._side[key] = cls(main.device, high_priority=True)
+        return cls._side[key]
 
     @classmethod
     def default(cls, device=None):
@@ -35,6 +47,16 @@ class Context:
 
     def sync(self):
         check(lib().pm_ctx_sync(self._h))
+
+    def record_event(self, event=None):
+        """Mark the point this context's stream has reached; returns the (re-usable) event handle."""
+        ev = event if event is not None else ctypes.c_void_p()
+        check(lib().pm_event_record(self._h, ctypes.byref(ev)))
+        return ev
+
+    def wait_event(self, event):
+        """Work submitted to this context from now on waits (on the GPU) for `event`."""
+        check(lib().pm_event_wait(self._h, event))
 
     def empty(self, n, dtype):
         return DeviceBuffer(self, int(n), np.dtype(dtype))
@@ -92,6 +114,16 @@ class Context:
             ms, n = ctypes.c_double(), ctypes.c_int64()
             check(lib().pm_prof_read(self._h, k, ctypes.byref(ms), ctypes.byref(n)))
             out[name] = (ms.value, n.value)
+        return out
+
+    def profile_work(self):
+        """{kernel class: (algorithmic HBM bytes, f64 flops)} of the launches profile_read() timed."""
+        from ._native import KERNEL_CLASSES
+        out = {}
+        for k, name in enumerate(KERNEL_CLASSES):
+            b, f = ctypes.c_double(), ctypes.c_double()
+            check(lib().pm_prof_work(self._h, k, ctypes.byref(b), ctypes.byref(f)))
+            out[name] = (b.value, f.value)
         return out
 
     def timer_start(self):

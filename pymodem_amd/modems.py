@@ -216,16 +216,41 @@ class AFSKModem(_DeviceStage):
         """demod() for a slicer: the output low-pass writes only the sign bitmap.  -> SignBits"""
         return self.back_end(self.front_end(input_audio), signs=True)
 
-    def back_end(self, a, device_out=False, signs=False):
-        """Correlators + output low-pass on an already band-passed stream (afsk.py:153-166)."""
+    def mark_key(self):
+        """Modems with equal keys see the same band-passed stream through the same mark correlators: their correlator banks
+        can run as one pm_afsk_correlate_group launch (chain_execute.process_chains_device)."""
+        return (self.front_end_key(), self.mark_correlator_i.tobytes(), self.mark_correlator_q.tobytes())
+
+    @staticmethod
+    def correlate_group(modems, a, out_key):
+        """Correlator banks of `modems` (equal mark_key) over the band-passed stream `a` in one launch -> one stream per modem."""
+        lead = modems[0]
+        ctx = lead._context()
+        m, g = len(lead.mark_correlator_i), len(modems)
+        if a.n < m:
+            raise ValueError("input shorter than the correlators")
+        nout = a.n - m + 1
+        stride = (nout + 63) // 64 * 64
+        space = np.stack([np.stack([md.space_correlator_i, md.space_correlator_q]) for md in modems])
+        out = ctx.scratch(out_key, stride * g, np.float64)
+        check(lib().pm_afsk_correlate_group(ctx.handle, a.ptr, a.n, lead._const("mi", lead.mark_correlator_i).ptr,
+                                            lead._const("mq", lead.mark_correlator_q).ptr, lead._const("space_group", space.reshape(-1)).ptr,
+                                            g, m, out.ptr, stride))
+        return [out.view(j * stride, nout) for j in range(g)]
+
+    def back_end(self, a, device_out=False, signs=False, correlated=None):
+        """Correlators + output low-pass on an already band-passed stream (afsk.py:153-166).  `correlated`: this modem's
+        correlator output when a group launch already produced it."""
         ctx = self._context()
         m = len(self.mark_correlator_i)
         if a.n < m:
             raise ValueError("input shorter than the correlators")
-        c = ctx.scratch((self._key(), "corr"), a.n - m + 1, np.float64)
-        check(lib().pm_afsk_correlate(ctx.handle, a.ptr, a.n, self._const("mi", self.mark_correlator_i).ptr,
-                                      self._const("mq", self.mark_correlator_q).ptr, self._const("si", self.space_correlator_i).ptr,
-                                      self._const("sq", self.space_correlator_q).ptr, m, c.ptr))
+        c = correlated
+        if c is None:
+            c = ctx.scratch((self._key(), "corr"), a.n - m + 1, np.float64)
+            check(lib().pm_afsk_correlate(ctx.handle, a.ptr, a.n, self._const("mi", self.mark_correlator_i).ptr,
+                                          self._const("mq", self.mark_correlator_q).ptr, self._const("si", self.space_correlator_i).ptr,
+                                          self._const("sq", self.space_correlator_q).ptr, m, c.ptr))
         if signs:
             bits, nout = self._fir_signs(c, False, "output_lpf", self.output_lpf)
             return SignBits(bits, None, nout)

@@ -101,11 +101,30 @@ class PacketTable:
         for c in range(len(names)):
             r = rows_by_chain.get(c)
             if r is not None and len(r):
-                r = r.copy()
-                r["source_decoder"] = c
+                r["source_decoder"] = c          # in place: the rows are the executor's own, fresh from the codec
                 parts.append(r)
-        self.rows = np.concatenate(parts) if parts else np.zeros(0, dtype=packet_dtype())
+        self.rows = self._stack(parts)
         self.unique_idx = None
+
+    @staticmethod
+    def _stack(parts):
+        """Chain-ordered row blocks -> one array.  No copy when they are consecutive slices of one array, which is how the group
+        executor delivers them (chain_execute._host_rows)."""
+        if not parts:
+            return np.zeros(0, dtype=packet_dtype())
+        if len(parts) == 1:
+            return parts[0]
+        base = parts[0].base
+        if isinstance(base, np.ndarray) and base.dtype == parts[0].dtype and all(p.base is base for p in parts):
+            addr = parts[0].ctypes.data
+            for p in parts:
+                if p.ctypes.data != addr or not p.flags.c_contiguous:
+                    break
+                addr += p.nbytes
+            else:
+                start = (parts[0].ctypes.data - base.ctypes.data) // base.dtype.itemsize
+                return base[start:start + sum(len(p) for p in parts)]
+        return np.concatenate(parts)
 
     def correlate(self, address_distance):
         """packet_meta.py:230-271 on the rows.  Sets unique_idx (rows of the unique packets, by stream address) and

@@ -71,10 +71,12 @@ class _SlicerBase:
         return slice_batch([self], [(bits_i, bits_q, n)])[0]
 
 
-def slice_batch(slicers, bitmaps):
+def slice_batch(slicers, bitmaps, ctx=None):
     """Stage 2 of slice() for many independent streams in ONE pm_slice_batch call (shared iteration launches).
-    bitmaps[k] = (bits_i, bits_q | None, n) from slicers[k].sign_bitmaps().  Returns one AddressedArray per stream."""
-    ctx = slicers[0]._ctx or Context.default()
+    bitmaps[k] = (bits_i, bits_q | None, n) from slicers[k].sign_bitmaps().  Returns one AddressedArray per stream.
+    `ctx`: the context (stream) to run on; the bitmaps must be complete (their producer stream synchronised) if it is not the
+    one that made them."""
+    ctx = ctx or slicers[0]._ctx or Context.default()
     out = [None] * len(slicers)
     for base in range(0, len(slicers), 64):
         group = list(range(base, min(base + 64, len(slicers))))

@@ -176,3 +176,26 @@ def test_work_buffers_do_not_accumulate(config_lines):
         gc.collect()
         sizes.append(len(ctx._pool))
     assert sizes[1] == sizes[2] == sizes[3], sizes
+
+
+def test_recording_pipeline_matches_one_at_a_time(golden, config_lines):
+    """RecordingPipeline (demod | slice on a side stream | host, overlapped across recordings) gives exactly what decoding the
+    recordings one at a time gives: different recordings in flight must not touch each other's double-buffered bitmaps."""
+    from pymodem_amd import chain_builder as cb, chain_execute as ce, dist as pdist
+    g = golden("wav_chains")
+    rate, wav = read_wav_pcm16(os.path.join(GOLDEN, "afsk_300_il2pc_noise.wav"))
+    lines = config_lines("afsk_300.json")
+    names = [l["object_name"] for l in lines]
+    recordings = [wav, wav[::-1].copy(), noise_i16(len(wav) // 2), wav, wav[1000:].copy(), wav]
+    want = [ce.process_chains_table([cb.build_chain(rate, l) for l in lines], r) for r in recordings]
+    pipe = ce.RecordingPipeline()
+    futures = [pipe.submit([cb.build_chain(rate, l) for l in lines], r) for r in recordings]
+    got = [f.result() for f in futures]
+    pipe.close()
+    for w, rows in zip(want, got):
+        for ci in range(len(lines)):
+            assert np.array_equal(w[ci], rows[ci])
+    table = pdist.gather_rows(dict(enumerate(got[-1])), len(lines), names).correlate(rate / 40)
+    assert table.CountGood() == 49 and table.CountBad() == 6
+    for ci in range(len(lines)):
+        assert np.array_equal(got[0][ci]["streamaddress"], g[f"afsk_300__c{ci}_pkt_addr"])

@@ -80,6 +80,37 @@ def test_afsk_correlate_bit_exact(ctx, m):
         assert np.array_equal(y.download(), O.afsk_correlate_canon(x, *taps)), (m, n)
 
 
+@pytest.mark.parametrize("groups", [1, 2, 3, 7, 8])
+@pytest.mark.parametrize("m", [1, 2, 3, 5, 40, 60, 61])
+def test_afsk_correlate_group_bit_exact(ctx, groups, m):
+    """Shared-mark correlator banks: every output stream equals the single-modem kernel's and the oracle's."""
+    rng = np.random.default_rng(1000 * groups + m)
+    mark = [rng.standard_normal(m) for _ in range(2)]
+    space = rng.standard_normal((groups, 2, m))
+    for n, aligned in [(m, True), (m + 511, True), (m + 512, False), (m + 513, True), (40000, True), (40001, False)]:
+        x = rng.standard_normal(n) * 300.0
+        dx = ctx.upload(x)
+        dm = [ctx.upload(t) for t in mark]
+        ds = ctx.upload(space.reshape(-1))
+        nout = n - m + 1
+        stride = (nout + 63) // 64 * 64 if aligned else nout + 1          # odd stride: the scalar-store path
+        y = ctx.empty(stride * groups, np.float64)
+        chk(L().pm_afsk_correlate_group(ctx.handle, dx.ptr, n, dm[0].ptr, dm[1].ptr, ds.ptr, groups, m, y.ptr, stride))
+        got = y.download()
+        for g in range(groups):
+            want = O.afsk_correlate_canon(x, mark[0], mark[1], space[g, 0], space[g, 1])
+            assert np.array_equal(got[g * stride:g * stride + nout], want), (groups, m, n, g)
+
+
+def test_afsk_correlate_group_rejects_bad_arguments(ctx):
+    from pymodem_amd import NativeError
+    d = ctx.upload(np.zeros(64))
+    with pytest.raises(NativeError):
+        chk(L().pm_afsk_correlate_group(ctx.handle, d.ptr, 64, d.ptr, d.ptr, d.ptr, 9, 4, d.ptr, 64))
+    with pytest.raises(NativeError):
+        chk(L().pm_afsk_correlate_group(ctx.handle, d.ptr, 64, d.ptr, d.ptr, d.ptr, 2, 4, d.ptr, 10))      # streams would overlap
+
+
 def test_sqrt_is_correctly_rounded(ctx):
     """The correlator magnitude relies on the device sqrt being IEEE: one tap turns the kernel into sqrt(a*a + 0)."""
     rng = np.random.default_rng(5)

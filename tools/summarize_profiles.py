@@ -29,21 +29,27 @@ for name, ctr in [("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")]:
     for k, (n, v) in agg.items():
         res.setdefault(k, {})[ctr + "_KB_avg_per_launch"] = round(v / n, 1)
         res[k][ctr + "_launches"] = n
-alg = {"afsk_correlate_kernel": 16.0, "fir_valid_kernel<double": 16.0, "fir_valid_kernel<short": 10.0, "signs_kernel": 8.125}
+CLASSES = {"fir_i16": ["fir_valid_kernel<short"], "fir_f64": ["fir_valid_kernel<double"],
+           "afsk_correlate": ["afsk_correlate_kernel", "afsk_group_kernel"], "signs": ["signs_kernel"],
+           "slice_iter": ["slice_iter_kernel"], "slice_emit": ["slice_count_kernel", "slice_scan_kernel", "slice_pack_kernel"]}
 out = {"workload": workload, "samples": samples,
        "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (two separate passes) --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
        "corrections": "bytes = counter * 1024; FETCH_SIZE doubled (gfx950 reports half the bytes of a coalesced streaming read, MI355X_MICROARCH.md "
                       "HBM section; calibrated in round 1 on signs_kernel: 230.4 MB read, 115.2 MB reported). Kernels that write only a sign bitmap "
-                      "(SIGNS variants) have ~N/8 bytes of writes.",
-       "kernels": {}}
+                      "(SIGNS variants) have ~N/8 bytes of writes.  `classes` groups kernel names the way pm_prof_* does (bench.py's "
+                      "roofline.traffic is classes[kernel].traffic_bytes_per_launch: all bytes of the class / all its launches).",
+       "kernels": {}, "classes": {}}
 for k, v in sorted(res.items()):
     f = v.get("FETCH_SIZE_KB_avg_per_launch", 0) * 1024 * 2
     w = v.get("WRITE_SIZE_KB_avg_per_launch", 0) * 1024
     v["hbm_read_bytes_corrected"], v["hbm_write_bytes"], v["traffic_bytes_per_launch"] = round(f), round(w), round(f + w)
-    for key, per in alg.items():
-        if k.startswith(key):
-            v["algorithmic_bytes_per_launch_full_output"] = per * samples
     out["kernels"][k] = v
+for cls, prefixes in CLASSES.items():
+    names = [k for k in out["kernels"] if any(k.startswith(p) for p in prefixes)]
+    n = sum(out["kernels"][k].get("FETCH_SIZE_launches", 0) for k in names)
+    if n:
+        total = sum(out["kernels"][k]["traffic_bytes_per_launch"] * out["kernels"][k].get("FETCH_SIZE_launches", 0) for k in names)
+        out["classes"][cls] = {"kernels": names, "launches": n, "traffic_bytes_per_launch": round(total / n)}
 json.dump(out, open(f"profiles/{tag}_{workload}_pmc.json", "w"), indent=1)
 shutil.copyfile("gpurun_out/kernel_bench.jsonl", f"profiles/{tag}_kernel_bench.jsonl")
 shutil.copyfile("gpurun_out/bench_default.json", f"profiles/{tag}_bench_default.json")

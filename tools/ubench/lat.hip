@@ -1,0 +1,65 @@
+// Micro-benchmark: dependent-chain latency and single-wave issue rate of the f64 / f32 VALU ops the sequential
+// kernels (slicer clock, carrier loops) are made of.  One wave per SIMD unless WAVES is raised.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define N 4096
+template <int MODE>
+__global__ void k(double *out, double a0, double c1, double c2, long long *cyc)
+{
+    double a = a0 + threadIdx.x, b = a0 * 2 + threadIdx.x, c = a0 * 3, d = a0 * 4;
+    long long t0 = __builtin_readcyclecounter();
+    long long s0 = clock64();
+#pragma unroll 1
+    for (int i = 0; i < N / 16; ++i) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (MODE == 0) { asm volatile("v_add_f64 %0, %0, %1" : "+v"(a) : "v"(c1)); }
+            if (MODE == 1) { asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a) : "v"(c2)); }
+            if (MODE == 2) { asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a) : "v"(c2), "v"(c1)); }
+            if (MODE == 3) { asm volatile("v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(c1)); }
+            if (MODE == 4) { float x = (float)a; asm volatile("v_add_f32 %0, %0, %1" : "+v"(x) : "v"((float)c1)); a = x; }
+            if (MODE == 5) {
+                int lo = __double2loint(a), hi = __double2hiint(a);
+                asm volatile("v_cmp_ge_f64 vcc, %2, %3\n v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %5, vcc"
+                             : "+v"(lo), "+v"(hi) : "v"(a), "v"(c1), "v"(lo ^ 1), "v"(hi) : "vcc");
+                a = __hiloint2double(hi, lo);
+            }
+            if (MODE == 6) { asm volatile("v_add_f64 %0, %0, %1\n v_mul_f64 %0, %0, %2" : "+v"(a) : "v"(c1), "v"(c2)); }
+        }
+    }
+    long long s1 = clock64();
+    long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a + b + c + d;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = s1 - s0; }
+}
+template <int MODE>
+void run(const char *name, int opsPerIter, int blocks, int threads)
+{
+    double *out; long long *cyc, h[2];
+    hipMalloc(&out, sizeof(double) * blocks * threads);
+    hipMalloc(&cyc, 16);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k<MODE><<<blocks, threads>>>(out, 1.0, 1.0, 0.999, cyc);
+    hipEventRecord(e0);
+    k<MODE><<<blocks, threads>>>(out, 1.0, 1.0, 0.999, cyc);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    hipMemcpy(h, cyc, 16, hipMemcpyDeviceToHost);
+    printf("%-34s blocks=%5d threads=%4d  %8.3f us  %7.2f ns/op-group  clock64 ticks/op %.2f  realtime ticks/op %.3f\n", name, blocks, threads, ms * 1e3,
+           ms * 1e6 / (N * 1.0), (double)h[1] / N, (double)h[0] / N);
+    hipFree(out); hipFree(cyc);
+}
+int main()
+{
+    for (int threads : {64, 128, 256, 512}) {
+        const int blocks = 256;
+        run<0>("dependent v_add_f64", 1, blocks, threads);
+        run<1>("dependent v_mul_f64", 1, blocks, threads);
+        run<2>("dependent v_fma_f64", 1, blocks, threads);
+        run<3>("4 independent v_add_f64", 4, blocks, threads);
+        run<5>("dependent cmp_f64+cndmask", 1, blocks, threads);
+        run<6>("dependent add+mul f64", 2, blocks, threads);
+    }
+    return 0;
+}
