@@ -160,14 +160,18 @@ def main():
         sys.exit("bench.py needs a GPU")
     dev_index = local % ndev                      # more ranks than GPUs only happens in the gloo rehearsal
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("PYMODEM_AMD_FORCE_GATHER"))      # the latter: one rank, collectives still run
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(args.backend)
-    coll_device = f"cuda:{dev_index}" if (world > 1 and args.backend == "nccl") else None
+    coll_device = f"cuda:{dev_index}" if (use_dist and args.backend == "nccl") else None
 
     import pymodem_amd
     from pymodem_amd import chain_builder as cb, chain_execute as ce, dist as pdist
@@ -242,7 +246,7 @@ def main():
         for sc in sides:
             sc.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
 
     run_steps(args.warmup)
@@ -274,7 +278,7 @@ def main():
         alone = ctx.profile_read()
         ctx.profile(False)
         args.overlap = saved
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device or "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -331,7 +335,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, [lines[c] for c in my])
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

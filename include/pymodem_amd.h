@@ -196,6 +196,18 @@ typedef struct pm_packet {
     uint8_t data[PM_PKT_MAX];
 } pm_packet;
 
+/* The first 40 bytes of pm_packet: everything the de-dup reads.  Arrays of heads stand in for arrays of full rows wherever a
+ * stride is passed (pm_correlate_strided), so rank 0 of a multi-GPU job never expands the payloads it gathers. */
+typedef struct pm_packet_head {
+    int64_t streamaddress;
+    int32_t len;
+    int32_t bytes_corrected;
+    int32_t calculated_crc, carried_crc;
+    int32_t valid_crc, valid_header;
+    int32_t source_decoder;
+    int32_t correlated_count;
+} pm_packet_head;
+
 typedef struct pm_codec pm_codec;
 /* kind 0 = AX25Codec (ax25.py:11-93), 1 = IL2PCodec (il2p.py:110-519). */
 int pm_codec_create(int kind, int crc, int disable_rs, int min_dist, int sync_tol, int source_decoder, pm_codec **out);
@@ -207,11 +219,26 @@ int pm_codec_decode(pm_codec *c, const uint8_t *h_data, const int64_t *h_addr, i
 int pm_codec_fetch(pm_codec *c, pm_packet *h_out, int64_t cap, int64_t *h_count);
 int pm_crc16_ccitt(const uint8_t *h_data, int64_t n);                    /* crc_functions.py:44-55 */
 
+/* Wire form of packet rows for the one exchange step of the multi-GPU path (the reference hands PacketMeta lists through a
+ * multiprocessing.Queue, pymodem.py:140,157-163): per packet the 40-byte record header followed by its `len` payload bytes.
+ * pm_packets_pack returns the bytes the n rows need and writes them when they fit in cap (returns the need either way);
+ * pm_packets_unpack rebuilds full rows (payload tails zeroed) and returns how many it wrote, or < 0 on a malformed stream. */
+int64_t pm_packets_pack(const pm_packet *h_rows, int64_t n, uint8_t *h_out, int64_t cap);
+int64_t pm_packets_unpack(const uint8_t *h_in, int64_t bytes, pm_packet *h_rows, int64_t cap_rows);
+
+/* Split a wire stream without expanding it: the record heads go to h_heads (dense), h_payload_at[k] is the offset of record
+ * k's payload inside h_in.  Returns the number of records or < 0. */
+int64_t pm_packets_index(const uint8_t *h_in, int64_t bytes, pm_packet_head *h_heads, int64_t *h_payload_at, int64_t cap_rows);
+
 /* PacketMetaArray.Correlate (packet_meta.py:230-271): h_pkts hold all chains' packets in config order
  * (h_chain_counts[c] packets for chain c).  Writes indices of the unique packets, sorted by stream address,
  * to h_unique_idx and sets correlated_count on them.  Returns the number of unique packets or < 0. */
 int64_t pm_correlate(pm_packet *h_pkts, const int64_t *h_chain_counts, int nchains, double address_distance,
                      int64_t *h_unique_idx, int32_t *h_corr_decoders, int64_t corr_cap);
+/* Same on records `stride` bytes apart that each begin with a pm_packet_head (stride = sizeof(pm_packet) for full rows,
+ * sizeof(pm_packet_head) for a dense array of heads). */
+int64_t pm_correlate_strided(void *h_records, int64_t stride, const int64_t *h_chain_counts, int nchains, double address_distance,
+                             int64_t *h_unique_idx, int32_t *h_corr_decoders, int64_t corr_cap);
 
 #ifdef __cplusplus
 }

@@ -63,6 +63,15 @@ def packet_dtype():
     return dt
 
 
+def head_dtype():
+    """NumPy view of pm_packet_head: the 40 bytes every pm_packet starts with."""
+    import numpy as np
+    dt = np.dtype([("streamaddress", "<i8"), ("len", "<i4"), ("bytes_corrected", "<i4"), ("calculated_crc", "<i4"), ("carried_crc", "<i4"),
+                   ("valid_crc", "<i4"), ("valid_header", "<i4"), ("source_decoder", "<i4"), ("correlated_count", "<i4")])
+    assert dt.itemsize == 40
+    return dt
+
+
 _vp, _i64, _int, _dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double
 _SIGS = {
     "pm_version": ([], _int),
@@ -106,6 +115,10 @@ _SIGS = {
     "pm_codec_destroy": ([_vp], _int),
     "pm_codec_decode": ([_vp, _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
     "pm_codec_fetch": ([_vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
+    "pm_packets_pack": ([_vp, _i64, _vp, _i64], _i64),
+    "pm_packets_unpack": ([_vp, _i64, _vp, _i64], _i64),
+    "pm_packets_index": ([_vp, _i64, _vp, _vp, _i64], _i64),
+    "pm_correlate_strided": ([_vp, _i64, ctypes.POINTER(_i64), _int, _dbl, _vp, _vp, _i64], _i64),
     "pm_crc16_ccitt": ([_vp, _i64], _int),
     "pm_correlate": ([_vp, ctypes.POINTER(_i64), _int, _dbl, _vp, _vp, _i64], _i64),
 }

@@ -662,10 +662,73 @@ int pm_codec_fetch(pm_codec *c, pm_packet *h_out, int64_t cap, int64_t *h_count)
 
 int pm_crc16_ccitt(const uint8_t *h_data, int64_t n) { return crc16(h_data, n); }
 
+int64_t pm_packets_pack(const pm_packet *rows, int64_t n, uint8_t *out, int64_t cap)
+{
+    if (n < 0 || (n > 0 && !rows) || cap < 0) return pm_set_error(PM_ERR_ARG, "pm_packets_pack: bad argument");
+    constexpr size_t H = offsetof(pm_packet, data);
+    int64_t need = 0;
+    for (int64_t k = 0; k < n; ++k) {
+        if (rows[k].len < 0 || rows[k].len > PM_PKT_MAX) return pm_set_error(PM_ERR_ARG, "pm_packets_pack: row %lld has len %d", (long long)k, rows[k].len);
+        need += (int64_t)H + rows[k].len;
+    }
+    if (need > cap || !out) return need;
+    uint8_t *w = out;
+    for (int64_t k = 0; k < n; ++k) {
+        memcpy(w, &rows[k], H + (size_t)rows[k].len);
+        w += H + (size_t)rows[k].len;
+    }
+    return need;
+}
+
+int64_t pm_packets_unpack(const uint8_t *in, int64_t bytes, pm_packet *rows, int64_t cap_rows)
+{
+    if (bytes < 0 || (bytes > 0 && !in) || cap_rows < 0 || (cap_rows > 0 && !rows)) return pm_set_error(PM_ERR_ARG, "pm_packets_unpack: bad argument");
+    constexpr size_t H = offsetof(pm_packet, data);
+    int64_t at = 0, k = 0;
+    while (at < bytes) {
+        if (bytes - at < (int64_t)H || k >= cap_rows) return pm_set_error(PM_ERR_ARG, "pm_packets_unpack: truncated stream or too many rows");
+        pm_packet &p = rows[k];
+        memcpy(&p, in + at, H);
+        if (p.len < 0 || p.len > PM_PKT_MAX || bytes - at - (int64_t)H < p.len) return pm_set_error(PM_ERR_ARG, "pm_packets_unpack: bad length");
+        memcpy(p.data, in + at + H, (size_t)p.len);
+        memset(p.data + p.len, 0, sizeof(p.data) - (size_t)p.len);
+        at += (int64_t)H + p.len;
+        ++k;
+    }
+    return k;
+}
+
+int64_t pm_packets_index(const uint8_t *in, int64_t bytes, pm_packet_head *heads, int64_t *payload_at, int64_t cap_rows)
+{
+    if (bytes < 0 || (bytes > 0 && !in) || cap_rows < 0 || (cap_rows > 0 && (!heads || !payload_at)))
+        return pm_set_error(PM_ERR_ARG, "pm_packets_index: bad argument");
+    constexpr size_t H = sizeof(pm_packet_head);
+    static_assert(sizeof(pm_packet_head) == offsetof(pm_packet, data), "pm_packet_head is the head of pm_packet");
+    int64_t at = 0, k = 0;
+    while (at < bytes) {
+        if (bytes - at < (int64_t)H || k >= cap_rows) return pm_set_error(PM_ERR_ARG, "pm_packets_index: truncated stream or too many records");
+        memcpy(&heads[k], in + at, H);
+        const int32_t len = heads[k].len;
+        if (len < 0 || len > PM_PKT_MAX || bytes - at - (int64_t)H < len) return pm_set_error(PM_ERR_ARG, "pm_packets_index: bad length");
+        payload_at[k] = at + (int64_t)H;
+        at += (int64_t)H + len;
+        ++k;
+    }
+    return k;
+}
+
 int64_t pm_correlate(pm_packet *p, const int64_t *counts, int nchains, double address_distance,
                      int64_t *uniq, int32_t *corr_decoders, int64_t corr_cap)
 {
-    if (!p || !counts || !uniq || nchains < 0) return pm_set_error(PM_ERR_ARG, "pm_correlate: bad argument");
+    return pm_correlate_strided(p, (int64_t)sizeof(pm_packet), counts, nchains, address_distance, uniq, corr_decoders, corr_cap);
+}
+
+int64_t pm_correlate_strided(void *records, int64_t stride, const int64_t *counts, int nchains, double address_distance,
+                             int64_t *uniq, int32_t *corr_decoders, int64_t corr_cap)
+{
+    if (!records || !counts || !uniq || nchains < 0 || stride < (int64_t)sizeof(pm_packet_head))
+        return pm_set_error(PM_ERR_ARG, "pm_correlate: bad argument");
+    auto rec = [&](int64_t i) -> pm_packet_head & { return *reinterpret_cast<pm_packet_head *>(static_cast<char *>(records) + i * stride); };
     // packet_meta.py:230-271.  Chains in config order; the first chain's valid packets are all unique; a later
     // packet is a duplicate of the FIRST unique packet (insertion order) from another decoder within
     // address_distance and with equal calculated CRC.
@@ -678,7 +741,7 @@ int64_t pm_correlate(pm_packet *p, const int64_t *counts, int nchains, double ad
     int64_t base = 0;
     for (int c = 0; c < nchains; ++c) {
         for (int64_t k = 0; k < counts[c]; ++k) {
-            pm_packet &r = p[base + k];
+            pm_packet_head &r = rec(base + k);
             if (!(r.valid_crc && r.valid_header)) continue;
             std::vector<Cand> &bucket = by_crc[r.calculated_crc];
             bool unique = true;
@@ -703,12 +766,12 @@ int64_t pm_correlate(pm_packet *p, const int64_t *counts, int nchains, double ad
     }
     std::vector<size_t> order(u.size());
     for (size_t i = 0; i < order.size(); ++i) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return p[u[a]].streamaddress < p[u[b]].streamaddress; });
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return rec(u[a]).streamaddress < rec(u[b]).streamaddress; });
     int64_t w = 0;
     for (size_t i = 0; i < order.size(); ++i) {
         const size_t j = order[i];
         uniq[i] = u[j];
-        p[u[j]].correlated_count = (int32_t)decoders[j].size();
+        rec(u[j]).correlated_count = (int32_t)decoders[j].size();
         if (corr_decoders)
             for (int32_t d : decoders[j])
                 if (w < corr_cap) corr_decoders[w++] = d;

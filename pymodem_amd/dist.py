@@ -70,49 +70,77 @@ def gather_packets(packets_by_chain, chain_names, device=None):
     return unpack_packets(np.concatenate(parts), chain_names)
 
 
+_GATHER_CAP = {}          # (world, nchains) -> bytes per rank of the exchange buffer; grows when a recording needs more
+
+
 def gather_rows(rows_by_chain, nchains, names, device=None):
-    """Table form of gather_packets: pm_packet rows in, PacketTable (all chains, config order) on rank 0, None elsewhere.
-    The rows travel as they are (header + the longest packet's bytes), no per-packet Python work."""
+    """The exchange step in table form: every rank's pm_packet rows in, PacketTable (all chains, config order) on rank 0, None
+    elsewhere.  ONE all_gather per recording in steady state: each rank contributes a fixed-capacity byte block
+        int64[2 + nchains]  = payload bytes, rows, rows of each global chain     (always fits)
+        payload             = its rows in wire form (40-byte header + len payload bytes each, pm_packets_pack)
+    The capacity is agreed without talking: every rank derives it from the headers of the previous exchange, which all ranks
+    saw.  If some rank's payload does not fit, every rank sees that in the gathered headers and the exchange is repeated once
+    with the capacity they all compute from them."""
+    import ctypes
+    import os
     import torch
     import torch.distributed as dist
-    from ._native import packet_dtype
+    from ._native import check, lib, packet_dtype
     from .packet_meta import PacketTable
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    # PYMODEM_AMD_FORCE_GATHER=1 runs the collective even with one rank (rehearses the RCCL path on a one-GPU box)
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not os.environ.get("PYMODEM_AMD_FORCE_GATHER")):
         return PacketTable(rows_by_chain, names)
+    import time
+    trace = os.environ.get("PYMODEM_AMD_GATHER_TRACE")
+    tt = [time.perf_counter()]
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = torch.device(device) if device is not None else torch.device("cpu")
     dt = packet_dtype()
-    mine = []
+    head = 8 * (2 + nchains)
+    counts = np.zeros(nchains, dtype=np.int64)
+    parts = []
     for c in sorted(rows_by_chain):
-        r = rows_by_chain[c].copy()
-        r["source_decoder"] = c
-        mine.append(r)
-    mine = np.concatenate(mine) if mine else np.zeros(0, dtype=dt)
-    width = 40 + (int(mine["len"].max()) if len(mine) else 0)               # header + longest payload
-    meta = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(meta, torch.tensor([len(mine), width], dtype=torch.int64, device=dev))
-    most, wide = max(int(m[0]) for m in meta), max(int(m[1]) for m in meta)
-    if most == 0:
-        return PacketTable({}, names) if rank == 0 else None
-    block = np.zeros((most, wide), dtype=np.uint8)
-    if len(mine):
-        block[:len(mine)] = mine.view(np.uint8).reshape(len(mine), dt.itemsize)[:, :wide]
-    t = torch.from_numpy(block.reshape(-1)).to(dev)
-    blocks = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(blocks, t)
+        r = rows_by_chain[c]
+        if len(r):
+            r["source_decoder"] = c
+            counts[c] = len(r)
+            parts.append(r)
+    mine = PacketTable._stack(parts)
+    mine = np.ascontiguousarray(mine)
+    need = check(lib().pm_packets_pack(mine.ctypes.data_as(ctypes.c_void_p), len(mine), None, 0))
+    key = (world, nchains)
+    cap = max(_GATHER_CAP.get(key, 1 << 16), 1 << 12)
+    while True:
+        block = np.zeros(head + cap, dtype=np.uint8)
+        hdr = block[:head].view(np.int64)
+        hdr[0], hdr[1], hdr[2:] = need, len(mine), counts
+        if need <= cap:
+            check(lib().pm_packets_pack(mine.ctypes.data_as(ctypes.c_void_p), len(mine), block[head:].ctypes.data_as(ctypes.c_void_p), cap))
+        tt.append(time.perf_counter())
+        t = torch.from_numpy(block).to(dev)
+        blocks = [torch.empty_like(t) for _ in range(world)]
+        tt.append(time.perf_counter())
+        dist.all_gather(blocks, t)
+        tt.append(time.perf_counter())
+        got = torch.stack(blocks).cpu().numpy()                          # one device->host copy
+        tt.append(time.perf_counter())
+        needs = got[:, :8].copy().view(np.int64).reshape(-1)
+        most = int(needs.max())
+        _GATHER_CAP[key] = max(1 << 16, (most + most // 4 + 4095) // 4096 * 4096)       # same value on every rank
+        if most <= cap:
+            break
+        cap = _GATHER_CAP[key]                                               # someone did not fit: once more, with room
     if rank != 0:
         return None
-    by_chain = {}
-    for b, m in zip(blocks, meta):
-        k = int(m[0])
-        if not k:
-            continue
-        full = np.zeros((k, dt.itemsize), dtype=np.uint8)
-        full[:, :wide] = b.cpu().numpy().reshape(most, wide)[:k]
-        rows = full.reshape(-1).view(dt)
-        for c in np.unique(rows["source_decoder"]):
-            by_chain[int(c)] = rows[rows["source_decoder"] == c]
-    return PacketTable(by_chain, names)
+    hdrs = got[:, :head].copy().view(np.int64).reshape(world, 2 + nchains)
+    streams = [got[r, head:head + int(hdrs[r, 0])] for r in range(world)]
+    table = PacketTable.from_streams(streams, hdrs[:, 2:].sum(axis=0).tolist(), names)     # heads only; payloads stay in `got`
+    tt.append(time.perf_counter())
+    if trace:
+        import sys
+        print("[gather] pack %.2f  h2d %.2f  all_gather %.2f  d2h %.2f  index %.2f ms (%d records, %d B/rank)" % (
+            *[(b - a) * 1e3 for a, b in zip(tt[:-1], tt[1:])][-5:], len(table.heads), head + cap), file=sys.stderr)
+    return table
 
 
 def correlate(packets_by_chain, nchains, address_distance):

@@ -90,9 +90,15 @@ def rows_to_packets(rows, decoder_name):
 
 
 class PacketTable:
-    """All chains' packets as one array of pm_packet rows (chain c's rows are contiguous, chains in config order,
-    source_decoder = chain index).  The fast path of the group executor and of the multi-GPU gather: CRC/header validity
-    come from the native codec, Correlate runs natively on the rows, PacketMeta objects exist only if asked for."""
+    """All chains' packets in config order (chain c's records are contiguous, source_decoder = chain index).  The fast path of
+    the group executor and of the multi-GPU gather: CRC/header validity come from the native codec, Correlate runs natively,
+    PacketMeta objects exist only if asked for.
+
+    Two storage forms behind one interface.  `heads` always exists: one record per packet with the pm_packet_head fields
+    (streamaddress, len, CRCs, validity, source_decoder, correlated_count) -- everything the de-dup and the counters read.
+      full     heads IS the array of pm_packet rows (1.3 KB apart), as the codecs wrote them (single rank);
+      compact  heads is a dense 40-byte array indexed out of the gathered wire streams; the payloads stay where the exchange
+               left them and `rows` expands them only if somebody asks (rank 0 of a multi-GPU job never does)."""
 
     def __init__(self, rows_by_chain, names):
         self.names = list(names)
@@ -103,8 +109,72 @@ class PacketTable:
             if r is not None and len(r):
                 r["source_decoder"] = c          # in place: the rows are the executor's own, fresh from the codec
                 parts.append(r)
-        self.rows = self._stack(parts)
+        self._rows = self._stack(parts)
+        self.heads = self._rows
+        self._streams = None
         self.unique_idx = None
+
+    @classmethod
+    def from_array(cls, rows, counts, names):
+        """All chains' rows already in one array, chain by chain in config order (counts[c] rows of chain c)."""
+        self = cls.__new__(cls)
+        self.names, self.counts, self._rows, self.unique_idx = list(names), [int(c) for c in counts], rows, None
+        self.heads, self._streams = rows, None
+        assert sum(self.counts) == len(rows) and len(self.counts) == len(self.names)
+        return self
+
+    @classmethod
+    def from_streams(cls, streams, counts, names):
+        """Compact form from wire streams (pm_packets_pack output, one uint8 array per contributing rank, in rank order).
+        Records are put in chain order if the ranks did not own consecutive chain blocks."""
+        from ._native import head_dtype
+        self = cls.__new__(cls)
+        self.names, self.counts, self._rows, self.unique_idx = list(names), [int(c) for c in counts], None, None
+        total = sum(self.counts)
+        heads = np.empty(total, dtype=head_dtype())
+        where = np.empty(total, dtype=np.int64)         # payload offset inside its stream
+        which = np.empty(total, dtype=np.int32)         # stream index
+        at = 0
+        for si, buf in enumerate(streams):
+            if len(buf) == 0:
+                continue
+            buf = np.ascontiguousarray(buf)
+            streams[si] = buf
+            k = check(lib().pm_packets_index(buf.ctypes.data_as(ctypes.c_void_p), len(buf), heads[at:].ctypes.data_as(ctypes.c_void_p),
+                                             where[at:].ctypes.data_as(ctypes.c_void_p), total - at))
+            which[at:at + k] = si
+            at += k
+        assert at == total
+        src = heads["source_decoder"]
+        if total and np.any(src[1:] < src[:-1]):
+            order = np.argsort(src, kind="stable")
+            heads, where, which = heads[order], where[order], which[order]
+        self.heads, self._streams, self._where, self._which = heads, list(streams), where, which
+        return self
+
+    @property
+    def rows(self):
+        """Full pm_packet rows (expanded on first use in the compact form)."""
+        if self._rows is None:
+            rows = np.zeros(len(self.heads), dtype=packet_dtype())
+            for name in self.heads.dtype.names:
+                rows[name] = self.heads[name]
+            data = rows["data"]
+            for k in range(len(rows)):
+                n, o = int(self.heads["len"][k]), int(self._where[k])
+                data[k, :n] = self._streams[self._which[k]][o:o + n]
+            self._rows = rows
+        elif self._streams is not None:
+            self._rows["correlated_count"] = self.heads["correlated_count"]
+        return self._rows
+
+    def payload(self, i):
+        """Packet i's bytes."""
+        n = int(self.heads["len"][i])
+        if self._streams is not None:
+            o = int(self._where[i])
+            return self._streams[self._which[i]][o:o + n].tobytes()
+        return self._rows["data"][i, :n].tobytes()
 
     @staticmethod
     def _stack(parts):
@@ -127,25 +197,36 @@ class PacketTable:
         return np.concatenate(parts)
 
     def correlate(self, address_distance):
-        """packet_meta.py:230-271 on the rows.  Sets unique_idx (rows of the unique packets, by stream address) and
-        correlated decoders per unique packet."""
-        n = len(self.rows)
+        """packet_meta.py:230-271 on the record heads.  Sets unique_idx (records of the unique packets, by stream address) and
+        the correlated decoders per unique packet."""
+        n = len(self.heads)
         counts = (ctypes.c_int64 * max(len(self.counts), 1))(*self.counts)
-        uniq = np.zeros(max(n, 1), dtype=np.int64)
-        corr = np.zeros(max(4 * n, 1), dtype=np.int32)
-        k = check(lib().pm_correlate(self.rows.ctypes.data_as(ctypes.c_void_p), counts, len(self.counts), float(address_distance),
-                                     uniq.ctypes.data_as(ctypes.c_void_p), corr.ctypes.data_as(ctypes.c_void_p), len(corr))) if n else 0
+        uniq = np.empty(max(n, 1), dtype=np.int64)
+        corr = np.empty(max(n, 1), dtype=np.int32)          # every valid packet names its decoder exactly once
+        heads = self.heads
+        assert n == 0 or heads.flags.c_contiguous
+        k = check(lib().pm_correlate_strided(heads.ctypes.data_as(ctypes.c_void_p), heads.strides[0] if n else 40, counts, len(self.counts),
+                                             float(address_distance), uniq.ctypes.data_as(ctypes.c_void_p),
+                                             corr.ctypes.data_as(ctypes.c_void_p), len(corr))) if n else 0
         self.unique_idx = uniq[:k]
-        cc = self.rows["correlated_count"][self.unique_idx]
-        ends = np.cumsum(cc)
-        self.unique_decoders = [[self.names[d] for d in corr[e - c:e]] for c, e in zip(cc.tolist(), ends.tolist())]
+        cc = heads["correlated_count"][self.unique_idx]
+        self._corr, self._corr_ends = corr, np.cumsum(cc)
+        self._unique_decoders = None
         return self
+
+    @property
+    def unique_decoders(self):
+        """Names of the decoders that produced each unique packet (built on first use)."""
+        if self._unique_decoders is None:
+            cc = self.heads["correlated_count"][self.unique_idx]
+            self._unique_decoders = [[self.names[d] for d in self._corr[e - c:e]] for c, e in zip(cc.tolist(), self._corr_ends.tolist())]
+        return self._unique_decoders
 
     def CountGood(self):
         return int(len(self.unique_idx))
 
     def CountBad(self):
-        return int(np.count_nonzero((self.rows["valid_crc"] == 0) | (self.rows["valid_header"] == 0)))
+        return int(np.count_nonzero((self.heads["valid_crc"] == 0) | (self.heads["valid_header"] == 0)))
 
     def packets(self, chain):
         """Materialise chain `chain`'s packets as PacketMeta objects."""
@@ -154,11 +235,11 @@ class PacketTable:
 
     def unique_packets(self):
         out = []
+        h = self.heads
         for i, decs in zip(self.unique_idx.tolist(), self.unique_decoders):
-            r = self.rows[i]
-            p = PacketMeta.from_bytes(r["data"][:int(r["len"])].tobytes(), r["streamaddress"], self.names[int(r["source_decoder"])], r["bytes_corrected"])
-            p.CalculatedCRC, p.CarriedCRC = int(r["calculated_crc"]), int(r["carried_crc"])
-            p.ValidCRC, p.ValidHeader = bool(r["valid_crc"]), bool(r["valid_header"])
+            p = PacketMeta.from_bytes(self.payload(i), h["streamaddress"][i], self.names[int(h["source_decoder"][i])], h["bytes_corrected"][i])
+            p.CalculatedCRC, p.CarriedCRC = int(h["calculated_crc"][i]), int(h["carried_crc"][i])
+            p.ValidCRC, p.ValidHeader = bool(h["valid_crc"][i]), bool(h["valid_header"][i])
             p.CorrelatedDecoders = list(decs)
             out.append(p)
         return out

@@ -41,8 +41,14 @@ for c, lst in pk.items():                # the same packets as pm_packet rows (w
         r[k]["calculated_crc"], r[k]["carried_crc"], r[k]["valid_crc"], r[k]["valid_header"] = p.CalculatedCRC, p.CarriedCRC, p.ValidCRC, p.ValidHeader
         r[k]["data"][:len(p.data)] = p.data
     rows[c] = r
-table = pdist.gather_rows(rows, len(names), names)
+pdist._GATHER_CAP[(world, len(names))] = 4096      # too small on purpose: the first exchange must notice and repeat itself
+first = pdist.gather_rows({c: r.copy() for c, r in rows.items()}, len(names), names)
+assert pdist._GATHER_CAP[(world, len(names))] > 4096
+table = pdist.gather_rows(rows, len(names), names)  # steady state: one collective
 if rank == 0:
+    assert np.array_equal(first.rows, table.rows) and first.counts == table.counts
+    assert table.counts == [len(g[f"afsk_300__c{c}_pkt_len"]) for c in range(len(names))]
+    assert np.all(np.diff(table.rows["source_decoder"]) >= 0)
     table.correlate(8000 / 40)
     print("TABLE " + json.dumps({"good": table.CountGood(), "bad": table.CountBad(), "addr": table.rows["streamaddress"][table.unique_idx].tolist(),
           "dec": table.unique_decoders}))
@@ -53,6 +59,9 @@ for _ in range(2):                       # twice: the exchange must be repeatabl
 if rank == 0:
     arr = pdist.correlate(got, len(names), 8000 / 40)
     u = arr.unique_packet_array
+    tu = table.unique_packets()                 # compact table: payloads come straight out of the gathered wire streams
+    assert [bytes(bytearray(p.data)) for p in u] == [bytes(bytearray(p.data)) for p in tu]
+    assert [list(p.CorrelatedDecoders) for p in u] == [list(p.CorrelatedDecoders) for p in tu]
     print("RESULT " + json.dumps({"good": arr.CountGood(), "bad": arr.CountBad(), "addr": [p.streamaddress for p in u],
           "dec": [list(p.CorrelatedDecoders) for p in u], "per_chain": {str(c): len(v) for c, v in got.items()}}))
 else:
