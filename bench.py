@@ -89,6 +89,7 @@ WORKLOADS = {
 }
 
 FP64_PEAK_TFLOPS = 78.6         # MI355X vector FP64 (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz); v_mfma_f64 has the same dense peak
+FP64_SUSTAINED_TFLOPS = 64.3    # what a pure register loop of v_fma_f64 holds on every SIMD (tools/ubench/lat.hip, profiles/r01_ubench_fp64.txt)
 
 
 SIGNAL_MODE = {"afsk_1200_super_opt": "afsk1200_ax25", "fsk_9600": "fsk9600_il2p", "bpsk_300": "bpsk300_il2p", "qpsk_2400": "qpsk2400_il2p"}
@@ -325,7 +326,10 @@ def main():
             "roofline_fp64": {"bound": "valu_f64", "kernel": dom, "achieved": round(tflops, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(tflops / FP64_PEAK_TFLOPS, 5), "algorithmic_flops_per_launch": round(per_launch_flops),
                               "alone_frac": None if alone_ms is None else round(per_launch_flops / (alone_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5),
-                              "note": "2 flops per fma of the FIR sums (epilogue sqrt / sign tests not counted) / the same HIP-event time"},
+                              "sustained_peak_measured": FP64_SUSTAINED_TFLOPS,
+                              "alone_frac_of_sustained": None if alone_ms is None else round(per_launch_flops / (alone_ms * 1e-3) / 1e12 / FP64_SUSTAINED_TFLOPS, 5),
+                              "note": "2 flops per fma of the FIR sums (epilogue sqrt / sign tests not counted) / the same HIP-event time; "
+                                      "sustained_peak_measured is the rate a pure v_fma_f64 register loop holds on this chip (clock under f64 load)"},
             "gpu_kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]},
             "pipeline_stage_ms_per_step": stage_ms or None,
             "slicer": chains_ref[0][2].last_stats if chains_ref else None,

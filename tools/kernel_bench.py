@@ -60,7 +60,20 @@ for m in [40, 60]:
     report(f"afsk_correlate m={m}", timeit(lambda: check(L.pm_afsk_correlate(ctx.handle, d_f64.ptr, N, t[0].ptr, t[1].ptr, t[2].ptr, t[3].ptr, m, d_out.ptr))),
            16.0 * N, 4 * m * N)
 bits = ctx.empty(N // 64 + 2, np.uint64)
+for m in [100, 241]:
+    h = ctx.upload(rng.standard_normal(m))
+    report(f"fir_signs_f64 m={m}", timeit(lambda: check(L.pm_fir_signs_f64(ctx.handle, d_f64.ptr, N, h.ptr, m, bits.ptr, 0))), 8.125 * N, m * N)
+for g, m in [(7, 60), (4, 40)]:
+    t = [ctx.upload(rng.standard_normal(m)) for _ in range(2)]
+    sp = ctx.upload(rng.standard_normal(g * 2 * m))
+    stride = (N - m + 1 + 63) // 64 * 64
+    og = ctx.scratch("kb_group", stride * g, np.float64)
+    report(f"afsk_correlate_group g={g} m={m}", timeit(lambda: check(L.pm_afsk_correlate_group(ctx.handle, d_f64.ptr, N, t[0].ptr, t[1].ptr, sp.ptr, g, m, og.ptr, stride))),
+           8.0 * N * (1 + g), (2 + 2 * g) * m * N)
 report("signs", timeit(lambda: check(L.pm_signs_f64(ctx.handle, d_f64.ptr, N, bits.ptr))), 8.125 * N)
+
+if os.environ.get("KB_ONLY") == "fir":
+    sys.exit(0)
 
 # slicer on a band-limited stream (realistic crossing density) and on raw noise
 sm = np.convolve(rng.standard_normal(N + 39), np.hanning(40), "valid")

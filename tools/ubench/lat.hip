@@ -50,8 +50,44 @@ void run(const char *name, int opsPerIter, int blocks, int threads)
            ms * 1e6 / (N * 1.0), (double)h[1] / N, (double)h[0] / N);
     hipFree(out); hipFree(cyc);
 }
+// Sustained vector-f64 FMA rate: 16 independent accumulators per lane, every SIMD full.
+__global__ __launch_bounds__(256) void fma_peak(double *out, double c1, double c2, int iters)
+{
+    double a[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = threadIdx.x + j;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = __builtin_fma(a[j], c1, c2);
+    }
+    double s = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += a[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+static void peak()
+{
+    double *out;
+    const int blocks = 256 * 8, threads = 256, iters = 20000;
+    hipMalloc(&out, sizeof(double) * blocks * threads);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    fma_peak<<<blocks, threads>>>(out, 0.999, 0.5, 100);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        fma_peak<<<blocks, threads>>>(out, 0.999, 0.5, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double fma = (double)blocks * threads * 16.0 * iters;
+        printf("sustained v_fma_f64: %.1f ms  %.2f TFMA/s = %.1f TFLOP/s  (equivalent clock at 64 FMA/clk/CU x 256 CU: %.2f GHz)\n", ms, fma / ms / 1e9,
+               2 * fma / ms / 1e9, fma / ms / 1e6 / (256.0 * 64.0) / 1e3 * 1e0);
+    }
+    hipFree(out);
+}
+
 int main()
 {
+    peak();
     for (int threads : {64, 128, 256, 512}) {
         const int blocks = 256;
         run<0>("dependent v_add_f64", 1, blocks, threads);
