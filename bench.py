@@ -89,7 +89,7 @@ WORKLOADS = {
 }
 
 FP64_PEAK_TFLOPS = 78.6         # MI355X vector FP64 (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz); v_mfma_f64 has the same dense peak
-FP64_SUSTAINED_TFLOPS = 64.3    # what a pure register loop of v_fma_f64 holds on every SIMD (tools/ubench/lat.hip, profiles/r01_ubench_fp64.txt)
+FP64_SUSTAINED_TFLOPS = 64.3    # what a pure register loop of v_fma_f64 holds on every SIMD (tools/ubench/lat.hip, profiles/r01_ubench.txt)
 
 
 SIGNAL_MODE = {"afsk_1200_super_opt": "afsk1200_ax25", "fsk_9600": "fsk9600_il2p", "bpsk_300": "bpsk300_il2p", "qpsk_2400": "qpsk2400_il2p"}
@@ -145,6 +145,8 @@ def main():
                     help="signal: seeded packet-bearing recording of the workload's mode + AWGN (pymodem_amd.siggen), tiled to --samples; "
                          "noise: BASELINE.md's default_rng(1234) noise buffer")
     ap.add_argument("--cpu-sample", type=int, default=0, help="samples for the CPU baseline leg (0 = auto)")
+    ap.add_argument("--also", type=int, default=1, help="1 (default, one GPU only): after the headline workload also measure fsk_9600, "
+                    "bpsk_300 and qpsk_2400 (BASELINE configs[2], [1], [4]) briefly and attach them under 'also'")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -174,6 +176,44 @@ def main():
             dist.init_process_group(args.backend)
     coll_device = f"cuda:{dev_index}" if (use_dist and args.backend == "nccl") else None
 
+    env = {"rank": rank, "world": world, "dev_index": dev_index, "use_dist": use_dist, "coll_device": coll_device}
+    out = measure(args, env)
+    if rank == 0:
+        if world == 1 and args.also:
+            out["also"] = also_workloads(args, env)
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def also_workloads(args, env):
+    """BASELINE configs[1], [2] and [4] measured after the headline workload in the same process (one GPU only): the single-chain
+    BPSK-300 Costas path and the 8-chain QPSK-2400 path are bound by their sequential carrier loops -- one step each
+    at full size -- and fsk_9600 is the shortest-tap FIR path.  Never allowed to break the main line."""
+    import copy
+    out = {}
+    for name, steps, warm in (("fsk_9600", 10, 2), ("bpsk_300", 1, 0), ("qpsk_2400", 1, 0)):
+        if name == args.workload:
+            continue
+        a = copy.copy(args)
+        a.workload, a.steps, a.warmup, a.no_cpu_baseline, a.chains_per_gpu = name, steps, warm, True, 0
+        try:
+            d = measure(a, env)
+            out[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": steps, "config": d["config"]["workload"],
+                         "chains_per_gpu": d["config"]["chains_per_gpu"], "samples_per_recording": a.samples,
+                         "gpu_kernel_ms_per_step": d["gpu_kernel_ms_per_step"], "packets": d["packets"],
+                         "roofline_kernel": d["roofline"]["kernel"], "roofline_frac_alone": (d["roofline"]["alone"] or {}).get("frac"),
+                         "roofline_fp64_alone_frac": d["roofline_fp64"]["alone_frac"], "dominant_by_time": d["roofline"]["dominant_by_time"]}
+        except Exception as e:                                   # noqa: BLE001
+            out[name] = {"error": repr(e)[:300]}
+    return out
+
+
+def measure(args, env):
+    """One workload: build the chain group, W warm-up steps, K timed steps -> the dict of the JSON line (rank 0) or None."""
+    import torch
+    rank, world, dev_index, use_dist, coll_device = env["rank"], env["world"], env["dev_index"], env["use_dist"], env["coll_device"]
     import pymodem_amd
     from pymodem_amd import chain_builder as cb, chain_execute as ce, dist as pdist
     ctx = pymodem_amd.Context.default(dev_index)  # the stage objects use the same per-process default context
@@ -284,6 +324,13 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the recording's way into HBM, outside the timed region (the boundary hands over a host buffer): pageable int16 -> device
+    t_up = time.perf_counter()
+    d_again = ctx.upload(audio)
+    ctx.sync()
+    h2d_ms = (time.perf_counter() - t_up) * 1e3
+    del d_again
+
     if rank == 0:
         total_samples = float(args.samples) * nchains * args.steps
         value = total_samples / elapsed / 1e6
@@ -331,6 +378,10 @@ def main():
                               "note": "2 flops per fma of the FIR sums (epilogue sqrt / sign tests not counted) / the same HIP-event time; "
                                       "sustained_peak_measured is the rate a pure v_fma_f64 register loop holds on this chip (clock under f64 load)"},
             "gpu_kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]},
+            "h2d": {"ms": round(h2d_ms, 3), "bytes": int(audio.nbytes),
+                    "value_with_h2d": round(float(args.samples) * nchains / (elapsed / args.steps + h2d_ms * 1e-3) / 1e6, 3),
+                    "note": "one upload of the recording from pageable host memory, measured after the timed region and added to every step "
+                            "un-overlapped; `value` itself has the recording resident in HBM"},
             "pipeline_stage_ms_per_step": stage_ms or None,
             "slicer": chains_ref[0][2].last_stats if chains_ref else None,
             "packets": {"unique_good": result.CountGood() if result is not None else None,
@@ -338,12 +389,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, [lines[c] for c in my])
-        print(json.dumps(out), flush=True)
-    if use_dist:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
-
-
+        return out
+    return None
 
 
 def pmc_traffic(args, kernel_class):
@@ -378,7 +425,16 @@ def cpu_baseline(args, lines):
         if time.perf_counter() - t0 > 12.0 or done >= 4 * len(lines):
             break
     dt = time.perf_counter() - t0
-    return {"value": round(len(audio) * done / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+    model = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(len(audio) * done / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port", "cpu_model": model,
+            "host_cores_available": os.cpu_count(),
             "sample": f"{done} chain passes (of {len(lines)} chains) x the first {len(audio)} samples of the same buffer, "
                       f"oracle = numpy.convolve FIRs + C loops + Python codecs, {dt:.1f} s on one core"}
 

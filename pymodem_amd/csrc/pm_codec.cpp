@@ -366,6 +366,13 @@ struct Il2p : pm_codec {
             // sync search (il2p.py:367-376): the last 32 bits before each of the byte's 8 bit positions, tested without a
             // per-bit loop; a hit (rare) hands the rest of the byte to the state machine
             const uint64_t win = ((uint64_t)word << 8) | d[k];
+            // exact match wanted (sync_tol 0, every bundled config): the previous byte lies wholly inside all eight candidate
+            // windows, so one table lookup on it tells which bit offsets can match at all -- almost always none
+            if (sync_tol == 0 && !sync_feasible()[(win >> 8) & 0xFF]) {
+                word = (uint32_t)win;
+                nbits += 8;
+                continue;
+            }
             int i = 0;
             bool hit = false;
 #define PM_SYNC_AT(S)                                                                                                   \
@@ -389,6 +396,24 @@ struct Il2p : pm_codec {
             state = kHeader;
             feed_bits(b, 8 - i, a[k], sink);
         }
+    }
+
+    // feasible[b] != 0 iff, with b as the byte before the current one, some bit offset S lets the 24-bit sync word 0xF15E48 (or
+    // the 32-bit pattern 0x5D57DF7F) end inside the current byte: b supplies window bits S+1 .. S+8 of either pattern.
+    static const uint8_t *sync_feasible()
+    {
+        static const struct Table {
+            uint8_t t[256];
+            Table()
+            {
+                memset(t, 0, sizeof(t));
+                for (int S = 0; S < 8; ++S) {
+                    t[(0xF15E48u >> (S + 1)) & 0xFF] |= (uint8_t)(1u << S);
+                    t[(0x5D57DF7Fu >> (S + 1)) & 0xFF] |= (uint8_t)(1u << S);
+                }
+            }
+        } table;
+        return table.t;
     }
 
     static void descramble(uint8_t *p, int n)

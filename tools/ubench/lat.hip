@@ -66,6 +66,40 @@ __global__ __launch_bounds__(256) void fma_peak(double *out, double c1, double c
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// Streaming copy: what HBM delivers to a plain 16-byte-per-lane read+write kernel (1 GiB in, 1 GiB out).
+__global__ __launch_bounds__(256) void copy_kernel(const double2 *__restrict__ a, double2 *__restrict__ b, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
+}
+__global__ __launch_bounds__(256) void read_kernel(const double2 *__restrict__ a, double *__restrict__ out, size_t n)
+{
+    double s = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { double2 v = a[i]; s += v.x + v.y; }
+    if (s == 12345.678) out[0] = s;
+}
+
+static void copy_peak()
+{
+    const size_t n = (size_t)1 << 26;               // 2^26 x 16 B = 1 GiB
+    double2 *a, *b; double *o;
+    hipMalloc(&a, n * 16); hipMalloc(&b, n * 16); hipMalloc(&o, 8);
+    hipMemset(a, 1, n * 16);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0);
+        copy_kernel<<<256 * 16, 256>>>(a, b, n);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        hipEventRecord(e0);
+        read_kernel<<<256 * 16, 256>>>(a, o, n);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms2; hipEventElapsedTime(&ms2, e0, e1);
+        printf("stream copy 1 GiB -> 1 GiB: %.3f ms = %.0f GB/s (read+write);  read-only 1 GiB: %.3f ms = %.0f GB/s\n", ms, 2.0 * n * 16 / ms / 1e6, ms2,
+               1.0 * n * 16 / ms2 / 1e6);
+    }
+    hipFree(a); hipFree(b); hipFree(o);
+}
+
 static void peak()
 {
     double *out;
@@ -87,6 +121,7 @@ static void peak()
 
 int main()
 {
+    copy_peak();
     peak();
     for (int threads : {64, 128, 256, 512}) {
         const int blocks = 256;
