@@ -178,6 +178,37 @@ int pm_slice_batch(pm_ctx *ctx, pm_slice_job *h_jobs, int njobs);           /* n
 /* Diagnostics of the last slicer call on this ctx: fixed-point iterations used, chunk length, chunks. */
 int pm_slicer_stats(pm_ctx *ctx, int32_t *iterations, int32_t *chunk_len, int64_t *chunks);
 
+/* ---- whole chain: modem + slicer in one call ---------------------------------------------------
+ * chain_execute.process_chain up to and including slicer.slice (chain_execute.py:8-14) for one demod_chain: the stage entry points
+ * above, strung together in the order of the reference's demod() (afsk.py:148-167, fsk.py:149-159, psk.py:162-195, psk.py:705-773,
+ * afsk_pll.py:140-170) with every intermediate kept on the device.  The host designs the taps (firwin / RRC / Hilbert / tones) and
+ * hands them over; pointers inside the desc are read during pm_chain_create only.  A chain carries the AGC envelope and the
+ * carrier-loop state from one pm_chain_run to the next, like the reference's stage objects; pm_chain_reset returns it to the
+ * just-created state.  Output: the slicer's bytes and 1-based stream addresses; when more than `cap` were produced the call
+ * returns PM_ERR_CAPACITY with the required size in *h_count. */
+enum { PM_MODEM_AFSK = 0, PM_MODEM_FSK = 1, PM_MODEM_BPSK = 2, PM_MODEM_MPSK = 3, PM_MODEM_AFSK_PLL = 4 };
+#define PM_CHAIN_INVERT 1       /* FSK: negate the filter output (fsk.py:153-154) */
+typedef struct pm_chain_desc {
+    int32_t modem;                                   /* PM_MODEM_* */
+    int32_t flags;
+    const double *input_fir;  int32_t n_input_fir;   /* input_bpf (afsk, bpsk, mpsk, afsk_pll) or input_lpf (fsk) */
+    const double *mark_i, *mark_q, *space_i, *space_q; int32_t n_corr;      /* afsk */
+    const double *hilbert;    int32_t n_hilbert, hilbert_delay;             /* mpsk: Hilbert taps; delay = (n_hilbert-1)/2 */
+    const double *output_fir; int32_t n_output_fir;  /* output_lpf (afsk, afsk_pll) or the RRC matched filter (bpsk; mpsk both arms) */
+    int32_t use_agc;          pm_agc_params agc;     /* bpsk, mpsk, afsk_pll */
+    pm_loop loop;                                    /* carrier loop parameters and initial state */
+    const double *wavetable;                         /* 256 entries (nco.py:22-24) */
+    const int32_t *pd_table;                         /* 64 x 64 (phase_detector.py:36-44), mpsk */
+    int32_t quadrature;                              /* 1: QuadratureSlicer (mpsk), 0: BinarySlicer */
+    pm_slicer_params slicer;
+} pm_chain_desc;
+typedef struct pm_chain pm_chain;
+int pm_chain_create(pm_ctx *ctx, const pm_chain_desc *desc, pm_chain **out);
+int pm_chain_run(pm_chain *chain, const int16_t *audio, int64_t n, int audio_on_device,
+                 uint8_t *h_data, int64_t *h_addr, int64_t cap, int64_t *h_count);
+int pm_chain_reset(pm_chain *chain);
+int pm_chain_destroy(pm_chain *chain);
+
 /* ---- host-integer stages (native C++, no GPU) --------------------------------------------------
  * These consume the slicer's byte stream; they are bit-serial state machines over KBs of data. */
 /* LFSR.stream_unscramble_8bit (lfsr.py:22-52).  *h_shift_register is read and written. */

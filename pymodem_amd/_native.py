@@ -41,6 +41,21 @@ class SliceJob(ctypes.Structure):
                 ("d_data", ctypes.c_void_p), ("d_addr", ctypes.c_void_p), ("cap", ctypes.c_int64), ("count", ctypes.c_int64)]
 
 
+class ChainDesc(ctypes.Structure):
+    """pm_chain_desc"""
+    _dp, _i32 = ctypes.POINTER(ctypes.c_double), ctypes.c_int32
+    _fields_ = [("modem", _i32), ("flags", _i32),
+                ("input_fir", _dp), ("n_input_fir", _i32),
+                ("mark_i", _dp), ("mark_q", _dp), ("space_i", _dp), ("space_q", _dp), ("n_corr", _i32),
+                ("hilbert", _dp), ("n_hilbert", _i32), ("hilbert_delay", _i32),
+                ("output_fir", _dp), ("n_output_fir", _i32),
+                ("use_agc", _i32), ("agc", AGCParams),
+                ("loop", Loop), ("wavetable", _dp), ("pd_table", ctypes.POINTER(ctypes.c_int32)),
+                ("quadrature", _i32), ("slicer", SlicerParams)]
+
+
+MODEM_AFSK, MODEM_FSK, MODEM_BPSK, MODEM_MPSK, MODEM_AFSK_PLL = range(5)
+CHAIN_INVERT = 1
 KERNEL_CLASSES = ("fir_i16", "fir_f64", "afsk_correlate", "signs", "slice_iter", "slice_emit", "agc", "loop")
 PKT_MAX = 1280
 
@@ -110,6 +125,10 @@ _SIGS = {
     "pm_slice_quadrature": ([_vp, _vp, _vp, _i64, ctypes.POINTER(SlicerParams), _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
     "pm_slice_batch": ([_vp, ctypes.POINTER(SliceJob), _int], _int),
     "pm_slicer_stats": ([_vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_i64)], _int),
+    "pm_chain_create": ([_vp, ctypes.POINTER(ChainDesc), ctypes.POINTER(_vp)], _int),
+    "pm_chain_run": ([_vp, _vp, _i64, _int, _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
+    "pm_chain_reset": ([_vp], _int),
+    "pm_chain_destroy": ([_vp], _int),
     "pm_lfsr_unscramble": ([_vp, _i64, ctypes.c_uint64, _int, ctypes.POINTER(ctypes.c_uint64), _vp], _int),
     "pm_codec_create": ([_int, _int, _int, _int, _int, _int, ctypes.POINTER(_vp)], _int),
     "pm_codec_destroy": ([_vp], _int),

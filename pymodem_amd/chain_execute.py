@@ -277,3 +277,80 @@ def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced
     if stages is not None:
         stages["sliced"] = sliced
     return packets
+
+
+class NativeChain:
+    """One demod_chain's modem + slicer behind the whole-chain C entry points (pm_chain_create / pm_chain_run): what a C or C++
+    host would call.  Built from the same stage objects chain_builder makes, so tap design stays on the host in one place.
+    `run(audio)` -> the slicer's AddressedArray; feed it to stream / codec as usual."""
+
+    def __init__(self, modem, slicer, ctx=None):
+        from . import _native as N
+        from .modems import FSKModem
+        self._ctx = ctx or Context.default()
+        d = N.ChainDesc()
+        keep = []
+
+        def vec(x, dtype=np.float64):
+            a = np.ascontiguousarray(x, dtype=dtype)
+            keep.append(a)
+            return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double if dtype == np.float64 else ctypes.c_int32)), len(a)
+        if isinstance(modem, AFSKModem):
+            d.modem = N.MODEM_AFSK
+            d.input_fir, d.n_input_fir = vec(modem.input_bpf)
+            d.mark_i, d.n_corr = vec(modem.mark_correlator_i)
+            d.mark_q, d.space_i, d.space_q = vec(modem.mark_correlator_q)[0], vec(modem.space_correlator_i)[0], vec(modem.space_correlator_q)[0]
+            d.output_fir, d.n_output_fir = vec(modem.output_lpf)
+        elif isinstance(modem, FSKModem):
+            d.modem, d.flags = N.MODEM_FSK, (N.CHAIN_INVERT if modem.invert else 0)
+            d.input_fir, d.n_input_fir = vec(modem.input_lpf)
+        else:
+            d.modem = {BPSKModem: N.MODEM_BPSK, MPSKModem: N.MODEM_MPSK, AFSKPLLModem: N.MODEM_AFSK_PLL}[type(modem)]
+            d.input_fir, d.n_input_fir = vec(modem.input_bpf)
+            a = modem.AGC
+            d.use_agc, d.agc = 1, N.AGCParams(a.attack_rate, a.decay_rate, a.sustain_time, a.sample_rate, a.target_amplitude)
+            ctypes.memmove(ctypes.byref(d.loop), modem._loop0, ctypes.sizeof(Loop))
+            d.wavetable = vec(modem.wavetable)[0]
+            if isinstance(modem, MPSKModem):
+                d.hilbert, d.n_hilbert = vec(modem.hilbert_taps)
+                d.hilbert_delay = modem.hilbert_delay
+                d.pd_table = vec(modem.phase_error_table.reshape(-1), np.int32)[0]
+                d.output_fir, d.n_output_fir = vec(modem.rrc_taps)
+            elif isinstance(modem, BPSKModem):
+                d.output_fir, d.n_output_fir = vec(modem.rrc_taps)
+            else:
+                d.output_fir, d.n_output_fir = vec(modem.output_lpf)
+        d.quadrature = int(isinstance(modem, MPSKModem))
+        d.slicer = slicer._params()
+        self._h = ctypes.c_void_p()
+        check(lib().pm_chain_create(self._ctx.handle, ctypes.byref(d), ctypes.byref(self._h)))
+        self._bps = slicer.bits_per_symbol
+
+    def run(self, audio):
+        from .data_classes import AddressedArray
+        if isinstance(audio, DeviceBuffer):
+            assert audio.dtype == np.dtype(np.int16)
+            ptr, n, on_dev = audio.ptr, audio.n, 1
+        else:
+            a = np.ascontiguousarray(audio, dtype=np.int16)
+            ptr, n, on_dev = a.ctypes.data_as(ctypes.c_void_p), len(a), 0
+        cap = n * self._bps // 8 + 8
+        data, addr = np.empty(cap, np.uint8), np.empty(cap, np.int64)
+        count = ctypes.c_int64()
+        check(lib().pm_chain_run(self._h, ptr, n, on_dev, data.ctypes.data_as(ctypes.c_void_p), addr.ctypes.data_as(ctypes.c_void_p), cap,
+                                 ctypes.byref(count)))
+        return AddressedArray(data[:count.value].copy(), addr[:count.value].copy())
+
+    def reset(self):
+        check(lib().pm_chain_reset(self._h))
+
+    def close(self):
+        if self._h:
+            lib().pm_chain_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -199,3 +199,44 @@ def test_recording_pipeline_matches_one_at_a_time(golden, config_lines):
     assert table.CountGood() == 49 and table.CountBad() == 6
     for ci in range(len(lines)):
         assert np.array_equal(got[0][ci]["streamaddress"], g[f"afsk_300__c{ci}_pkt_addr"])
+
+
+@pytest.mark.parametrize("cfg,rate", [("afsk_1200.json", 48000), ("fsk_9600.json", 48000), ("bpsk_300.json", 48000), ("qpsk_2400.json", 48000),
+                                      ("afsk_300_pll.json", 8000), ("afsk_300.json", 8000)])
+def test_whole_chain_entry_point_matches_the_stage_path(config_lines, cfg, rate):
+    """pm_chain_create / pm_chain_run (modem + slicer in one C call, host or device audio) give the slicer bytes and addresses of
+    the stage-by-stage path and of the oracle, for every modem family; a second run after pm_chain_reset repeats them."""
+    from pymodem_amd import chain_builder as cb, chain_execute as ce
+    import pymodem_amd
+    ctx = pymodem_amd.Context.default()
+    n = 120000 if rate == 48000 else 60000
+    audio = noise_i16(n)
+    for line in config_lines(cfg):
+        chain = cb.build_chain(rate, line)
+        want = chain[2].slice(chain[1].demod(audio, device_out=True))
+        o = O.build_chain(rate, line)
+        od, oa = o[1].slice(o[0].demod(audio, canon=True))
+        assert np.array_equal(want.data, od) and np.array_equal(want.address, oa)
+        fresh = cb.build_chain(rate, line)
+        nc = ce.NativeChain(fresh[1], fresh[2])
+        got = nc.run(audio)
+        assert np.array_equal(got.data, od) and np.array_equal(got.address, oa), line["object_name"]
+        nc.reset()
+        again = nc.run(ctx.upload(audio))                 # audio already in HBM
+        assert np.array_equal(again.data, od) and np.array_equal(again.address, oa)
+        # the rest of the chain runs on the slicer output as usual
+        p1 = fresh[4].decode(fresh[3].stream_unscramble_8bit(got))
+        p2 = chain[4].decode(chain[3].stream_unscramble_8bit(want))
+        assert [p.streamaddress for p in p1] == [p.streamaddress for p in p2]
+        nc.close()
+
+
+def test_whole_chain_entry_point_errors():
+    from pymodem_amd import NativeError, chain_builder as cb, chain_execute as ce
+    line = {"object_name": "x", "object_type": "demod_chain", "modem": {"type": "afsk", "config": "1200", "options": {}},
+            "slicer": {"type": "binary", "config": "1200", "options": {}}, "stream": {"type": "lfsr", "options": {}}, "codec": {"type": "ax25"}}
+    ch = cb.build_chain(48000, line)
+    nc = ce.NativeChain(ch[1], ch[2])
+    with pytest.raises(NativeError):
+        nc.run(noise_i16(100))                            # shorter than the input filter
+    assert len(nc.run(np.zeros(0, np.int16))) == 0
