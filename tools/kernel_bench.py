@@ -72,6 +72,20 @@ for g, m in [(7, 60), (4, 40)]:
            8.0 * N * (1 + g), (2 + 2 * g) * m * N)
 report("signs", timeit(lambda: check(L.pm_signs_f64(ctx.handle, d_f64.ptr, N, bits.ptr))), 8.125 * N)
 
+# a 10-minute buffer is tens of microseconds at roofline, so the HBM-bound short-tap FIR is also timed on 2^28 samples
+# (0.5 GB in, 2.1 GB out per launch) where launch ramp and tail no longer matter
+if os.environ.get("KB_BIG", "1") == "1":
+    NB = 1 << 28
+    big_in = ctx.upload(np.tile(xi[:1 << 20], NB >> 20))
+    big_out = ctx.empty(NB, np.float64)
+    big_bits = ctx.empty(NB // 64 + 2, np.uint64)
+    for m in [8, 40]:
+        h = ctx.upload(rng.standard_normal(m))
+        report(f"fir_i16 m={m} N=2^28", timeit(lambda: check(L.pm_fir_valid_i16(ctx.handle, big_in.ptr, NB, h.ptr, m, big_out.ptr, 0)), reps=3), 10.0 * NB, m * NB)
+    h = ctx.upload(rng.standard_normal(8))
+    report("fir_signs_i16 m=8 N=2^28", timeit(lambda: check(L.pm_fir_signs_i16(ctx.handle, big_in.ptr, NB, h.ptr, 8, big_bits.ptr, 0)), reps=3), 2.125 * NB, 8 * NB)
+    big_in.free(); big_out.free(); big_bits.free()
+
 if os.environ.get("KB_ONLY") == "fir":
     sys.exit(0)
 
