@@ -150,6 +150,22 @@ __global__ __launch_bounds__(kThreads) void fir_valid_kernel(const InT *__restri
         }
 #undef PM_FIR_TAIL
     }
+    if (SIGNS) {
+        // This thread's 8 consecutive outputs are exactly one byte of the little-endian bitmap (tile0 is a multiple of 2048): no
+        // trip through LDS, the 64 lanes of a wave store 64 consecutive bytes.  Bits past nout are written as 0 up to the end of
+        // the last 64-bit word.
+        static_assert(R == 8, "one bitmap byte per thread");
+        const int64_t go = tile0 + (int64_t)t * R;
+        unsigned byte = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double v = NEG ? -acc[r] : acc[r];
+            byte |= (unsigned)(v >= 0.0 && go + r < nout) << r;
+        }
+        const int64_t bi = go >> 3;
+        if (bi < ((nout + 63) >> 6) * 8) reinterpret_cast<uint8_t *>(bits)[bi] = (uint8_t)byte;
+        return;
+    }
     lds_barrier();
     {
         double *op = xs + t * (R + 1);     // this thread's R outputs occupy R consecutive slots
@@ -157,16 +173,7 @@ __global__ __launch_bounds__(kThreads) void fir_valid_kernel(const InT *__restri
         for (int r = 0; r < R; ++r) op[r] = NEG ? -acc[r] : acc[r];
     }
     lds_barrier();
-    if (SIGNS) {
-        // tile0 is a multiple of 2048, so every wave's 64 consecutive outputs are exactly one bitmap word
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int idx = r * kThreads + t;
-            const int64_t go = tile0 + idx;
-            const uint64_t word = __ballot(go < nout && xs[slot<R>(idx)] >= 0.0);
-            if ((t & 63) == 0 && go < nout) bits[go >> 6] = word;
-        }
-    } else if (VEC) {
+    if (VEC) {
 #pragma unroll
         for (int r = 0; r < R / 2; ++r) {
             const int idx = 2 * (r * kThreads + t);            // even: idx and idx+1 sit in adjacent slots
