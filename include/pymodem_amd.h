@@ -128,6 +128,10 @@ typedef struct pm_loop {             /* one carrier loop = NCO (nco.py) + IIR_1 
     double phase, control, sine, cosine;
     double x0, x1, y0;
     double integral, proportional;
+    /* QPSK Costas loop only (psk.py:223-240): the two branch low-pass filters share coefficients; their states */
+    double bb0, bb1, ba1;            /* Cosine_LPF / Sine_LPF coefficients       iir.py:15-29 */
+    double cx0, cx1, cy0;            /* Cosine_LPF state */
+    double sx0, sx1, sy0;            /* Sine_LPF state */
 } pm_loop;
 
 /* nloops independent loops over the SAME input (chains that differ only in carrier_freq, e.g.
@@ -142,6 +146,12 @@ int pm_pll_afsk(pm_ctx *ctx, pm_loop *h_loops, int nloops, const double *d_table
 int pm_mpsk_loop(pm_ctx *ctx, pm_loop *h_loops, int nloops, const double *d_table, const int32_t *d_pd_table,
                  const double *d_re, const double *d_im, int64_t x_stride, int64_t n,
                  double *d_i_out, double *d_q_out, int64_t out_stride);                                     /* psk.py:734-747 */
+
+/* QPSKModem's Costas loop (psk.py:434-467): both mixer products are low-passed (Cosine_LPF, Sine_LPF); the phase detector is
+ * cos_lp*sgn(sin_lp) - sin_lp*sgn(cos_lp).  d_i_out receives the SINE branch and d_q_out the COSINE branch, as the reference
+ * appends them (psk.py:452-453). */
+int pm_costas_qpsk(pm_ctx *ctx, pm_loop *h_loops, int nloops, const double *d_table,
+                   const double *d_x, int64_t x_stride, int64_t n, double *d_i_out, double *d_q_out, int64_t out_stride);
 
 /* ---- slicers ----------------------------------------------------------------------------------
  * Symbol-timing PLL + bit decision + byte packing.  Input is the sign bitmap(s) of the demodulated
@@ -186,7 +196,7 @@ int pm_slicer_stats(pm_ctx *ctx, int32_t *iterations, int32_t *chunk_len, int64_
  * carrier-loop state from one pm_chain_run to the next, like the reference's stage objects; pm_chain_reset returns it to the
  * just-created state.  Output: the slicer's bytes and 1-based stream addresses; when more than `cap` were produced the call
  * returns PM_ERR_CAPACITY with the required size in *h_count. */
-enum { PM_MODEM_AFSK = 0, PM_MODEM_FSK = 1, PM_MODEM_BPSK = 2, PM_MODEM_MPSK = 3, PM_MODEM_AFSK_PLL = 4 };
+enum { PM_MODEM_AFSK = 0, PM_MODEM_FSK = 1, PM_MODEM_BPSK = 2, PM_MODEM_MPSK = 3, PM_MODEM_AFSK_PLL = 4, PM_MODEM_QPSK = 5 };
 #define PM_CHAIN_INVERT 1       /* FSK: negate the filter output (fsk.py:153-154) */
 typedef struct pm_chain_desc {
     int32_t modem;                                   /* PM_MODEM_* */
@@ -199,7 +209,7 @@ typedef struct pm_chain_desc {
     pm_loop loop;                                    /* carrier loop parameters and initial state */
     const double *wavetable;                         /* 256 entries (nco.py:22-24) */
     const int32_t *pd_table;                         /* 64 x 64 (phase_detector.py:36-44), mpsk */
-    int32_t quadrature;                              /* 1: QuadratureSlicer (mpsk), 0: BinarySlicer */
+    int32_t quadrature;                              /* 1: QuadratureSlicer (mpsk, qpsk), 0: BinarySlicer */
     pm_slicer_params slicer;
 } pm_chain_desc;
 typedef struct pm_chain pm_chain;

@@ -293,6 +293,15 @@ def costas_bpsk(L, x, table=None):
     return out
 
 
+def costas_qpsk(L, branch, x, table=None):
+    """branch: float64[9] = b0, b1, a1 and the two branch filters' (x0, x1, y0); state carried like the loop's."""
+    x = _f64(x)
+    table = nco_table() if table is None else table
+    oi, oq = np.empty(len(x)), np.empty(len(x))
+    lib().pmo_costas_qpsk(ctypes.byref(L), _p(branch), _p(table), _p(x), ctypes.c_int64(len(x)), _p(oi), _p(oq))
+    return oi, oq
+
+
 def pll_afsk(L, x, table=None):
     x = _f64(x)
     table = nco_table() if table is None else table
@@ -430,6 +439,45 @@ class BPSKModem:
         agc_apply(a, self.sample_rate, att, sus, dec, 1.0)
         d = costas_bpsk(self.loop, a)
         return fir(d, self.rrc)
+
+
+class QPSKModem:
+    """psk.py:197-476."""
+    PRESETS = {   # psk.py:203-338
+        "600": dict(agc=(500.0, 1.0, 50.0), symbol_rate=300.0, lo=1200.0, hi=1800.0, span=1.5, carrier=1500.0, rolloff=0.6, rrc_span=6,
+                    max_off=37.5, branch=300.0, lpf=100.0, p=0.02, i=0.02 / 651, gain=858),
+        "3600": dict(agc=(5000.0, 0.1, 50.0), symbol_rate=1800, lo=300.0, hi=3000.0, span=5, carrier=1650.0, rolloff=0.3, rrc_span=8,
+                     max_off=50, branch=1450.0, lpf=200.0, p=0.15, i=0.15 / 1000, gain=1350.0),
+        "2400": dict(agc=(500.0, 1, 50.0), symbol_rate=1200.0, lo=200.0, hi=2800.0, span=4.8, carrier=1800.0, rolloff=0.9, rrc_span=3,
+                     max_off=87.5, branch=1200.0, lpf=200.0, p=.1, i=.1 / 500, gain=450.0),
+    }
+
+    def __init__(self, sample_rate=44100.0, config="600", options=None):
+        self.p = p = dict(self.PRESETS[config])
+        o = options or {}
+        # all three IIR_1 filters are built in __init__ with the constructor's sample rate (psk.py:223-240)
+        self.loop = make_loop(sample_rate, 0.0, p["lpf"], 1.0, p["p"], p["i"], p["max_off"], p["gain"])
+        b0, b1, a1 = iir1_coefs(sample_rate, p["branch"], 1.0)
+        self.branch = np.array([b0, b1, a1, 0, 0, 0, 0, 0, 0], dtype=np.float64)
+        p["symbol_rate"] = _fopt(o, "symbol_rate", p["symbol_rate"])          # psk.py:357-366
+        p["lo"] = _fopt(o, "input_bpf_low_cutoff", p["lo"])
+        p["hi"] = _fopt(o, "input_bpf_high_cutoff", p["hi"])
+        p["span"] = _fopt(o, "input_bpf_span", p["span"])
+        self.sample_rate = fs = _fopt(o, "sample_rate", sample_rate) if "sample_rate" in o else sample_rate
+        p["carrier"] = _fopt(o, "carrier_freq", p["carrier"])
+        self.input_bpf = firwin_hamming(round(fs * p["span"] / p["symbol_rate"]), [p["lo"], p["hi"]], fs, False)
+        self.rrc = rrc_taps(fs, p["symbol_rate"], p["rrc_span"], p["rolloff"])
+        self.loop.phase_scaling = 2.0 * math.pi / fs
+        self.loop.set_frequency = p["carrier"]
+        self.output_sample_rate = fs
+
+    def demod(self, audio, canon=False):          # psk.py:426-476
+        fir = fir_canon if canon else fir_ref
+        a = np.ascontiguousarray(fir(audio, self.input_bpf), dtype=np.float64)
+        att, sus, dec = self.p["agc"]
+        agc_apply(a, self.sample_rate, att, sus, dec, 1.0)
+        i_arm, q_arm = costas_qpsk(self.loop, self.branch, a)
+        return fir(i_arm, self.rrc), fir(q_arm, self.rrc)
 
 
 class MPSKModem:
@@ -1060,7 +1108,7 @@ def correlate(packet_lists, address_distance):
 def build_chain(sample_rate, line):
     """chain_builder.py:17-69 + pymodem.py:67-115 for one 'demod_chain' config line."""
     m = line["modem"]
-    cls = {"afsk": AFSKModem, "fsk": FSKModem, "bpsk": BPSKModem, "mpsk": MPSKModem, "afsk_pll": AFSKPLLModem}[m["type"]]
+    cls = {"afsk": AFSKModem, "fsk": FSKModem, "bpsk": BPSKModem, "mpsk": MPSKModem, "afsk_pll": AFSKPLLModem, "qpsk": QPSKModem}[m["type"]]
     modem = cls(sample_rate=sample_rate, config=m["config"], options=m.get("options", {}))
     srate = getattr(modem, "output_sample_rate", sample_rate)
     s = line["slicer"]

@@ -240,6 +240,36 @@ void pmo_costas_bpsk(pmo_loop *L, const double *table, const double *x, int64_t 
     loop_close(L, &o, &f, &c);
 }
 
+/* QPSK Costas loop of QPSKModem, psk.py:434-467.  branch[9] = {b0, b1, a1, cos x0, x1, y0, sin x0, x1, y0}: the two branch
+ * low-pass filters (Cosine_LPF, Sine_LPF; same coefficients), state read and written.  out_i <- Sine_LPF, out_q <- Cosine_LPF. */
+void pmo_costas_qpsk(pmo_loop *L, double *branch, const double *table, const double *x, int64_t n, double *out_i, double *out_q)
+{
+    pmo_nco o; pmo_iir1 f; pmo_pi c;
+    loop_open(L, table, &o, &f, &c);
+    pmo_iir1 fc, fs;
+    fc.b0 = fs.b0 = branch[0]; fc.b1 = fs.b1 = branch[1]; fc.a1 = fs.a1 = branch[2];
+    fc.x0 = branch[3]; fc.x1 = branch[4]; fc.y0 = branch[5];
+    fs.x0 = branch[6]; fs.x1 = branch[7]; fs.y0 = branch[8];
+    for (int64_t k = 0; k < n; ++k) {
+        double s = x[k];
+        nco_update(&o);
+        double i_mixer = s * o.cosine;                       /* psk.py:438 */
+        double cl = iir_update(&fc, i_mixer);                /* psk.py:440 */
+        int cosine_sgn = cl >= 0 ? 1 : -1;                   /* psk.py:444-447 */
+        double q_mixer = s * o.sine;                         /* psk.py:448 */
+        double sl = iir_update(&fs, q_mixer);                /* psk.py:450 */
+        out_i[k] = sl;                                       /* psk.py:451: i_data <- Sine_LPF */
+        out_q[k] = cl;                                       /* psk.py:452: q_data <- Cosine_LPF */
+        int sine_sgn = sl >= 0 ? 1 : -1;                     /* psk.py:454-457 */
+        double loop_mixer = (cl * sine_sgn) - (sl * cosine_sgn);   /* psk.py:458 */
+        double lp = iir_update(&f, loop_mixer);
+        o.control = pi_update_saturate(&c, lp);              /* psk.py:462 */
+    }
+    branch[3] = fc.x0; branch[4] = fc.x1; branch[5] = fc.y0;
+    branch[6] = fs.x0; branch[7] = fs.x1; branch[8] = fs.y0;
+    loop_close(L, &o, &f, &c);
+}
+
 /* AFSK PLL, afsk_pll.py:153-165.  out[k] = PI proportional term. */
 void pmo_pll_afsk(pmo_loop *L, const double *table, const double *x, int64_t n, double *out)
 {

@@ -27,7 +27,8 @@ class Loop(ctypes.Structure):
     """pm_loop"""
     _fields_ = [(k, ctypes.c_double) for k in (
         "phase_scaling", "index_scaling", "set_frequency", "b0", "b1", "a1", "p_rate", "i_rate", "i_limit", "gain",
-        "phase", "control", "sine", "cosine", "x0", "x1", "y0", "integral", "proportional")]
+        "phase", "control", "sine", "cosine", "x0", "x1", "y0", "integral", "proportional",
+        "bb0", "bb1", "ba1", "cx0", "cx1", "cy0", "sx0", "sx1", "sy0")]
 
 
 class SlicerParams(ctypes.Structure):
@@ -54,7 +55,7 @@ class ChainDesc(ctypes.Structure):
                 ("quadrature", _i32), ("slicer", SlicerParams)]
 
 
-MODEM_AFSK, MODEM_FSK, MODEM_BPSK, MODEM_MPSK, MODEM_AFSK_PLL = range(5)
+MODEM_AFSK, MODEM_FSK, MODEM_BPSK, MODEM_MPSK, MODEM_AFSK_PLL, MODEM_QPSK = range(6)
 CHAIN_INVERT = 1
 KERNEL_CLASSES = ("fir_i16", "fir_f64", "afsk_correlate", "signs", "slice_iter", "slice_emit", "agc", "loop")
 PKT_MAX = 1280
@@ -119,6 +120,7 @@ _SIGS = {
     "pm_signs_f64": ([_vp, _vp, _i64, _vp], _int),
     "pm_agc_apply": ([_vp, _vp, _i64, ctypes.POINTER(AGCParams), ctypes.POINTER(_dbl)], _int),
     "pm_costas_bpsk": ([_vp, ctypes.POINTER(Loop), _int, _vp, _vp, _i64, _i64, _vp, _i64], _int),
+    "pm_costas_qpsk": ([_vp, ctypes.POINTER(Loop), _int, _vp, _vp, _i64, _i64, _vp, _vp, _i64], _int),
     "pm_pll_afsk": ([_vp, ctypes.POINTER(Loop), _int, _vp, _vp, _i64, _i64, _vp, _i64], _int),
     "pm_mpsk_loop": ([_vp, ctypes.POINTER(Loop), _int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64], _int),
     "pm_slice_binary": ([_vp, _vp, _i64, ctypes.POINTER(SlicerParams), _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),

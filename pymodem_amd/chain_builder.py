@@ -2,7 +2,7 @@
 {"type", "config", "options"} dicts give the GPU-backed stage objects.  Unknown types return [] like there."""
 from . import codecs, lfsr, modems, slicer
 
-_MODEMS = {'mpsk': modems.MPSKModem, 'bpsk': modems.BPSKModem, 'fsk': modems.FSKModem, 'afsk': modems.AFSKModem,
+_MODEMS = {'qpsk': modems.QPSKModem, 'mpsk': modems.MPSKModem, 'bpsk': modems.BPSKModem, 'fsk': modems.FSKModem, 'afsk': modems.AFSKModem,
            'afsk_pll': modems.AFSKPLLModem}
 _SLICERS = {'quadrature': slicer.QuadratureSlicer, 'binary': slicer.BinarySlicer}
 

@@ -15,7 +15,7 @@ import numpy as np
 
 from ._native import Loop, check, lib
 from .device import Context, DeviceBuffer
-from .modems import AFSKModem, AFSKPLLModem, BPSKModem, MPSKModem
+from .modems import AFSKModem, AFSKPLLModem, BPSKModem, MPSKModem, QPSKModem
 from .slicer import slice_batch
 
 
@@ -305,7 +305,7 @@ class NativeChain:
             d.modem, d.flags = N.MODEM_FSK, (N.CHAIN_INVERT if modem.invert else 0)
             d.input_fir, d.n_input_fir = vec(modem.input_lpf)
         else:
-            d.modem = {BPSKModem: N.MODEM_BPSK, MPSKModem: N.MODEM_MPSK, AFSKPLLModem: N.MODEM_AFSK_PLL}[type(modem)]
+            d.modem = {BPSKModem: N.MODEM_BPSK, MPSKModem: N.MODEM_MPSK, AFSKPLLModem: N.MODEM_AFSK_PLL, QPSKModem: N.MODEM_QPSK}[type(modem)]
             d.input_fir, d.n_input_fir = vec(modem.input_bpf)
             a = modem.AGC
             d.use_agc, d.agc = 1, N.AGCParams(a.attack_rate, a.decay_rate, a.sustain_time, a.sample_rate, a.target_amplitude)
@@ -316,11 +316,11 @@ class NativeChain:
                 d.hilbert_delay = modem.hilbert_delay
                 d.pd_table = vec(modem.phase_error_table.reshape(-1), np.int32)[0]
                 d.output_fir, d.n_output_fir = vec(modem.rrc_taps)
-            elif isinstance(modem, BPSKModem):
+            elif isinstance(modem, (BPSKModem, QPSKModem)):
                 d.output_fir, d.n_output_fir = vec(modem.rrc_taps)
             else:
                 d.output_fir, d.n_output_fir = vec(modem.output_lpf)
-        d.quadrature = int(isinstance(modem, MPSKModem))
+        d.quadrature = int(isinstance(modem, (MPSKModem, QPSKModem)))
         d.slicer = slicer._params()
         self._h = ctypes.c_void_p()
         check(lib().pm_chain_create(self._ctx.handle, ctypes.byref(d), ctypes.byref(self._h)))

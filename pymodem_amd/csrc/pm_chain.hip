@@ -54,13 +54,14 @@ int pm_chain_create(pm_ctx *ctx, const pm_chain_desc *desc, pm_chain **out)
     PM_CTX(ctx);
     PM_ARG(desc != nullptr && out != nullptr);
     const pm_chain_desc &d = *desc;
-    PM_ARG(d.modem >= PM_MODEM_AFSK && d.modem <= PM_MODEM_AFSK_PLL);
+    PM_ARG(d.modem >= PM_MODEM_AFSK && d.modem <= PM_MODEM_QPSK);
     PM_ARG(d.input_fir && d.n_input_fir >= 1);
     if (d.modem == PM_MODEM_AFSK) PM_ARG(d.mark_i && d.mark_q && d.space_i && d.space_q && d.n_corr >= 1);
     if (d.modem != PM_MODEM_FSK) PM_ARG(d.output_fir && d.n_output_fir >= 1);
     if (d.modem == PM_MODEM_MPSK) PM_ARG(d.hilbert && d.n_hilbert >= 1 && d.hilbert_delay >= 0 && d.hilbert_delay < d.n_hilbert && d.pd_table);
-    if (d.modem == PM_MODEM_BPSK || d.modem == PM_MODEM_MPSK || d.modem == PM_MODEM_AFSK_PLL) PM_ARG(d.wavetable != nullptr);
-    PM_ARG((d.quadrature != 0) == (d.modem == PM_MODEM_MPSK));
+    if (d.modem == PM_MODEM_BPSK || d.modem == PM_MODEM_MPSK || d.modem == PM_MODEM_AFSK_PLL || d.modem == PM_MODEM_QPSK)
+        PM_ARG(d.wavetable != nullptr);
+    PM_ARG((d.quadrature != 0) == (d.modem == PM_MODEM_MPSK || d.modem == PM_MODEM_QPSK));
     pm_chain *c = new pm_chain();
     c->ctx = ctx;
     c->d = d;
@@ -168,6 +169,15 @@ int pm_chain_run(pm_chain *c, const int16_t *audio, int64_t n, int audio_on_devi
                 if (int rc = bits_for(ns)) return rc;
                 if (int rc = pm_fir_signs_f64(ctx, i_mix, n2, T + c->o_out, mo, c->d_bits_i, 0)) return rc;
                 if (int rc = pm_fir_signs_f64(ctx, q_mix, n2, T + c->o_out, mo, c->d_bits_q, 0)) return rc;
+            } else if (d.modem == PM_MODEM_QPSK) {                              // psk.py:426-476
+                if (n1 < mo) return pm_set_error(PM_ERR_ARG, "pm_chain_run: input shorter than the matched filter");
+                if (int rc = grow(ctx, c->d_b, c->b_n, (size_t)n1 * 2)) return rc;      // i (sine branch) | q (cosine branch)
+                double *i_arm = c->d_b, *q_arm = c->d_b + n1;
+                if (int rc = pm_costas_qpsk(ctx, &c->loop, 1, T + c->o_wave, c->d_a, 0, n1, i_arm, q_arm, n1)) return rc;
+                ns = n1 - mo + 1;
+                if (int rc = bits_for(ns)) return rc;
+                if (int rc = pm_fir_signs_f64(ctx, i_arm, n1, T + c->o_out, mo, c->d_bits_i, 0)) return rc;
+                if (int rc = pm_fir_signs_f64(ctx, q_arm, n1, T + c->o_out, mo, c->d_bits_q, 0)) return rc;
             } else {                                                            // psk.py:162-195, afsk_pll.py:140-170
                 if (n1 < mo) return pm_set_error(PM_ERR_ARG, "pm_chain_run: input shorter than the output filter");
                 if (int rc = grow(ctx, c->d_b, c->b_n, (size_t)n1)) return rc;

@@ -26,7 +26,20 @@ constexpr double kTwoPi = 2.0 * 3.141592653589793;
 struct LoopRegs {
     double phase_scaling, index_scaling, set_frequency, b0, b1, a1, p_rate, i_rate, i_limit, gain;
     double phase, control, sine, cosine, x0, x1, y0, integral, proportional;
+    double bb0, bb1, ba1, cx0, cx1, cy0, sx0, sx1, sy0;      // QPSK Costas branch filters
 };
+
+__device__ __forceinline__ double iir1(double b0, double b1, double a1, double &x0, double &x1, double &y0, double sample)
+{
+    x1 = x0;                                                             // iir.py:40-42
+    x0 = sample;
+    double v = 0.0;
+    v += x0 * b0;                                                        // iir.py:45-46
+    v += x1 * b1;
+    v += y0 * a1;                                                        // iir.py:48-52
+    y0 = v;
+    return v;
+}
 
 // The bodies below are written branch-free: a lone wave pays ~5 cycles per instruction and far more per taken branch, and
 // every statement is on the loop-carried path.  Each select reproduces the reference's `if`/`while` exactly:
@@ -87,7 +100,7 @@ __device__ __forceinline__ int pd_lookup(const int32_t *tbl, double re, double i
     return tbl[row * 64 + col];
 }
 
-enum { kCostas = 0, kPll = 1, kMpsk = 2 };
+enum { kCostas = 0, kPll = 1, kMpsk = 2, kQpsk = 3 };
 
 // LDS layout (doubles): tab[256] | in0[rows_in][kPad] | in1[...] (mpsk) | out0[kG][kPad] | out1[kG][kPad] (mpsk) | pd[4096 int32] (mpsk)
 template <int MODE>
@@ -105,6 +118,7 @@ __global__ __launch_bounds__(64) void loop_kernel(pm_loop *__restrict__ loops, i
     double *tab = lds;
     double *in0 = tab + 256;
     double *in1 = in0 + rows_in * kPad;
+    constexpr bool kTwoOut = MODE == kMpsk || MODE == kQpsk;
     double *out0 = MODE == kMpsk ? in1 + rows_in * kPad : in1;
     double *out1 = out0 + kG * kPad;
     int32_t *pdt = (int32_t *)(out1 + kG * kPad);
@@ -122,6 +136,10 @@ __global__ __launch_bounds__(64) void loop_kernel(pm_loop *__restrict__ loops, i
         L.p_rate = s.p_rate; L.i_rate = s.i_rate; L.i_limit = s.i_limit; L.gain = s.gain;
         L.phase = s.phase; L.control = s.control; L.sine = s.sine; L.cosine = s.cosine;
         L.x0 = s.x0; L.x1 = s.x1; L.y0 = s.y0; L.integral = s.integral; L.proportional = s.proportional;
+        if (MODE == kQpsk) {
+            L.bb0 = s.bb0; L.bb1 = s.bb1; L.ba1 = s.ba1;
+            L.cx0 = s.cx0; L.cx1 = s.cx1; L.cy0 = s.cy0; L.sx0 = s.sx0; L.sx1 = s.sx1; L.sy0 = s.sy0;
+        }
     }
 
     for (int64_t tile0 = 0; tile0 < n; tile0 += kTile) {
@@ -155,6 +173,17 @@ __global__ __launch_bounds__(64) void loop_kernel(pm_loop *__restrict__ loops, i
                     const double lp = iir_update(L, mixer);
                     L.control = pi_update(L, lp);                     // afsk_pll.py:160
                     q0[k] = L.proportional;                           // afsk_pll.py:163
+                } else if (MODE == kQpsk) {
+                    const double s = p0[k];
+                    nco_update(L, tab);
+                    const double cl = iir1(L.bb0, L.bb1, L.ba1, L.cx0, L.cx1, L.cy0, s * L.cosine);   // psk.py:438-440
+                    const double sl = iir1(L.bb0, L.bb1, L.ba1, L.sx0, L.sx1, L.sy0, s * L.sine);     // psk.py:449-451
+                    const double a = sl >= 0 ? cl : -cl;              // cos_lp * sgn(sin_lp)            psk.py:455-459
+                    const double b = cl >= 0 ? sl : -sl;              // sin_lp * sgn(cos_lp)            psk.py:444-447
+                    const double lp = iir_update(L, a - b);           // psk.py:459-461
+                    L.control = pi_update(L, lp);                     // psk.py:463
+                    q0[k] = sl;                                       // i_data <- Sine_LPF              psk.py:452
+                    q1[k] = cl;                                       // q_data <- Cosine_LPF            psk.py:453
                 } else {
                     const double sr = p0[k], si = p1[k];
                     nco_update(L, tab);
@@ -175,7 +204,7 @@ __global__ __launch_bounds__(64) void loop_kernel(pm_loop *__restrict__ loops, i
             const int64_t off = (int64_t)(g0 + r) * out_stride + tile0;
             for (int k = lane; k < len; k += 64) {
                 o0[off + k] = out0[r * kPad + k];
-                if (MODE == kMpsk) o1[off + k] = out1[r * kPad + k];
+                if (kTwoOut) o1[off + k] = out1[r * kPad + k];
             }
         }
     }
@@ -183,6 +212,7 @@ __global__ __launch_bounds__(64) void loop_kernel(pm_loop *__restrict__ loops, i
         pm_loop &s = loops[g0 + lane];
         s.phase = L.phase; s.control = L.control; s.sine = L.sine; s.cosine = L.cosine;
         s.x0 = L.x0; s.x1 = L.x1; s.y0 = L.y0; s.integral = L.integral; s.proportional = L.proportional;
+        if (MODE == kQpsk) { s.cx0 = L.cx0; s.cx1 = L.cx1; s.cy0 = L.cy0; s.sx0 = L.sx0; s.sx1 = L.sx1; s.sy0 = L.sy0; }
     }
 }
 
@@ -201,7 +231,7 @@ int loop_launch(pm_ctx *ctx, pm_loop *h_loops, int nloops, const double *d_table
     PM_CTX(ctx);
     PM_ARG(h_loops && nloops >= 1 && d_table && n >= 0);
     if (n == 0) return PM_OK;
-    PM_ARG(d_x0 && d_o0 && (MODE != kMpsk || (d_x1 && d_o1 && d_pd)));
+    PM_ARG(d_x0 && d_o0 && (MODE != kMpsk || (d_x1 && d_o1 && d_pd)) && (MODE != kQpsk || d_o1));
     PM_ARG(nloops == 1 || out_stride >= n);
     const size_t bytes = sizeof(pm_loop) * (size_t)nloops;
     if (int rc = pm_scratch_reserve(ctx, bytes)) return rc;
@@ -363,6 +393,12 @@ int pm_mpsk_loop(pm_ctx *ctx, pm_loop *h_loops, int nloops, const double *d_tabl
                  double *d_i_out, double *d_q_out, int64_t out_stride)
 {
     return loop_launch<kMpsk>(ctx, h_loops, nloops, d_table, d_pd_table, d_re, d_im, x_stride, n, d_i_out, d_q_out, out_stride);
+}
+
+int pm_costas_qpsk(pm_ctx *ctx, pm_loop *h_loops, int nloops, const double *d_table,
+                   const double *d_x, int64_t x_stride, int64_t n, double *d_i_out, double *d_q_out, int64_t out_stride)
+{
+    return loop_launch<kQpsk>(ctx, h_loops, nloops, d_table, nullptr, d_x, nullptr, x_stride, n, d_i_out, d_q_out, out_stride);
 }
 
 int pm_agc_apply(pm_ctx *ctx, double *d_buf, int64_t n, const pm_agc_params *hp, double *h_state)

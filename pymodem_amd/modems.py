@@ -4,8 +4,7 @@ attribute names as the reference's classes, so they drop in under chain_builder 
 pm_costas_bpsk, pm_mpsk_loop, pm_pll_afsk); there is no CPU path.
 
 Reference: AFSKModem afsk.py:13-167, FSKModem fsk.py:15-159, BPSKModem psk.py:20-195,
-MPSKModem psk.py:479-773, AFSKPLLModem afsk_pll.py:16-170.  QPSKModem (psk.py:197-476) is not provided:
-no bundled config uses type "qpsk" (SURVEY 2).
+QPSKModem psk.py:197-476, MPSKModem psk.py:479-773, AFSKPLLModem afsk_pll.py:16-170.
 
 Inputs: a host ndarray (int16 as scipy.io.wavfile returns it, or float64) or a DeviceBuffer already in HBM.
 Outputs: host float64 ndarray / IQData by default (the reference's contract); with `device_out=True`
@@ -381,6 +380,95 @@ class BPSKModem(_DeviceStage):
             return SignBits(bits, None, nout)
         y = self._fir(d, False, "rrc", self.rrc_taps)
         return self._finish(y, device_out)
+
+    def demod_signs(self, input_audio):
+        return self.demod(input_audio, signs=True)
+
+
+# =============================================================================================
+class QPSKModem(_DeviceStage):
+    """psk.py:197-476: band-pass -> AGC -> QPSK Costas loop with low-passed branches (pm_costas_qpsk) -> RRC on both arms.
+    chain_builder type 'qpsk'; no bundled config uses it, the generated recordings of tests/golden/qpsk_modem.npz do."""
+    _PRESETS = {   # psk.py:203-338
+        '600': dict(agc=(500.0, 1.0, 50.0), symbol_rate=300.0, lo=1200.0, hi=1800.0, span=1.5, carrier=1500.0, out_cut=200.0, out_span=1.5,
+                    rolloff=0.6, rrc_span=6, max_off=37.5, branch=300.0, loop=100.0, p=0.02, i_div=651, gain=858),
+        '3600': dict(agc=(5000.0, 0.1, 50.0), symbol_rate=1800, lo=300.0, hi=3000.0, span=5, carrier=1650.0, out_cut=900.0, out_span=1.5,
+                     rolloff=0.3, rrc_span=8, max_off=50, branch=1450.0, loop=200.0, p=0.15, i_div=1000, gain=1350.0),
+        '2400': dict(agc=(500.0, 1, 50.0), symbol_rate=1200.0, lo=200.0, hi=2800.0, span=4.8, carrier=1800.0, out_cut=900.0, out_span=1.5,
+                     rolloff=0.9, rrc_span=3, max_off=87.5, branch=1200.0, loop=200.0, p=.1, i_div=500, gain=450.0),
+    }
+
+    def __init__(self, **kwargs):
+        self.definition = kwargs.get('config', '600')
+        self.sample_rate = kwargs.get('sample_rate', 44100.0)
+        if self.definition not in self._PRESETS:
+            raise AttributeError(f"QPSKModem has no preset {self.definition!r}")   # the reference fails on a missing attribute
+        p = self._PRESETS[self.definition]
+        self.agc_attack_rate, self.agc_sustain_time, self.agc_decay_rate = p['agc']
+        self.symbol_rate = p['symbol_rate']
+        self.input_bpf_low_cutoff, self.input_bpf_high_cutoff, self.input_bpf_span = p['lo'], p['hi'], p['span']
+        self.carrier_freq = p['carrier']
+        self.output_lpf_cutoff, self.output_lpf_span = p['out_cut'], p['out_span']
+        self.rrc_rolloff_rate, self.rrc_span, self.max_freq_offset = p['rolloff'], p['rrc_span'], p['max_off']
+        # the three IIR_1 filters take the constructor's sample rate (psk.py:223-240), not a later retune's
+        self.Cosine_LPF = _LoopFilterSettings(self.sample_rate, p['branch'], 1.0)
+        self.Sine_LPF = _LoopFilterSettings(self.sample_rate, p['branch'], 1.0)
+        self.Loop_LPF = _LoopFilterSettings(self.sample_rate, p['loop'], 1.0)
+        self.FeedbackController = _PISettings(p['p'], p['p'] / p['i_div'], self.max_freq_offset, p['gain'])
+        self.oscillator_amplitude = 1.0
+        self.tune()
+
+    _KEYS = ('symbol_rate', 'input_bpf_low_cutoff', 'input_bpf_high_cutoff', 'input_bpf_span', 'output_lpf_cutoff', 'output_lpf_span',
+             'sample_rate', 'carrier_freq')
+
+    def retune(self, **kwargs):               # psk.py:346-355
+        for k in self._KEYS:
+            setattr(self, k, kwargs.get(k, getattr(self, k)))
+        self.tune()
+
+    def StringOptionsRetune(self, options):   # psk.py:357-366
+        for k in self._KEYS:
+            setattr(self, k, float(options.get(k, getattr(self, k))))
+        self.tune()
+
+    def tune(self):                           # psk.py:368-424
+        self.input_bpf_tap_count = round(self.sample_rate * self.input_bpf_span / self.symbol_rate)
+        self.output_lpf_tap_count = round(self.sample_rate * self.output_lpf_span / self.symbol_rate)
+        self.input_bpf = T.windowed_sinc(self.input_bpf_tap_count, [self.input_bpf_low_cutoff, self.input_bpf_high_cutoff],
+                                         self.sample_rate, pass_zero=False)
+        self.output_lpf = T.windowed_sinc(self.output_lpf_tap_count, self.output_lpf_cutoff, self.sample_rate, pass_zero=True)   # designed, never applied
+        self.AGC = _AGCSettings(self.sample_rate, self.agc_attack_rate, self.agc_sustain_time, self.agc_decay_rate, self.oscillator_amplitude)
+        self.wavetable = T.sine_wavetable(self.oscillator_amplitude, 256)
+        self.rrc_taps = T.root_raised_cosine(self.sample_rate, self.symbol_rate, self.rrc_span, self.rrc_rolloff_rate)
+        self._loop = _make_loop(self.sample_rate, self.carrier_freq, self.Loop_LPF, self.FeedbackController)
+        self._loop.bb0, self._loop.bb1, self._loop.ba1 = self.Cosine_LPF.b_coefs[0], self.Cosine_LPF.b_coefs[1], self.Cosine_LPF.a_coefs[1]
+        self._loop0 = _snapshot(self._loop)
+        self.output_sample_rate = self.sample_rate
+
+    def front_end(self, input_audio):
+        x, is_i16 = self._input(input_audio)
+        a = self._fir(x, is_i16, "input_bpf", self.input_bpf)
+        self._agc(a)
+        return a
+
+    def demod(self, input_audio, device_out=False, signs=False):   # psk.py:426-476
+        a = self.front_end(input_audio)
+        ctx = self._ctx
+        i_arm = ctx.scratch((self._key(), "i_arm"), a.n, np.float64)
+        q_arm = ctx.scratch((self._key(), "q_arm"), a.n, np.float64)
+        check(lib().pm_costas_qpsk(ctx.handle, ctypes.byref(self._loop), 1, self._const("wavetable", self.wavetable).ptr,
+                                   a.ptr, 0, a.n, i_arm.ptr, q_arm.ptr, a.n))
+        if signs:
+            bi, nout = self._fir_signs(i_arm, False, "rrc", self.rrc_taps, tag="i")
+            bq, _ = self._fir_signs(q_arm, False, "rrc", self.rrc_taps, tag="q")
+            return SignBits(bi, bq, nout)
+        i_out = self._fir(i_arm, False, "rrc", self.rrc_taps, tag="i_out")
+        q_out = self._fir(q_arm, False, "rrc", self.rrc_taps, tag="q_out")
+        if device_out:
+            return DeviceIQ(i_out, q_out)
+        out = IQData()
+        out.i_data, out.q_data = i_out.download(), q_out.download()
+        return out
 
     def demod_signs(self, input_audio):
         return self.demod(input_audio, signs=True)

@@ -477,6 +477,55 @@ def gen_signal_chains():
         json.dump({"cases": [list(c) for c in SIGNAL_CASES], "results": summary}, f, indent=1)
 
 
+QPSK_CASES = [   # (preset, slicer preset, sample rate, siggen mode, carrier)
+    ("600", "qpsk_600", 8000, "qpsk600_il2p", 1500.0), ("600", "qpsk_600", 48000, "qpsk600_il2p", 1500.0),
+    ("2400", "qpsk_2400", 48000, "qpsk2400_il2p", 1800.0), ("3600", "qpsk_3600", 48000, "qpsk3600_il2p", 1650.0),
+]
+
+
+def qpsk_line(preset, slicer, carrier=None):
+    opts = {} if carrier is None else {"carrier_freq": str(carrier)}
+    return {"object_name": f"QPSK {preset}", "object_type": "demod_chain", "modem": {"type": "qpsk", "config": preset, "options": opts},
+            "slicer": {"type": "quadrature", "config": slicer, "options": {}},
+            "stream": {"type": "lfsr", "options": {"poly": "0x1", "invert": "False"}},
+            "codec": {"type": "il2p", "options": {"crc": "yes", "disable_rs": "no", "min_dist": "0", "sync_tol": "0"}}}
+
+
+def gen_qpsk_modem():
+    """QPSKModem (psk.py:197-476; chain_builder type 'qpsk', no bundled config uses it): every preset on seeded noise (all stage
+    outputs) and on a generated packet-bearing recording of the matching mode (pymodem_amd.siggen, both spectral senses)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from pymodem_amd import siggen
+    d, summary = {}, {}
+    for preset, slicer, rate, mode, carrier in QPSK_CASES:
+        tag = f"qpsk{preset}_{rate}"
+        chain = build_chain(rate, qpsk_line(preset, slicer))
+        run_chain(chain, noise(24000), d, tag + "__noise", keep_demod=True)
+        m = chain[1]
+        d[tag + "__taps_bpf"] = np.asarray(m.input_bpf, dtype=np.float64)
+        d[tag + "__taps_rrc"] = np.asarray(m.rrc.taps, dtype=np.float64)
+        best = None
+        for conj in (False, True):
+            audio, frames = siggen.recording(mode, rate, packets=4, seed=77, noise_sigma=300.0, carrier=carrier, conj=conj)
+            chain = build_chain(rate, qpsk_line(preset, slicer))
+            dd = {}
+            pkts = run_chain(chain, audio, dd, f"{tag}__sig{int(conj)}", keep_demod=False)
+            good = 0
+            for p in pkts:
+                p.CalcCRC()
+                good += bool(p.ValidCRC)
+            summary[f"{tag}__sig{int(conj)}"] = {"packets": len(pkts), "good_crc": good, "sent": len(frames), "samples": len(audio)}
+            if best is None or good > best[0]:
+                best = (good, conj, dd, audio)
+        d.update(best[2])
+        d[f"{tag}__sig_audio"] = best[3]
+        summary[tag] = {"kept_conj": bool(best[1])}
+    np.savez_compressed(os.path.join(OUT, "qpsk_modem.npz"), **d)
+    with open(os.path.join(OUT, "qpsk_modem_summary.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+    print("qpsk_modem.npz:", len(d), "arrays;", json.dumps(summary))
+
+
 def gen_reports():
     """Report text of the reference (packet_meta.py:283-370) for the bundled recording and two generated ones, chains added
     in config order (the reference CLI's own order depends on process completion)."""
@@ -513,11 +562,13 @@ def copy_data_files():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["taps", "prims", "synth", "wav", "signal", "reports", "copy"]
+    which = sys.argv[1:] or ["taps", "prims", "synth", "wav", "signal", "reports", "copy", "qpsk"]
     if "taps" in which:
         gen_taps()
     if "prims" in which:
         gen_primitives()
+    if "qpsk" in which:
+        gen_qpsk_modem()
     if "synth" in which:
         gen_synth_chains()
     if "wav" in which:

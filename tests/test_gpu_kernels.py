@@ -208,7 +208,7 @@ def loops_pair(rate, carrier, cutoff, p, i, lim, gain, integral0=0.0):
     from pymodem_amd._native import Loop
     a = O.make_loop(rate, carrier, cutoff, 1.0, p, i, lim, gain, integral0)
     b = Loop()
-    for f, _ in Loop._fields_:
+    for f, _ in a._fields_:                # the product's pm_loop has these and the QPSK branch-filter fields after them
         setattr(b, f, getattr(a, f))
     return a, b
 
@@ -234,6 +234,34 @@ def test_costas_and_pll_bit_exact(ctx, n):
         assert np.array_equal(out.download(), want)
         for f, _ in a._fields_:
             assert getattr(a, f) == getattr(b, f), f           # end state identical too
+
+
+@pytest.mark.parametrize("n", [1, 255, 256, 257, 20000])
+def test_costas_qpsk_bit_exact(ctx, n):
+    """QPSKModem's loop (psk.py:434-467): both arms, loop state and branch-filter state against the oracle; 5 loops in one launch."""
+    tab = O.nco_table()
+    dt = ctx.upload(tab)
+    x = agc_like(n, 3 * n + 1)
+    dx = ctx.upload(x)
+    from pymodem_amd._native import Loop
+    nl = 5
+    loops = (Loop * nl)()
+    want = []
+    for k in range(nl):
+        a, b = loops_pair(48000.0, 1800.0 + 3.0 * k, 200.0, 0.1, 0.1 / 500, 87.5, 450.0)
+        br = np.array(list(O.iir1_coefs(48000.0, 1200.0, 1.0)) + [0.0] * 6)
+        b.bb0, b.bb1, b.ba1 = br[:3]
+        ctypes.memmove(ctypes.byref(loops[k]), ctypes.byref(b), ctypes.sizeof(Loop))
+        oi, oq = O.costas_qpsk(a, br, x, tab)
+        want.append((oi, oq, a, br))
+    oi_d, oq_d = ctx.empty(n * nl, np.float64), ctx.empty(n * nl, np.float64)
+    chk(L().pm_costas_qpsk(ctx.handle, loops, nl, dt.ptr, dx.ptr, 0, n, oi_d.ptr, oq_d.ptr, n))
+    gi, gq = oi_d.download().reshape(nl, n), oq_d.download().reshape(nl, n)
+    for k, (oi, oq, a, br) in enumerate(want):
+        assert np.array_equal(gi[k], oi) and np.array_equal(gq[k], oq), k
+        for f, _ in a._fields_:
+            assert getattr(a, f) == getattr(loops[k], f), f
+        assert [loops[k].cx0, loops[k].cx1, loops[k].cy0, loops[k].sx0, loops[k].sx1, loops[k].sy0] == list(br[3:])
 
 
 def test_mpsk_loop_batch_bit_exact(ctx):
