@@ -174,6 +174,19 @@ int pm_slice_quadrature(pm_ctx *ctx, const uint64_t *d_bits_i, const uint64_t *d
                         int64_t *h_count);                                                                  /* slicer.py:193-242 */
 /* Many streams in one launch sequence (chains are independent; batching them shares the iteration launches and the
  * host checks).  d_bits_q == NULL selects the binary slicer for that stream.  `count` is written per job. */
+/* What a slicer object carries from one slice() call to the next (slicer.py:49-56,193-202): a second call on the same object
+ * continues the first, mid-byte if need be.  All zero (last samples counting as >= 0) is the just-tuned state. */
+typedef struct pm_slicer_state {
+    double phase_clock;
+    int32_t last_i_negative;         /* 1 if the previous call's last I (or only) sample was < 0 */
+    int32_t last_q_negative;
+    int32_t working_byte;            /* the bits shifted in since the last emitted byte (low working_bits bits are meaningful) */
+    int32_t working_bits;
+    int32_t state_register;          /* quadrature: previous symbol(s), slicer.py:210 */
+    int32_t reserved;
+    int64_t streamaddress;           /* samples seen so far: the next sample's address is streamaddress + 1 */
+} pm_slicer_state;
+
 typedef struct pm_slice_job {
     const uint64_t *d_bits_i;
     const uint64_t *d_bits_q;
@@ -183,6 +196,7 @@ typedef struct pm_slice_job {
     int64_t *d_addr;
     int64_t cap;
     int64_t count;                   /* out */
+    pm_slicer_state *h_state;        /* in/out; NULL = start from the just-tuned state and do not report the end state */
 } pm_slice_job;
 int pm_slice_batch(pm_ctx *ctx, pm_slice_job *h_jobs, int njobs);           /* njobs <= 64 */
 /* Diagnostics of the last slicer call on this ctx: fixed-point iterations used, chunk length, chunks. */

@@ -436,7 +436,7 @@ class BPSKModem:
         fir = fir_canon if canon else fir_ref
         a = np.ascontiguousarray(fir(audio, self.input_bpf), dtype=np.float64)
         att, sus, dec = self.p["agc"]
-        agc_apply(a, self.sample_rate, att, sus, dec, 1.0)
+        agc_apply(a, self.sample_rate, att, sus, dec, 1.0, state=self._agc_state())
         d = costas_bpsk(self.loop, a)
         return fir(d, self.rrc)
 
@@ -475,7 +475,7 @@ class QPSKModem:
         fir = fir_canon if canon else fir_ref
         a = np.ascontiguousarray(fir(audio, self.input_bpf), dtype=np.float64)
         att, sus, dec = self.p["agc"]
-        agc_apply(a, self.sample_rate, att, sus, dec, 1.0)
+        agc_apply(a, self.sample_rate, att, sus, dec, 1.0, state=self._agc_state())
         i_arm, q_arm = costas_qpsk(self.loop, self.branch, a)
         return fir(i_arm, self.rrc), fir(q_arm, self.rrc)
 
@@ -522,7 +522,7 @@ class MPSKModem:
         fir = fir_canon if canon else fir_ref
         a = np.ascontiguousarray(fir(audio, self.input_bpf), dtype=np.float64)
         att, sus, dec = self.p["agc"]
-        agc_apply(a, self.sample_rate, att, sus, dec, 1.0)
+        agc_apply(a, self.sample_rate, att, sus, dec, 1.0, state=self._agc_state())
         imag = fir(a, self.hilbert)                                            # psk.py:714
         if canon:
             real = a[self.delay:len(a) - self.delay].copy()                    # delay FIR = pure shift
@@ -553,7 +553,7 @@ class AFSKPLLModem:
     def demod(self, audio, canon=False):          # afsk_pll.py:140-170
         fir = fir_canon if canon else fir_ref
         a = np.ascontiguousarray(fir(audio, self.input_bpf), dtype=np.float64)
-        agc_apply(a, self.sample_rate, 500.0, 1.0, 50.0, 1.0)
+        agc_apply(a, self.sample_rate, 500.0, 1.0, 50.0, 1.0, state=self._agc_state())
         d = pll_afsk(self.loop, a)
         return fir(d, self.output_lpf)
 
@@ -1103,6 +1103,17 @@ def correlate(packet_lists, address_distance):
                 uniq.append(p)
         first = False
     return sorted(uniq, key=lambda q: q.streamaddress)
+
+
+def _agc_state(self):
+    """The AGC object lives as long as the modem (agc.py:7-24): envelope and sustain count carry from demod() to demod()."""
+    if not hasattr(self, "_agc_st"):
+        self._agc_st = np.zeros(2)
+    return self._agc_st
+
+
+for _cls in (BPSKModem, QPSKModem, MPSKModem, AFSKPLLModem):
+    _cls._agc_state = _agc_state
 
 
 def build_chain(sample_rate, line):

@@ -36,10 +36,18 @@ class SlicerParams(ctypes.Structure):
                 ("bits_per_symbol", ctypes.c_int32), ("state_mask", ctypes.c_int32), ("demap", ctypes.c_int32 * 16)]
 
 
+class SlicerState(ctypes.Structure):
+    """pm_slicer_state: what a slicer object carries from one slice() call to the next"""
+    _fields_ = [("phase_clock", ctypes.c_double), ("last_i_negative", ctypes.c_int32), ("last_q_negative", ctypes.c_int32),
+                ("working_byte", ctypes.c_int32), ("working_bits", ctypes.c_int32), ("state_register", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("streamaddress", ctypes.c_int64)]
+
+
 class SliceJob(ctypes.Structure):
     """pm_slice_job"""
     _fields_ = [("d_bits_i", ctypes.c_void_p), ("d_bits_q", ctypes.c_void_p), ("n", ctypes.c_int64), ("params", SlicerParams),
-                ("d_data", ctypes.c_void_p), ("d_addr", ctypes.c_void_p), ("cap", ctypes.c_int64), ("count", ctypes.c_int64)]
+                ("d_data", ctypes.c_void_p), ("d_addr", ctypes.c_void_p), ("cap", ctypes.c_int64), ("count", ctypes.c_int64),
+                ("h_state", ctypes.POINTER(SlicerState))]
 
 
 class ChainDesc(ctypes.Structure):

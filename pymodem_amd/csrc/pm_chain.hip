@@ -16,6 +16,7 @@ struct pm_chain {
     int32_t *d_pd = nullptr;
     pm_loop loop0{}, loop{};
     double agc_state[2] = {0.0, 0.0};
+    pm_slicer_state slicer_state{};
     // device work buffers (grown on demand)
     uint8_t *d_audio = nullptr; size_t audio_bytes = 0;
     double *d_a = nullptr, *d_b = nullptr; size_t a_n = 0, b_n = 0;
@@ -96,6 +97,7 @@ int pm_chain_reset(pm_chain *c)
     PM_ARG(c != nullptr);
     c->loop = c->loop0;
     c->agc_state[0] = c->agc_state[1] = 0.0;
+    c->slicer_state = pm_slicer_state{};
     return PM_OK;
 }
 
@@ -193,15 +195,21 @@ int pm_chain_run(pm_chain *c, const int16_t *audio, int64_t n, int audio_on_devi
         }
     }
     // slicer.slice: at most one symbol per sample
-    const int64_t need = ns * d.slicer.bits_per_symbol / 8 + 4;
+    const int64_t need = ns * d.slicer.bits_per_symbol / 8 + 5;
     if (int rc = grow(ctx, c->d_data, c->data_n, (size_t)need + 4)) return rc;
     if (int rc = grow(ctx, c->d_addr, c->addr_n, (size_t)need)) return rc;
-    int64_t count = 0;
-    if (d.quadrature) {
-        if (int rc = pm_slice_quadrature(ctx, c->d_bits_i, c->d_bits_q, ns, &d.slicer, c->d_data, c->d_addr, need, &count)) return rc;
-    } else {
-        if (int rc = pm_slice_binary(ctx, c->d_bits_i, ns, &d.slicer, c->d_data, c->d_addr, need, &count)) return rc;
-    }
+    pm_slice_job job;
+    memset(&job, 0, sizeof(job));
+    job.d_bits_i = c->d_bits_i;
+    job.d_bits_q = d.quadrature ? c->d_bits_q : nullptr;
+    job.n = ns;
+    job.params = d.slicer;
+    job.d_data = c->d_data;
+    job.d_addr = c->d_addr;
+    job.cap = need;
+    job.h_state = &c->slicer_state;                        // the slicer continues from run to run like the reference's object
+    if (int rc = pm_slice_batch(ctx, &job, 1)) return rc;
+    const int64_t count = job.count;
     *h_count = count;
     if (count > cap) return pm_set_error(PM_ERR_CAPACITY, "pm_chain_run: %lld bytes decoded, caller's buffers hold %lld", (long long)count, (long long)cap);
     if (count) {

@@ -41,6 +41,13 @@ struct JobDev {
     uint32_t *data32;
     int64_t *addr;
     int64_t cap;
+    // state carried in from the previous call on the same slicer object (all zero for a fresh one)
+    double clk0;
+    int li0, lq0;                  // 1 if the previous sample was >= 0
+    int nb0, wb0;                  // bits already shifted into the working byte, and their value
+    int sreg0;                     // previous symbol (quadrature)
+    int64_t addr0;
+    uint32_t *tail;                // the trailing partial byte of this call, left-aligned
 };
 
 __device__ __forceinline__ uint64_t dbits(double v) { return (uint64_t)__double_as_longlong(v); }
@@ -100,9 +107,9 @@ __global__ __launch_bounds__(kBlock) void slice_iter_kernel(const JobDev *__rest
     const int64_t w0 = c * lc_words;
     const int64_t w1 = min(w0 + (int64_t)lc_words, J.nwords);
     // last_sample starts at 0.0, i.e. ">= 0" (slicer.py:55,164-165)
-    uint64_t li = w0 == 0 ? 1ull : (J.bi[w0 - 1] >> 63);
+    uint64_t li = w0 == 0 ? (uint64_t)J.li0 : (J.bi[w0 - 1] >> 63);
     uint64_t lq = 1ull;
-    if (J.quad) lq = w0 == 0 ? 1ull : (J.bq[w0 - 1] >> 63);
+    if (J.quad) lq = w0 == 0 ? (uint64_t)J.lq0 : (J.bq[w0 - 1] >> 63);
     const double thr = J.thr, neg_sps = -J.sps;
     const double lock = J.lock;
     uint64_t *sm = symmap + J.word0;
@@ -170,7 +177,8 @@ __global__ __launch_bounds__(kBlock) void slice_count_kernel(const JobDev *__res
 // Per stream: exclusive scan of symbol counts and the "last symbol before this chunk" carry.  One workgroup per stream.
 __global__ __launch_bounds__(1024) void slice_scan_kernel(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ count,
                                                           const uint8_t *__restrict__ lastsym, uint64_t *__restrict__ offset,
-                                                          uint8_t *__restrict__ prevsym, uint64_t *__restrict__ totals)
+                                                          uint8_t *__restrict__ prevsym, uint64_t *__restrict__ totals,
+                                                          const uint64_t *__restrict__ s_end, int njobs)
 {
     __shared__ uint64_t sums[1024];
     __shared__ int lasts[1024];
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(1024) void slice_scan_kernel(const JobDev *__restri
     __syncthreads();
     if (t == 0) {
         uint64_t run = 0;
-        int carry = 0;                                     // state_register starts at 0 (slicer.py:202)
+        int carry = J.sreg0 & 3;                           // state_register starts at 0 (slicer.py:202) or where the last call left it
         for (int i = 0; i < 1024; ++i) {
             const uint64_t v = sums[i];
             const int lv = lasts[i];
@@ -204,6 +212,13 @@ __global__ __launch_bounds__(1024) void slice_scan_kernel(const JobDev *__restri
         }
         off[J.nchunks] = run;
         totals[blockIdx.x] = run;
+        // end state for the next call on this slicer object: clock after the last chunk, signs of the last sample, last symbol
+        totals[njobs + blockIdx.x] = s_end[J.chunk0 + blockIdx.x + J.nchunks];
+        const int64_t last = J.n - 1;
+        uint64_t signs = (J.bi[last >> 6] >> (last & 63)) & 1;
+        if (J.quad) signs |= ((J.bq[last >> 6] >> (last & 63)) & 1) << 1;
+        totals[2 * njobs + blockIdx.x] = signs;
+        totals[3 * njobs + blockIdx.x] = (uint64_t)carry;
     }
     __syncthreads();
     uint64_t run = sums[t];
@@ -229,8 +244,14 @@ __global__ __launch_bounds__(kBlock) void slice_pack_kernel(const JobDev *__rest
     const uint64_t *off = offset + J.chunk0 + j;
     uint64_t g = off[c];
     const uint64_t total = off[J.nchunks];
-    const int bps = J.bps, spb = 8 / bps;                  // symbols per byte
-    const uint64_t nbytes = total / (uint64_t)spb;         // a trailing partial byte is never emitted (slicer.py:94-96)
+    const int bps = J.bps;
+    const uint64_t nb0 = (uint64_t)J.nb0;                  // bits the previous call left in the working byte come first
+    const uint64_t nbytes = (nb0 + total * (uint64_t)bps) >> 3;   // a trailing partial byte is not emitted (slicer.py:94-96): it is the end state
+    if (c == 0 && nb0) {
+        const uint32_t head = ((uint32_t)J.wb0 & ((1u << nb0) - 1u)) << (8 - nb0);
+        if (nbytes > 0) { if (J.cap > 0) atomicOr(&J.data32[0], head); }
+        else atomicOr(J.tail, head);
+    }
     uint32_t prev = prevsym[gc];
     const int64_t w0 = c * lc_words, w1 = min(w0 + (int64_t)lc_words, J.nwords);
     const uint64_t *sm = symmap + J.word0;
@@ -252,14 +273,15 @@ __global__ __launch_bounds__(kBlock) void slice_pack_kernel(const JobDev *__rest
             } else {
                 v = (uint32_t)((si >> b) & 1);                                         // slicer.py:85-90
             }
-            const int k = (int)(g % (uint64_t)spb);
-            acc |= v << (8 - bps * (k + 1));
+            const uint64_t bitpos = nb0 + g * (uint64_t)bps;
+            const int inbyte = (int)(bitpos & 7);
+            acc |= v << (8 - bps - inbyte);
             pending = true;
-            if (k == spb - 1) {
-                const uint64_t idx = g / (uint64_t)spb;
+            if (inbyte + bps == 8) {
+                const uint64_t idx = bitpos >> 3;
                 if (idx < (uint64_t)J.cap) {
                     atomicOr(&J.data32[idx >> 2], (acc & 0xFF) << ((idx & 3) * 8));
-                    J.addr[idx] = (w << 6) + b + 1;        // streamaddress, 1-based
+                    J.addr[idx] = J.addr0 + (w << 6) + b + 1;      // streamaddress, 1-based, continuing the previous call's count
                 }
                 acc = 0;
                 pending = false;
@@ -267,9 +289,10 @@ __global__ __launch_bounds__(kBlock) void slice_pack_kernel(const JobDev *__rest
             ++g;
         }
     }
-    if (pending) {                                         // head of a byte that a later chunk completes
-        const uint64_t idx = g / (uint64_t)spb;
-        if (idx < nbytes && idx < (uint64_t)J.cap) atomicOr(&J.data32[idx >> 2], (acc & 0xFF) << ((idx & 3) * 8));
+    if (pending) {                                         // head of a byte that a later chunk (or a later call) completes
+        const uint64_t idx = (nb0 + (g - 1) * (uint64_t)bps) >> 3;
+        if (idx < nbytes) { if (idx < (uint64_t)J.cap) atomicOr(&J.data32[idx >> 2], (acc & 0xFF) << ((idx & 3) * 8)); }
+        else atomicOr(J.tail, acc & 0xFF);
     }
 }
 
@@ -282,7 +305,8 @@ __global__ void slice_init_kernel(const JobDev *__restrict__ jobs, int njobs, in
     const int j = find_job(jobs, njobs, gc);
     const int64_t so = gc + j;
     // cold start everywhere: phase_clock = 0.0, which for chunk 0 is the true initial state (slicer.py:50)
-    sa[so] = 0ull; sb[so] = 0ull; da[so] = 1; db[so] = 0;
+    const uint64_t start = gc == jobs[j].chunk0 ? dbits(jobs[j].clk0) : 0ull;      // chunk 0: the carried (or zero) phase clock
+    sa[so] = start; sb[so] = start; da[so] = 1; db[so] = 0;
     if (gc - jobs[j].chunk0 == jobs[j].nchunks - 1) { sa[so + 1] = 0ull; sb[so + 1] = 0ull; da[so + 1] = 0; db[so + 1] = 0; }
 }
 
@@ -341,6 +365,17 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
         d.data32 = (uint32_t *)q.d_data;
         d.addr = q.d_addr;
         d.cap = q.cap;
+        d.li0 = d.lq0 = 1;
+        if (const pm_slicer_state *st = q.h_state) {
+            PM_ARG(st->working_bits >= 0 && st->working_bits < 8 && st->working_bits % q.params.bits_per_symbol == 0 && st->streamaddress >= 0);
+            d.clk0 = st->phase_clock;
+            d.li0 = st->last_i_negative ? 0 : 1;
+            d.lq0 = st->last_q_negative ? 0 : 1;
+            d.nb0 = st->working_bits;
+            d.wb0 = st->working_byte;
+            d.sreg0 = st->state_register;
+            d.addr0 = st->streamaddress;
+        }
         total_chunks += d.nchunks;
         total_words += d.nwords;
         jd.push_back(d);
@@ -355,7 +390,7 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_jobs = carve(sizeof(JobDev) * nj), o_sa = carve(e * 8), o_sb = carve(e * 8), o_da = carve(e), o_db = carve(e),
                  o_cnt = carve((size_t)total_chunks * 4), o_ls = carve(total_chunks), o_off = carve(e * 8), o_ps = carve(total_chunks),
-                 o_sym = carve((size_t)total_words * 8), o_tot = carve((size_t)nj * 8), o_ch = carve(256);
+                 o_sym = carve((size_t)total_words * 8), o_tot = carve((size_t)nj * 8 * 4), o_tail = carve((size_t)nj * 4), o_ch = carve(256);
     if (int rc = pm_scratch_reserve(ctx, off)) return rc;
     char *base = (char *)ctx->d_scratch;
     JobDev *d_jobs = (JobDev *)(base + o_jobs);
@@ -365,6 +400,9 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
     uint8_t *ls = (uint8_t *)(base + o_ls), *ps = (uint8_t *)(base + o_ps);
     uint64_t *offs = (uint64_t *)(base + o_off), *symmap = (uint64_t *)(base + o_sym), *totals = (uint64_t *)(base + o_tot);
     int *changed = (int *)(base + o_ch);
+    uint32_t *tails = (uint32_t *)(base + o_tail);
+    for (int k = 0; k < nj; ++k) jd[k].tail = tails + k;
+    PM_HIP(hipMemsetAsync(tails, 0, (size_t)nj * 4, ctx->stream));
 
     PM_HIP(hipMemcpyAsync(d_jobs, jd.data(), sizeof(JobDev) * nj, hipMemcpyHostToDevice, ctx->stream));
     const unsigned grid = (unsigned)pm_cdiv(total_chunks, kBlock);
@@ -401,19 +439,33 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
     {
         PmProf prof(ctx, PM_K_SLICE_EMIT);
         hipLaunchKernelGGL(slice_count_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_jobs, nj, (int)lc_words, total_chunks, symmap, cnt, ls);
-        hipLaunchKernelGGL(slice_scan_kernel, dim3(nj), dim3(1024), 0, ctx->stream, d_jobs, cnt, ls, offs, ps, totals);
+        hipLaunchKernelGGL(slice_scan_kernel, dim3(nj), dim3(1024), 0, ctx->stream, d_jobs, cnt, ls, offs, ps, totals, sa, nj);
         for (const JobDev &d : jd)
             if (d.cap > 0) PM_HIP(hipMemsetAsync(d.data32, 0, align_up((size_t)d.cap, 4), ctx->stream));
         hipLaunchKernelGGL(slice_pack_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_jobs, nj, (int)lc_words, total_chunks, symmap, offs, ps);
     }
-    std::vector<uint64_t> h_tot(nj);
-    PM_HIP(hipMemcpyAsync(h_tot.data(), totals, (size_t)nj * 8, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<uint64_t> h_tot((size_t)nj * 4);
+    std::vector<uint32_t> h_tail(nj);
+    PM_HIP(hipMemcpyAsync(h_tot.data(), totals, (size_t)nj * 8 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PM_HIP(hipMemcpyAsync(h_tail.data(), tails, (size_t)nj * 4, hipMemcpyDeviceToHost, ctx->stream));
     PM_HIP(hipStreamSynchronize(ctx->stream));
     PM_HIP(hipGetLastError());
     int rc = PM_OK;
     for (int k = 0; k < nj; ++k) {
         pm_slice_job &q = jobs[live[k]];
-        q.count = (int64_t)(h_tot[k] / (uint64_t)(8 / jd[k].bps));
+        const uint64_t bits = (uint64_t)jd[k].nb0 + h_tot[k] * (uint64_t)jd[k].bps;
+        q.count = (int64_t)(bits >> 3);
+        if (pm_slicer_state *st = q.h_state) {
+            double clk;
+            memcpy(&clk, &h_tot[(size_t)nj + k], 8);
+            st->phase_clock = clk;
+            st->last_i_negative = (h_tot[(size_t)2 * nj + k] & 1) ? 0 : 1;
+            st->last_q_negative = jd[k].quad ? ((h_tot[(size_t)2 * nj + k] & 2) ? 0 : 1) : 0;
+            st->working_bits = (int32_t)(bits & 7);
+            st->working_byte = st->working_bits ? (int32_t)((h_tail[k] & 0xFF) >> (8 - st->working_bits)) : 0;
+            st->state_register = (int32_t)h_tot[(size_t)3 * nj + k];
+            st->streamaddress = jd[k].addr0 + jd[k].n;
+        }
         if (q.count > q.cap)
             rc = pm_set_error(PM_ERR_CAPACITY, "slicer stream %d produced %lld bytes, capacity %lld", live[k], (long long)q.count, (long long)q.cap);
     }

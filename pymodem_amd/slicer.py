@@ -5,7 +5,7 @@ import ctypes
 
 import numpy as np
 
-from ._native import SliceJob, SlicerParams, check, lib
+from ._native import SliceJob, SlicerParams, SlicerState, check, lib
 from .data_classes import AddressedArray, DeviceIQ, IQData, SignBits
 from .device import Context, DeviceBuffer
 
@@ -35,6 +35,7 @@ class _SlicerBase:
         self.samples_per_symbol = self.sample_rate / self.symbol_rate
         self.rollover_threshold = (self.samples_per_symbol / 2.0) - 0.5
         self.streamaddress = 0
+        self._state = SlicerState()        # phase clock, last sample sign(s), partial byte, address: carried from slice() to slice()
 
     def _params(self):
         p = SlicerParams()
@@ -84,7 +85,7 @@ def slice_batch(slicers, bitmaps, ctx=None):
         bufs = []
         for j, k in enumerate(group):
             sl, (bi, bq, n) = slicers[k], bitmaps[k]
-            cap = n * sl.bits_per_symbol // 8 + 4          # at most one symbol per sample
+            cap = n * sl.bits_per_symbol // 8 + 5          # at most one symbol per sample, plus a byte the last call left open
             sl._ctx = sl._ctx or ctx
             data = ctx.scratch((sl._own_key(), "bytes"), cap + 4, np.uint8)
             addr = ctx.scratch((sl._own_key(), "addr"), cap, np.int64)
@@ -94,11 +95,13 @@ def slice_batch(slicers, bitmaps, ctx=None):
             jobs[j].n = n
             jobs[j].params = sl._params()
             jobs[j].d_data, jobs[j].d_addr, jobs[j].cap = data.ptr, addr.ptr, cap
+            jobs[j].h_state = ctypes.pointer(sl._state)
         check(lib().pm_slice_batch(ctx.handle, jobs, len(group)))
         it, cl, nc = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
         lib().pm_slicer_stats(ctx.handle, ctypes.byref(it), ctypes.byref(cl), ctypes.byref(nc))
         for j, k in enumerate(group):
             slicers[k].last_stats = {"iterations": it.value, "chunk_len": cl.value, "chunks": nc.value}
+            slicers[k].phase_clock, slicers[k].streamaddress = slicers[k]._state.phase_clock, slicers[k]._state.streamaddress
             out[k] = AddressedArray(bufs[j][0].download(jobs[j].count), bufs[j][1].download(jobs[j].count))
     return out
 

@@ -526,6 +526,35 @@ def gen_qpsk_modem():
     print("qpsk_modem.npz:", len(d), "arrays;", json.dumps(summary))
 
 
+SEGMENT_CASES = [("afsk_1200.json", "afsk1200_ax25"), ("bpsk_300.json", "bpsk300_il2p"), ("fsk_9600.json", "fsk9600_il2p"),
+                 ("qpsk_2400.json", "qpsk2400_il2p")]
+
+
+def gen_segments():
+    """The reference's stage objects are stateful: one chain fed a recording in two pieces (second process_chain on the same
+    objects).  Recording: pymodem_amd.siggen, 3 packets, seed 5, sigma 400; cut at len//2 + 137."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from pymodem_amd import siggen
+    d, summary = {}, {}
+    for cfgname, mode in SEGMENT_CASES:
+        audio, _ = siggen.recording(mode, 48000, packets=3, seed=5, noise_sigma=400.0, payload_len=(20, 40))
+        cut = len(audio) // 2 + 137
+        line = [l for l in load_config(cfgname) if l.get("object_type") == "demod_chain"][0]
+        chain = build_chain(48000, line)
+        tag = cfgname[:-5]
+        d[tag + "__audio"] = audio
+        counts = []
+        for k, seg in enumerate((audio[:cut], audio[cut:])):
+            pk = run_chain(chain, seg, d, f"{tag}__seg{k}", keep_demod=False)
+            counts.append(len(pk))
+        whole = run_chain(build_chain(48000, line), audio, {}, "x", keep_demod=False)
+        summary[tag] = {"cut": cut, "samples": len(audio), "packets_per_segment": counts, "packets_uncut": len(whole)}
+    np.savez_compressed(os.path.join(OUT, "segments.npz"), **d)
+    with open(os.path.join(OUT, "segments_summary.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+    print("segments.npz:", len(d), "arrays;", json.dumps(summary))
+
+
 def gen_reports():
     """Report text of the reference (packet_meta.py:283-370) for the bundled recording and two generated ones, chains added
     in config order (the reference CLI's own order depends on process completion)."""
@@ -562,11 +591,13 @@ def copy_data_files():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["taps", "prims", "synth", "wav", "signal", "reports", "copy", "qpsk"]
+    which = sys.argv[1:] or ["taps", "prims", "synth", "wav", "signal", "reports", "copy", "qpsk", "segments"]
     if "taps" in which:
         gen_taps()
     if "prims" in which:
         gen_primitives()
+    if "segments" in which:
+        gen_segments()
     if "qpsk" in which:
         gen_qpsk_modem()
     if "synth" in which:

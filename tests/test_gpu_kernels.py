@@ -186,6 +186,51 @@ def test_quadrature_slicer_bit_exact(ctx, rate, cfg, lock, kind):
         assert np.array_equal(got.data, d) and np.array_equal(got.address, a), (n, kind, s.last_stats)
 
 
+@pytest.mark.parametrize("kind", ["noise", "smooth", "alternating"])
+def test_slicers_continue_across_calls(ctx, kind):
+    """A slicer object carries phase clock, last sample sign, the open byte and the address count from one slice() to the next
+    (slicer.py:49-56): cutting a stream anywhere and slicing the pieces one after another gives the uncut result."""
+    from pymodem_amd.data_classes import IQData
+    from pymodem_amd.slicer import BinarySlicer, QuadratureSlicer
+    rng = np.random.default_rng(42)
+    n = 120000
+    xi, xq = slicer_input(n, 11, kind), slicer_input(n, 12, "smooth" if kind == "alternating" else kind)
+    for trial in range(4):
+        cuts = np.unique(np.concatenate([[0, n], rng.integers(1, n, 6), [1, 63, 64, 65, 4097][:trial + 1]]))
+        # binary
+        s = BinarySlicer(sample_rate=48000, config="1200")
+        s.StringOptionsRetune({"lock_rate": "0.77"})
+        o = O.BinarySlicer(48000, "1200", {"lock_rate": "0.77"})
+        whole_d, whole_a = O.BinarySlicer(48000, "1200", {"lock_rate": "0.77"}).slice(xi)
+        parts_d, parts_a = [], []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            got = s.slice(xi[lo:hi])
+            od, oa = o.slice(xi[lo:hi])
+            assert np.array_equal(got.data, od) and np.array_equal(got.address, oa), (kind, lo, hi)
+            assert s._state.phase_clock == o.state[0] and s._state.working_bits == int(o.state[4]) and s._state.streamaddress == int(o.state[5])
+            parts_d.append(got.data)
+            parts_a.append(got.address)
+        assert np.array_equal(np.concatenate(parts_d), whole_d) and np.array_equal(np.concatenate(parts_a), whole_a)
+        # quadrature, differential demap across the cut
+        q = QuadratureSlicer(sample_rate=48000, config="qpsk_2400")
+        oq = O.QuadratureSlicer(48000, "qpsk_2400", {})
+        whole_d, whole_a = O.QuadratureSlicer(48000, "qpsk_2400", {}).slice((xi, xq))
+        parts_d, parts_a = [], []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            iq = IQData()
+            iq.i_data, iq.q_data = xi[lo:hi], xq[lo:hi]
+            got = q.slice(iq)
+            od, oa = oq.slice((xi[lo:hi], xq[lo:hi]))
+            assert np.array_equal(got.data, od) and np.array_equal(got.address, oa), (kind, lo, hi)
+            parts_d.append(got.data)
+            parts_a.append(got.address)
+        assert np.array_equal(np.concatenate(parts_d), whole_d) and np.array_equal(np.concatenate(parts_a), whole_a)
+    s.tune()                                   # retuning returns the object to the just-built state
+    again = s.slice(xi)
+    fresh = O.BinarySlicer(48000, "1200", {"lock_rate": "0.77"}).slice(xi)
+    assert np.array_equal(again.data, fresh[0]) and np.array_equal(again.address, fresh[1])
+
+
 def test_agc_bit_exact(ctx, golden):
     from pymodem_amd._native import AGCParams
     g = golden("primitives")
