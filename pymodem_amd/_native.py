@@ -134,6 +134,7 @@ _SIGS = {
     "pm_slice_binary": ([_vp, _vp, _i64, ctypes.POINTER(SlicerParams), _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
     "pm_slice_quadrature": ([_vp, _vp, _vp, _i64, ctypes.POINTER(SlicerParams), _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
     "pm_slice_batch": ([_vp, ctypes.POINTER(SliceJob), _int], _int),
+    "pm_slicer_tune": ([_vp, _i64], _int),
     "pm_slicer_stats": ([_vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_i64)], _int),
     "pm_chain_create": ([_vp, ctypes.POINTER(ChainDesc), ctypes.POINTER(_vp)], _int),
     "pm_chain_run": ([_vp, _vp, _i64, _int, _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),

@@ -72,7 +72,7 @@ def _pool():
     global _POOL
     if _POOL is None:
         import os
-        _POOL = ThreadPoolExecutor(max_workers=max(2, min(8, (os.cpu_count() or 4) // 2)))
+        _POOL = ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 4) // 2)))
     return _POOL
 
 
@@ -99,7 +99,7 @@ class RecordingPipeline:
       demod   FIR / correlator / loop kernels (vector-f64 ALU and HBM)                 default stream, caller's thread
       slice   chunk-parallel timing recovery: ~1 resident wave per SIMD, dependent-     `slice_workers` high-priority side streams,
               latency bound, so TWO recordings' slicers share the GPU almost for free    one thread each
-      host    LFSR + codec (native, GIL released)                                       same thread, fanned out to the pool
+      host    LFSR + codec (native, GIL released)                                       two threads, each fanning out to the pool
       finish  the caller's `finish(rows per chain)`: gather / de-dup                    one thread, submission order (collectives)
 
     While recordings k and k-1 are being sliced, recording k+1 is demodulated and k-2 finished.  The only GPU buffers that cross
@@ -110,6 +110,7 @@ class RecordingPipeline:
         from collections import deque
         self._workers = max(1, int(slice_workers))
         self._slice = ThreadPoolExecutor(max_workers=self._workers)
+        self._host = ThreadPoolExecutor(max_workers=2)        # LFSR + codec of two recordings at a time (each fans out to the pool)
         self._finish = ThreadPoolExecutor(max_workers=1)
         self._inflight = deque()
         self._n = 0
@@ -132,17 +133,22 @@ class RecordingPipeline:
         self._events[slot] = ready = Context.default().record_event(self._events[slot])   # bitmaps complete at this point of the stream
         acc["demod"] += time.perf_counter() - t0
 
-        def slice_and_decode():
+        def slice_stage():
             t = time.perf_counter()
             side.wait_event(ready)
             sliced = slice_batch([ch[2] for ch in chains], bitmaps, side)
-            t1 = time.perf_counter()
+            acc["slice"] += time.perf_counter() - t
+            return sliced
+        f_sliced = self._slice.submit(slice_stage)
+        self._inflight.append(f_sliced)                       # the bitmap slot is free again once the slicer has read it
+
+        def host_stage():
+            sliced = f_sliced.result()
+            t = time.perf_counter()
             rows = _host_rows(chains, sliced)
-            acc["slice"] += t1 - t
-            acc["host"] += time.perf_counter() - t1
+            acc["host"] += time.perf_counter() - t
             return rows
-        f_rows = self._slice.submit(slice_and_decode)
-        self._inflight.append(f_rows)
+        f_rows = self._host.submit(host_stage)
 
         def finish_stage():
             rows = f_rows.result()
@@ -156,6 +162,7 @@ class RecordingPipeline:
 
     def close(self):
         self._slice.shutdown(wait=True)
+        self._host.shutdown(wait=True)
         self._finish.shutdown(wait=True)
 
 

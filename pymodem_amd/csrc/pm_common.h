@@ -26,6 +26,7 @@ struct pm_ctx {
     // slicer diagnostics
     int32_t sl_iterations = 0, sl_chunk_len = 0;
     int64_t sl_chunks = 0;
+    int64_t sl_target_lanes = 65536;   // chunks a slicer batch is cut into (pm_slicer_tune)
 };
 
 int pm_set_error(int code, const char *fmt, ...);

@@ -90,6 +90,9 @@ __global__ __launch_bounds__(kBlock) void slice_iter_kernel(const JobDev *__rest
                                                         const uint8_t *__restrict__ d_in, uint8_t *__restrict__ d_out,
                                                         uint64_t *__restrict__ symmap, int *__restrict__ changed, int iter)
 {
+    // These waves are bound by their own dependent chain; when FIR waves of another stream share the SIMD (pipelined executor)
+    // every issue slot they lose lengthens the chain, while the FIR waves only need the slots in between: take issue priority.
+    __builtin_amdgcn_s_setprio(3);
     const int64_t gc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gc >= total_chunks) return;
     const int j = find_job(jobs, njobs, gc);
@@ -153,6 +156,7 @@ __global__ __launch_bounds__(kBlock) void slice_count_kernel(const JobDev *__res
                                                          const uint64_t *__restrict__ symmap, uint32_t *__restrict__ count,
                                                          uint8_t *__restrict__ lastsym)
 {
+    __builtin_amdgcn_s_setprio(3);          // short kernels on the slicer stream's critical path (see slice_iter_kernel)
     const int64_t gc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gc >= total_chunks) return;
     const int j = find_job(jobs, njobs, gc);
@@ -178,8 +182,10 @@ __global__ __launch_bounds__(kBlock) void slice_count_kernel(const JobDev *__res
 __global__ __launch_bounds__(1024) void slice_scan_kernel(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ count,
                                                           const uint8_t *__restrict__ lastsym, uint64_t *__restrict__ offset,
                                                           uint8_t *__restrict__ prevsym, uint64_t *__restrict__ totals,
-                                                          const uint64_t *__restrict__ s_end, int njobs)
+                                                          const uint64_t *__restrict__ s_end, int njobs,
+                                                          const JobDev *__restrict__ iter_jobs)
 {
+    __builtin_amdgcn_s_setprio(3);
     __shared__ uint64_t sums[1024];
     __shared__ int lasts[1024];
     const JobDev &J = jobs[blockIdx.x];
@@ -213,7 +219,8 @@ __global__ __launch_bounds__(1024) void slice_scan_kernel(const JobDev *__restri
         off[J.nchunks] = run;
         totals[blockIdx.x] = run;
         // end state for the next call on this slicer object: clock after the last chunk, signs of the last sample, last symbol
-        totals[njobs + blockIdx.x] = s_end[J.chunk0 + blockIdx.x + J.nchunks];
+        const JobDev &I = iter_jobs[blockIdx.x];           // the state arrays are laid out by the ITERATION's chunks
+        totals[njobs + blockIdx.x] = s_end[I.chunk0 + blockIdx.x + I.nchunks];
         const int64_t last = J.n - 1;
         uint64_t signs = (J.bi[last >> 6] >> (last & 63)) & 1;
         if (J.quad) signs |= ((J.bq[last >> 6] >> (last & 63)) & 1) << 1;
@@ -236,6 +243,7 @@ __global__ __launch_bounds__(kBlock) void slice_pack_kernel(const JobDev *__rest
                                                         const uint64_t *__restrict__ symmap, const uint64_t *__restrict__ offset,
                                                         const uint8_t *__restrict__ prevsym)
 {
+    __builtin_amdgcn_s_setprio(3);          // short kernels on the slicer stream's critical path (see slice_iter_kernel)
     const int64_t gc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gc >= total_chunks) return;
     const int j = find_job(jobs, njobs, gc);
@@ -337,7 +345,7 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
     // (65536 lanes), but never below 1024 samples.  PM_SLICER_CHUNK_WORDS overrides (tuning).
     int64_t all_words = 0;
     for (int j = 0; j < njobs; ++j) all_words += pm_cdiv(jobs[j].n, 64);
-    int64_t lc_words = std::max<int64_t>(16, std::min<int64_t>(pm_cdiv(all_words, 65536), 1024));
+    int64_t lc_words = std::max<int64_t>(16, std::min<int64_t>(pm_cdiv(all_words, ctx->sl_target_lanes), 1024));
     if (const char *e = getenv("PM_SLICER_CHUNK_WORDS")) { if (atoi(e) > 0) lc_words = atoi(e); }
     std::vector<JobDev> jd;
     jd.reserve(njobs);
@@ -384,16 +392,27 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
     const int nj = (int)jd.size();
     ctx->sl_chunk_len = (int32_t)(lc_words * 64);
     ctx->sl_chunks = total_chunks;
+    // The count / scan / pack kernels only read the symbol bitmap the iteration left: they are cut independently of it, finely
+    // (throughput kernels: ~4 waves per SIMD), however long the iteration's chunks are.
+    const int64_t le_words = std::max<int64_t>(4, std::min<int64_t>(lc_words, pm_cdiv(total_words, 262144)));
+    std::vector<JobDev> je = jd;
+    int64_t emit_chunks = 0;
+    for (JobDev &d : je) {
+        d.chunk0 = emit_chunks;
+        d.nchunks = pm_cdiv(d.nwords, le_words);
+        emit_chunks += d.nchunks;
+    }
 
     const size_t e = (size_t)total_chunks + nj;             // nchunks+1 state entries per stream
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    const size_t o_jobs = carve(sizeof(JobDev) * nj), o_sa = carve(e * 8), o_sb = carve(e * 8), o_da = carve(e), o_db = carve(e),
-                 o_cnt = carve((size_t)total_chunks * 4), o_ls = carve(total_chunks), o_off = carve(e * 8), o_ps = carve(total_chunks),
+    const size_t ee = (size_t)emit_chunks + nj;
+    const size_t o_jobs = carve(sizeof(JobDev) * nj), o_ejobs = carve(sizeof(JobDev) * nj), o_sa = carve(e * 8), o_sb = carve(e * 8), o_da = carve(e),
+                 o_db = carve(e), o_cnt = carve((size_t)emit_chunks * 4), o_ls = carve(emit_chunks), o_off = carve(ee * 8), o_ps = carve(emit_chunks),
                  o_sym = carve((size_t)total_words * 8), o_tot = carve((size_t)nj * 8 * 4), o_tail = carve((size_t)nj * 4), o_ch = carve(256);
     if (int rc = pm_scratch_reserve(ctx, off)) return rc;
     char *base = (char *)ctx->d_scratch;
-    JobDev *d_jobs = (JobDev *)(base + o_jobs);
+    JobDev *d_jobs = (JobDev *)(base + o_jobs), *d_ejobs = (JobDev *)(base + o_ejobs);
     uint64_t *sa = (uint64_t *)(base + o_sa), *sb = (uint64_t *)(base + o_sb);
     uint8_t *da = (uint8_t *)(base + o_da), *db = (uint8_t *)(base + o_db);
     uint32_t *cnt = (uint32_t *)(base + o_cnt);
@@ -401,10 +420,11 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
     uint64_t *offs = (uint64_t *)(base + o_off), *symmap = (uint64_t *)(base + o_sym), *totals = (uint64_t *)(base + o_tot);
     int *changed = (int *)(base + o_ch);
     uint32_t *tails = (uint32_t *)(base + o_tail);
-    for (int k = 0; k < nj; ++k) jd[k].tail = tails + k;
+    for (int k = 0; k < nj; ++k) jd[k].tail = je[k].tail = tails + k;
     PM_HIP(hipMemsetAsync(tails, 0, (size_t)nj * 4, ctx->stream));
 
     PM_HIP(hipMemcpyAsync(d_jobs, jd.data(), sizeof(JobDev) * nj, hipMemcpyHostToDevice, ctx->stream));
+    PM_HIP(hipMemcpyAsync(d_ejobs, je.data(), sizeof(JobDev) * nj, hipMemcpyHostToDevice, ctx->stream));
     const unsigned grid = (unsigned)pm_cdiv(total_chunks, kBlock);
     hipLaunchKernelGGL(slice_init_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_jobs, nj, total_chunks, sa, sb, da, db, changed);
 
@@ -416,7 +436,7 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
     bool converged = false;
     while (!converged) {
         // a burst of iterations between host checks keeps the launch queue full
-        const int burst = 4;
+        const int burst = 8;                               // iterations after the fixed point find nothing dirty and cost microseconds
         for (int b = 0; b < burst; ++b) {
             PmProf prof(ctx, PM_K_SLICE_ITER);
             hipLaunchKernelGGL(slice_iter_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_jobs, nj, (int)lc_words, total_chunks,
@@ -438,11 +458,12 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
 
     {
         PmProf prof(ctx, PM_K_SLICE_EMIT);
-        hipLaunchKernelGGL(slice_count_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_jobs, nj, (int)lc_words, total_chunks, symmap, cnt, ls);
-        hipLaunchKernelGGL(slice_scan_kernel, dim3(nj), dim3(1024), 0, ctx->stream, d_jobs, cnt, ls, offs, ps, totals, sa, nj);
+        const unsigned egrid = (unsigned)pm_cdiv(emit_chunks, kBlock);
+        hipLaunchKernelGGL(slice_count_kernel, dim3(egrid), dim3(kBlock), 0, ctx->stream, d_ejobs, nj, (int)le_words, emit_chunks, symmap, cnt, ls);
+        hipLaunchKernelGGL(slice_scan_kernel, dim3(nj), dim3(1024), 0, ctx->stream, d_ejobs, cnt, ls, offs, ps, totals, sa, nj, d_jobs);
         for (const JobDev &d : jd)
             if (d.cap > 0) PM_HIP(hipMemsetAsync(d.data32, 0, align_up((size_t)d.cap, 4), ctx->stream));
-        hipLaunchKernelGGL(slice_pack_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_jobs, nj, (int)lc_words, total_chunks, symmap, offs, ps);
+        hipLaunchKernelGGL(slice_pack_kernel, dim3(egrid), dim3(kBlock), 0, ctx->stream, d_ejobs, nj, (int)le_words, emit_chunks, symmap, offs, ps);
     }
     std::vector<uint64_t> h_tot((size_t)nj * 4);
     std::vector<uint32_t> h_tail(nj);
@@ -507,6 +528,13 @@ int pm_slice_quadrature(pm_ctx *ctx, const uint64_t *d_bits_i, const uint64_t *d
     const int rc = pm_slice_batch(ctx, &job, 1);
     *h_count = job.count;
     return rc;
+}
+
+int pm_slicer_tune(pm_ctx *ctx, int64_t target_lanes)
+{
+    PM_ARG(ctx != nullptr && target_lanes >= 0);
+    ctx->sl_target_lanes = target_lanes ? std::max<int64_t>(64, target_lanes) : 65536;
+    return PM_OK;
 }
 
 int pm_slicer_stats(pm_ctx *ctx, int32_t *iterations, int32_t *chunk_len, int64_t *chunks)

@@ -26,6 +26,7 @@ class Context:
         key = (os.getpid(), main.device, int(index))
         if key not in cls._side:
             cls._side[key] = cls(main.device, high_priority=True)
+            check(lib().pm_slicer_tune(cls._side[key]._h, 12288))     # fewer, longer chunks while other streams share the CUs
         return cls._side[key]
 
     @classmethod

@@ -7,7 +7,7 @@ import numpy as np
 
 from ._native import SliceJob, SlicerParams, SlicerState, check, lib
 from .data_classes import AddressedArray, DeviceIQ, IQData, SignBits
-from .device import Context, DeviceBuffer
+from .device import Context, DeviceBuffer, NativeError
 
 
 class _SlicerBase:
@@ -81,29 +81,57 @@ def slice_batch(slicers, bitmaps, ctx=None):
     out = [None] * len(slicers)
     for base in range(0, len(slicers), 64):
         group = list(range(base, min(base + 64, len(slicers))))
-        jobs = (SliceJob * len(group))()
-        bufs = []
-        for j, k in enumerate(group):
-            sl, (bi, bq, n) = slicers[k], bitmaps[k]
-            cap = n * sl.bits_per_symbol // 8 + 5          # at most one symbol per sample, plus a byte the last call left open
-            sl._ctx = sl._ctx or ctx
-            data = ctx.scratch((sl._own_key(), "bytes"), cap + 4, np.uint8)
-            addr = ctx.scratch((sl._own_key(), "addr"), cap, np.int64)
-            bufs.append((data, addr))
-            jobs[j].d_bits_i = bi.ptr if bi is not None else None
-            jobs[j].d_bits_q = bq.ptr if bq is not None else None
-            jobs[j].n = n
-            jobs[j].params = sl._params()
-            jobs[j].d_data, jobs[j].d_addr, jobs[j].cap = data.ptr, addr.ptr, cap
-            jobs[j].h_state = ctypes.pointer(sl._state)
-        check(lib().pm_slice_batch(ctx.handle, jobs, len(group)))
-        it, cl, nc = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
-        lib().pm_slicer_stats(ctx.handle, ctypes.byref(it), ctypes.byref(cl), ctypes.byref(nc))
-        for j, k in enumerate(group):
-            slicers[k].last_stats = {"iterations": it.value, "chunk_len": cl.value, "chunks": nc.value}
-            slicers[k].phase_clock, slicers[k].streamaddress = slicers[k]._state.phase_clock, slicers[k]._state.streamaddress
-            out[k] = AddressedArray(bufs[j][0].download(jobs[j].count), bufs[j][1].download(jobs[j].count))
+        saved = [SlicerState.from_buffer_copy(slicers[k]._state) for k in group]
+        try:
+            _slice_group(ctx, slicers, bitmaps, group, out, tight=True)
+        except NativeError as e:                      # a stream produced more than twice its nominal symbol count: full-size buffers
+            if "capacity" not in str(e):
+                raise
+            for k, st in zip(group, saved):
+                ctypes.memmove(ctypes.byref(slicers[k]._state), ctypes.byref(st), ctypes.sizeof(SlicerState))
+            _slice_group(ctx, slicers, bitmaps, group, out, tight=False)
     return out
+
+
+_TIGHT_FACTOR = 2.2
+
+
+def _slice_group(ctx, slicers, bitmaps, group, out, tight):
+    jobs = (SliceJob * len(group))()
+    # One device block for the whole batch's output (addresses first, then bytes) and ONE device-to-host copy per batch.  The
+    # hard bound is one symbol per sample; the clock can at most double its nominal rate (every crossing pulls it towards zero,
+    # from where half a symbol period remains), so 2.2x the nominal count is tried first.
+    caps, a_off, d_off, at = [], [], [], 0
+    for k in group:
+        n, sl = bitmaps[k][2], slicers[k]
+        cap = n * sl.bits_per_symbol // 8 + 5
+        if tight:
+            cap = min(cap, int(n * sl.bits_per_symbol / (8.0 * sl.samples_per_symbol) * _TIGHT_FACTOR) + 64)
+        caps.append(cap)
+        a_off.append(at)
+        at += cap * 8
+    for cap in caps:
+        d_off.append(at)
+        at += (cap + 4 + 7) // 8 * 8
+    block = ctx.scratch((slicers[group[0]]._own_key(), "slice_out"), at, np.uint8)
+    for j, k in enumerate(group):
+        sl, (bi, bq, n) = slicers[k], bitmaps[k]
+        sl._ctx = sl._ctx or ctx
+        jobs[j].d_bits_i = bi.ptr if bi is not None else None
+        jobs[j].d_bits_q = bq.ptr if bq is not None else None
+        jobs[j].n = n
+        jobs[j].params = sl._params()
+        jobs[j].d_data, jobs[j].d_addr, jobs[j].cap = block.ptr.value + d_off[j], block.ptr.value + a_off[j], caps[j]
+        jobs[j].h_state = ctypes.pointer(sl._state)
+    check(lib().pm_slice_batch(ctx.handle, jobs, len(group)))
+    it, cl, nc = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
+    lib().pm_slicer_stats(ctx.handle, ctypes.byref(it), ctypes.byref(cl), ctypes.byref(nc))
+    host = block.download(at)
+    for j, k in enumerate(group):
+        cnt = jobs[j].count
+        slicers[k].last_stats = {"iterations": it.value, "chunk_len": cl.value, "chunks": nc.value}
+        slicers[k].phase_clock, slicers[k].streamaddress = slicers[k]._state.phase_clock, slicers[k]._state.streamaddress
+        out[k] = AddressedArray(host[d_off[j]:d_off[j] + cnt].copy(), host[a_off[j]:a_off[j] + cnt * 8].view(np.int64).copy())
 
 
 class BinarySlicer(_SlicerBase):

@@ -225,6 +225,16 @@ def test_slicers_continue_across_calls(ctx, kind):
             parts_d.append(got.data)
             parts_a.append(got.address)
         assert np.array_equal(np.concatenate(parts_d), whole_d) and np.array_equal(np.concatenate(parts_a), whole_a)
+    # output buffers are sized for 2.2x the nominal symbol count; when a stream exceeds that the batch is redone with the hard bound
+    import pymodem_amd.slicer as slicer_mod
+    s.tune()
+    slicer_mod._TIGHT_FACTOR = 0.001
+    try:
+        a1, a2 = s.slice(xi[:70000]), s.slice(xi[70000:])
+    finally:
+        slicer_mod._TIGHT_FACTOR = 2.2
+    whole = O.BinarySlicer(48000, "1200", {"lock_rate": "0.77"}).slice(xi)
+    assert np.array_equal(np.concatenate([a1.data, a2.data]), whole[0]) and np.array_equal(np.concatenate([a1.address, a2.address]), whole[1])
     s.tune()                                   # retuning returns the object to the just-built state
     again = s.slice(xi)
     fresh = O.BinarySlicer(48000, "1200", {"lock_rate": "0.77"}).slice(xi)
