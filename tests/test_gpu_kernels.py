@@ -358,3 +358,74 @@ def test_fir_signs_fused(ctx, m):
                 y = O.fir_canon(x, h)
                 want = (-y if flags else y) >= 0
                 assert np.array_equal(got, want), (m, n, x.dtype, flags)
+
+
+def _signs(ctx, fn, x, h, flags=0):
+    n, m = len(x), len(h)
+    nout = n - m + 1
+    bits = ctx.empty((nout + 63) // 64 + 1, np.uint64)
+    dx, dh = ctx.upload(x), ctx.upload(h)
+    chk(fn(ctx.handle, dx.ptr, n, dh.ptr, m, bits.ptr, flags))
+    words = bits.download()
+    got = np.unpackbits(words.view(np.uint8), bitorder="little")
+    assert not got[nout:((nout + 63) // 64) * 64].any()                  # padding bits of the last word are zero
+    return got[:nout].astype(bool)
+
+
+@pytest.mark.parametrize("m", [16, 17, 40, 100, 241, 961])
+def test_fir_signs_on_the_decision_boundary(ctx, m):
+    """The fused sign output on inputs made to sit ON the decision boundary: outputs that are exactly zero, tiny against their
+    neighbours, sums that cancel, huge dynamic range, denormals, values beyond binary32, non-finite samples -- every bit must be the
+    sign of the canonical binary64 sum (any reduced-precision shortcut would show here)."""
+    rng = np.random.default_rng(900 + m)
+    n = 3 * 4096 + m + 77
+    h_rand = rng.standard_normal(m)
+    h_anti = h_rand - h_rand[::-1]                                       # antisymmetric: symmetric inputs give exact zeros
+    cases = []
+    base = rng.standard_normal(n)
+    cases.append(("noise", base, h_rand))
+    sym = np.concatenate([base[:n // 2], base[:n - n // 2][::-1]])
+    cases.append(("cancelling", np.round(sym * 64) / 64, np.round(h_anti * 64) / 64))      # exact products: true zeros appear
+    quiet = base * 1e-9
+    quiet[::4096] = 1e6                                                  # one huge sample per tile: E is large, most outputs fall back
+    cases.append(("dynamic range", quiet, h_rand))
+    cases.append(("zeros", np.zeros(n), h_rand))
+    cases.append(("denormal", base * 1e-310, h_rand))
+    cases.append(("beyond binary32", base * 1e200, h_rand))
+    cases.append(("tiny taps", base, h_rand * 1e-60))
+    nf = base.copy()
+    nf[1000], nf[5000], nf[9000] = np.inf, -np.inf, np.nan
+    cases.append(("non-finite", nf, h_rand))
+    slow = np.sin(np.arange(n) * 0.002) * 1e4 + 1e-3 * rng.standard_normal(n)       # many outputs close to zero at each crossing
+    cases.append(("slow sine", slow, np.ones(m) / m))
+    for name, x, h in cases:
+        for flags in (0, 1):
+            got = _signs(ctx, L().pm_fir_signs_f64, x, h, flags)
+            with np.errstate(all="ignore"):
+                y = O.fir_canon(x, h)
+                want = (-y if flags else y) >= 0
+            assert np.array_equal(got, want), (name, m, flags, int(np.count_nonzero(got != want)))
+    xi = np.clip(np.rint(base * 8000), -32768, 32767).astype(np.int16)
+    xi[2000:2600] = 0
+    for flags in (0, 1):
+        got = _signs(ctx, L().pm_fir_signs_i16, xi, h_anti, flags)
+        y = O.fir_canon(xi, h_anti)
+        assert np.array_equal(got, (-y if flags else y) >= 0), ("int16", m, flags)
+
+
+def test_fir_signs_full_size_matches_exact_kernel(ctx):
+    """28.8 M samples of an AFSK-correlator-like stream: the fused bitmap against (unfused FIR output >= 0)."""
+    rng = np.random.default_rng(4)
+    n = 28_800_000
+    t = np.arange(n)
+    x = np.sin(2 * np.pi * t / 40.0 + 3.0 * np.sin(t / 9000.0)) * (1.0 + 0.5 * np.sin(t / 70000.0)) * 3e5 + 2e4 * rng.standard_normal(n)
+    from pymodem_amd import taps as T
+    h = T.windowed_sinc(100, 900.0, 48000.0, pass_zero=True)
+    dx, dh = ctx.upload(x), ctx.upload(h)
+    nout = n - len(h) + 1
+    y = ctx.empty(nout, np.float64)
+    chk(L().pm_fir_valid_f64(ctx.handle, dx.ptr, n, dh.ptr, len(h), y.ptr, 0))
+    bits = ctx.empty((nout + 63) // 64 + 1, np.uint64)
+    chk(L().pm_fir_signs_f64(ctx.handle, dx.ptr, n, dh.ptr, len(h), bits.ptr, 0))
+    got = np.unpackbits(bits.download().view(np.uint8), bitorder="little")[:nout].astype(bool)
+    assert np.array_equal(got, y.download() >= 0)

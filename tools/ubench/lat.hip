@@ -100,6 +100,42 @@ static void copy_peak()
     hipFree(a); hipFree(b); hipFree(o);
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+// Sustained packed-f32 FMA rate (v_pk_fma_f32: two fmas per lane per instruction).
+__global__ __launch_bounds__(256) void pkfma_peak(float *out, float c1, float c2, int iters)
+{
+    f2 a[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = f2{(float)threadIdx.x + j, (float)j};
+    const f2 g = {c1, c1}, b = {c2, c2};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = __builtin_elementwise_fma(a[j], g, b);
+    }
+    float s = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += a[j].x + a[j].y;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+static void pk_peak()
+{
+    float *out;
+    const int blocks = 256 * 8, threads = 256, iters = 20000;
+    hipMalloc(&out, sizeof(float) * blocks * threads);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    pkfma_peak<<<blocks, threads>>>(out, 0.999f, 0.5f, 100);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        pkfma_peak<<<blocks, threads>>>(out, 0.999f, 0.5f, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double fma = (double)blocks * threads * 32.0 * iters;
+        printf("sustained v_pk_fma_f32: %.1f ms  %.2f TFMA/s = %.1f TFLOP/s\n", ms, fma / ms / 1e9, 2 * fma / ms / 1e9);
+    }
+    hipFree(out);
+}
+
 static void peak()
 {
     double *out;
@@ -123,6 +159,7 @@ int main()
 {
     copy_peak();
     peak();
+    pk_peak();
     for (int threads : {64, 128, 256, 512}) {
         const int blocks = 256;
         run<0>("dependent v_add_f64", 1, blocks, threads);
