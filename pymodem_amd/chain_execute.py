@@ -99,7 +99,7 @@ class RecordingPipeline:
       demod   FIR / correlator / loop kernels (vector-f64 ALU and HBM)                 default stream, caller's thread
       slice   chunk-parallel timing recovery: ~1 resident wave per SIMD, dependent-     `slice_workers` high-priority side streams,
               latency bound, so TWO recordings' slicers share the GPU almost for free    one thread each
-      host    LFSR + codec (native, GIL released)                                       two threads, each fanning out to the pool
+      host    LFSR + codec (native, GIL released)                                       three threads, each fanning out to the pool
       finish  the caller's `finish(rows per chain)`: gather / de-dup                    one thread, submission order (collectives)
 
     While recordings k and k-1 are being sliced, recording k+1 is demodulated and k-2 finished.  The only GPU buffers that cross
@@ -110,7 +110,7 @@ class RecordingPipeline:
         from collections import deque
         self._workers = max(1, int(slice_workers))
         self._slice = ThreadPoolExecutor(max_workers=self._workers)
-        self._host = ThreadPoolExecutor(max_workers=2)        # LFSR + codec of two recordings at a time (each fans out to the pool)
+        self._host = ThreadPoolExecutor(max_workers=3)        # LFSR + codec of up to three recordings at a time (each fans out to the pool)
         self._finish = ThreadPoolExecutor(max_workers=1)
         self._inflight = deque()
         self._n = 0
