@@ -4,6 +4,9 @@
 A step = one pass of the rank's demod_chains (modem -> slicer on the GPU, LFSR -> codec native on the host, packet
 gather + de-dup) over one synthetic recording that is already resident in HBM.  Weak scaling: every rank runs
 --chains-per-gpu chains, chains are independent (no data-path collective); the only exchange is the packet gather.
+By default successive steps are pipelined the way a service decoding one recording after another would run them
+(chain_execute.RecordingPipeline, --overlap 2): demod kernels, slicer streams and host stages of neighbouring steps overlap;
+all K steps complete inside the timed region.  --overlap 0 times them strictly one after the other.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--samples S] [--chains-per-gpu C]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -22,7 +25,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the 8-tap FIR moves 6.3 TB/s, a plain copy kernel 4.7 (profiles/r01_ubench.txt)
 
 
 # ---- workloads: BASELINE.json configs as lists of 'demod_chain' lines --------------------------------------------

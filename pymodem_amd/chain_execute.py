@@ -5,8 +5,11 @@
 `process_chains_device` runs a whole group of independent chains over one recording the way the hardware wants it:
 chains with the same front end share it (every chain of afsk_1200_ax25_super_opt.json has the same input band-pass;
 the qpsk_2400.json chains share band-pass, AGC and Hilbert pair), MPSK carrier loops of such a group run in one
-launch (one lane each), all slicers run in one pm_slice_batch call, and the host-integer stages (LFSR, codec) of the
-chains run concurrently in a small thread pool (the native calls release the GIL).
+launch (one lane each), AFSK correlator banks that share their mark filters run as one pm_afsk_correlate_group launch, all
+slicers run in one pm_slice_batch call, and the host-integer stages (LFSR, codec) of the chains run concurrently in a
+small thread pool (the native calls release the GIL).
+`RecordingPipeline` overlaps those stages ACROSS successive recordings (separate HIP streams and threads).
+`NativeChain` is the Python face of the whole-chain C entry points (pm_chain_create / pm_chain_run).
 """
 import ctypes
 from concurrent.futures import ThreadPoolExecutor

@@ -14,11 +14,11 @@
 // crossing, so a few iterations suffice on real signals; the worst case (no crossings at all) degrades
 // to nchunks iterations, i.e. sequential cost, never to a wrong answer.
 //
-// A lone wave is instruction-issue bound (~5 cycles per VALU instruction), so the sample step is kept to
-// about ten instructions: the symbol decision and the crossing enter as multiplicands (x - sps*{0,1}
-// through one fma, x*{1,lock}), which is bitwise the reference's `clk -= sps` / `clk *= lock_rate`, and each
-// run leaves a bitmap of the samples at which it took a symbol.  After the fixed point a count/scan/pack
-// pipeline turns symbol bitmap + sign bitmap(s) into bytes and the 1-based address of each byte's last symbol.
+// A lone wave pays both the loop-carried chain (add -> compare -> select -> multiply, ~45 cycles with the latencies measured
+// by tools/ubench) and the issue of the ~12 VALU instructions of a step (~5.5 cycles each): ~85 cycles per sample.  Each run
+// leaves a bitmap of the samples at which it took a symbol.  After the fixed point a count/scan/pack pipeline, chunked on its
+// own (finely), turns symbol bitmap + sign bitmap(s) into bytes and the 1-based address of each byte's last symbol.  A slicer
+// object's state (clock, last sign, open byte, address count, differential state) enters and leaves through pm_slicer_state.
 #include "pm_common.h"
 #include <algorithm>
 #include <cstdlib>
@@ -64,8 +64,7 @@ __device__ __forceinline__ int find_job(const JobDev *jobs, int njobs, int64_t g
 // 32 samples, most significant bit first: zc = crossing flags (bit 31 = first sample).  Returns the symbol flags in
 // the same orientation.  clk is updated in place.
 //
-// A lone wave is bound by the dependent-issue latency of this loop-carried chain (~15 cycles per level), so the step
-// is arranged in four levels: a = clk + 1.0 | b = a - sps speculatively, beside the compare a >= thr | c = select(b, a) |
+// The step is arranged in four levels: a = clk + 1.0 | b = a - sps speculatively, beside the compare a >= thr | c = select(b, a) |
 // clk = c * m, where m = {lock, 1.0} is picked from the crossing flag off the chain (c * 1.0 == c exactly).  Every
 // arithmetic operation is the reference's own: clk + 1.0, clk >= thr, clk - sps, clk * lock_rate.
 __device__ __forceinline__ uint32_t step32(double &clk, uint32_t zc, double thr, double neg_sps, double lock)
