@@ -429,3 +429,38 @@ def test_fir_signs_full_size_matches_exact_kernel(ctx):
     chk(L().pm_fir_signs_f64(ctx.handle, dx.ptr, n, dh.ptr, len(h), bits.ptr, 0))
     got = np.unpackbits(bits.download().view(np.uint8), bitorder="little")[:nout].astype(bool)
     assert np.array_equal(got, y.download() >= 0)
+
+
+def test_fir_limits_and_unaligned_buffers(ctx):
+    """Largest supported filter (8192 taps: the LDS image needs the raised dynamic-LDS limit), one tap more is refused, and device
+    pointers that are not 16-byte aligned take the scalar load/store paths of every FIR-class kernel with the same bits."""
+    from pymodem_amd import NativeError
+    rng = np.random.default_rng(8192)
+    h = rng.standard_normal(8192)
+    x = rng.standard_normal(8192 + 3000)
+    assert np.array_equal(fir_gpu(ctx, x, h), O.fir_canon(x, h))
+    xi = np.clip(np.rint(rng.standard_normal(8192 + 700) * 8000), -32768, 32767).astype(np.int16)
+    assert np.array_equal(fir_gpu(ctx, xi, h), O.fir_canon(xi, h))
+    dx, dh, dy = ctx.upload(x), ctx.upload(np.ones(8193)), ctx.empty(len(x), np.float64)
+    with pytest.raises(NativeError):
+        chk(L().pm_fir_valid_f64(ctx.handle, dx.ptr, len(x), dh.ptr, 8193, dy.ptr, 0))
+    # unaligned: inputs and outputs start one element into their allocations
+    m, n = 45, 9000
+    h = rng.standard_normal(m)
+    dh = ctx.upload(h)
+    xf = rng.standard_normal(n + 1)
+    big_in, big_out = ctx.upload(xf), ctx.empty(n + 2, np.float64)
+    vin, vout = big_in.view(1, n), big_out.view(1, n - m + 1)
+    chk(L().pm_fir_valid_f64(ctx.handle, vin.ptr, n, dh.ptr, m, vout.ptr, 0))
+    assert np.array_equal(vout.download(), O.fir_canon(xf[1:], h))
+    xs = np.clip(np.rint(rng.standard_normal(n + 1) * 8000), -32768, 32767).astype(np.int16)
+    big_i = ctx.upload(xs)
+    chk(L().pm_fir_valid_i16(ctx.handle, big_i.view(1, n).ptr, n, dh.ptr, m, vout.ptr, 0))
+    assert np.array_equal(vout.download(), O.fir_canon(xs[1:], h))
+    t = [ctx.upload(rng.standard_normal(m)) for _ in range(4)]
+    chk(L().pm_afsk_correlate(ctx.handle, vin.ptr, n, t[0].ptr, t[1].ptr, t[2].ptr, t[3].ptr, m, vout.ptr))
+    assert np.array_equal(vout.download(), O.afsk_correlate_canon(xf[1:], *[b.download() for b in t]))
+    bits = ctx.empty((n - m + 1 + 63) // 64 + 1, np.uint64)
+    chk(L().pm_fir_signs_f64(ctx.handle, vin.ptr, n, dh.ptr, m, bits.ptr, 0))
+    got = np.unpackbits(bits.download().view(np.uint8), bitorder="little")[:n - m + 1].astype(bool)
+    assert np.array_equal(got, O.fir_canon(xf[1:], h) >= 0)
