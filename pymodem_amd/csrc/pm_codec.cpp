@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 #include <unordered_map>
 #include <vector>
 
@@ -350,8 +351,11 @@ struct Il2p : pm_codec {
     bool fail = false;
     std::vector<uint8_t> data;
 
+    const uint8_t *feasible = nullptr;
+
     Il2p(int src, bool crc, bool norx, int md, int tol) : want_crc(crc), disable_rs(norx), min_dist(md), sync_tol(tol)
     {
+        feasible = sync_feasible(tol);
         source = src;
         memset(buf, 0, sizeof(buf));
     }
@@ -366,9 +370,9 @@ struct Il2p : pm_codec {
             // sync search (il2p.py:367-376): the last 32 bits before each of the byte's 8 bit positions, tested without a
             // per-bit loop; a hit (rare) hands the rest of the byte to the state machine
             const uint64_t win = ((uint64_t)word << 8) | d[k];
-            // exact match wanted (sync_tol 0, every bundled config): the previous byte lies wholly inside all eight candidate
-            // windows, so one table lookup on it tells which bit offsets can match at all -- almost always none
-            if (sync_tol == 0 && !sync_feasible()[(win >> 8) & 0xFF]) {
+            // The two bytes before the current one lie wholly inside all eight candidate windows, so one table lookup on them
+            // tells which bit offsets can still be within sync_tol of either pattern -- almost always none
+            if (feasible && !feasible[(win >> 8) & 0xFFFF]) {
                 word = (uint32_t)win;
                 nbits += 8;
                 continue;
@@ -398,22 +402,25 @@ struct Il2p : pm_codec {
         }
     }
 
-    // feasible[b] != 0 iff, with b as the byte before the current one, some bit offset S lets the 24-bit sync word 0xF15E48 (or
-    // the 32-bit pattern 0x5D57DF7F) end inside the current byte: b supplies window bits S+1 .. S+8 of either pattern.
-    static const uint8_t *sync_feasible()
+    // sync_feasible(tol)[v] != 0 iff, with v as the 16 bits before the current byte, some bit offset S lets the 24-bit sync word
+    // 0xF15E48 or the 32-bit pattern 0x5D57DF7F end inside the current byte within `tol` mismatches: v supplies window bits
+    // S+1 .. S+16 of either pattern, and they alone must not exceed the tolerance.  One 64 KB table per tolerance, built once.
+    static const uint8_t *sync_feasible(int tol)
     {
-        static const struct Table {
-            uint8_t t[256];
-            Table()
-            {
-                memset(t, 0, sizeof(t));
-                for (int S = 0; S < 8; ++S) {
-                    t[(0xF15E48u >> (S + 1)) & 0xFF] |= (uint8_t)(1u << S);
-                    t[(0x5D57DF7Fu >> (S + 1)) & 0xFF] |= (uint8_t)(1u << S);
-                }
+        constexpr int kMaxTol = 8;                       // beyond that nearly every value is feasible: no filter
+        if (tol < 0 || tol > kMaxTol) return nullptr;
+        static std::once_flag once[kMaxTol + 1];
+        static std::vector<uint8_t> table[kMaxTol + 1];
+        std::call_once(once[tol], [tol] {
+            std::vector<uint8_t> t(65536, 0);
+            for (int S = 0; S < 8; ++S) {
+                const uint32_t a = (0xF15E48u >> (S + 1)) & 0xFFFF, b = (0x5D57DF7Fu >> (S + 1)) & 0xFFFF;
+                for (uint32_t v = 0; v < 65536; ++v)
+                    if (__builtin_popcount(v ^ a) <= tol || __builtin_popcount(v ^ b) <= tol) t[v] |= (uint8_t)(1u << S);
             }
-        } table;
-        return table.t;
+            table[tol].swap(t);
+        });
+        return table[tol].data();
     }
 
     static void descramble(uint8_t *p, int n)

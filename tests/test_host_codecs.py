@@ -140,3 +140,35 @@ def test_packet_table_path_matches_the_object_path(golden, config_lines):
         assert [p.streamaddress for p in u] == g[k + "__uniq_addr"].tolist() and all(p.ValidCRC for p in u)
         for ci in range(len(lines)):
             assert [p.streamaddress for p in t.packets(ci)] == g[f"{k}__c{ci}_pkt_addr"].tolist()
+
+
+@pytest.mark.parametrize("tol", [0, 1, 2, 3, 5])
+def test_il2p_sync_search_at_every_bit_offset(tol):
+    """Real IL2P frames (pymodem_amd.siggen) dropped at random BIT offsets into random bits, their sync word 0xF15E48 hit by up to
+    tol+1 bit errors anywhere in it: frames within the tolerance must come out, the others must not, exactly as the bit-serial
+    oracle decides -- the table-filtered byte-wise search sees every offset."""
+    from pymodem_amd import siggen
+    from pymodem_amd.codecs import IL2PCodec
+    from pymodem_amd.data_classes import AddressedArray
+    rng = np.random.default_rng(77 + tol)
+    chunks, planted, within = [], 0, 0
+    for k in range(160):
+        chunks.append(rng.integers(0, 2, int(rng.integers(40, 400)), dtype=np.uint8))
+        info = [int(c) for c in rng.integers(32, 127, int(rng.integers(1, 40)))]
+        frame = np.array(siggen.il2p_frame_bits("CQ", f"N0CAL{k % 10}", info, src_ssid=k % 16, preamble=2), dtype=np.uint8)
+        flips = int(rng.integers(0, tol + 2))
+        for f in rng.choice(24, flips, replace=False):
+            frame[16 + f] ^= 1                               # the sync word follows the 2 preamble bytes
+        chunks.append(frame)
+        planted += 1
+        within += flips <= tol
+    bits = np.concatenate(chunks + [rng.integers(0, 2, 300, dtype=np.uint8)])
+    bits = bits[:len(bits) // 8 * 8]
+    data = np.packbits(bits)
+    addr = np.arange(len(data), dtype=np.int64) * 8 + 3
+    c = IL2PCodec(ident="x", crc=True, min_dist=0, sync_tol=tol)
+    o = O.IL2PCodec("x", True, False, 0, tol)
+    got, want = c.decode(AddressedArray(data, addr)), o.decode(data, addr)
+    assert pk(got) == pk(want), (tol, len(got), len(want))
+    # the frames inside the tolerance really are decoded (a loose tolerance also fires inside the random filler and eats some)
+    assert within > 20 and len(want) >= within * (0.9 if tol <= 2 else 0.4)
