@@ -103,7 +103,8 @@ class RecordingPipeline:
       slice   chunk-parallel timing recovery: ~1 resident wave per SIMD, dependent-     `slice_workers` high-priority side streams,
               latency bound, so TWO recordings' slicers share the GPU almost for free    one thread each
       host    LFSR + codec (native, GIL released)                                       three threads, each fanning out to the pool
-      finish  the caller's `finish(rows per chain)`: gather / de-dup                    one thread, submission order (collectives)
+      finish  the caller's `finish(rows per chain)`: the packet exchange                 one thread, submission order (collectives)
+      post    the caller's `post(...)`: rank 0's indexing and de-dup                     two threads
 
     While recordings k and k-1 are being sliced, recording k+1 is demodulated and k-2 finished.  The only GPU buffers that cross
     stages are the sign bitmaps (one bit per sample), kept in slice_workers + 2 rotating slots (demod runs one recording ahead); a GPU event, not a host wait,
@@ -115,14 +116,16 @@ class RecordingPipeline:
         self._slice = ThreadPoolExecutor(max_workers=self._workers)
         self._host = ThreadPoolExecutor(max_workers=3)        # LFSR + codec of up to three recordings at a time (each fans out to the pool)
         self._finish = ThreadPoolExecutor(max_workers=1)
+        self._post = ThreadPoolExecutor(max_workers=2)        # whatever follows the ordered step (rank 0's indexing and de-dup)
         self._inflight = deque()
         self._n = 0
         self._slots = self._workers + 2                      # bitmaps: one set per slicer in flight, one being written, one ready
         self._events = [None] * self._slots
         self.stage_seconds = {"demod": 0.0, "slice": 0.0, "host": 0.0, "finish": 0.0}   # busy time per stage, summed over recordings
 
-    def submit(self, chains, input_audio, finish=None):
-        """Start one recording; returns a Future of finish(rows per chain) (rows per chain when finish is None)."""
+    def submit(self, chains, input_audio, finish=None, post=None):
+        """Start one recording; returns a Future of post(finish(rows per chain)) (either may be None = identity).  `finish` calls
+        run one at a time in submission order (the place for collectives); `post` calls run in parallel with later recordings."""
         import time
         acc = self.stage_seconds
         slots = self._slots
@@ -161,12 +164,24 @@ class RecordingPipeline:
             out = finish(rows)
             acc["finish"] += time.perf_counter() - t
             return out
-        return self._finish.submit(finish_stage)
+        f_fin = self._finish.submit(finish_stage)
+        if post is None:
+            return f_fin
+
+        def post_stage():
+            x = f_fin.result()
+            t = time.perf_counter()
+            out = post(x)
+            acc["post"] = acc.get("post", 0.0) + time.perf_counter() - t
+            return out
+        return self._post.submit(post_stage)
 
     def close(self):
+        """Waits for everything submitted."""
         self._slice.shutdown(wait=True)
         self._host.shutdown(wait=True)
         self._finish.shutdown(wait=True)
+        self._post.shutdown(wait=True)
 
 
 def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced_only=False, _bitmaps_only=False, _slot=0):

@@ -4,6 +4,8 @@ records to rank 0 for the cross-chain de-dup (PacketMetaArray.Correlate, packet_
 reference is a multiprocessing.Queue (pymodem.py:140,157-163).  One process per GPU, torch.distributed:
 backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.  Payload is KBs: latency-bound.
 """
+import contextlib
+
 import numpy as np
 
 from .packet_meta import PacketMeta, PacketMetaArray
@@ -70,32 +72,39 @@ def gather_packets(packets_by_chain, chain_names, device=None):
     return unpack_packets(np.concatenate(parts), chain_names)
 
 
+_SIDE_STREAM = {}
 _GATHER_CAP = {}          # (world, nchains) -> bytes per rank of the exchange buffer; grows when a recording needs more
 
 
 def gather_rows(rows_by_chain, nchains, names, device=None):
     """The exchange step in table form: every rank's pm_packet rows in, PacketTable (all chains, config order) on rank 0, None
-    elsewhere.  ONE all_gather per recording in steady state: each rank contributes a fixed-capacity byte block
+    elsewhere.  = table_from_exchange(exchange_rows(...)); the two halves exist separately so that a pipelined caller can keep the
+    collective in one ordered thread and do the indexing / de-dup of rank 0 elsewhere."""
+    return table_from_exchange(exchange_rows(rows_by_chain, nchains, device), names)
+
+
+def exchange_rows(rows_by_chain, nchains, device=None):
+    """The collective half.  ONE all_gather per recording in steady state: each rank contributes a fixed-capacity byte block
         int64[2 + nchains]  = payload bytes, rows, rows of each global chain     (always fits)
         payload             = its rows in wire form (40-byte header + len payload bytes each, pm_packets_pack)
     The capacity is agreed without talking: every rank derives it from the headers of the previous exchange, which all ranks
     saw.  If some rank's payload does not fit, every rank sees that in the gathered headers and the exchange is repeated once
-    with the capacity they all compute from them."""
+    with the capacity they all compute from them.  Ranks other than 0 copy only the headers back from the device.
+    -> an opaque value for table_from_exchange (None on ranks other than 0)."""
     import ctypes
     import os
     import torch
     import torch.distributed as dist
-    from ._native import check, lib, packet_dtype
+    from ._native import check, lib
     from .packet_meta import PacketTable
     # PYMODEM_AMD_FORCE_GATHER=1 runs the collective even with one rank (rehearses the RCCL path on a one-GPU box)
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not os.environ.get("PYMODEM_AMD_FORCE_GATHER")):
-        return PacketTable(rows_by_chain, names)
+        return ("local", rows_by_chain)
     import time
     trace = os.environ.get("PYMODEM_AMD_GATHER_TRACE")
     tt = [time.perf_counter()]
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = torch.device(device) if device is not None else torch.device("cpu")
-    dt = packet_dtype()
     head = 8 * (2 + nchains)
     counts = np.zeros(nchains, dtype=np.int64)
     parts = []
@@ -110,37 +119,54 @@ def gather_rows(rows_by_chain, nchains, names, device=None):
     need = check(lib().pm_packets_pack(mine.ctypes.data_as(ctypes.c_void_p), len(mine), None, 0))
     key = (world, nchains)
     cap = max(_GATHER_CAP.get(key, 1 << 16), 1 << 12)
-    while True:
-        block = np.zeros(head + cap, dtype=np.uint8)
-        hdr = block[:head].view(np.int64)
-        hdr[0], hdr[1], hdr[2:] = need, len(mine), counts
-        if need <= cap:
-            check(lib().pm_packets_pack(mine.ctypes.data_as(ctypes.c_void_p), len(mine), block[head:].ctypes.data_as(ctypes.c_void_p), cap))
-        tt.append(time.perf_counter())
-        t = torch.from_numpy(block).to(dev)
-        blocks = [torch.empty_like(t) for _ in range(world)]
-        tt.append(time.perf_counter())
-        dist.all_gather(blocks, t)
-        tt.append(time.perf_counter())
-        got = torch.stack(blocks).cpu().numpy()                          # one device->host copy
-        tt.append(time.perf_counter())
-        needs = got[:, :8].copy().view(np.int64).reshape(-1)
-        most = int(needs.max())
-        _GATHER_CAP[key] = max(1 << 16, (most + most // 4 + 4095) // 4096 * 4096)       # same value on every rank
-        if most <= cap:
-            break
-        cap = _GATHER_CAP[key]                                               # someone did not fit: once more, with room
+    side = None
+    if dev.type == "cuda":                                   # copies and the collective on a high-priority stream of their own
+        side = _SIDE_STREAM.get(dev)
+        if side is None:
+            side = _SIDE_STREAM[dev] = torch.cuda.Stream(device=dev, priority=-1)
+    ctxmgr = torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
+    with ctxmgr:
+        while True:
+            block = np.zeros(head + cap, dtype=np.uint8)
+            hdr = block[:head].view(np.int64)
+            hdr[0], hdr[1], hdr[2:] = need, len(mine), counts
+            if need <= cap:
+                check(lib().pm_packets_pack(mine.ctypes.data_as(ctypes.c_void_p), len(mine), block[head:].ctypes.data_as(ctypes.c_void_p), cap))
+            tt.append(time.perf_counter())
+            t = torch.from_numpy(block).to(dev)
+            blocks = [torch.empty_like(t) for _ in range(world)]
+            tt.append(time.perf_counter())
+            dist.all_gather(blocks, t)
+            tt.append(time.perf_counter())
+            heads = torch.stack([b[:head] for b in blocks]).cpu().numpy()       # every rank needs the headers (capacity agreement)
+            hdrs = heads.copy().view(np.int64).reshape(world, 2 + nchains)
+            most = int(hdrs[:, 0].max())
+            _GATHER_CAP[key] = max(1 << 16, (most + most // 4 + 4095) // 4096 * 4096)       # same value on every rank
+            if most <= cap:
+                break
+            cap = _GATHER_CAP[key]                                               # someone did not fit: once more, with room
     if rank != 0:
         return None
-    hdrs = got[:, :head].copy().view(np.int64).reshape(world, 2 + nchains)
-    streams = [got[r, head:head + int(hdrs[r, 0])] for r in range(world)]
-    table = PacketTable.from_streams(streams, hdrs[:, 2:].sum(axis=0).tolist(), names)     # heads only; payloads stay in `got`
+    used = int(hdrs[:, 0].max())
+    with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+        got = torch.stack([b[head:head + used] for b in blocks]).cpu().numpy()  # rank 0 only: the payloads, trimmed to the longest
     tt.append(time.perf_counter())
     if trace:
         import sys
-        print("[gather] pack %.2f  h2d %.2f  all_gather %.2f  d2h %.2f  index %.2f ms (%d records, %d B/rank)" % (
-            *[(b - a) * 1e3 for a, b in zip(tt[:-1], tt[1:])][-5:], len(table.heads), head + cap), file=sys.stderr)
-    return table
+        print("[exchange] pack %.2f  h2d %.2f  all_gather %.2f  d2h %.2f ms (%d B/rank)" % (
+            *[(b - a) * 1e3 for a, b in zip(tt[:-1], tt[1:])][-4:], head + cap), file=sys.stderr)
+    streams = [got[r, :int(hdrs[r, 0])] for r in range(world)]
+    return ("streams", streams, hdrs[:, 2:].sum(axis=0).tolist())
+
+
+def table_from_exchange(x, names):
+    """The local half on rank 0: index the gathered wire streams into a PacketTable of record heads (payloads stay where they are)."""
+    from .packet_meta import PacketTable
+    if x is None:
+        return None
+    if x[0] == "local":
+        return PacketTable(x[1], names)
+    return PacketTable.from_streams(x[1], x[2], names)
 
 
 def correlate(packets_by_chain, nchains, address_distance):
