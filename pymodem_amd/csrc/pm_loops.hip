@@ -23,6 +23,8 @@ constexpr int kTile = 256;       // samples per LDS tile
 constexpr int kPad = kTile + 1;  // row pitch (doubles): rows of different lanes start on different banks
 constexpr double kTwoPi = 2.0 * 3.141592653589793;
 
+typedef double double2v __attribute__((ext_vector_type(2)));
+
 struct LoopRegs {
     double phase_scaling, index_scaling, set_frequency, b0, b1, a1, p_rate, i_rate, i_limit, gain;
     double phase, control, sine, cosine, x0, x1, y0, integral, proportional;
@@ -44,22 +46,29 @@ __device__ __forceinline__ double iir1(double b0, double b1, double a1, double &
 // The bodies below are written branch-free: a lone wave pays ~5 cycles per instruction and far more per taken branch, and
 // every statement is on the loop-carried path.  Each select reproduces the reference's `if`/`while` exactly:
 //   while (p >= 2pi) p -= 2pi  ==  one conditional subtract, then (never in practice) the loop for what is left.
-__device__ __forceinline__ void nco_update(LoopRegs &L, const double *tab)
+// tab2: 257 (sine, cosine) pairs in LDS, tab2[i] = {table[i], table[(i + 64) & 255]} and tab2[256] = {-, table[64]}: one 16-byte
+// read serves both outputs of the NCO.
+__device__ __forceinline__ void nco_update(LoopRegs &L, const double2v *tab2)
 {
-    double ph = L.phase + L.phase_scaling * (L.set_frequency + L.control);   // nco.py:35
-    const double down = ph - kTwoPi;
-    ph = ph >= kTwoPi ? down : ph;                                          // nco.py:36-37, first trip
+    const double ph0 = L.phase + L.phase_scaling * (L.set_frequency + L.control);   // nco.py:35
+    // nco.py:36-39: `while p >= 2pi: p -= 2pi` then `while p < 0: p += 2pi`.  For -2pi <= p < 4pi each loop makes at most one
+    // trip: two selects (2pi <= p < 4pi: p - 2pi is exact and < 2pi; -2pi <= p < 0: p + 2pi may round to exactly 2pi, and stays,
+    // as there).  Anything beyond (|control| above one turn per sample) takes the loops as written.
+    const double down = ph0 - kTwoPi;
+    double ph = ph0 >= kTwoPi ? down : ph0;
     const double up = ph + kTwoPi;
-    ph = ph < 0 ? up : ph;                                                  // nco.py:38-39, first trip
-    if (__builtin_expect(!(ph >= 0 && ph < kTwoPi), 0)) {                   // |control| beyond one turn per sample
+    ph = ph < 0 ? up : ph;
+    if (__builtin_expect(!(ph0 >= -kTwoPi && ph0 < 2.0 * kTwoPi), 0)) {
+        ph = ph0;
         while (ph >= kTwoPi) ph = ph - kTwoPi;
         while (ph < 0) ph = ph + kTwoPi;
     }
     L.phase = ph;
     const int idx = (int)(ph * L.index_scaling);                            // nco.py:40, int() truncates; 0..256
-    const double s_new = tab[min(idx, 255) & 255];
-    L.sine = idx < 256 ? s_new : L.sine;                                    // nco.py:41-45: index 256 keeps the old value
-    L.cosine = tab[(idx + 64) & 255];                                       // nco.py:46-51
+    double2v sc = tab2[min(max(idx, 0), 256)];
+    asm volatile("" : "+v"(sc));                                            // one unconditional ds_read_b128, no branch around it
+    L.sine = idx < 256 ? sc.x : L.sine;                                     // nco.py:41-45: index 256 keeps the old value
+    L.cosine = sc.y;                                                        // nco.py:46-51
 }
 
 __device__ __forceinline__ double iir_update(LoopRegs &L, double sample)
@@ -102,7 +111,7 @@ __device__ __forceinline__ int pd_lookup(const int32_t *tbl, double re, double i
 
 enum { kCostas = 0, kPll = 1, kMpsk = 2, kQpsk = 3 };
 
-// LDS layout (doubles): tab[256] | in0[rows_in][kPad] | in1[...] (mpsk) | out0[kG][kPad] | out1[kG][kPad] (mpsk) | pd[4096 int32] (mpsk)
+// LDS layout (doubles): tab2[257 pairs, 516] | in0[rows_in][kPad] | in1[...] (mpsk) | out0[kG][kPad] | out1[kG][kPad] (mpsk) | pd[4096 int32] (mpsk)
 template <int MODE>
 __global__ __launch_bounds__(64) void loop_kernel(pm_loop *__restrict__ loops, int nloops, const double *__restrict__ table,
                                                   const int32_t *__restrict__ pd, const double *__restrict__ x0,
@@ -115,15 +124,15 @@ __global__ __launch_bounds__(64) void loop_kernel(pm_loop *__restrict__ loops, i
     const int ng = min(kG, nloops - g0);
     const bool shared_in = x_stride == 0;
     const int rows_in = shared_in ? 1 : kG;
-    double *tab = lds;
-    double *in0 = tab + 256;
+    double2v *tab2 = reinterpret_cast<double2v *>(lds);
+    double *in0 = lds + 516;                               // 257 pairs, rounded up to a multiple of 16 bytes
     double *in1 = in0 + rows_in * kPad;
     constexpr bool kTwoOut = MODE == kMpsk || MODE == kQpsk;
     double *out0 = MODE == kMpsk ? in1 + rows_in * kPad : in1;
     double *out1 = out0 + kG * kPad;
     int32_t *pdt = (int32_t *)(out1 + kG * kPad);
 
-    for (int i = lane; i < 256; i += 64) tab[i] = table[i];
+    for (int i = lane; i < 257; i += 64) tab2[i] = double2v{table[i & 255], table[(i + 64) & 255]};
     if (MODE == kMpsk)
         for (int i = lane; i < 4096; i += 64) pdt[i] = pd[i];
 
@@ -161,21 +170,21 @@ __global__ __launch_bounds__(64) void loop_kernel(pm_loop *__restrict__ loops, i
             for (int k = 0; k < len; ++k) {
                 if (MODE == kCostas) {
                     const double s = p0[k];
-                    nco_update(L, tab);
+                    nco_update(L, tab2);
                     const double i_mixer = s * L.cosine;              // psk.py:177
                     const double q_mixer = s * (-L.sine);             // psk.py:182
                     const double lp = iir_update(L, i_mixer * q_mixer);
                     L.control = pi_update(L, lp);                     // psk.py:187
                     q0[k] = i_mixer;
                 } else if (MODE == kPll) {
-                    nco_update(L, tab);
+                    nco_update(L, tab2);
                     const double mixer = p0[k] * L.sine;              // afsk_pll.py:156
                     const double lp = iir_update(L, mixer);
                     L.control = pi_update(L, lp);                     // afsk_pll.py:160
                     q0[k] = L.proportional;                           // afsk_pll.py:163
                 } else if (MODE == kQpsk) {
                     const double s = p0[k];
-                    nco_update(L, tab);
+                    nco_update(L, tab2);
                     const double cl = iir1(L.bb0, L.bb1, L.ba1, L.cx0, L.cx1, L.cy0, s * L.cosine);   // psk.py:438-440
                     const double sl = iir1(L.bb0, L.bb1, L.ba1, L.sx0, L.sx1, L.sy0, s * L.sine);     // psk.py:449-451
                     const double a = sl >= 0 ? cl : -cl;              // cos_lp * sgn(sin_lp)            psk.py:455-459
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(64) void loop_kernel(pm_loop *__restrict__ loops, i
                     q1[k] = cl;                                       // q_data <- Cosine_LPF            psk.py:453
                 } else {
                     const double sr = p0[k], si = p1[k];
-                    nco_update(L, tab);
+                    nco_update(L, tab2);
                     const double ar = L.cosine, ai = -L.sine;         // nco.py:52-53
                     const double re = (sr * ar) - (si * ai);          // complexmath.py:16
                     const double im = (ar * si) + (sr * ai);          // complexmath.py:17
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(64) void loop_kernel(pm_loop *__restrict__ loops, i
 size_t loop_lds_bytes(int mode, bool shared_in)
 {
     const int rows_in = shared_in ? 1 : kG;
-    size_t d = 256 + (size_t)rows_in * kPad * (mode == kMpsk ? 2 : 1) + (size_t)kG * kPad * 2;
+    size_t d = 516 + (size_t)rows_in * kPad * (mode == kMpsk ? 2 : 1) + (size_t)kG * kPad * 2;
     return d * 8 + (mode == kMpsk ? 4096 * 4 : 0);
 }
 
