@@ -240,3 +240,28 @@ def test_whole_chain_entry_point_errors():
     with pytest.raises(NativeError):
         nc.run(noise_i16(100))                            # shorter than the input filter
     assert len(nc.run(np.zeros(0, np.int16))) == 0
+
+
+def test_recording_pipeline_soak(config_lines):
+    """Sixty recordings of three different kinds through one pipeline, several in flight on every stage: each result equals the
+    one-at-a-time result for its kind (bitmap slots, slicer streams, host and post stages never mix recordings up)."""
+    from pymodem_amd import chain_builder as cb, chain_execute as ce, siggen
+    lines = config_lines("afsk_1200_ax25_super_opt.json")
+    kinds = [siggen.recording("afsk1200_ax25", 48000, packets=4, seed=s, noise_sigma=500.0, payload_len=(20, 60))[0] for s in (1, 2, 3)]
+    kinds[1] = kinds[1][: len(kinds[1]) * 2 // 3].copy()                       # different lengths too
+    want = [ce.process_chains_table([cb.build_chain(48000, l) for l in lines], a) for a in kinds]
+    pipe = ce.RecordingPipeline()
+    seen = []
+    futures = []
+    for k in range(60):
+        which = (k * 7 + k // 5) % 3
+        futures.append((which, pipe.submit([cb.build_chain(48000, l) for l in lines], kinds[which],
+                                           finish=lambda rows, k=k: (seen.append(k), rows)[1],
+                                           post=lambda rows: [r.copy() for r in rows])))
+    for which, f in futures:
+        rows = f.result()
+        for ci in range(len(lines)):
+            assert np.array_equal(rows[ci], want[which][ci]), (which, ci)
+    pipe.close()
+    assert seen == list(range(60))                                              # the ordered stage ran in submission order
+    assert sum(len(r) for r in want[0].values()) > 0
