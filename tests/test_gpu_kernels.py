@@ -464,3 +464,51 @@ def test_fir_limits_and_unaligned_buffers(ctx):
     chk(L().pm_fir_signs_f64(ctx.handle, vin.ptr, n, dh.ptr, m, bits.ptr, 0))
     got = np.unpackbits(bits.download().view(np.uint8), bitorder="little")[:n - m + 1].astype(bool)
     assert np.array_equal(got, O.fir_canon(xf[1:], h) >= 0)
+
+
+def test_slice_batch_many_streams_and_ragged_lengths(ctx):
+    """More streams than one pm_slice_batch call takes (64): the host splits the batch; lengths from 1 sample to a few thousand,
+    binary and quadrature mixed, an empty stream in the middle -- each equals its own oracle run."""
+    from pymodem_amd.data_classes import IQData
+    from pymodem_amd.slicer import BinarySlicer, QuadratureSlicer, slice_batch
+    rng = np.random.default_rng(2024)
+    slicers, inputs, wants = [], [], []
+    for k in range(70):
+        n = int(rng.integers(1, 6000)) if k != 33 else 1
+        xi, xq = slicer_input(n, 500 + k, "smooth"), slicer_input(n, 900 + k, "smooth")
+        if k % 3 == 0:
+            s = QuadratureSlicer(sample_rate=48000, config="qpsk_2400")
+            iq = IQData()
+            iq.i_data, iq.q_data = xi, xq
+            inputs.append(iq)
+            wants.append(O.QuadratureSlicer(48000, "qpsk_2400", {}).slice((xi, xq)))
+        else:
+            s = BinarySlicer(sample_rate=48000, config="9600" if k % 2 else "1200")
+            inputs.append(xi)
+            wants.append(O.BinarySlicer(48000, "9600" if k % 2 else "1200", {}).slice(xi))
+        slicers.append(s)
+    bitmaps = [s.sign_bitmaps(x) for s, x in zip(slicers, inputs)]
+    got = slice_batch(slicers, bitmaps)
+    for k, (g, w) in enumerate(zip(got, wants)):
+        assert np.array_equal(g.data, w[0]) and np.array_equal(g.address, w[1]), k
+
+
+def test_slice_batch_rejects_bad_jobs(ctx):
+    from pymodem_amd import NativeError
+    from pymodem_amd._native import SliceJob
+    bits = ctx.upload(np.zeros(4, np.uint64))
+    out = ctx.empty(64, np.uint8)
+    addr = ctx.empty(64, np.int64)
+    def job(**kw):
+        j = (SliceJob * 1)()
+        j[0].d_bits_i, j[0].n, j[0].d_data, j[0].d_addr, j[0].cap = bits.ptr, 100, out.ptr, addr.ptr, 64
+        j[0].params.samples_per_symbol, j[0].params.lock_rate, j[0].params.bits_per_symbol, j[0].params.state_mask = 40.0, 0.75, 1, 3
+        for k, v in kw.items():
+            setattr(j[0].params, k, v)
+        return j
+    chk(L().pm_slice_batch(ctx.handle, job(), 1))
+    for bad in (dict(bits_per_symbol=3), dict(samples_per_symbol=0.0), dict(lock_rate=float("nan"))):
+        with pytest.raises(NativeError):
+            chk(L().pm_slice_batch(ctx.handle, job(**bad), 1))
+    with pytest.raises(NativeError):
+        chk(L().pm_slice_batch(ctx.handle, job(), 65))
