@@ -143,6 +143,7 @@ def main():
                          "step k on a high-priority side stream, host half (LFSR, codec, packet gather, de-dup) of step k-1 in threads; "
                          "1: only the host half runs behind the next step's GPU half; 0: strictly one after the other")
     ap.add_argument("--slice-workers", type=int, default=3, help="--overlap 2: recordings whose slicers may be in flight at once")
+    ap.add_argument("--demod-streams", type=int, default=2, help="--overlap 2: streams the demod kernels of successive recordings alternate on")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--buffer", default="signal", choices=["signal", "noise"],
                     help="signal: seeded packet-bearing recording of the workload's mode + AWGN (pymodem_amd.siggen), tiled to --samples; "
@@ -281,7 +282,7 @@ def measure(args, env):
                 res = step()
             return res
         if args.overlap >= 2:
-            pipe = ce.RecordingPipeline(slice_workers=args.slice_workers)
+            pipe = ce.RecordingPipeline(slice_workers=args.slice_workers, demod_streams=args.demod_streams)
             last = None
             for _ in range(k):
                 last = pipe.submit(build_chains(), d_audio, exchange, dedupe)
@@ -301,6 +302,8 @@ def measure(args, env):
             return pending.result() if pending is not None else None
 
     sides = [pymodem_amd.Context.side(dev_index, i) for i in range(args.slice_workers)] if args.overlap >= 2 else []
+    if args.overlap >= 2 and args.demod_streams >= 2:
+        sides.append(pymodem_amd.Context.side(dev_index, 100, high_priority=False))       # the second demod stream
 
     def fence():
         ctx.sync()

@@ -110,9 +110,10 @@ class RecordingPipeline:
     stages are the sign bitmaps (one bit per sample), kept in slice_workers + 2 rotating slots (demod runs one recording ahead); a GPU event, not a host wait,
     orders slicer after demod.  Results are identical to process_chains_table on each recording (tests/test_gpu_chains.py)."""
 
-    def __init__(self, slice_workers=2):
+    def __init__(self, slice_workers=2, demod_streams=2):
         from collections import deque
         self._workers = max(1, int(slice_workers))
+        self._demod_streams = int(demod_streams)
         self._slice = ThreadPoolExecutor(max_workers=self._workers)
         self._host = ThreadPoolExecutor(max_workers=3)        # LFSR + codec of up to three recordings at a time (each fans out to the pool)
         self._finish = ThreadPoolExecutor(max_workers=1)
@@ -135,8 +136,11 @@ class RecordingPipeline:
         while len(self._inflight) >= slots - 1:               # the slicer that read this slot `slots` recordings ago is done
             self._inflight.popleft().result()
         t0 = time.perf_counter()
-        bitmaps = process_chains_device(chains, input_audio, _bitmaps_only=True, _slot=slot)
-        self._events[slot] = ready = Context.default().record_event(self._events[slot])   # bitmaps complete at this point of the stream
+        # two demod streams, alternating: the tail of one recording's FIR launches (the last, partly filled round of workgroups)
+        # overlaps the head of the next one's instead of leaving CUs idle
+        dctx = Context.default() if (self._demod_streams < 2 or (self._n & 1)) else Context.side(index=100, high_priority=False)
+        bitmaps = process_chains_device(chains, input_audio, _bitmaps_only=True, _slot=slot, _ctx=dctx)
+        self._events[slot] = ready = dctx.record_event(self._events[slot])   # bitmaps complete at this point of the stream
         acc["demod"] += time.perf_counter() - t0
 
         def slice_stage():
@@ -184,10 +188,14 @@ class RecordingPipeline:
         self._post.shutdown(wait=True)
 
 
-def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced_only=False, _bitmaps_only=False, _slot=0):
+def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced_only=False, _bitmaps_only=False, _slot=0, _ctx=None):
     """[chain, ...] -> [packets of chain 0, packets of chain 1, ...] (config order), identical to running
     process_chain on each.  See the module docstring for what is shared and batched."""
-    ctx = Context.default()
+    ctx = _ctx or Context.default()
+    if _ctx is not None:
+        for ch in chains:
+            ch[1].use_context(ctx)
+            ch[2]._ctx = ctx
     audio = input_audio
     if not isinstance(audio, DeviceBuffer):
         a = np.asarray(audio)

@@ -5,12 +5,12 @@
 //     clk += 1.0;  if (clk >= sps/2 - 0.5) { clk -= sps;  take a symbol from sign(x[k]) }
 //     if sign(x[k]) != sign(x[k-1]):  clk *= lock_rate
 // is sequential in `clk` only.  Every stream is cut into chunks of L samples, one lane per chunk.
-// Iteration r runs every chunk from the start state handed to it and hands its end state to the next
-// chunk; chunk 0 of a stream always starts from the true state.  A chunk whose start state did not
-// change is not re-run.  When an iteration changes no start state, every chunk started from the end
-// state of its predecessor, so by induction from chunk 0 the per-chunk runs ARE the sequential run, bit
-// for bit: each lane executes the reference's operations in the reference's order, only the starting
-// value is guessed.  Two trajectories that see the same zero crossings contract by lock_rate per
+// An iteration runs the chunks on its work list from the start states handed to them; a chunk whose end
+// state changes hands it to the next chunk and puts that chunk on the next list; chunk 0 of a stream
+// always starts from the true state.  When a list comes up empty, every chunk's last run started from
+// the final end state of its predecessor, so by induction from chunk 0 the per-chunk runs ARE the
+// sequential run, bit for bit: each lane executes the reference's operations in the reference's order,
+// only the starting value is guessed.  Two trajectories that see the same zero crossings contract by lock_rate per
 // crossing, so a few iterations suffice on real signals; the worst case (no crossings at all) degrades
 // to nchunks iterations, i.e. sequential cost, never to a wrong answer.
 //
@@ -83,29 +83,29 @@ __device__ __forceinline__ uint32_t step32(double &clk, uint32_t zc, double thr,
     return sym;
 }
 
-// One fixed-point iteration over all chunks of all streams.
-__global__ __launch_bounds__(kBlock) void slice_iter_kernel(const JobDev *__restrict__ jobs, int njobs, int lc_words, int64_t total_chunks,
-                                                        const uint64_t *__restrict__ s_in, uint64_t *__restrict__ s_out,
-                                                        const uint8_t *__restrict__ d_in, uint8_t *__restrict__ d_out,
-                                                        uint64_t *__restrict__ symmap, int *__restrict__ changed, int iter)
+// One fixed-point iteration.  Work is a list of chunk ids: iteration 0 holds every chunk; a chunk whose run changes its END state
+// writes it into the state array and puts its successor on the next iteration's list.  Lists are dense, so the waves of an iteration
+// are as many as there are chunks to re-run (the thin tail of the iteration costs a handful of waves, not the whole grid) and the
+// iteration after the fixed point finds an empty list.  The state array is updated in place: a chunk may read its start state
+// while its predecessor is rewriting it in the same iteration -- either value is a valid 8-byte state, and whenever the
+// predecessor did change it the chunk is on the next list and runs again, so at the fixed point every chunk's last run started
+// from the final end state of its predecessor (the induction of the header comment).
+__global__ __launch_bounds__(kBlock) void slice_iter_kernel(const JobDev *__restrict__ jobs, int njobs, int lc_words,
+                                                        uint64_t *__restrict__ state, const int32_t *__restrict__ list_in,
+                                                        int32_t *__restrict__ list_out, int *__restrict__ counts, int iter,
+                                                        uint64_t *__restrict__ symmap)
 {
     // These waves are bound by their own dependent chain; when FIR waves of another stream share the SIMD (pipelined executor)
     // every issue slot they lose lengthens the chain, while the FIR waves only need the slots in between: take issue priority.
     __builtin_amdgcn_s_setprio(3);
-    const int64_t gc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gc >= total_chunks) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= counts[iter]) return;                   // whole waves beyond the list leave at once
+    const int64_t gc = list_in[i];
     const int j = find_job(jobs, njobs, gc);
     const JobDev &J = jobs[j];
     const int64_t c = gc - J.chunk0;
-    const int64_t so = gc + j;                       // state arrays hold nchunks+1 entries per stream
-    // chunk 0 starts from the true state: it runs once.  Nobody writes d_in[so] for c == 0, so it is not consulted.
-    const bool dirty = c == 0 ? (iter == 0) : (d_in[so] != 0);
-    if (!dirty) {                                    // start state unchanged: end state and symbol bitmap stand
-        s_out[so + 1] = s_in[so + 1];
-        d_out[so + 1] = 0;
-        return;
-    }
-    double clk = bitsd(s_in[so]);
+    const int64_t so = gc + j;                       // the state array holds nchunks+1 entries per stream
+    double clk = bitsd(__builtin_nontemporal_load(&state[so]));
     const int64_t w0 = c * lc_words;
     const int64_t w1 = min(w0 + (int64_t)lc_words, J.nwords);
     // last_sample starts at 0.0, i.e. ">= 0" (slicer.py:55,164-165)
@@ -144,10 +144,19 @@ __global__ __launch_bounds__(kBlock) void slice_iter_kernel(const JobDev *__rest
         sm[w] = sym;
     }
     const uint64_t e = dbits(clk);
-    const bool ch = e != s_in[so + 1];
-    s_out[so + 1] = e;
-    d_out[so + 1] = ch ? 1 : 0;
-    if (ch && c + 1 < J.nchunks) atomicAdd(changed, 1);
+    const bool ch = e != state[so + 1];
+    if (ch) state[so + 1] = e;
+    // successors of the chunks whose end state moved go on the next list: one atomic per wave
+    const bool add = ch && c + 1 < J.nchunks;
+    const uint64_t mask = __ballot(add);
+    if (mask) {
+        const int lane = threadIdx.x & 63;
+        const int leader = __ffsll((long long)mask) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&counts[iter + 1], __popcll(mask));
+        base = __shfl(base, leader);
+        if (add) list_out[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)(gc + 1);
+    }
 }
 
 // Symbols per chunk and the (i<<1|q) bits of its last symbol (0xFF if it took none).
@@ -303,18 +312,18 @@ __global__ __launch_bounds__(kBlock) void slice_pack_kernel(const JobDev *__rest
     }
 }
 
-__global__ void slice_init_kernel(const JobDev *__restrict__ jobs, int njobs, int64_t total_chunks, uint64_t *sa, uint64_t *sb,
-                                  uint8_t *da, uint8_t *db, int *changed)
+__global__ void slice_init_kernel(const JobDev *__restrict__ jobs, int njobs, int64_t total_chunks, uint64_t *state, int32_t *list0,
+                                  int *counts, int ncounts)
 {
     const int64_t gc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gc == 0) *changed = 0;
+    if (gc < ncounts) counts[gc] = gc == 0 ? (int)total_chunks : 0;       // iteration 0 runs every chunk
     if (gc >= total_chunks) return;
     const int j = find_job(jobs, njobs, gc);
     const int64_t so = gc + j;
-    // cold start everywhere: phase_clock = 0.0, which for chunk 0 is the true initial state (slicer.py:50)
-    const uint64_t start = gc == jobs[j].chunk0 ? dbits(jobs[j].clk0) : 0ull;      // chunk 0: the carried (or zero) phase clock
-    sa[so] = start; sb[so] = start; da[so] = 1; db[so] = 0;
-    if (gc - jobs[j].chunk0 == jobs[j].nchunks - 1) { sa[so + 1] = 0ull; sb[so + 1] = 0ull; da[so + 1] = 0; db[so + 1] = 0; }
+    // cold start everywhere (phase_clock = 0.0); chunk 0 of a stream starts from its true state, carried in or zero (slicer.py:50)
+    state[so] = gc == jobs[j].chunk0 ? dbits(jobs[j].clk0) : 0ull;
+    if (gc - jobs[j].chunk0 == jobs[j].nchunks - 1) state[so + 1] = ~0ull;   // "no end state yet": any first run differs from it
+    list0[gc] = (int32_t)gc;
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -406,51 +415,50 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t ee = (size_t)emit_chunks + nj;
-    const size_t o_jobs = carve(sizeof(JobDev) * nj), o_ejobs = carve(sizeof(JobDev) * nj), o_sa = carve(e * 8), o_sb = carve(e * 8), o_da = carve(e),
-                 o_db = carve(e), o_cnt = carve((size_t)emit_chunks * 4), o_ls = carve(emit_chunks), o_off = carve(ee * 8), o_ps = carve(emit_chunks),
-                 o_sym = carve((size_t)total_words * 8), o_tot = carve((size_t)nj * 8 * 4), o_tail = carve((size_t)nj * 4), o_ch = carve(256);
+    int64_t most_chunks = 0;
+    for (const JobDev &d : jd) most_chunks = std::max(most_chunks, d.nchunks);
+    const int burst = 8;                                   // iterations after the fixed point find an empty list and cost microseconds
+    const int64_t max_iters = most_chunks + 2;
+    const int ncounts = (int)std::min<int64_t>(max_iters + 2 * burst + 8, 1 << 22);
+    const size_t o_jobs = carve(sizeof(JobDev) * nj), o_ejobs = carve(sizeof(JobDev) * nj), o_state = carve(e * 8),
+                 o_la = carve((size_t)total_chunks * 4), o_lb = carve((size_t)total_chunks * 4), o_counts = carve((size_t)ncounts * 4),
+                 o_cnt = carve((size_t)emit_chunks * 4), o_ls = carve(emit_chunks), o_off = carve(ee * 8), o_ps = carve(emit_chunks),
+                 o_sym = carve((size_t)total_words * 8), o_tot = carve((size_t)nj * 8 * 4), o_tail = carve((size_t)nj * 4);
     if (int rc = pm_scratch_reserve(ctx, off)) return rc;
     char *base = (char *)ctx->d_scratch;
     JobDev *d_jobs = (JobDev *)(base + o_jobs), *d_ejobs = (JobDev *)(base + o_ejobs);
-    uint64_t *sa = (uint64_t *)(base + o_sa), *sb = (uint64_t *)(base + o_sb);
-    uint8_t *da = (uint8_t *)(base + o_da), *db = (uint8_t *)(base + o_db);
+    uint64_t *state = (uint64_t *)(base + o_state);
+    int32_t *list_a = (int32_t *)(base + o_la), *list_b = (int32_t *)(base + o_lb);
+    int *counts = (int *)(base + o_counts);
     uint32_t *cnt = (uint32_t *)(base + o_cnt);
     uint8_t *ls = (uint8_t *)(base + o_ls), *ps = (uint8_t *)(base + o_ps);
     uint64_t *offs = (uint64_t *)(base + o_off), *symmap = (uint64_t *)(base + o_sym), *totals = (uint64_t *)(base + o_tot);
-    int *changed = (int *)(base + o_ch);
     uint32_t *tails = (uint32_t *)(base + o_tail);
     for (int k = 0; k < nj; ++k) jd[k].tail = je[k].tail = tails + k;
     PM_HIP(hipMemsetAsync(tails, 0, (size_t)nj * 4, ctx->stream));
 
     PM_HIP(hipMemcpyAsync(d_jobs, jd.data(), sizeof(JobDev) * nj, hipMemcpyHostToDevice, ctx->stream));
     PM_HIP(hipMemcpyAsync(d_ejobs, je.data(), sizeof(JobDev) * nj, hipMemcpyHostToDevice, ctx->stream));
-    const unsigned grid = (unsigned)pm_cdiv(total_chunks, kBlock);
-    hipLaunchKernelGGL(slice_init_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_jobs, nj, total_chunks, sa, sb, da, db, changed);
+    const unsigned grid = (unsigned)pm_cdiv(std::max<int64_t>(total_chunks, ncounts), kBlock);
+    hipLaunchKernelGGL(slice_init_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_jobs, nj, total_chunks, state, list_a, counts, ncounts);
 
     int *h_flag = (int *)ctx->h_pinned;
     int iters = 0;
-    int64_t most_chunks = 0;
-    for (const JobDev &d : jd) most_chunks = std::max(most_chunks, d.nchunks);
-    const int64_t max_iters = most_chunks + 2;
     bool converged = false;
     while (!converged) {
         // a burst of iterations between host checks keeps the launch queue full
-        const int burst = 8;                               // iterations after the fixed point find nothing dirty and cost microseconds
         for (int b = 0; b < burst; ++b) {
             PmProf prof(ctx, PM_K_SLICE_ITER);
-            hipLaunchKernelGGL(slice_iter_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_jobs, nj, (int)lc_words, total_chunks,
-                               sa, sb, da, db, symmap, changed, iters);
-            std::swap(sa, sb);
-            std::swap(da, db);
+            hipLaunchKernelGGL(slice_iter_kernel, dim3((unsigned)pm_cdiv(total_chunks, kBlock)), dim3(kBlock), 0, ctx->stream, d_jobs, nj,
+                               (int)lc_words, state, (iters & 1) ? list_b : list_a, (iters & 1) ? list_a : list_b, counts, iters, symmap);
             ++iters;
         }
-        PM_HIP(hipMemcpyAsync(h_flag, changed, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        PM_HIP(hipMemsetAsync(changed, 0, sizeof(int), ctx->stream));
+        // counts[iters] = chunks the burst's last iteration put on the next list: none means the fixed point is reached
+        PM_HIP(hipMemcpyAsync(h_flag, counts + iters, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         PM_HIP(hipStreamSynchronize(ctx->stream));
-        // `changed` accumulates over the burst: a burst with no change at all ends on a fixed point
         converged = (*h_flag == 0);
-        if (getenv("PM_SLICER_TRACE")) fprintf(stderr, "[slicer] after %d iterations: %d start states changed in the last burst\n", iters, *h_flag);
-        if (!converged && iters > max_iters + 8)
+        if (getenv("PM_SLICER_TRACE")) fprintf(stderr, "[slicer] after %d iterations: %d chunks still to re-run\n", iters, *h_flag);
+        if (!converged && (iters > max_iters + burst || iters + burst + 1 >= ncounts))
             return pm_set_error(PM_ERR_NOCONVERGE, "slicer fixed point not reached after %d iterations (%lld chunks)", iters, (long long)most_chunks);
     }
     ctx->sl_iterations = iters;
@@ -459,7 +467,7 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
         PmProf prof(ctx, PM_K_SLICE_EMIT);
         const unsigned egrid = (unsigned)pm_cdiv(emit_chunks, kBlock);
         hipLaunchKernelGGL(slice_count_kernel, dim3(egrid), dim3(kBlock), 0, ctx->stream, d_ejobs, nj, (int)le_words, emit_chunks, symmap, cnt, ls);
-        hipLaunchKernelGGL(slice_scan_kernel, dim3(nj), dim3(1024), 0, ctx->stream, d_ejobs, cnt, ls, offs, ps, totals, sa, nj, d_jobs);
+        hipLaunchKernelGGL(slice_scan_kernel, dim3(nj), dim3(1024), 0, ctx->stream, d_ejobs, cnt, ls, offs, ps, totals, state, nj, d_jobs);
         for (const JobDev &d : jd)
             if (d.cap > 0) PM_HIP(hipMemsetAsync(d.data32, 0, align_up((size_t)d.cap, 4), ctx->stream));
         hipLaunchKernelGGL(slice_pack_kernel, dim3(egrid), dim3(kBlock), 0, ctx->stream, d_ejobs, nj, (int)le_words, emit_chunks, symmap, offs, ps);

@@ -18,14 +18,15 @@ class Context:
         check(lib().pm_ctx_create_prio(device, int(bool(high_priority)), ctypes.byref(self._h)))
 
     @classmethod
-    def side(cls, device=None, index=0):
-        """Additional high-priority streams on the default context's GPU (one per process, device and index): the pipelined
-        executor runs slicers there while the next recording's FIR/correlator kernels run on the default stream."""
+    def side(cls, device=None, index=0, high_priority=True):
+        """Additional streams on the default context's GPU (one per process, device and index).  The pipelined executor runs
+        slicers on high-priority ones while the next recordings' FIR/correlator kernels run on the default stream and on one more
+        normal-priority stream."""
         import os
         main = cls.default(device)
         key = (os.getpid(), main.device, int(index))
         if key not in cls._side:
-            cls._side[key] = cls(main.device, high_priority=True)
+            cls._side[key] = cls(main.device, high_priority=high_priority)
             check(lib().pm_slicer_tune(cls._side[key]._h, 12288))     # fewer, longer chunks while other streams share the CUs
         return cls._side[key]
 

@@ -38,8 +38,16 @@ class _DeviceStage:
     def _context(self):
         if self._ctx is None:
             self._ctx = Context.default()
+        if not hasattr(self, "_dev"):
             self._dev = {}
         return self._ctx
+
+    def use_context(self, ctx):
+        """Run this stage's next calls on `ctx` (its stream and work-buffer pool).  Uploaded constants stay valid: device memory is
+        shared by all contexts of a GPU."""
+        self._ctx = ctx
+        if not hasattr(self, "_dev"):
+            self._dev = {}
 
     def _const(self, name, host, dtype=np.float64):
         """Upload a constant array once per (name, contents)."""
