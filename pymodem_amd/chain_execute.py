@@ -110,7 +110,7 @@ class RecordingPipeline:
     stages are the sign bitmaps (one bit per sample), kept in slice_workers + 2 rotating slots (demod runs one recording ahead); a GPU event, not a host wait,
     orders slicer after demod.  Results are identical to process_chains_table on each recording (tests/test_gpu_chains.py)."""
 
-    def __init__(self, slice_workers=2, demod_streams=2):
+    def __init__(self, slice_workers=2, demod_streams=1):
         from collections import deque
         self._workers = max(1, int(slice_workers))
         self._demod_streams = int(demod_streams)
