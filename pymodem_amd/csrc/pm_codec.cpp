@@ -23,16 +23,22 @@ int pm_set_error(int code, const char *fmt, ...);
 namespace {
 
 // ---- CRC-16 (reflected CCITT 0x8408, init 0xFFFF, final xor 0xFFFF) -----------------------------
+// crc_functions.py:44-55, bit by bit there; here eight bits per table step (the same reflected polynomial 0x8408).
 int crc16(const uint8_t *d, int64_t n)
 {
-    unsigned crc = 0xFFFF;
-    for (int64_t k = 0; k < n; ++k) {
-        unsigned b = d[k];
-        for (int i = 0; i < 8; ++i) {
-            crc = ((crc ^ b) & 1) ? (crc >> 1) ^ 0x8408 : crc >> 1;
-            b >>= 1;
+    static const struct Table {
+        uint16_t t[256];
+        Table()
+        {
+            for (unsigned v = 0; v < 256; ++v) {
+                unsigned c = v;
+                for (int i = 0; i < 8; ++i) c = (c & 1) ? (c >> 1) ^ 0x8408 : c >> 1;
+                t[v] = (uint16_t)c;
+            }
         }
-    }
+    } table;
+    unsigned crc = 0xFFFF;
+    for (int64_t k = 0; k < n; ++k) crc = (crc >> 8) ^ table.t[(crc ^ d[k]) & 0xFF];
     return (int)(crc ^ 0xFFFF);
 }
 
