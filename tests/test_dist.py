@@ -99,15 +99,19 @@ def test_record_round_trip(golden):
         assert all(p.SourceDecoder == f"chain{c}" for p in back.get(c, []))
 
 
-def test_two_rank_gather_and_dedup(tmp_path, golden):
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_rank_gather_and_dedup(tmp_path, golden, world):
+    """world 2: ranks interleave the 5 chains; world 4: one rank owns two chains, one of the others none with packets -- the
+    exchange must cope with empty contributions as well."""
     g = golden("wav_chains")
     summ = json.load(open(os.path.join(GOLDEN, "wav_chains_summary.json")))["afsk_300"]
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     port = 29500 + os.getpid() % 2000
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    port += world
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=300) for p in procs]
     for p, (o, e) in zip(procs, outs):
