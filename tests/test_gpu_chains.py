@@ -242,7 +242,8 @@ def test_whole_chain_entry_point_errors():
     assert len(nc.run(np.zeros(0, np.int16))) == 0
 
 
-def test_recording_pipeline_soak(config_lines):
+@pytest.mark.parametrize("demod_streams", [1, 2])
+def test_recording_pipeline_soak(config_lines, demod_streams):
     """Sixty recordings of three different kinds through one pipeline, several in flight on every stage: each result equals the
     one-at-a-time result for its kind (bitmap slots, slicer streams, host and post stages never mix recordings up)."""
     from pymodem_amd import chain_builder as cb, chain_execute as ce, siggen
@@ -250,7 +251,7 @@ def test_recording_pipeline_soak(config_lines):
     kinds = [siggen.recording("afsk1200_ax25", 48000, packets=4, seed=s, noise_sigma=500.0, payload_len=(20, 60))[0] for s in (1, 2, 3)]
     kinds[1] = kinds[1][: len(kinds[1]) * 2 // 3].copy()                       # different lengths too
     want = [ce.process_chains_table([cb.build_chain(48000, l) for l in lines], a) for a in kinds]
-    pipe = ce.RecordingPipeline()
+    pipe = ce.RecordingPipeline(demod_streams=demod_streams)
     seen = []
     futures = []
     for k in range(60):
