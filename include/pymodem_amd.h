@@ -92,6 +92,10 @@ int pm_fir_valid_f64(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_
  * feeds slicer.slice() and nothing else (afsk.py:166, fsk.py:151, psk.py:193,750-751, afsk_pll.py:168). */
 int pm_fir_signs_i16(pm_ctx *ctx, const int16_t *d_x, int64_t n, const double *d_taps, int m, uint64_t *d_bits, int flags);
 int pm_fir_signs_f64(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_taps, int m, uint64_t *d_bits, int flags);
+/* The same for up to 16 streams that share their taps, in ONE launch: the output low-passes of a chain group (every chain of
+ * afsk_1200_ax25_super_opt.json has the same output_lpf).  h_x / h_n / h_bits are HOST arrays of `count` device pointers / lengths. */
+int pm_fir_signs_f64_batch(pm_ctx *ctx, int count, const double *const *h_x, const int64_t *h_n, const double *d_taps, int m,
+                           uint64_t *const *h_bits, int flags);
 
 /* AFSK mark/space quadrature correlators fused with magnitude and difference (afsk.py:153-162):
  * y[k] = sqrt(mi*x ^2 + mq*x ^2) - sqrt(si*x ^2 + sq*x ^2), each product a 'valid' convolution. */

@@ -123,6 +123,7 @@ _SIGS = {
     "pm_fir_valid_f64": ([_vp, _vp, _i64, _vp, _int, _vp, _int], _int),
     "pm_fir_signs_i16": ([_vp, _vp, _i64, _vp, _int, _vp, _int], _int),
     "pm_fir_signs_f64": ([_vp, _vp, _i64, _vp, _int, _vp, _int], _int),
+    "pm_fir_signs_f64_batch": ([_vp, _int, ctypes.POINTER(_vp), ctypes.POINTER(_i64), _vp, _int, ctypes.POINTER(_vp), _int], _int),
     "pm_afsk_correlate": ([_vp, _vp, _i64, _vp, _vp, _vp, _vp, _int, _vp], _int),
     "pm_afsk_correlate_group": ([_vp, _vp, _i64, _vp, _vp, _vp, _int, _int, _vp, _i64], _int),
     "pm_signs_f64": ([_vp, _vp, _i64, _vp], _int),

@@ -262,40 +262,40 @@ def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced
             modem.scratch_key = (group_key, "loop_back")
             bitmaps[k] = chains[k][2].sign_bitmaps(modem.back_end(mix.view(j * n, n), signs=True))
 
-    # ---- AFSK correlator banks that share their mark filters: one launch per group of up to 8 --------------------------
-    afsk_groups = {}
+    # ---- AFSK: correlator banks that share their mark filters run as one launch per group of up to 8, the rest one by one;
+    # then the output low-passes of all chains with equal taps run as one batched sign-only launch ----------------------------
+    afsk_groups, corr = {}, {}
     for k, ch in enumerate(chains):
         if isinstance(ch[1], AFSKModem):
+            ch[1].use_context(ctx)
             afsk_groups.setdefault(ch[1].mark_key(), []).append(k)
     gi = 0
     for key, members in afsk_groups.items():
         for base in range(0, len(members), 8):
             part = members[base:base + 8]
-            if len(part) < 2:
-                continue
             mods = [chains[k][1] for k in part]
             bpf = shared_front(mods[0])
-            for md in mods:
-                md._context()
-            streams = AFSKModem.correlate_group(mods, bpf, (group_key, "afsk_corr_group", gi))
-            gi += 1
-            for k, md, c in zip(part, mods, streams):
-                md.scratch_key = (group_key, "afsk_back")
-                bitmaps[k] = chains[k][2].sign_bitmaps(md.back_end(bpf, signs=True, correlated=c))
+            if len(part) >= 2:
+                streams = AFSKModem.correlate_group(mods, bpf, (group_key, "afsk_corr_group", gi))
+                gi += 1
+            else:
+                streams = [mods[0].correlate(bpf, (group_key, "afsk_corr_single", part[0]))]
+            for k, c in zip(part, streams):
+                corr[k] = c
+    lpf_groups = {}
+    for k in corr:
+        lpf_groups.setdefault(chains[k][1].output_lpf.tobytes(), []).append(k)
+    for members in lpf_groups.values():
+        for k, sb in zip(members, AFSKModem.lpf_signs_batch([chains[k][1] for k in members], [corr[k] for k in members])):
+            bitmaps[k] = chains[k][2].sign_bitmaps(sb)
 
     # ---- everything else, chain by chain (work buffers shared across the group) ----------------------------------
     for k, ch in enumerate(chains):
         if bitmaps[k] is not None:
             continue
         modem = ch[1]
-        if isinstance(modem, AFSKModem):
-            bpf = shared_front(modem)
-            modem.scratch_key = (group_key, "afsk_back")
-            out = modem.back_end(bpf, signs=True)
-        else:
-            modem.scratch_key = (group_key, type(modem).__name__)
-            out = modem.demod_signs(audio)
-        bitmaps[k] = ch[2].sign_bitmaps(out)
+        modem.scratch_key = (group_key, type(modem).__name__)
+        bitmaps[k] = ch[2].sign_bitmaps(modem.demod_signs(audio))
 
     # ---- all slicers in one batch, host stages in parallel ---------------------------------------------------------
     if _bitmaps_only:

@@ -17,6 +17,7 @@
 #include "pm_common.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -72,15 +73,14 @@ __device__ __forceinline__ void stage_vec(const int16_t *__restrict__ x, int64_t
 
 // SIGNS: instead of the float64 outputs, write only their (y >= 0) bitmap -- all a slicer reads of them.
 template <typename InT, int R, bool NEG, bool VEC, bool SIGNS>
-__global__ __launch_bounds__(kThreads) void fir_valid_kernel(const InT *__restrict__ x, int64_t n,
-                                                             const double *__restrict__ h, int m,
-                                                             double *__restrict__ y, int64_t nout, uint64_t *__restrict__ bits)
+__device__ __forceinline__ void fir_tile(const InT *__restrict__ x, int64_t n, const double *__restrict__ h, int m,
+                                         double *__restrict__ y, int64_t nout, uint64_t *__restrict__ bits, int64_t tile)
 {
     extern __shared__ double xs[];
     constexpr int T = kThreads * R;
     const int t = threadIdx.x;
     const int span = T + m - 1;
-    const int64_t tile0 = (int64_t)blockIdx.x * T;
+    const int64_t tile0 = tile * T;
     if (VEC) {
         stage_vec<R>(x, n, tile0, span, t, xs);
     } else {
@@ -191,6 +191,32 @@ __global__ __launch_bounds__(kThreads) void fir_valid_kernel(const InT *__restri
             if (go < nout) y[go] = xs[slot<R>(idx)];
         }
     }
+}
+
+template <typename InT, int R, bool NEG, bool VEC, bool SIGNS>
+__global__ __launch_bounds__(kThreads) void fir_valid_kernel(const InT *__restrict__ x, int64_t n,
+                                                             const double *__restrict__ h, int m,
+                                                             double *__restrict__ y, int64_t nout, uint64_t *__restrict__ bits)
+{
+    fir_tile<InT, R, NEG, VEC, SIGNS>(x, n, h, m, y, nout, bits, (int64_t)blockIdx.x);
+}
+
+// Several sign-only FIRs with the same taps in ONE launch (blockIdx.y = stream): the output low-passes of a chain group.  One ramp
+// and one tail for the whole stage instead of one per chain.
+constexpr int kFirBatchMax = 16;
+struct FirBatch {
+    const double *x[kFirBatchMax];
+    uint64_t *bits[kFirBatchMax];
+    int64_t n[kFirBatchMax];
+};
+
+template <int R, bool NEG, bool VEC>
+__global__ __launch_bounds__(kThreads) void fir_signs_batch_kernel(FirBatch B, const double *__restrict__ h, int m)
+{
+    const int s = blockIdx.y;
+    const int64_t n = B.n[s], nout = n - m + 1;
+    if ((int64_t)blockIdx.x * (kThreads * R) >= nout) return;          // the grid is sized for the longest stream
+    fir_tile<double, R, NEG, VEC, true>(B.x[s], n, h, m, nullptr, nout, B.bits[s], (int64_t)blockIdx.x);
 }
 
 // Four correlators over one staged window; R outputs x 4 filters = 4R accumulators per thread.
@@ -506,6 +532,47 @@ int pm_fir_signs_i16(pm_ctx *ctx, const int16_t *d_x, int64_t n, const double *d
 int pm_fir_signs_f64(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_taps, int m, uint64_t *d_bits, int flags)
 {
     return fir_launch<double>(ctx, d_x, n, d_taps, m, nullptr, d_bits, flags);
+}
+
+int pm_fir_signs_f64_batch(pm_ctx *ctx, int count, const double *const *h_x, const int64_t *h_n, const double *d_taps, int m,
+                           uint64_t *const *h_bits, int flags)
+{
+    PM_CTX(ctx);
+    PM_ARG(count >= 1 && count <= kFirBatchMax && h_x && h_n && d_taps && h_bits);
+    PM_ARG(m >= 1 && m <= kMaxTaps);
+    constexpr int R = 8;
+    FirBatch B;
+    memset(&B, 0, sizeof(B));
+    int64_t longest = 0;
+    bool vec = true;
+    double bytes = 0, flops = 0;
+    for (int k = 0; k < count; ++k) {
+        PM_ARG(h_x[k] && h_bits[k] && h_n[k] >= m);
+        B.x[k] = h_x[k];
+        B.bits[k] = h_bits[k];
+        B.n[k] = h_n[k];
+        longest = std::max(longest, h_n[k] - m + 1);
+        vec = vec && (((uintptr_t)h_x[k]) & 15) == 0;
+        bytes += (double)h_n[k] * 8 + (double)(h_n[k] - m + 1) / 8;
+        flops += 2.0 * m * (double)(h_n[k] - m + 1);
+    }
+    const int64_t ntiles = pm_cdiv(longest, (int64_t)kThreads * R);
+    PM_ARG(ntiles < (1LL << 31));
+    const size_t lds = lds_bytes<R>(m);
+    const bool neg = (flags & PM_FIR_NEGATE) != 0;
+    PmProf prof(ctx, PM_K_FIR_F64);
+    prof.work(bytes, flops);
+#define PM_BATCH_GO(NEGF, VECF)                                                                                             \
+    {                                                                                                                       \
+        if (int rc = allow_lds(fir_signs_batch_kernel<R, NEGF, VECF>, lds)) return rc;                                       \
+        hipLaunchKernelGGL((fir_signs_batch_kernel<R, NEGF, VECF>), dim3((unsigned)ntiles, (unsigned)count), dim3(kThreads), lds, ctx->stream, \
+                           B, d_taps, m);                                                                                   \
+    }
+    if (neg) { if (vec) PM_BATCH_GO(true, true) else PM_BATCH_GO(true, false) }
+    else { if (vec) PM_BATCH_GO(false, true) else PM_BATCH_GO(false, false) }
+#undef PM_BATCH_GO
+    PM_HIP(hipGetLastError());
+    return PM_OK;
 }
 
 int pm_fir_valid_f64(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_taps, int m, double *d_y, int flags)

@@ -245,6 +245,44 @@ class AFSKModem(_DeviceStage):
                                             g, m, out.ptr, stride))
         return [out.view(j * stride, nout) for j in range(g)]
 
+    def correlate(self, a, out_key=None):
+        """This modem's correlator bank over the band-passed stream `a` (afsk.py:153-162) -> DeviceBuffer."""
+        ctx = self._context()
+        m = len(self.mark_correlator_i)
+        if a.n < m:
+            raise ValueError("input shorter than the correlators")
+        c = ctx.scratch(out_key or (self._key(), "corr"), a.n - m + 1, np.float64)
+        check(lib().pm_afsk_correlate(ctx.handle, a.ptr, a.n, self._const("mi", self.mark_correlator_i).ptr,
+                                      self._const("mq", self.mark_correlator_q).ptr, self._const("si", self.space_correlator_i).ptr,
+                                      self._const("sq", self.space_correlator_q).ptr, m, c.ptr))
+        return c
+
+    @staticmethod
+    def lpf_signs_batch(modems, corrs):
+        """Output low-pass (afsk.py:166) of several modems with EQUAL output_lpf taps over their correlator streams, sign bitmaps
+        only, in one launch per 16 streams (pm_fir_signs_f64_batch) -> one SignBits per modem."""
+        lead = modems[0]
+        ctx = lead._context()
+        m = len(lead.output_lpf)
+        taps = lead._const("output_lpf", lead.output_lpf)
+        out = []
+        for base in range(0, len(modems), 16):
+            mods, cs = modems[base:base + 16], corrs[base:base + 16]
+            g = len(mods)
+            xs, ns, bs = (ctypes.c_void_p * g)(), (ctypes.c_int64 * g)(), (ctypes.c_void_p * g)()
+            bufs = []
+            for j, (md, c) in enumerate(zip(mods, cs)):
+                if c.n < m:
+                    raise ValueError("input shorter than the output filter")
+                md._context()
+                nout = c.n - m + 1
+                bits = ctx.scratch((md._own_key(), "signs", "output_lpf"), (nout + 63) // 64 + 1, np.uint64)
+                xs[j], ns[j], bs[j] = c.ptr.value, c.n, bits.ptr.value
+                bufs.append((bits, nout))
+            check(lib().pm_fir_signs_f64_batch(ctx.handle, g, xs, ns, taps.ptr, m, bs, 0))
+            out += [SignBits(b, None, n) for b, n in bufs]
+        return out
+
     def back_end(self, a, device_out=False, signs=False, correlated=None):
         """Correlators + output low-pass on an already band-passed stream (afsk.py:153-166).  `correlated`: this modem's
         correlator output when a group launch already produced it."""

@@ -512,3 +512,32 @@ def test_slice_batch_rejects_bad_jobs(ctx):
             chk(L().pm_slice_batch(ctx.handle, job(**bad), 1))
     with pytest.raises(NativeError):
         chk(L().pm_slice_batch(ctx.handle, job(), 65))
+
+
+def test_fir_signs_batch_matches_single_launches(ctx):
+    """pm_fir_signs_f64_batch: several streams of different lengths, one launch; each bitmap equals its own pm_fir_signs_f64."""
+    rng = np.random.default_rng(64)
+    m = 100
+    h = rng.standard_normal(m)
+    dh = ctx.upload(h)
+    lens = [m, m + 1, 5000, 70003, 69983, 12345, 4096 + m - 1, 300000, 299981]
+    xs = [rng.standard_normal(n) for n in lens]
+    dx = [ctx.upload(x) for x in xs]
+    bits = [ctx.empty((n - m + 1 + 63) // 64 + 1, np.uint64) for n in lens]
+    g = len(lens)
+    px, pn, pb = (ctypes.c_void_p * g)(), (ctypes.c_int64 * g)(), (ctypes.c_void_p * g)()
+    for j in range(g):
+        px[j], pn[j], pb[j] = dx[j].ptr.value, lens[j], bits[j].ptr.value
+    for flags in (0, 1):
+        chk(L().pm_fir_signs_f64_batch(ctx.handle, g, px, pn, dh.ptr, m, pb, flags))
+        for j in range(g):
+            nout = lens[j] - m + 1
+            got = np.unpackbits(bits[j].download().view(np.uint8), bitorder="little")[:nout].astype(bool)
+            y = O.fir_canon(xs[j], h)
+            assert np.array_equal(got, (-y if flags else y) >= 0), (j, flags)
+    from pymodem_amd import NativeError
+    with pytest.raises(NativeError):
+        chk(L().pm_fir_signs_f64_batch(ctx.handle, 17, px, pn, dh.ptr, m, pb, 0))
+    pn[0] = m - 1
+    with pytest.raises(NativeError):
+        chk(L().pm_fir_signs_f64_batch(ctx.handle, g, px, pn, dh.ptr, m, pb, 0))
