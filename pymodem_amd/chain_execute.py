@@ -120,6 +120,10 @@ class RecordingPipeline:
         self._post = ThreadPoolExecutor(max_workers=2)        # whatever follows the ordered step (rank 0's indexing and de-dup)
         self._inflight = deque()
         self._n = 0
+        import queue
+        self._free_sides = queue.Queue()
+        for i in range(self._workers):
+            self._free_sides.put(Context.side(index=i))
         self._slots = self._workers + 2                      # bitmaps: one set per slicer in flight, one being written, one ready
         self._events = [None] * self._slots
         self.stage_seconds = {"demod": 0.0, "slice": 0.0, "host": 0.0, "finish": 0.0}   # busy time per stage, summed over recordings
@@ -131,7 +135,6 @@ class RecordingPipeline:
         acc = self.stage_seconds
         slots = self._slots
         slot = self._n % slots
-        side = Context.side(index=self._n % self._workers)
         self._n += 1
         while len(self._inflight) >= slots - 1:               # the slicer that read this slot `slots` recordings ago is done
             self._inflight.popleft().result()
@@ -145,8 +148,12 @@ class RecordingPipeline:
 
         def slice_stage():
             t = time.perf_counter()
-            side.wait_event(ready)
-            sliced = slice_batch([ch[2] for ch in chains], bitmaps, side)
+            side = self._free_sides.get()                      # a slicer stream nobody else is using (a ctx is not thread-safe)
+            try:
+                side.wait_event(ready)
+                sliced = slice_batch([ch[2] for ch in chains], bitmaps, side)
+            finally:
+                self._free_sides.put(side)
             acc["slice"] += time.perf_counter() - t
             return sliced
         f_sliced = self._slice.submit(slice_stage)
