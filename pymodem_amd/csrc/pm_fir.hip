@@ -94,7 +94,6 @@ __device__ __forceinline__ void fir_tile(const InT *__restrict__ x, int64_t n, c
     double acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.0;
-    const int base = t * R;
     // Window registers: two sets of R that alternate between "carry" (last R-1 values of the previous block) and "new".
     // With base = t*R the padded LDS index of input p = base + k is t*(R+1) + k + k/R: the lane part is constant and the
     // tap part is the same for every lane, so each read is lane_base + compile-time offset and only lp advances per block.
@@ -244,7 +243,6 @@ __global__ __launch_bounds__(kThreads) void afsk_correlate_kernel(const double *
     double a[R], b[R], c[R], d[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) a[r] = b[r] = c[r] = d[r] = 0.0;
-    const int base = t * R;
     static_assert(R == 4, "the block schedule below is written for 4 outputs per thread and 4 taps per block");
     double s0[R], s1[R];                     // alternating carry / new window sets, as in fir_valid_kernel
     const double *lp = xs + t * (R + 1);

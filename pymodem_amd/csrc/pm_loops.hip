@@ -261,7 +261,6 @@ int loop_launch(pm_ctx *ctx, pm_loop *h_loops, int nloops, const double *d_table
 }
 
 // ---- AGC ---------------------------------------------------------------------------------------
-constexpr int kAgcTile = 1024;
 
 __global__ __launch_bounds__(256) void max_partial_kernel(const double *__restrict__ x, int64_t n, double *__restrict__ partial)
 {
