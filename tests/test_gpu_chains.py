@@ -244,17 +244,18 @@ def test_whole_chain_entry_point_errors():
 
 @pytest.mark.parametrize("demod_streams", [1, 2])
 def test_recording_pipeline_soak(config_lines, demod_streams):
-    """Sixty recordings of three different kinds through one pipeline, several in flight on every stage: each result equals the
+    """Ninety recordings of three different kinds through one pipeline, several in flight on every stage: each result equals the
     one-at-a-time result for its kind (bitmap slots, slicer streams, host and post stages never mix recordings up)."""
     from pymodem_amd import chain_builder as cb, chain_execute as ce, siggen
     lines = config_lines("afsk_1200_ax25_super_opt.json")
     kinds = [siggen.recording("afsk1200_ax25", 48000, packets=4, seed=s, noise_sigma=500.0, payload_len=(20, 60))[0] for s in (1, 2, 3)]
-    kinds[1] = kinds[1][: len(kinds[1]) * 2 // 3].copy()                       # different lengths too
+    kinds[1] = kinds[1][: len(kinds[1]) // 4].copy()          # very different lengths: slicers finish out of submission order,
+    kinds[2] = np.tile(kinds[2], 3)                           # so a slicer stream must belong to a task, not to a recording index
     want = [ce.process_chains_table([cb.build_chain(48000, l) for l in lines], a) for a in kinds]
     pipe = ce.RecordingPipeline(demod_streams=demod_streams)
     seen = []
     futures = []
-    for k in range(60):
+    for k in range(90):
         which = (k * 7 + k // 5) % 3
         futures.append((which, pipe.submit([cb.build_chain(48000, l) for l in lines], kinds[which],
                                            finish=lambda rows, k=k: (seen.append(k), rows)[1],
@@ -264,5 +265,5 @@ def test_recording_pipeline_soak(config_lines, demod_streams):
         for ci in range(len(lines)):
             assert np.array_equal(rows[ci], want[which][ci]), (which, ci)
     pipe.close()
-    assert seen == list(range(60))                                              # the ordered stage ran in submission order
+    assert seen == list(range(90))                                              # the ordered stage ran in submission order
     assert sum(len(r) for r in want[0].values()) > 0
