@@ -120,6 +120,10 @@ class RecordingPipeline:
         self._post = ThreadPoolExecutor(max_workers=2)        # whatever follows the ordered step (rank 0's indexing and de-dup)
         self._inflight = deque()
         self._n = 0
+        self._upload = ThreadPoolExecutor(max_workers=1)      # host -> HBM copies of the NEXT recording, on a stream of their own
+        self._uploads = 0
+        self._upload_guard = {}                               # upload slot -> event after which its buffer may be overwritten
+        self._upload_done = {}                                # upload slot -> event marking the end of its copy (re-used)
         import queue
         self._free_sides = queue.Queue()
         for i in range(self._workers):
@@ -127,6 +131,26 @@ class RecordingPipeline:
         self._slots = self._workers + 2                      # bitmaps: one set per slicer in flight, one being written, one ready
         self._events = [None] * self._slots
         self.stage_seconds = {"demod": 0.0, "slice": 0.0, "host": 0.0, "finish": 0.0}   # busy time per stage, summed over recordings
+
+    def prefetch(self, host_audio):
+        """Start copying a recording (host int16 / float64 array) into HBM on a copy stream; returns a handle for submit().  Call
+        it one recording ahead and the copy runs while the previous recording is demodulated (three rotating device buffers; a
+        buffer is overwritten only after the demod that read it has finished, which the copy stream waits for on the GPU)."""
+        a = np.asarray(host_audio)
+        a = np.ascontiguousarray(a if a.dtype == np.int16 else a.astype(np.float64))
+        k = self._uploads % 3
+        self._uploads += 1
+        guard = self._upload_guard.get(k)
+        cctx = Context.side(index=200, high_priority=False)
+
+        def copy():
+            if guard is not None:
+                cctx.wait_event(guard)
+            buf = cctx.scratch(("upload", k), a.size, a.dtype)
+            check(lib().pm_h2d(cctx.handle, buf.ptr, a.ctypes.data_as(ctypes.c_void_p), a.nbytes))
+            self._upload_done[k] = done = cctx.record_event(self._upload_done.get(k))
+            return buf, done, k
+        return self._upload.submit(copy)
 
     def submit(self, chains, input_audio, finish=None, post=None):
         """Start one recording; returns a Future of post(finish(rows per chain)) (either may be None = identity).  `finish` calls
@@ -142,8 +166,14 @@ class RecordingPipeline:
         # two demod streams, alternating: the tail of one recording's FIR launches (the last, partly filled round of workgroups)
         # overlaps the head of the next one's instead of leaving CUs idle
         dctx = Context.default() if (self._demod_streams < 2 or (self._n & 1)) else Context.side(index=100, high_priority=False)
+        upload_slot = None
+        if hasattr(input_audio, "result"):                    # a prefetch() handle: the demod stream waits for the copy on the GPU
+            input_audio, copied, upload_slot = input_audio.result()
+            dctx.wait_event(copied)
         bitmaps = process_chains_device(chains, input_audio, _bitmaps_only=True, _slot=slot, _ctx=dctx)
         self._events[slot] = ready = dctx.record_event(self._events[slot])   # bitmaps complete at this point of the stream
+        if upload_slot is not None:
+            self._upload_guard[upload_slot] = dctx.record_event(self._upload_guard.get(upload_slot))   # its own event, re-used per slot
         acc["demod"] += time.perf_counter() - t0
 
         def slice_stage():
@@ -189,6 +219,7 @@ class RecordingPipeline:
 
     def close(self):
         """Waits for everything submitted."""
+        self._upload.shutdown(wait=True)
         self._slice.shutdown(wait=True)
         self._host.shutdown(wait=True)
         self._finish.shutdown(wait=True)

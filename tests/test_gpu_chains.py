@@ -267,3 +267,24 @@ def test_recording_pipeline_soak(config_lines, demod_streams):
     pipe.close()
     assert seen == list(range(90))                                              # the ordered stage ran in submission order
     assert sum(len(r) for r in want[0].values()) > 0
+
+
+def test_recording_pipeline_prefetch(config_lines):
+    """Recordings that start in host memory: prefetch() copies the next one into HBM on a copy stream while the previous one is
+    demodulated; three rotating device buffers must never be overwritten under a demod that still reads them."""
+    from pymodem_amd import chain_builder as cb, chain_execute as ce, siggen
+    lines = config_lines("afsk_1200_ax25_super_opt.json")
+    kinds = [siggen.recording("afsk1200_ax25", 48000, packets=3, seed=s, noise_sigma=500.0, payload_len=(20, 60))[0] for s in (11, 12, 13, 14)]
+    want = [ce.process_chains_table([cb.build_chain(48000, l) for l in lines], a) for a in kinds]
+    pipe = ce.RecordingPipeline()
+    order = [(k * 5 + k // 3) % 4 for k in range(40)]
+    futures = []
+    nxt = pipe.prefetch(kinds[order[0]])
+    for i, which in enumerate(order):
+        cur, nxt = nxt, (pipe.prefetch(kinds[order[i + 1]]) if i + 1 < len(order) else None)
+        futures.append((which, pipe.submit([cb.build_chain(48000, l) for l in lines], cur)))
+    for which, f in futures:
+        rows = f.result()
+        for ci in range(len(lines)):
+            assert np.array_equal(rows[ci], want[which][ci]), (which, ci)
+    pipe.close()
