@@ -40,3 +40,44 @@ def test_loading_does_not_need_or_touch_a_gpu():
         m = cb.ModemConfigurator(48000, {"type": "fsk", "config": "9600", "options": {}})
         with pytest.raises(pymodem_amd.NativeError):
             m.demod(np.zeros(1000, dtype=np.int16))
+
+
+def test_header_is_plain_c_and_ctypes_mirrors_match(tmp_path):
+    """include/pymodem_amd.h compiles as C11 (-pedantic) and links against the library from a C program; the struct sizes and field
+    offsets the C compiler sees are the ones the ctypes mirrors in pymodem_amd/_native.py use."""
+    import ctypes
+    import shutil
+    import subprocess
+    from pymodem_amd import _native as N
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    structs = {"pm_packet": N.Packet, "pm_loop": N.Loop, "pm_agc_params": N.AGCParams, "pm_slicer_params": N.SlicerParams,
+               "pm_slicer_state": N.SlicerState, "pm_slice_job": N.SliceJob, "pm_chain_desc": N.ChainDesc}
+    fields = [("pm_packet", "data"), ("pm_packet", "correlated_count"), ("pm_loop", "bb0"), ("pm_loop", "sy0"), ("pm_slice_job", "h_state"),
+              ("pm_slice_job", "count"), ("pm_slicer_state", "streamaddress"), ("pm_chain_desc", "slicer"), ("pm_chain_desc", "loop"),
+              ("pm_chain_desc", "pd_table"), ("pm_chain_desc", "agc"), ("pm_slicer_params", "demap")]
+    src = ['#include "pymodem_amd.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void) {",
+           '    printf("version %d\\n", pm_version());']
+    for name in structs:
+        src.append(f'    printf("sizeof {name} %zu\\n", sizeof({name}));')
+    for s, f in fields:
+        src.append(f'    printf("offsetof {s} {f} %zu\\n", offsetof({s}, {f}));')
+    src += ['    printf("head %zu %zu\\n", sizeof(pm_packet_head), offsetof(pm_packet, data));', "    return pm_device_count() < 0;", "}"]
+    c = tmp_path / "abi.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "abi"
+    libdir = os.path.join(ROOT, "pymodem_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe),
+                           "-L", libdir, "-lpymodem_amd", f"-Wl,-rpath,{libdir}"])
+    out = subprocess.check_output([str(exe)], text=True).splitlines()
+    assert out[0].startswith("version 1")
+    seen = {}
+    for line in out[1:]:
+        parts = line.split()
+        if parts[0] == "sizeof":
+            assert ctypes.sizeof(structs[parts[1]]) == int(parts[2]), line
+        elif parts[0] == "offsetof":
+            assert getattr(structs[parts[1]], parts[2]).offset == int(parts[3]), line
+        seen[parts[0]] = True
+    assert seen.get("sizeof") and seen.get("offsetof")
+    assert out[-1] == "head 40 40"
