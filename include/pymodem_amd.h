@@ -243,7 +243,7 @@ int pm_chain_destroy(pm_chain *chain);
 
 /* ---- host-integer stages (native C++, no GPU) --------------------------------------------------
  * These consume the slicer's byte stream; they are bit-serial state machines over KBs of data. */
-/* LFSR.stream_unscramble_8bit (lfsr.py:22-52).  *h_shift_register is read and written. */
+/* LFSR.stream_unscramble_8bit (lfsr.py:22-52).  *h_shift_register is read and written.  h_out must not alias h_in. */
 int pm_lfsr_unscramble(const uint8_t *h_in, int64_t n, uint64_t poly, int invert, uint64_t *h_shift_register, uint8_t *h_out);
 
 /* Packet record shared by the codecs and the de-dup (PacketMeta, packet_meta.py:178-195). */
