@@ -95,3 +95,29 @@ def test_quadrature_slicer_and_agc_at_full_size(ctx):
     check(lib().pm_agc_apply(ctx.handle, dbuf.ptr, N, ctypes.byref(p), st))
     assert np.array_equal(dbuf.download(), want)
     assert st[0] == st_o[0] and st[1] == st_o[1]
+
+
+def test_headline_workload_end_to_end_at_full_size(ctx):
+    """The bench's headline workload (8 AFSK-1200 chains, 28.8 M-sample packet-bearing buffer) through the group executor; three of
+    the chains (the one with its own correlators, the first and the last of the shared-mark group) against the oracle: slicer
+    bytes, addresses and every packet identical.  (tools/fullsize_parity.py does all chains of all four workloads.)"""
+    import bench
+    from pymodem_amd import chain_builder as cb, chain_execute as ce
+
+    class A:
+        pass
+    args = A()
+    args.samples, args.rate, args.workload, args.buffer = N, 48000, "afsk_1200_super_opt", "signal"
+    audio = bench.make_buffer(args)
+    factory, cpg, _ = bench.WORKLOADS[args.workload]
+    lines = [factory(c) for c in range(cpg)]
+    stages = {}
+    pk = ce.process_chains_device([cb.build_chain(48000, l) for l in lines], audio, stages=stages)
+    assert [len(p) for p in pk] == [691, 690, 690, 610, 500, 420, 340, 260]
+    for c in (0, 1, 7):
+        r = O.run_chain(O.build_chain(48000, lines[c]), audio, canon=True)
+        sl = stages["sliced"][c]
+        assert np.array_equal(sl.data, r["slice_data"]) and np.array_equal(sl.address, r["slice_addr"]), c
+        got = [(p.streamaddress, bytes(bytearray(p.data))) for p in pk[c]]
+        want = [(p.streamaddress, bytes(bytearray(p.data))) for p in r["packets"]]
+        assert got == want, c
