@@ -370,6 +370,14 @@ struct Il2p : pm_codec {
     {
         for (int64_t k = 0; k < n; ++k) {
             if (state != kSync) {
+                // inside a packet: an input byte completes exactly one packet byte, nbits bits into it.  Unless that byte ends a
+                // block (header, payload block, CRC) nothing else can happen in this input byte: take it in one step.
+                const int needed = state == kHeader ? 15 : state == kCrc ? 4 : block_size + 16;
+                if (nbuf + 1 < needed) {
+                    buf[nbuf++] = (uint8_t)((word << (8 - nbits)) | ((unsigned)d[k] >> nbits));
+                    word = d[k];                              // the last eight bits seen
+                    continue;
+                }
                 feed(d[k], a[k], sink);
                 continue;
             }
