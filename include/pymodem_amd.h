@@ -110,6 +110,21 @@ int pm_afsk_correlate(pm_ctx *ctx, const double *d_x, int64_t n, const double *d
 int pm_afsk_correlate_group(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_mark_i, const double *d_mark_q,
                             const double *d_space, int groups, int m, double *d_y, int64_t y_stride);
 
+/* Gain sweep: `groups` (<= 8) AFSK modems over the same band-passed stream that share their mark correlators and whose space
+ * correlators are ONE unit pair (d_unit_i/q, space_gain 1.0) scaled by each modem's space_gain (afsk.py:144-145), all with the same
+ * output low-pass: writes every modem's slicer sign bitmap (what afsk.py:148-167 followed by `>= 0` gives) from two correlator
+ * pairs and two low-passes for the whole sweep.  The bitmaps are certified: a sample whose sign the shared computation cannot
+ * guarantee is recomputed by the exact chain of that modem (d_space = [groups][2][m], the modems' own space taps), and if there are
+ * more such samples than a fixed list holds (degenerate input) the exact chains of all modems run instead, decided on the device:
+ * every bit equals pm_afsk_correlate + pm_fir_signs_f64 for that modem, and the call never waits for the GPU.  x_bound: a bound on
+ * |d_x| the caller vouches for (sum|input_bpf| * 32768 for int16 audio); lpf_abs_sum = sum|output_lpf|.
+ * pm_afsk_sweep_last (diagnostics; waits for the stream): how many samples the last sweep on this ctx could not certify (above
+ * 65536 the exact chains ran). */
+int pm_afsk_sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound, const double *d_mark_i, const double *d_mark_q,
+                        const double *d_unit_i, const double *d_unit_q, const double *d_space, const double *h_gains, int groups, int m,
+                        const double *d_lpf, int ml, double lpf_abs_sum, uint64_t *const *h_bits);
+int pm_afsk_sweep_last(pm_ctx *ctx, int64_t *h_uncertain);
+
 /* Sign bitmap of a float64 stream: bit k of the little-endian uint64 array = (x[k] >= 0), the only
  * property of a sample the slicers read (slicer.py:85,99-102,210-232).  d_bits holds (n+63)/64 words. */
 int pm_signs_f64(pm_ctx *ctx, const double *d_x, int64_t n, uint64_t *d_bits);

@@ -126,6 +126,9 @@ _SIGS = {
     "pm_fir_signs_f64_batch": ([_vp, _int, ctypes.POINTER(_vp), ctypes.POINTER(_i64), _vp, _int, ctypes.POINTER(_vp), _int], _int),
     "pm_afsk_correlate": ([_vp, _vp, _i64, _vp, _vp, _vp, _vp, _int, _vp], _int),
     "pm_afsk_correlate_group": ([_vp, _vp, _i64, _vp, _vp, _vp, _int, _int, _vp, _i64], _int),
+    "pm_afsk_sweep_signs": ([_vp, _vp, _i64, _dbl, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(_dbl), _int, _int, _vp, _int, _dbl,
+                            ctypes.POINTER(_vp)], _int),
+    "pm_afsk_sweep_last": ([_vp, ctypes.POINTER(_i64)], _int),
     "pm_signs_f64": ([_vp, _vp, _i64, _vp], _int),
     "pm_agc_apply": ([_vp, _vp, _i64, ctypes.POINTER(AGCParams), ctypes.POINTER(_dbl)], _int),
     "pm_costas_bpsk": ([_vp, ctypes.POINTER(Loop), _int, _vp, _vp, _i64, _i64, _vp, _i64], _int),

@@ -69,13 +69,14 @@ def _host_rows(chains, sliced):
 
 
 _POOL = None
+_USE_SWEEP = True          # pm_afsk_sweep_signs for gain sweeps (tests switch it off to compare against the exact group path)
 
 
 def _pool():
     global _POOL
     if _POOL is None:
         import os
-        _POOL = ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 4) // 2)))
+        _POOL = ThreadPoolExecutor(max_workers=max(2, min(int(os.environ.get("PYMODEM_AMD_HOST_THREADS", "24")), (os.cpu_count() or 4) // 2)))
     return _POOL
 
 
@@ -303,12 +304,32 @@ def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced
     # ---- AFSK: correlator banks that share their mark filters run as one launch per group of up to 8, the rest one by one;
     # then the output low-passes of all chains with equal taps run as one batched sign-only launch ----------------------------
     afsk_groups, corr = {}, {}
+    int16_audio = audio.dtype == np.dtype(np.int16)
     for k, ch in enumerate(chains):
         if isinstance(ch[1], AFSKModem):
             ch[1].use_context(ctx)
             afsk_groups.setdefault(ch[1].mark_key(), []).append(k)
     gi = 0
     for key, members in afsk_groups.items():
+        # a gain sweep (members differ in space_gain only, int16 audio so that |band-passed| <= sum|bpf| * 32768): certified sign
+        # bitmaps from two correlator pairs and two low-passes for the whole sweep (pm_afsk_sweep_signs)
+        sweeps = {}
+        if int16_audio and _USE_SWEEP:
+            for k in members:
+                sk = chains[k][1].sweep_key()
+                if sk is not None:
+                    sweeps.setdefault(sk, []).append(k)
+        for part_all in sweeps.values():
+            for base in range(0, len(part_all), 8):
+                part = part_all[base:base + 8]
+                if len(part) < 2:
+                    continue
+                mods = [chains[k][1] for k in part]
+                bpf = shared_front(mods[0])
+                got = AFSKModem.sweep_signs(mods, bpf, float(np.abs(mods[0].input_bpf).sum()) * 32768.0)
+                for k, sb in zip(part, got):
+                    bitmaps[k] = chains[k][2].sign_bitmaps(sb)
+        members = [k for k in members if bitmaps[k] is None]
         for base in range(0, len(members), 8):
             part = members[base:base + 8]
             mods = [chains[k][1] for k in part]

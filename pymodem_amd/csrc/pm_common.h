@@ -27,6 +27,7 @@ struct pm_ctx {
     int32_t sl_iterations = 0, sl_chunk_len = 0;
     int64_t sl_chunks = 0;
     int64_t sl_target_lanes = 65536;   // chunks a slicer batch is cut into (pm_slicer_tune)
+    int *sweep_count = nullptr;        // device counter of the last pm_afsk_sweep_signs on this ctx (inside d_scratch)
 };
 
 int pm_set_error(int code, const char *fmt, ...);

@@ -210,8 +210,10 @@ struct FirBatch {
 };
 
 template <int R, bool NEG, bool VEC>
-__global__ __launch_bounds__(kThreads) void fir_signs_batch_kernel(FirBatch B, const double *__restrict__ h, int m)
+__global__ __launch_bounds__(kThreads) void fir_signs_batch_kernel(FirBatch B, const double *__restrict__ h, int m,
+                                                                   const int *__restrict__ gate = nullptr, int gate_above = 0)
 {
+    if (gate && *gate <= gate_above) return;                          // a launch that only matters if an earlier kernel said so
     const int s = blockIdx.y;
     const int64_t n = B.n[s], nout = n - m + 1;
     if ((int64_t)blockIdx.x * (kThreads * R) >= nout) return;          // the grid is sized for the longest stream
@@ -219,11 +221,12 @@ __global__ __launch_bounds__(kThreads) void fir_signs_batch_kernel(FirBatch B, c
 }
 
 // Four correlators over one staged window; R outputs x 4 filters = 4R accumulators per thread.
-template <int R, bool VEC>
+// SPLIT: write the two magnitudes as separate streams (y = mark, y2 = space) instead of their difference (pm_afsk_sweep_signs).
+template <int R, bool VEC, bool SPLIT = false>
 __global__ __launch_bounds__(kThreads) void afsk_correlate_kernel(const double *__restrict__ x, int64_t n,
                                                                   const double *__restrict__ mi, const double *__restrict__ mq,
                                                                   const double *__restrict__ si, const double *__restrict__ sq,
-                                                                  int m, double *__restrict__ y, int64_t nout)
+                                                                  int m, double *__restrict__ y, int64_t nout, double *__restrict__ y2 = nullptr)
 {
     extern __shared__ double xs[];
     constexpr int T = kThreads * R;
@@ -304,32 +307,46 @@ __global__ __launch_bounds__(kThreads) void afsk_correlate_kernel(const double *
         }
 #undef PM_CORR_TAIL
     }
-    lds_barrier();
+    double markv[R], spacev[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         // afsk.py:153-162: sqrt(i**2 + q**2) with separately rounded squares and sum, then mark - space
-        const double mark = __builtin_sqrt(a[r] * a[r] + b[r] * b[r]);
-        const double space = __builtin_sqrt(c[r] * c[r] + d[r] * d[r]);
-        xs[t * (R + 1) + r] = mark - space;
+        markv[r] = __builtin_sqrt(a[r] * a[r] + b[r] * b[r]);
+        spacev[r] = __builtin_sqrt(c[r] * c[r] + d[r] * d[r]);
     }
-    lds_barrier();
-    if (VEC) {
+    // results go back through the LDS image so that the global stores are lane-contiguous
+    auto emit = [&](const double (&v)[R], double *__restrict__ dst) {
+        lds_barrier();
 #pragma unroll
-        for (int r = 0; r < R / 2; ++r) {
-            const int idx = 2 * (r * kThreads + t);
-            const int64_t go = tile0 + idx;
-            const int s0i = slot<R>(idx);
-            const double2v v = {xs[s0i], xs[s0i + 1]};
-            if (go + 1 < nout) *reinterpret_cast<double2v *>(y + go) = v;
-            else if (go < nout) y[go] = v.x;
+        for (int r = 0; r < R; ++r) xs[t * (R + 1) + r] = v[r];
+        lds_barrier();
+        if (VEC) {
+#pragma unroll
+            for (int r = 0; r < R / 2; ++r) {
+                const int idx = 2 * (r * kThreads + t);
+                const int64_t go = tile0 + idx;
+                const int s0i = slot<R>(idx);
+                const double2v w = {xs[s0i], xs[s0i + 1]};
+                if (go + 1 < nout) *reinterpret_cast<double2v *>(dst + go) = w;
+                else if (go < nout) dst[go] = w.x;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int idx = r * kThreads + t;
+                const int64_t go = tile0 + idx;
+                if (go < nout) dst[go] = xs[slot<R>(idx)];
+            }
         }
+    };
+    if (SPLIT) {
+        emit(markv, y);
+        emit(spacev, y2);
     } else {
+        double diff[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int idx = r * kThreads + t;
-            const int64_t go = tile0 + idx;
-            if (go < nout) y[go] = xs[slot<R>(idx)];
-        }
+        for (int r = 0; r < R; ++r) diff[r] = markv[r] - spacev[r];
+        emit(diff, y);
     }
 }
 
@@ -349,9 +366,11 @@ __global__ void pack_group_taps_kernel(const double *__restrict__ mi, const doub
 
 template <int G, bool VEC>
 __global__ __launch_bounds__(kThreads) void afsk_group_kernel(const double *__restrict__ x, int64_t n, const double *__restrict__ w,
-                                                              int m, double *__restrict__ y, int64_t y_stride, int64_t nout)
+                                                              int m, double *__restrict__ y, int64_t y_stride, int64_t nout,
+                                                              const int *__restrict__ gate = nullptr, int gate_above = 0)
 {
     extern __shared__ double xs[];
+    if (gate && *gate <= gate_above) return;                          // see fir_signs_batch_kernel
     constexpr int R = 2, F = 2 + 2 * G, T = kThreads * R;
     const int t = threadIdx.x;
     const int span = T + m - 1;
@@ -427,6 +446,77 @@ __global__ __launch_bounds__(kThreads) void afsk_group_kernel(const double *__re
     }
 }
 
+// ---- gain sweep: G AFSK modems that differ in space_gain only, sign bitmaps certified against the exact chain --------------------
+// The chains of afsk_1200_ax25_super_opt.json share tones and span and sweep space_gain, which the reference folds into the space
+// taps (afsk.py:144-145: taps_g = fl(g * c)).  In exact arithmetic chain g's output is LPF(M) - g * LPF(S), with M the mark
+// magnitude and S the space magnitude for the UNIT taps c -- two correlator pairs and two low-passes for the whole sweep instead
+// of 2 + 2G pairs and G low-passes.  In binary64 the two routes differ by rounding only, and the slicer reads nothing but the sign:
+//     y~_g = fma(-g, B, A),  A = LPF(M), B = LPF(S)   (both by the canonical kernels)
+// satisfies |y~_g - y_g| <= E for the bound below, so wherever |y~_g| > E the sign of the exact chain's output y_g is the sign of
+// y~_g, and the few samples with |y~_g| <= E are recomputed by the exact chain itself (every fma in its canonical order, one thread
+// per sample).  Every bit of every bitmap is therefore the bit the exact kernels write; tests compare them over whole recordings.
+//
+// Bound.  u = 2^-53, mc / ml = correlator / low-pass taps, X >= max|x|.  Space sums: the taps differ by relative u and each chain of
+// mc fmas has relative error <= mc u/(1 - mc u) in sum|t x|, so |sum_g - g sum_1| <= (2 mc + 2) u g mc X; the magnitude sqrt(a^2+b^2)
+// is 1-Lipschitz in (a, b) and adds 3 roundings, so |space_g - g S| <= (2 mc + 6) sqrt2 u g mc X; y = M - space adds u |y|.  The
+// low-pass is linear up to (ml + 2) u sum|h|(|M| + g|S|) of its own rounding (three canonical sums), and fma(-g, B, A) adds one
+// more.  With |M|, |S| <= sqrt2 mc X everything is below  (2 mc + ml + 12) * 2.9 u * sum|h| (1 + g) mc X  ~ 1e-13 * scale; E is
+// taken as 1e-10 * sum|h| (1 + g_max) mc sqrt2 X, a thousand times that, which still flags only ~1e-8 of the samples.
+constexpr int kSweepMax = 8;
+struct SweepArgs {
+    double gain[kSweepMax];
+    uint64_t *bits[kSweepMax];
+};
+
+__global__ __launch_bounds__(256) void sweep_combine_kernel(const double *__restrict__ A, const double *__restrict__ B, int64_t nout, int G,
+                                                            SweepArgs P, double E, unsigned long long *__restrict__ list,
+                                                            int *__restrict__ count, int cap)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;         // one sample per lane: a wave is one bitmap word
+    const bool in = k < nout;
+    const double a = in ? A[k] : 0.0, b = in ? B[k] : 0.0;
+    for (int g = 0; g < G; ++g) {
+        const double y = __builtin_fma(-P.gain[g], b, a);
+        const uint64_t word = __ballot(in && y >= 0.0);
+        if ((threadIdx.x & 63) == 0 && in) P.bits[g][k >> 6] = word;
+        if (in && !(fabs(y) > E)) {                                          // cannot be certified (NaN lands here too)
+            const int idx = atomicAdd(count, 1);
+            if (idx < cap) list[idx] = ((unsigned long long)g << 48) | (unsigned long long)k;
+        }
+    }
+}
+
+// The exact chain for single samples: correlator bank of modem g at the ml positions the low-pass needs, then the low-pass, every
+// sum in the canonical order of afsk_correlate_kernel / fir_valid_kernel.  Runs after the combine kernel (bitmap words are final).
+__global__ __launch_bounds__(64) void sweep_exact_kernel(const double *__restrict__ x, const double *__restrict__ mi, const double *__restrict__ mq,
+                                                         const double *__restrict__ space, int mc, const double *__restrict__ lpf, int ml,
+                                                         SweepArgs P, const unsigned long long *__restrict__ list, const int *__restrict__ count, int cap)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= min(*count, cap)) return;
+    const int g = (int)(list[i] >> 48);
+    const int64_t k = (int64_t)(list[i] & 0xFFFFFFFFFFFFull);
+    const double *si = space + (size_t)g * 2 * mc, *sq = si + mc;
+    double acc = 0.0;
+    for (int j = 0; j < ml; ++j) {
+        const double *xp = x + k + j;
+        double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+        for (int t = 0; t < mc; ++t) {
+            const double v = xp[t];
+            a = __builtin_fma(mi[mc - 1 - t], v, a);
+            b = __builtin_fma(mq[mc - 1 - t], v, b);
+            c = __builtin_fma(si[mc - 1 - t], v, c);
+            d = __builtin_fma(sq[mc - 1 - t], v, d);
+        }
+        const double mark = __builtin_sqrt(a * a + b * b);
+        const double spc = __builtin_sqrt(c * c + d * d);
+        acc = __builtin_fma(lpf[ml - 1 - j], mark - spc, acc);
+    }
+    unsigned long long *w = reinterpret_cast<unsigned long long *>(P.bits[g]) + (k >> 6);
+    const unsigned long long bit = 1ull << (k & 63);
+    if (acc >= 0.0) atomicOr(w, bit); else atomicAnd(w, ~bit);
+}
+
 // One 64-bit word per wave per step: lane l tests sample 64*w + l, the ballot is the word.
 __global__ __launch_bounds__(kThreads) void signs_kernel(const double *__restrict__ x, int64_t n,
                                                          uint64_t *__restrict__ bits, int64_t nwords)
@@ -494,7 +584,8 @@ int fir_launch(pm_ctx *ctx, const InT *d_x, int64_t n, const double *d_taps, int
 }  // namespace
 
 template <int G>
-static int afsk_group_go(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_w, int m, double *d_y, int64_t y_stride, int64_t nout)
+static int afsk_group_go(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_w, int m, double *d_y, int64_t y_stride, int64_t nout,
+                         const int *gate = nullptr, int gate_above = 0)
 {
     constexpr int R = 2;
     const int64_t ntiles = pm_cdiv(nout, (int64_t)kThreads * R);
@@ -502,13 +593,15 @@ static int afsk_group_go(pm_ctx *ctx, const double *d_x, int64_t n, const double
     const size_t lds = lds_bytes<R>(m) + 4 * (R + 1) * sizeof(double);        // the last block's look-ahead load
     const bool vec = ((((uintptr_t)d_x | (uintptr_t)d_y) & 15) == 0) && (y_stride % 2 == 0);
     PmProf prof(ctx, PM_K_AFSK_CORR);
-    prof.work((double)n * 8 + (double)G * nout * 8, 2.0 * (2 + 2 * G) * m * (double)nout);
+    if (!gate) prof.work((double)n * 8 + (double)G * nout * 8, 2.0 * (2 + 2 * G) * m * (double)nout);
     if (vec) {
         if (int rc = allow_lds(afsk_group_kernel<G, true>, lds)) return rc;
-        hipLaunchKernelGGL((afsk_group_kernel<G, true>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, d_x, n, d_w, m, d_y, y_stride, nout);
+        hipLaunchKernelGGL((afsk_group_kernel<G, true>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, d_x, n, d_w, m, d_y, y_stride, nout,
+                           gate, gate_above);
     } else {
         if (int rc = allow_lds(afsk_group_kernel<G, false>, lds)) return rc;
-        hipLaunchKernelGGL((afsk_group_kernel<G, false>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, d_x, n, d_w, m, d_y, y_stride, nout);
+        hipLaunchKernelGGL((afsk_group_kernel<G, false>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, d_x, n, d_w, m, d_y, y_stride, nout,
+                           gate, gate_above);
     }
     PM_HIP(hipGetLastError());
     return PM_OK;
@@ -632,6 +725,133 @@ int pm_afsk_correlate_group(pm_ctx *ctx, const double *d_x, int64_t n, const dou
     case 7: return afsk_group_go<7>(ctx, d_x, n, d_w, m, d_y, y_stride, nout);
     default: return afsk_group_go<8>(ctx, d_x, n, d_w, m, d_y, y_stride, nout);
     }
+}
+
+static int afsk_group_dispatch(pm_ctx *ctx, int groups, const double *d_x, int64_t n, const double *d_w, int m, double *d_y, int64_t y_stride,
+                               int64_t nout, const int *gate, int gate_above)
+{
+    switch (groups) {
+    case 1: return afsk_group_go<1>(ctx, d_x, n, d_w, m, d_y, y_stride, nout, gate, gate_above);
+    case 2: return afsk_group_go<2>(ctx, d_x, n, d_w, m, d_y, y_stride, nout, gate, gate_above);
+    case 3: return afsk_group_go<3>(ctx, d_x, n, d_w, m, d_y, y_stride, nout, gate, gate_above);
+    case 4: return afsk_group_go<4>(ctx, d_x, n, d_w, m, d_y, y_stride, nout, gate, gate_above);
+    case 5: return afsk_group_go<5>(ctx, d_x, n, d_w, m, d_y, y_stride, nout, gate, gate_above);
+    case 6: return afsk_group_go<6>(ctx, d_x, n, d_w, m, d_y, y_stride, nout, gate, gate_above);
+    case 7: return afsk_group_go<7>(ctx, d_x, n, d_w, m, d_y, y_stride, nout, gate, gate_above);
+    default: return afsk_group_go<8>(ctx, d_x, n, d_w, m, d_y, y_stride, nout, gate, gate_above);
+    }
+}
+
+int pm_afsk_sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound, const double *d_mark_i, const double *d_mark_q,
+                        const double *d_unit_i, const double *d_unit_q, const double *d_space, const double *h_gains, int groups, int m,
+                        const double *d_lpf, int ml, double lpf_abs_sum, uint64_t *const *h_bits)
+{
+    PM_CTX(ctx);
+    PM_ARG(d_x && d_mark_i && d_mark_q && d_unit_i && d_unit_q && d_space && h_gains && d_lpf && h_bits);
+    PM_ARG(groups >= 1 && groups <= kSweepMax && m >= 1 && m <= kMaxTaps && ml >= 1 && ml <= kMaxTaps);
+    PM_ARG(x_bound > 0.0 && x_bound < 1e300 && lpf_abs_sum > 0.0 && lpf_abs_sum < 1e300);
+    PM_ARG(n >= (int64_t)m + ml - 1);
+    const int64_t nc = n - m + 1, nl = nc - ml + 1;
+    SweepArgs P;
+    memset(&P, 0, sizeof(P));
+    double gmax = 0.0;
+    for (int g = 0; g < groups; ++g) {
+        PM_ARG(h_bits[g] != nullptr && h_gains[g] >= 0.0 && h_gains[g] < 1e100);
+        P.gain[g] = h_gains[g];
+        P.bits[g] = h_bits[g];
+        gmax = std::max(gmax, h_gains[g]);
+    }
+    const int cap = 65536;                                 // more uncertain samples than this: the gated exact path below takes over
+    const int F = 2 + 2 * groups;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const int64_t stride = (nc + 63) / 64 * 64;
+    const size_t b_m = up((size_t)nc * 8), b_a = up((size_t)nl * 8), b_list = up((size_t)cap * 8), b_w = up((size_t)F * m * 8),
+                 b_c = up((size_t)stride * groups * 8);
+    if (int rc = pm_scratch_reserve(ctx, 2 * b_m + 2 * b_a + b_list + 256 + b_w + b_c)) return rc;
+    char *base = (char *)ctx->d_scratch;
+    double *M = (double *)base, *S = (double *)(base + b_m), *A = (double *)(base + 2 * b_m), *B = (double *)(base + 2 * b_m + b_a);
+    unsigned long long *list = (unsigned long long *)(base + 2 * b_m + 2 * b_a);
+    int *count = (int *)(base + 2 * b_m + 2 * b_a + b_list);
+    double *d_w = (double *)(base + 2 * b_m + 2 * b_a + b_list + 256);
+    double *C = (double *)(base + 2 * b_m + 2 * b_a + b_list + 256 + b_w);
+    ctx->sweep_count = count;
+    {   // mark and unit-gain space magnitudes, one pass over the band-passed stream
+        constexpr int R = 4;
+        const int64_t ntiles = pm_cdiv(nc, (int64_t)kThreads * R);
+        PM_ARG(ntiles < (1LL << 31));
+        const size_t lds = lds_bytes<R>(m);
+        PmProf prof(ctx, PM_K_AFSK_CORR);
+        prof.work((double)n * 8 + 2.0 * nc * 8, 2.0 * 4 * m * (double)nc);
+        if ((((uintptr_t)d_x) & 15) == 0) {
+            if (int rc = allow_lds(afsk_correlate_kernel<R, true, true>, lds)) return rc;
+            hipLaunchKernelGGL((afsk_correlate_kernel<R, true, true>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, d_x, n, d_mark_i,
+                               d_mark_q, d_unit_i, d_unit_q, m, M, nc, S);
+        } else {
+            if (int rc = allow_lds(afsk_correlate_kernel<R, false, true>, lds)) return rc;
+            hipLaunchKernelGGL((afsk_correlate_kernel<R, false, true>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, d_x, n, d_mark_i,
+                               d_mark_q, d_unit_i, d_unit_q, m, M, nc, S);
+        }
+        PM_HIP(hipGetLastError());
+    }
+    if (int rc = fir_launch<double>(ctx, M, nc, d_lpf, ml, A, nullptr, 0)) return rc;
+    if (int rc = fir_launch<double>(ctx, S, nc, d_lpf, ml, B, nullptr, 0)) return rc;
+    const double E = 1e-10 * lpf_abs_sum * (1.0 + gmax) * (double)m * 1.4143 * x_bound;
+    PM_HIP(hipMemsetAsync(count, 0, sizeof(int), ctx->stream));
+    {
+        PmProf prof(ctx, PM_K_SIGNS);
+        prof.work(2.0 * nl * 8 + (double)groups * nl / 8, 2.0 * groups * (double)nl);
+        const int64_t words = pm_cdiv(nl, 64);
+        hipLaunchKernelGGL(sweep_combine_kernel, dim3((unsigned)pm_cdiv(words * 64, 256)), dim3(256), 0, ctx->stream, A, B, nl, groups, P, E, list,
+                           count, cap);
+        hipLaunchKernelGGL(sweep_exact_kernel, dim3((unsigned)pm_cdiv(cap, 64)), dim3(64), 0, ctx->stream, d_x, d_mark_i, d_mark_q, d_space, m, d_lpf,
+                           ml, P, list, count, cap);
+    }
+    PM_HIP(hipGetLastError());
+    // More uncertain samples than the list holds (degenerate input: silence, amplitudes far below the caller's bound): the exact
+    // chain of every modem runs after all -- the same launches as pm_afsk_correlate_group + pm_fir_signs_f64_batch, each workgroup
+    // of which first looks at the counter and leaves at once in the normal case.  No host round trip either way.
+    hipLaunchKernelGGL(pack_group_taps_kernel, dim3((unsigned)pm_cdiv((int64_t)F * m, 256)), dim3(256), 0, ctx->stream, d_mark_i, d_mark_q,
+                       d_space, m, F, d_w);
+    if (int rc = afsk_group_dispatch(ctx, groups, d_x, n, d_w, m, C, stride, nc, count, cap)) return rc;
+    {
+        constexpr int R = 8;
+        FirBatch FB;
+        memset(&FB, 0, sizeof(FB));
+        bool vec = true;
+        for (int g = 0; g < groups; ++g) {
+            FB.x[g] = C + (size_t)g * stride;
+            FB.bits[g] = h_bits[g];
+            FB.n[g] = nc;
+            vec = vec && (((uintptr_t)FB.x[g]) & 15) == 0;
+        }
+        const int64_t ntiles = pm_cdiv(nl, (int64_t)kThreads * R);
+        const size_t lds = lds_bytes<R>(ml);
+        PmProf prof(ctx, PM_K_FIR_F64);
+        if (vec) {
+            if (int rc = allow_lds(fir_signs_batch_kernel<R, false, true>, lds)) return rc;
+            hipLaunchKernelGGL((fir_signs_batch_kernel<R, false, true>), dim3((unsigned)ntiles, (unsigned)groups), dim3(kThreads), lds, ctx->stream, FB,
+                               d_lpf, ml, count, cap);
+        } else {
+            if (int rc = allow_lds(fir_signs_batch_kernel<R, false, false>, lds)) return rc;
+            hipLaunchKernelGGL((fir_signs_batch_kernel<R, false, false>), dim3((unsigned)ntiles, (unsigned)groups), dim3(kThreads), lds, ctx->stream, FB,
+                               d_lpf, ml, count, cap);
+        }
+    }
+    PM_HIP(hipGetLastError());
+    return PM_OK;
+}
+
+int pm_afsk_sweep_last(pm_ctx *ctx, int64_t *h_uncertain)
+{
+    PM_CTX(ctx);
+    PM_ARG(h_uncertain != nullptr);
+    *h_uncertain = -1;
+    if (!ctx->sweep_count) return PM_OK;
+    int v = 0;
+    PM_HIP(hipMemcpyAsync(&v, ctx->sweep_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PM_HIP(hipStreamSynchronize(ctx->stream));
+    *h_uncertain = v;
+    return PM_OK;
 }
 
 int pm_signs_f64(pm_ctx *ctx, const double *d_x, int64_t n, uint64_t *d_bits)

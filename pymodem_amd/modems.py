@@ -283,6 +283,57 @@ class AFSKModem(_DeviceStage):
             out += [SignBits(b, None, n) for b, n in bufs]
         return out
 
+    def unit_space_correlators(self):
+        """The space correlators this modem would have with space_gain 1.0 (afsk.py:144-145 without the factor)."""
+        _, _, ui, uq = T.afsk_tone_correlators(self.sample_rate, self.symbol_rate, self.mark_freq, self.space_freq, 1.0,
+                                               self.correlator_span, self.correlator_offset)
+        return ui, uq
+
+    def sweep_key(self):
+        """Modems with equal keys differ in space_gain only (same band-pass, tones, span, output low-pass) AND their space taps are
+        exactly gain * unit taps: they can take pm_afsk_sweep_signs together.  None if this modem's taps are not of that form."""
+        ui, uq = self.unit_space_correlators()
+        if not (np.array_equal(self.space_correlator_i, self.space_gain * ui) and np.array_equal(self.space_correlator_q, self.space_gain * uq)):
+            return None
+        return (self.mark_key(), ui.tobytes(), uq.tobytes(), self.output_lpf.tobytes())
+
+    @staticmethod
+    def sweep_signs(modems, a, x_bound):
+        """Sign bitmaps of a gain sweep (equal sweep_key) over the band-passed stream `a`, |a| <= x_bound guaranteed by the caller
+        -> [SignBits per modem].  Never waits for the GPU; `sweep_uncertain(ctx)` tells afterwards how many samples had to be
+        recomputed exactly."""
+        lead = modems[0]
+        ctx = lead._context()
+        mc, ml, g = len(lead.mark_correlator_i), len(lead.output_lpf), len(modems)
+        if a.n < mc + ml - 1:
+            raise ValueError("input shorter than the correlators and the output filter")
+        nout = a.n - mc - ml + 2
+        ui, uq = lead.unit_space_correlators()
+        space = np.stack([np.stack([md.space_correlator_i, md.space_correlator_q]) for md in modems])
+        gains = (ctypes.c_double * g)(*[float(md.space_gain) for md in modems])
+        bits, ptrs = [], (ctypes.c_void_p * g)()
+        for j, md in enumerate(modems):
+            md._context()
+            b = ctx.scratch((md._own_key(), "signs", "output_lpf"), (nout + 63) // 64 + 1, np.uint64)
+            bits.append(b)
+            ptrs[j] = b.ptr.value
+        check(lib().pm_afsk_sweep_signs(ctx.handle, a.ptr, a.n, float(x_bound), lead._const("mi", lead.mark_correlator_i).ptr,
+                                        lead._const("mq", lead.mark_correlator_q).ptr, lead._const("unit_i", ui).ptr,
+                                        lead._const("unit_q", uq).ptr, lead._const("space_group", space.reshape(-1)).ptr, gains, g, mc,
+                                        lead._const("output_lpf", lead.output_lpf).ptr, ml, float(np.abs(lead.output_lpf).sum()), ptrs))
+        AFSKModem.sweeps_run += 1
+        return [SignBits(b, None, nout) for b in bits]
+
+    @staticmethod
+    def sweep_uncertain(ctx):
+        """Samples the last pm_afsk_sweep_signs on `ctx` could not certify (recomputed exactly; above 65536 the exact chains ran)."""
+        v = ctypes.c_int64()
+        check(lib().pm_afsk_sweep_last(ctx.handle, ctypes.byref(v)))
+        return v.value
+
+    sweeps_run = 0
+
+
     def back_end(self, a, device_out=False, signs=False, correlated=None):
         """Correlators + output low-pass on an already band-passed stream (afsk.py:153-166).  `correlated`: this modem's
         correlator output when a group launch already produced it."""

@@ -288,3 +288,29 @@ def test_recording_pipeline_prefetch(config_lines):
         for ci in range(len(lines)):
             assert np.array_equal(rows[ci], want[which][ci]), (which, ci)
     pipe.close()
+
+
+def test_gain_sweep_path_equals_exact_group_path(config_lines):
+    """Group executor on afsk_1200_ax25_super_opt.json with the certified gain-sweep entry (default) and with it switched off (the
+    exact correlator-group + batched low-pass path): identical slicer bytes, addresses and packets for every chain."""
+    from pymodem_amd import chain_builder as cb, chain_execute as ce, siggen
+    from pymodem_amd.modems import AFSKModem
+    lines = config_lines("afsk_1200_ax25_super_opt.json")
+    audio, _ = siggen.recording("afsk1200_ax25", 48000, packets=12, seed=21, noise_sigma=1500.0, payload_len=(20, 80))
+    res = {}
+    for on in (True, False):
+        ce._USE_SWEEP = on
+        before = AFSKModem.sweeps_run
+        try:
+            st = {}
+            pk = ce.process_chains_device([cb.build_chain(48000, l) for l in lines], audio, stages=st)
+        finally:
+            ce._USE_SWEEP = True
+        res[on] = (st["sliced"], pk, AFSKModem.sweeps_run - before)
+    assert res[True][2] == 1 and res[False][2] == 0           # the sweep entry ran, and only when enabled
+    import pymodem_amd
+    assert 0 <= AFSKModem.sweep_uncertain(pymodem_amd.Context.default()) < 1000
+    for c in range(len(lines)):
+        a, b = res[True][0][c], res[False][0][c]
+        assert np.array_equal(a.data, b.data) and np.array_equal(a.address, b.address), c
+        assert [(p.streamaddress, bytes(bytearray(p.data))) for p in res[True][1][c]] == [(p.streamaddress, bytes(bytearray(p.data))) for p in res[False][1][c]]

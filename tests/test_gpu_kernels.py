@@ -541,3 +541,67 @@ def test_fir_signs_batch_matches_single_launches(ctx):
     pn[0] = m - 1
     with pytest.raises(NativeError):
         chk(L().pm_fir_signs_f64_batch(ctx.handle, g, px, pn, dh.ptr, m, pb, 0))
+
+
+def _exact_afsk_signs(ctx, x, mark, space_pair, lpf):
+    n, m, ml = len(x), len(mark[0]), len(lpf)
+    dx = ctx.upload(x)
+    t = [ctx.upload(v) for v in (mark[0], mark[1], space_pair[0], space_pair[1])]
+    c = ctx.empty(n - m + 1, np.float64)
+    chk(L().pm_afsk_correlate(ctx.handle, dx.ptr, n, t[0].ptr, t[1].ptr, t[2].ptr, t[3].ptr, m, c.ptr))
+    nout = n - m - ml + 2
+    bits = ctx.empty((nout + 63) // 64 + 1, np.uint64)
+    dl = ctx.upload(lpf)
+    chk(L().pm_fir_signs_f64(ctx.handle, c.ptr, c.n, dl.ptr, ml, bits.ptr, 0))
+    return np.unpackbits(bits.download().view(np.uint8), bitorder="little")[:nout].astype(bool)
+
+
+def _sweep(ctx, x, x_bound, mark, unit, gains, lpf):
+    n, m, ml, g = len(x), len(mark[0]), len(lpf), len(gains)
+    nout = n - m - ml + 2
+    space = np.stack([np.stack([gn * unit[0], gn * unit[1]]) for gn in gains])
+    dx, dl = ctx.upload(x), ctx.upload(lpf)
+    t = [ctx.upload(v) for v in (mark[0], mark[1], unit[0], unit[1])]
+    ds = ctx.upload(space.reshape(-1))
+    bits = [ctx.empty((nout + 63) // 64 + 1, np.uint64) for _ in range(g)]
+    ptrs = (ctypes.c_void_p * g)(*[b.ptr.value for b in bits])
+    gs = (ctypes.c_double * g)(*gains)
+    redo = ctypes.c_int64()
+    chk(L().pm_afsk_sweep_signs(ctx.handle, dx.ptr, n, float(x_bound), t[0].ptr, t[1].ptr, t[2].ptr, t[3].ptr, ds.ptr, gs, g, m, dl.ptr, ml,
+                                float(np.abs(lpf).sum()), ptrs))
+    chk(L().pm_afsk_sweep_last(ctx.handle, ctypes.byref(redo)))
+    out = [np.unpackbits(b.download().view(np.uint8), bitorder="little")[:nout].astype(bool) for b in bits]
+    return out, redo.value, space
+
+
+def test_afsk_gain_sweep_signs_are_the_exact_chain_s(ctx):
+    """pm_afsk_sweep_signs: bitmaps of a space_gain sweep from ONE unit space correlator pair and two low-passes, certified against
+    the exact chain -- every bit must equal pm_afsk_correlate + pm_fir_signs_f64 with that modem's own (gain-scaled) taps, on an
+    AFSK-like signal, on noise at several amplitudes (the smaller the amplitude against the caller's bound, the more samples are
+    recomputed exactly, and past 65536 of them the exact chains of all modems run instead, decided on the device)."""
+    from pymodem_amd import taps as T
+    rng = np.random.default_rng(1200)
+    mi, mq, ui, uq = T.afsk_tone_correlators(48000.0, 1200.0, 1300.0, 2100.0, 1.0, 1.5, 0.0)
+    lpf = T.windowed_sinc(100, 900.0, 48000.0, pass_zero=True)
+    gains = [1.25, 1.5, 1.75, 2.0, 2.25, 2.5, 2.75]
+    n = 300000
+    t = np.arange(n)
+    tone = np.where((t // 40) % 3 == 0, 1300.0, 2100.0)
+    afsk = 8000.0 * np.sin(2 * np.pi * np.cumsum(tone) / 48000.0) + 800.0 * rng.standard_normal(n)
+    cases = [("afsk", afsk, 4.0e4), ("noise", 3000.0 * rng.standard_normal(n), 4.0e4), ("quiet noise", 3.0 * rng.standard_normal(n), 4.0e4),
+             ("very quiet", 1e-3 * rng.standard_normal(n), 4.0e4)]
+    took_exact_chains = []
+    for name, x, bound in cases:
+        got, redo, space = _sweep(ctx, x, bound, (mi, mq), (ui, uq), gains, lpf)
+        if redo > 65536:
+            took_exact_chains.append(name)                    # too many uncertain samples: the gated exact chains wrote the bitmaps
+        for g, gn in enumerate(gains):
+            assert np.array_equal(gn * ui, space[g, 0])
+            want = _exact_afsk_signs(ctx, x, (mi, mq), (space[g, 0], space[g, 1]), lpf)
+            assert np.array_equal(got[g], want), (name, gn, int(np.count_nonzero(got[g] != want)), redo)
+    assert "afsk" not in took_exact_chains and "noise" not in took_exact_chains and "very quiet" in took_exact_chains
+    z = np.zeros(150000)
+    got, redo, space = _sweep(ctx, z, 4.0e4, (mi, mq), (ui, uq), gains, lpf)
+    assert redo > 65536                                       # every output is exactly zero: nothing can be certified ...
+    for g in range(len(gains)):                               # ... and the exact chains say ">= 0" everywhere
+        assert got[g].all()
