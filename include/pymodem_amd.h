@@ -295,6 +295,25 @@ int pm_codec_destroy(pm_codec *c);
  * cap of them out, oldest first, with CRC and header validity filled (packet_meta.py:197-208). */
 int pm_codec_decode(pm_codec *c, const uint8_t *h_data, const int64_t *h_addr, int64_t n, int64_t *h_pending);
 int pm_codec_fetch(pm_codec *c, pm_packet *h_out, int64_t cap, int64_t *h_count);
+
+/* The host half of a whole chain group in two calls (chain_execute.py:20-26 for every chain of the group at once): per job
+ * pm_lfsr_unscramble into a library-owned buffer, then pm_codec_decode; per codec pm_codec_fetch into consecutive row blocks
+ * of h_out (counts[j] rows each).  One chain per task on up to `threads` threads (the caller's included) that belong to the
+ * library, so a language binding crosses the boundary twice per recording, not 3 x chains times.  No two jobs may share a
+ * codec.  The first failing job's code is returned (its status field holds it too). */
+typedef struct pm_host_job {
+    pm_codec *codec;
+    const uint8_t *h_data;        /* the slicer's bytes ...                       */
+    const int64_t *h_addr;        /* ... and their stream addresses               */
+    int64_t n;
+    uint64_t lfsr_poly;
+    uint64_t lfsr_state;          /* in/out: LFSR.shift_register                  */
+    int64_t pending;              /* out: packets waiting in the codec            */
+    int32_t lfsr_invert;
+    int32_t status;               /* out */
+} pm_host_job;
+int pm_host_decode_batch(pm_host_job *jobs, int njobs, int threads);
+int pm_codec_fetch_batch(pm_codec *const *codecs, const int64_t *counts, int n, pm_packet *h_out, int threads);
 int pm_crc16_ccitt(const uint8_t *h_data, int64_t n);                    /* crc_functions.py:44-55 */
 
 /* Wire form of packet rows for the one exchange step of the multi-GPU path (the reference hands PacketMeta lists through a

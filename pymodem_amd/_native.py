@@ -50,6 +50,13 @@ class SliceJob(ctypes.Structure):
                 ("h_state", ctypes.POINTER(SlicerState))]
 
 
+class HostJob(ctypes.Structure):
+    """pm_host_job"""
+    _fields_ = [("codec", ctypes.c_void_p), ("h_data", ctypes.c_void_p), ("h_addr", ctypes.c_void_p), ("n", ctypes.c_int64),
+                ("lfsr_poly", ctypes.c_uint64), ("lfsr_state", ctypes.c_uint64), ("pending", ctypes.c_int64),
+                ("lfsr_invert", ctypes.c_int32), ("status", ctypes.c_int32)]
+
+
 class ChainDesc(ctypes.Structure):
     """pm_chain_desc"""
     _dp, _i32 = ctypes.POINTER(ctypes.c_double), ctypes.c_int32
@@ -149,6 +156,8 @@ _SIGS = {
     "pm_codec_destroy": ([_vp], _int),
     "pm_codec_decode": ([_vp, _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
     "pm_codec_fetch": ([_vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
+    "pm_host_decode_batch": ([ctypes.POINTER(HostJob), _int, _int], _int),
+    "pm_codec_fetch_batch": ([ctypes.POINTER(_vp), ctypes.POINTER(_i64), _int, _vp, _int], _int),
     "pm_packets_pack": ([_vp, _i64, _vp, _i64], _i64),
     "pm_packets_unpack": ([_vp, _i64, _vp, _i64], _i64),
     "pm_packets_index": ([_vp, _i64, _vp, _vp, _i64], _i64),

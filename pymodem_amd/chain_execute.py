@@ -52,19 +52,53 @@ def _host_pending(chain, sliced):
     return chain[4].decode_pending(chain[3].stream_unscramble_8bit(sliced))
 
 
+def _host_threads():
+    import os
+    return max(1, min(int(os.environ.get("PYMODEM_AMD_HOST_THREADS", "16")), (os.cpu_count() or 2)))
+
+
 def _host_rows(chains, sliced):
-    """LFSR + codec of every chain (thread pool; the native calls release the GIL) -> one pm_packet row block per chain, all of them
-    consecutive slices of ONE array the codecs wrote straight into (PacketTable then takes the whole array without a copy)."""
-    from ._native import packet_dtype
-    pool = _pool()
-    counts = [f.result() for f in [pool.submit(_host_pending, ch, sl) for ch, sl in zip(chains, sliced)]]
+    """LFSR + codec of every chain -> one pm_packet row block per chain, all of them consecutive slices of ONE array the codecs
+    wrote straight into (PacketTable then takes the whole array without a copy).  Two native calls per recording
+    (pm_host_decode_batch, pm_codec_fetch_batch): the library's own threads take one chain each, the interpreter lock is
+    released throughout."""
+    import ctypes
+    from ._native import HostJob, check, lib, packet_dtype
+    from .data_classes import AddressedArray
+    from .lfsr import LFSR
+    n = len(chains)
+    if not all(isinstance(ch[3], LFSR) and hasattr(ch[4], "_handle") for ch in chains):      # foreign stream / codec objects
+        pool = _pool()
+        counts = [f.result() for f in [pool.submit(_host_pending, ch, sl) for ch, sl in zip(chains, sliced)]]
+        block = np.empty(sum(counts), dtype=packet_dtype())
+        views, at = [], 0
+        for c in counts:
+            views.append(block[at:at + c])
+            at += c
+        for f in [pool.submit(ch[4].fetch_into, v) for ch, v in zip(chains, views)]:
+            f.result()
+        return views
+    jobs = (HostJob * n)()
+    keep = []
+    for j, (ch, sl) in enumerate(zip(chains, sliced)):
+        src = AddressedArray.coerce(sl)
+        keep.append(src)
+        jobs[j].codec = ch[4]._handle()
+        jobs[j].h_data, jobs[j].h_addr, jobs[j].n = src.data.ctypes.data, src.address.ctypes.data, len(src)
+        jobs[j].lfsr_poly, jobs[j].lfsr_state, jobs[j].lfsr_invert = ch[3].polynomial, ch[3].shift_register, int(bool(ch[3].invert))
+    threads = _host_threads()
+    rc = lib().pm_host_decode_batch(jobs, n, threads)
+    for j, ch in enumerate(chains):             # the registers move on even when a later job failed
+        ch[3].shift_register = jobs[j].lfsr_state
+    check(rc)
+    counts = (ctypes.c_int64 * n)(*[jobs[j].pending for j in range(n)])
+    handles = (ctypes.c_void_p * n)(*[jobs[j].codec for j in range(n)])
     block = np.empty(sum(counts), dtype=packet_dtype())
+    check(lib().pm_codec_fetch_batch(handles, counts, n, block.ctypes.data_as(ctypes.c_void_p), threads))
     views, at = [], 0
-    for n in counts:
-        views.append(block[at:at + n])
-        at += n
-    for f in [pool.submit(ch[4].fetch_into, v) for ch, v in zip(chains, views)]:
-        f.result()
+    for c in counts:
+        views.append(block[at:at + c])
+        at += c
     return views
 
 
@@ -76,7 +110,7 @@ def _pool():
     global _POOL
     if _POOL is None:
         import os
-        _POOL = ThreadPoolExecutor(max_workers=max(2, min(int(os.environ.get("PYMODEM_AMD_HOST_THREADS", "24")), (os.cpu_count() or 4) // 2)))
+        _POOL = ThreadPoolExecutor(max_workers=max(2, min(int(os.environ.get("PYMODEM_AMD_HOST_THREADS", "16")), (os.cpu_count() or 4) // 2)))
     return _POOL
 
 

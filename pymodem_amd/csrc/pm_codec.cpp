@@ -10,9 +10,16 @@
 // Behaviour follows the reference including its quirks (noted inline), because packet parity is
 // "identical bytes, CRCs and stream addresses", not "a better decoder".
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <deque>
+#include <functional>
+#include <memory>
 #include <mutex>
+#include <thread>
+#include <unistd.h>
 #include <unordered_map>
 #include <vector>
 
@@ -613,6 +620,96 @@ struct Il2p : pm_codec {
     }
 };
 
+// ---- worker threads of the batched host stage ---------------------------------------------------
+// pm_host_decode_batch / pm_codec_fetch_batch run one chain per task.  The workers live as long as the process (started on
+// demand, and again in a forked child, which inherits none of them); a batch's caller works through the tasks itself as
+// well, so a batch completes even when every worker is busy with other callers' batches.
+class HostPool {
+public:
+    static HostPool &get()
+    {
+        static std::mutex m;
+        static HostPool *pool = nullptr;
+        static pid_t owner = 0;
+        std::lock_guard<std::mutex> g(m);
+        if (!pool || owner != getpid()) {          // first use, or a forked child: the parent's object is left alone
+            pool = new HostPool();
+            owner = getpid();
+        }
+        return *pool;
+    }
+
+    // fn(k) for k in [0, n), on at most `threads` threads including the caller
+    void run(int n, int threads, const std::function<void(int)> &fn)
+    {
+        if (n <= 0) return;
+        auto st = std::make_shared<Batch>();
+        st->n = n;
+        st->fn = &fn;
+        const int helpers = std::max(0, std::min(std::min(n, threads) - 1, kMaxWorkers));
+        if (helpers > 0) {
+            {
+                std::lock_guard<std::mutex> g(m_);
+                for (int h = 0; h < helpers; ++h) q_.push_back(st);
+                const int want = std::min(kMaxWorkers - workers_, (int)q_.size() - idle_);
+                for (int w = 0; w < want; ++w) {
+                    std::thread([this] { loop(); }).detach();
+                    ++workers_;
+                }
+            }
+            cv_.notify_all();
+        }
+        work(*st);
+        std::unique_lock<std::mutex> g(st->m);
+        st->cv.wait(g, [&] { return st->done == st->n; });
+    }
+
+private:
+    static constexpr int kMaxWorkers = 64;
+    struct Batch {
+        int n = 0;
+        const std::function<void(int)> *fn = nullptr;
+        std::atomic<int> next{0};
+        int done = 0;
+        std::mutex m;
+        std::condition_variable cv;
+    };
+    static void work(Batch &b)
+    {
+        int mine = 0;
+        for (;;) {
+            const int k = b.next.fetch_add(1);
+            if (k >= b.n) break;
+            (*b.fn)(k);                            // run() has not returned while any index is unfinished: fn is alive
+            ++mine;
+        }
+        if (mine) {
+            std::lock_guard<std::mutex> g(b.m);
+            b.done += mine;
+            if (b.done == b.n) b.cv.notify_all();
+        }
+    }
+    void loop()
+    {
+        for (;;) {
+            std::shared_ptr<Batch> b;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                ++idle_;
+                cv_.wait(g, [&] { return !q_.empty(); });
+                --idle_;
+                b = q_.front();
+                q_.pop_front();
+            }
+            work(*b);
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<std::shared_ptr<Batch>> q_;
+    int workers_ = 0, idle_ = 0;
+};
+
 }  // namespace
 
 extern "C" {
@@ -703,6 +800,48 @@ int pm_codec_fetch(pm_codec *c, pm_packet *h_out, int64_t cap, int64_t *h_count)
     }
     c->sink.q.erase(c->sink.q.begin(), c->sink.q.begin() + take);
     *h_count = take;
+    return PM_OK;
+}
+
+int pm_host_decode_batch(pm_host_job *jobs, int njobs, int threads)
+{
+    if (njobs < 0 || (njobs > 0 && !jobs) || threads < 1) return pm_set_error(PM_ERR_ARG, "pm_host_decode_batch: bad argument");
+    for (int j = 0; j < njobs; ++j) {
+        const pm_host_job &q = jobs[j];
+        if (!q.codec || q.n < 0 || (q.n > 0 && (!q.h_data || !q.h_addr)))
+            return pm_set_error(PM_ERR_ARG, "pm_host_decode_batch: job %d: bad argument", j);
+        for (int i = 0; i < j; ++i)
+            if (jobs[i].codec == q.codec) return pm_set_error(PM_ERR_ARG, "pm_host_decode_batch: jobs %d and %d share a codec", i, j);
+    }
+    HostPool::get().run(njobs, threads, [&](int j) {
+        pm_host_job &q = jobs[j];
+        thread_local std::vector<uint8_t> plain;
+        if ((int64_t)plain.size() < q.n) plain.resize((size_t)q.n);
+        q.status = pm_lfsr_unscramble(q.h_data, q.n, q.lfsr_poly, q.lfsr_invert, &q.lfsr_state, plain.data());
+        if (q.status == PM_OK) q.status = pm_codec_decode(q.codec, plain.data(), q.h_addr, q.n, &q.pending);
+    });
+    for (int j = 0; j < njobs; ++j)
+        if (jobs[j].status != PM_OK) return jobs[j].status;
+    return PM_OK;
+}
+
+int pm_codec_fetch_batch(pm_codec *const *codecs, const int64_t *counts, int n, pm_packet *h_out, int threads)
+{
+    if (n < 0 || (n > 0 && (!codecs || !counts)) || threads < 1) return pm_set_error(PM_ERR_ARG, "pm_codec_fetch_batch: bad argument");
+    std::vector<int64_t> at((size_t)n + 1, 0);
+    for (int j = 0; j < n; ++j) {
+        if (!codecs[j] || counts[j] < 0 || counts[j] > (int64_t)codecs[j]->sink.q.size())
+            return pm_set_error(PM_ERR_ARG, "pm_codec_fetch_batch: codec %d: bad count", j);
+        at[(size_t)j + 1] = at[(size_t)j] + counts[j];
+    }
+    if (at[(size_t)n] > 0 && !h_out) return pm_set_error(PM_ERR_ARG, "pm_codec_fetch_batch: no output");
+    std::vector<int> rc((size_t)n, PM_OK);
+    HostPool::get().run(n, threads, [&](int j) {
+        int64_t got = 0;
+        if (counts[j] > 0) rc[(size_t)j] = pm_codec_fetch(codecs[j], h_out + at[(size_t)j], counts[j], &got);
+    });
+    for (int j = 0; j < n; ++j)
+        if (rc[(size_t)j] != PM_OK) return rc[(size_t)j];
     return PM_OK;
 }
 

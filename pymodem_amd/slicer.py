@@ -94,7 +94,6 @@ def slice_batch(slicers, bitmaps, ctx=None):
 
 
 _TIGHT_FACTOR = 2.2
-TIMING = {"native": 0.0, "download": 0.0, "bytes": 0, "calls": 0, "post": 0.0}
 
 
 def _slice_group(ctx, slicers, bitmaps, group, out, tight):
@@ -124,26 +123,16 @@ def _slice_group(ctx, slicers, bitmaps, group, out, tight):
         jobs[j].params = sl._params()
         jobs[j].d_data, jobs[j].d_addr, jobs[j].cap = block.ptr.value + d_off[j], block.ptr.value + a_off[j], caps[j]
         jobs[j].h_state = ctypes.pointer(sl._state)
-    import time as _t
-    _t0 = _t.perf_counter()
     check(lib().pm_slice_batch(ctx.handle, jobs, len(group)))
-    _t1 = _t.perf_counter()
     it, cl, nc = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
     lib().pm_slicer_stats(ctx.handle, ctypes.byref(it), ctypes.byref(cl), ctypes.byref(nc))
     host = block.download(at)
-    _t2 = _t.perf_counter()
-    TIMING["native"] += _t1 - _t0
-    TIMING["download"] += _t2 - _t1
-    TIMING["bytes"] += at
-    TIMING["calls"] += 1
     for j, k in enumerate(group):
         cnt = jobs[j].count
         slicers[k].last_stats = {"iterations": it.value, "chunk_len": cl.value, "chunks": nc.value}
         slicers[k].phase_clock, slicers[k].streamaddress = slicers[k]._state.phase_clock, slicers[k]._state.streamaddress
-        _t3 = _t.perf_counter()
         # views into this call's own download (a fresh array every call): no second copy
         out[k] = AddressedArray(host[d_off[j]:d_off[j] + cnt], host[a_off[j]:a_off[j] + cnt * 8].view(np.int64))
-        TIMING["post"] += _t.perf_counter() - _t3
 
 
 class BinarySlicer(_SlicerBase):

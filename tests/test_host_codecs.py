@@ -172,3 +172,59 @@ def test_il2p_sync_search_at_every_bit_offset(tol):
     assert pk(got) == pk(want), (tol, len(got), len(want))
     # the frames inside the tolerance really are decoded (a loose tolerance also fires inside the random filler and eats some)
     assert within > 20 and len(want) >= within * (0.9 if tol <= 2 else 0.4)
+
+
+@pytest.mark.parametrize("threads", [1, 3, 16])
+def test_batched_host_stage_equals_the_per_chain_calls(threads, monkeypatch):
+    """pm_host_decode_batch + pm_codec_fetch_batch (chain_execute._host_rows) against stream_unscramble_8bit + decode_rows chain by
+    chain: same rows, same LFSR registers, codec state carried across two recordings, callers running concurrently."""
+    from concurrent.futures import ThreadPoolExecutor
+    from pymodem_amd import chain_execute as CE
+    from pymodem_amd.codecs import AX25Codec, IL2PCodec
+    from pymodem_amd.data_classes import AddressedArray
+    from pymodem_amd.lfsr import LFSR
+    monkeypatch.setenv("PYMODEM_AMD_HOST_THREADS", str(threads))
+
+    def group(seed):
+        rng = np.random.default_rng(seed)
+        chains, streams = [], []
+        for k in range(9):
+            il2p = k % 3 == 2
+            codec = IL2PCodec(ident=f"c{k}") if il2p else AX25Codec(ident=f"c{k}")
+            chains.append([f"c{k}", None, None, LFSR(poly=[0x3, 0x63003, 0x1][k % 3], invert=k % 2 == 0), codec])
+            two = []
+            for n in (0 if k == 4 else 20000 + 977 * k, 15000):
+                data = il2p_stream(rng, n, 700) if il2p else biased_bytes(rng, n, 0.55)
+                two.append(AddressedArray(data, np.cumsum(rng.integers(1, 50, n)).astype(np.int64)))
+            streams.append(two)
+        return chains, streams
+
+    def run(seed, batched):
+        chains, streams = group(seed)
+        out = []
+        for rec in range(2):
+            sliced = [s[rec] for s in streams]
+            if batched:
+                rows = CE._host_rows(chains, sliced)
+            else:
+                rows = [ch[4].decode_rows(ch[3].stream_unscramble_8bit(sl)) for ch, sl in zip(chains, sliced)]
+            out.append([r.tobytes() for r in rows])
+        return out, [ch[3].shift_register for ch in chains]
+
+    want = [run(seed, False) for seed in range(4)]
+    assert sum(len(b) for rec in want[0][0] for b in rec) > 0
+    with ThreadPoolExecutor(4) as ex:
+        got = list(ex.map(lambda seed: run(seed, True), range(4)))
+    assert got == want
+
+
+def test_batched_host_stage_rejects_a_shared_codec():
+    import ctypes
+    from pymodem_amd._native import HostJob, NativeError, check, lib
+    from pymodem_amd.codecs import AX25Codec
+    c = AX25Codec(ident="x")
+    jobs = (HostJob * 2)()
+    for j in range(2):
+        jobs[j].codec = c._handle()
+    with pytest.raises(NativeError, match="share a codec"):
+        check(lib().pm_host_decode_batch(jobs, 2, 4))
