@@ -71,10 +71,10 @@ __device__ __forceinline__ void stage_vec(const int16_t *__restrict__ x, int64_t
     }
 }
 
-// SIGNS: instead of the float64 outputs, write only their (y >= 0) bitmap -- all a slicer reads of them.
-template <typename InT, int R, bool NEG, bool VEC, bool SIGNS>
-__device__ __forceinline__ void fir_tile(const InT *__restrict__ x, int64_t n, const double *__restrict__ h, int m,
-                                         double *__restrict__ y, int64_t nout, uint64_t *__restrict__ bits, int64_t tile)
+// The sums of one tile: acc[r] = output tile*T + t*R + r of the valid-mode FIR, every sum in ascending input order, one fma per tap.
+template <typename InT, int R, bool VEC>
+__device__ __forceinline__ void fir_tile_acc(const InT *__restrict__ x, int64_t n, const double *__restrict__ h, int m, int64_t tile,
+                                             double (&acc)[R])
 {
     extern __shared__ double xs[];
     constexpr int T = kThreads * R;
@@ -91,7 +91,6 @@ __device__ __forceinline__ void fir_tile(const InT *__restrict__ x, int64_t n, c
     }
     lds_barrier();
 
-    double acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.0;
     // Window registers: two sets of R that alternate between "carry" (last R-1 values of the previous block) and "new".
@@ -149,6 +148,19 @@ __device__ __forceinline__ void fir_tile(const InT *__restrict__ x, int64_t n, c
         }
 #undef PM_FIR_TAIL
     }
+}
+
+// SIGNS: instead of the float64 outputs, write only their (y >= 0) bitmap -- all a slicer reads of them.
+template <typename InT, int R, bool NEG, bool VEC, bool SIGNS>
+__device__ __forceinline__ void fir_tile(const InT *__restrict__ x, int64_t n, const double *__restrict__ h, int m,
+                                         double *__restrict__ y, int64_t nout, uint64_t *__restrict__ bits, int64_t tile)
+{
+    extern __shared__ double xs[];
+    constexpr int T = kThreads * R;
+    const int t = threadIdx.x;
+    const int64_t tile0 = tile * T;
+    double acc[R];
+    fir_tile_acc<InT, R, VEC>(x, n, h, m, tile, acc);
     if (SIGNS) {
         // This thread's 8 consecutive outputs are exactly one byte of the little-endian bitmap (tile0 is a multiple of 2048): no
         // trip through LDS, the 64 lanes of a wave store 64 consecutive bytes.  Bits past nout are written as 0 up to the end of
@@ -468,26 +480,44 @@ struct SweepArgs {
     uint64_t *bits[kSweepMax];
 };
 
-__global__ __launch_bounds__(256) void sweep_combine_kernel(const double *__restrict__ A, const double *__restrict__ B, int64_t nout, int G,
-                                                            SweepArgs P, double E, unsigned long long *__restrict__ list,
-                                                            int *__restrict__ count, int cap)
+// The second low-pass of the sweep with the combine step as its epilogue: B = LPF(S) stays in registers, A = LPF(M) is read back
+// (the thread's eight consecutive values), and what leaves the kernel is one bitmap byte per modem and thread plus the list of
+// samples that could not be certified.
+template <int R, bool VEC>
+__global__ __launch_bounds__(kThreads) void fir_sweep_kernel(const double *__restrict__ S, int64_t n, const double *__restrict__ h, int m,
+                                                             const double *__restrict__ A, int64_t nout, int G, SweepArgs P, double E,
+                                                             unsigned long long *__restrict__ list, int *__restrict__ count, int cap)
 {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;         // one sample per lane: a wave is one bitmap word
-    const bool in = k < nout;
-    const double a = in ? A[k] : 0.0, b = in ? B[k] : 0.0;
+    static_assert(R == 8, "one bitmap byte per thread");
+    double b[R];
+    fir_tile_acc<double, R, VEC>(S, n, h, m, (int64_t)blockIdx.x, b);
+    const int64_t go = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * R;
+    if (go >= ((nout + 63) >> 6) * 64) return;
+    double a[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) a[r] = go + r < nout ? A[go + r] : 0.0;
     for (int g = 0; g < G; ++g) {
-        const double y = __builtin_fma(-P.gain[g], b, a);
-        const uint64_t word = __ballot(in && y >= 0.0);
-        if ((threadIdx.x & 63) == 0 && in) P.bits[g][k >> 6] = word;
-        if (in && !(fabs(y) > E)) {                                          // cannot be certified (NaN lands here too)
+        const double mg = -P.gain[g];
+        unsigned byte = 0, unsure = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double y = __builtin_fma(mg, b[r], a[r]);
+            const bool in = go + r < nout;
+            byte |= (unsigned)(in && y >= 0.0) << r;
+            unsure |= (unsigned)(in && !(fabs(y) > E)) << r;                 // cannot be certified (NaN lands here too)
+        }
+        reinterpret_cast<uint8_t *>(P.bits[g])[go >> 3] = (uint8_t)byte;     // bits past nout: 0 up to the end of the last word
+        while (unsure) {
+            const int r = __ffs((int)unsure) - 1;
+            unsure &= unsure - 1;
             const int idx = atomicAdd(count, 1);
-            if (idx < cap) list[idx] = ((unsigned long long)g << 48) | (unsigned long long)k;
+            if (idx < cap) list[idx] = ((unsigned long long)g << 48) | (unsigned long long)(go + r);
         }
     }
 }
 
 // The exact chain for single samples: correlator bank of modem g at the ml positions the low-pass needs, then the low-pass, every
-// sum in the canonical order of afsk_correlate_kernel / fir_valid_kernel.  Runs after the combine kernel (bitmap words are final).
+// sum in the canonical order of afsk_correlate_kernel / fir_valid_kernel.  Runs after fir_sweep_kernel (its bitmap bytes are final).
 __global__ __launch_bounds__(64) void sweep_exact_kernel(const double *__restrict__ x, const double *__restrict__ mi, const double *__restrict__ mq,
                                                          const double *__restrict__ space, int mc, const double *__restrict__ lpf, int ml,
                                                          SweepArgs P, const unsigned long long *__restrict__ list, const int *__restrict__ count, int cap)
@@ -767,13 +797,13 @@ int pm_afsk_sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_boun
     const int64_t stride = (nc + 63) / 64 * 64;
     const size_t b_m = up((size_t)nc * 8), b_a = up((size_t)nl * 8), b_list = up((size_t)cap * 8), b_w = up((size_t)F * m * 8),
                  b_c = up((size_t)stride * groups * 8);
-    if (int rc = pm_scratch_reserve(ctx, 2 * b_m + 2 * b_a + b_list + 256 + b_w + b_c)) return rc;
+    if (int rc = pm_scratch_reserve(ctx, 2 * b_m + b_a + b_list + 256 + b_w + b_c)) return rc;
     char *base = (char *)ctx->d_scratch;
-    double *M = (double *)base, *S = (double *)(base + b_m), *A = (double *)(base + 2 * b_m), *B = (double *)(base + 2 * b_m + b_a);
-    unsigned long long *list = (unsigned long long *)(base + 2 * b_m + 2 * b_a);
-    int *count = (int *)(base + 2 * b_m + 2 * b_a + b_list);
-    double *d_w = (double *)(base + 2 * b_m + 2 * b_a + b_list + 256);
-    double *C = (double *)(base + 2 * b_m + 2 * b_a + b_list + 256 + b_w);
+    double *M = (double *)base, *S = (double *)(base + b_m), *A = (double *)(base + 2 * b_m);
+    unsigned long long *list = (unsigned long long *)(base + 2 * b_m + b_a);
+    int *count = (int *)(base + 2 * b_m + b_a + b_list);
+    double *d_w = (double *)(base + 2 * b_m + b_a + b_list + 256);
+    double *C = (double *)(base + 2 * b_m + b_a + b_list + 256 + b_w);
     ctx->sweep_count = count;
     {   // mark and unit-gain space magnitudes, one pass over the band-passed stream
         constexpr int R = 4;
@@ -794,15 +824,28 @@ int pm_afsk_sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_boun
         PM_HIP(hipGetLastError());
     }
     if (int rc = fir_launch<double>(ctx, M, nc, d_lpf, ml, A, nullptr, 0)) return rc;
-    if (int rc = fir_launch<double>(ctx, S, nc, d_lpf, ml, B, nullptr, 0)) return rc;
     const double E = 1e-10 * lpf_abs_sum * (1.0 + gmax) * (double)m * 1.4143 * x_bound;
     PM_HIP(hipMemsetAsync(count, 0, sizeof(int), ctx->stream));
+    {   // B = LPF(S) and the combine step in one pass: B never reaches memory
+        constexpr int R = 8;
+        const int64_t ntiles = pm_cdiv(nl, (int64_t)kThreads * R);
+        PM_ARG(ntiles < (1LL << 31));
+        const size_t lds = lds_bytes<R>(ml);
+        PmProf prof(ctx, PM_K_FIR_F64);
+        prof.work((double)nc * 8 + (double)nl * 8 + (double)groups * nl / 8, 2.0 * ml * (double)nl + 2.0 * groups * (double)nl);
+        if ((((uintptr_t)S) & 15) == 0) {
+            if (int rc = allow_lds(fir_sweep_kernel<R, true>, lds)) return rc;
+            hipLaunchKernelGGL((fir_sweep_kernel<R, true>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, S, nc, d_lpf, ml, A, nl, groups,
+                               P, E, list, count, cap);
+        } else {
+            if (int rc = allow_lds(fir_sweep_kernel<R, false>, lds)) return rc;
+            hipLaunchKernelGGL((fir_sweep_kernel<R, false>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, S, nc, d_lpf, ml, A, nl, groups,
+                               P, E, list, count, cap);
+        }
+        PM_HIP(hipGetLastError());
+    }
     {
         PmProf prof(ctx, PM_K_SIGNS);
-        prof.work(2.0 * nl * 8 + (double)groups * nl / 8, 2.0 * groups * (double)nl);
-        const int64_t words = pm_cdiv(nl, 64);
-        hipLaunchKernelGGL(sweep_combine_kernel, dim3((unsigned)pm_cdiv(words * 64, 256)), dim3(256), 0, ctx->stream, A, B, nl, groups, P, E, list,
-                           count, cap);
         hipLaunchKernelGGL(sweep_exact_kernel, dim3((unsigned)pm_cdiv(cap, 64)), dim3(64), 0, ctx->stream, d_x, d_mark_i, d_mark_q, d_space, m, d_lpf,
                            ml, P, list, count, cap);
     }
