@@ -26,8 +26,11 @@ class Context:
         main = cls.default(device)
         key = (os.getpid(), main.device, int(index))
         if key not in cls._side:
+            if "PYMODEM_AMD_SIDE_PRIORITY" in os.environ:                     # tuning knobs
+                high_priority = os.environ["PYMODEM_AMD_SIDE_PRIORITY"] != "0"
             cls._side[key] = cls(main.device, high_priority=high_priority)
-            check(lib().pm_slicer_tune(cls._side[key]._h, 12288))     # fewer, longer chunks while other streams share the CUs
+            # fewer, longer chunks while other streams share the CUs
+            check(lib().pm_slicer_tune(cls._side[key]._h, int(os.environ.get("PYMODEM_AMD_SIDE_LANES", "12288"))))
         return cls._side[key]
 
     @classmethod
