@@ -330,7 +330,13 @@ def measure(args, env):
     for sc in sides:
         sc.profile(True)
     t0 = time.perf_counter()
-    result = run_steps(args.steps)
+    if os.environ.get("BENCH_PYPROFILE"):                     # where the submitting thread's time goes (diagnostic, stderr)
+        import cProfile, pstats
+        pr = cProfile.Profile()
+        result = pr.runcall(run_steps, args.steps)
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(28)
+    else:
+        result = run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_read()

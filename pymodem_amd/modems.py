@@ -285,17 +285,28 @@ class AFSKModem(_DeviceStage):
 
     def unit_space_correlators(self):
         """The space correlators this modem would have with space_gain 1.0 (afsk.py:144-145 without the factor)."""
-        _, _, ui, uq = T.afsk_tone_correlators(self.sample_rate, self.symbol_rate, self.mark_freq, self.space_freq, 1.0,
-                                               self.correlator_span, self.correlator_offset)
-        return ui, uq
+        args = (self.sample_rate, self.symbol_rate, self.mark_freq, self.space_freq, self.correlator_span, self.correlator_offset)
+        hit = getattr(self, "_unit_memo", None)
+        if hit is None or hit[0] != args:
+            _, _, ui, uq = T.afsk_tone_correlators(args[0], args[1], args[2], args[3], 1.0, args[4], args[5])
+            hit = self._unit_memo = (args, ui, uq)
+        return hit[1], hit[2]
 
     def sweep_key(self):
         """Modems with equal keys differ in space_gain only (same band-pass, tones, span, output low-pass) AND their space taps are
-        exactly gain * unit taps: they can take pm_afsk_sweep_signs together.  None if this modem's taps are not of that form."""
+        exactly gain * unit taps: they can take pm_afsk_sweep_signs together.  None if this modem's taps are not of that form.
+        (Remembered for as long as the tap arrays are the same objects and the gain is the same.)"""
+        deps = (self.input_bpf, self.mark_correlator_i, self.mark_correlator_q, self.space_correlator_i, self.space_correlator_q,
+                self.output_lpf)
+        hit = getattr(self, "_sweep_memo", None)
+        if hit is not None and hit[1] == self.space_gain and len(hit[0]) == len(deps) and all(a is b for a, b in zip(hit[0], deps)):
+            return hit[2]
         ui, uq = self.unit_space_correlators()
-        if not (np.array_equal(self.space_correlator_i, self.space_gain * ui) and np.array_equal(self.space_correlator_q, self.space_gain * uq)):
-            return None
-        return (self.mark_key(), ui.tobytes(), uq.tobytes(), self.output_lpf.tobytes())
+        key = None
+        if np.array_equal(self.space_correlator_i, self.space_gain * ui) and np.array_equal(self.space_correlator_q, self.space_gain * uq):
+            key = (self.mark_key(), ui.tobytes(), uq.tobytes(), self.output_lpf.tobytes())
+        self._sweep_memo = (deps, self.space_gain, key)
+        return key
 
     @staticmethod
     def sweep_signs(modems, a, x_bound):

@@ -93,14 +93,15 @@ def slice_batch(slicers, bitmaps, ctx=None):
     return out
 
 
-_TIGHT_FACTOR = 2.2
+_TIGHT_FACTOR = 1.5
 
 
 def _slice_group(ctx, slicers, bitmaps, group, out, tight):
     jobs = (SliceJob * len(group))()
     # One device block for the whole batch's output (addresses first, then bytes) and ONE device-to-host copy per batch.  The
     # hard bound is one symbol per sample; the clock can at most double its nominal rate (every crossing pulls it towards zero,
-    # from where half a symbol period remains), so 2.2x the nominal count is tried first.
+    # from where half a symbol period remains); real streams stay within a few percent of nominal, so 1.5x the nominal count is
+    # tried first and the full bound only after a capacity error.
     caps, a_off, d_off, at = [], [], [], 0
     for k in group:
         n, sl = bitmaps[k][2], slicers[k]
@@ -126,7 +127,7 @@ def _slice_group(ctx, slicers, bitmaps, group, out, tight):
     check(lib().pm_slice_batch(ctx.handle, jobs, len(group)))
     it, cl, nc = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
     lib().pm_slicer_stats(ctx.handle, ctypes.byref(it), ctypes.byref(cl), ctypes.byref(nc))
-    host = block.download(at)
+    host = block.download(at, recycle=True)
     for j, k in enumerate(group):
         cnt = jobs[j].count
         slicers[k].last_stats = {"iterations": it.value, "chunk_len": cl.value, "chunks": nc.value}
