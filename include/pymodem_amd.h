@@ -220,7 +220,7 @@ typedef struct pm_slice_job {
 int pm_slice_batch(pm_ctx *ctx, pm_slice_job *h_jobs, int njobs);           /* njobs <= 64 */
 /* How many chunks (lanes) a batch is cut into on this ctx; 0 restores the default 65536 = one wave per SIMD, the fastest when the
  * slicer has the GPU to itself.  Fewer, longer chunks mean fewer dependent launches and fewer resident waves: better when other
- * streams keep the CUs busy (the pipelined executor sets 12288 on its slicer streams).  Results do not depend on it. */
+ * streams keep the CUs busy (the pipelined executor sets 24576 on its slicer streams).  Results do not depend on it. */
 int pm_slicer_tune(pm_ctx *ctx, int64_t target_lanes);
 /* Diagnostics of the last slicer call on this ctx: fixed-point iterations used, chunk length, chunks. */
 int pm_slicer_stats(pm_ctx *ctx, int32_t *iterations, int32_t *chunk_len, int64_t *chunks);

@@ -31,7 +31,7 @@ class Context:
                 high_priority = os.environ["PYMODEM_AMD_SIDE_PRIORITY"] != "0"
             cls._side[key] = cls(main.device, high_priority=high_priority)
             # fewer, longer chunks while other streams share the CUs
-            check(lib().pm_slicer_tune(cls._side[key]._h, int(os.environ.get("PYMODEM_AMD_SIDE_LANES", "12288"))))
+            check(lib().pm_slicer_tune(cls._side[key]._h, int(os.environ.get("PYMODEM_AMD_SIDE_LANES", "24576"))))
         return cls._side[key]
 
     @classmethod
