@@ -123,6 +123,29 @@ int pm_afsk_correlate_group(pm_ctx *ctx, const double *d_x, int64_t n, const dou
 int pm_afsk_sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound, const double *d_mark_i, const double *d_mark_q,
                         const double *d_unit_i, const double *d_unit_q, const double *d_space, const double *h_gains, int groups, int m,
                         const double *d_lpf, int ml, double lpf_abs_sum, uint64_t *const *h_bits);
+/* The same sweep when the correlator templates are what afsk.py:134-144 makes them, the powers of one rotation per tone
+ * (template[j] = cos / sin of j*w): the two magnitude streams come from a sliding sum, Z(k+1) = x[k+m] + r Z(k) - r^m x[k], 6 fused
+ * operations per tone and sample instead of 2m, restarted from the direct sum every 16 outputs.  Nothing changes in what is
+ * guaranteed: the sliding sums only feed the certified decision, whose bound grows by their (small) error, and every bit still
+ * equals the exact chain's.  rot = r = (template_i[1], template_q[1]); end = r^m rounded to double; tap_dev = the largest
+ * |template[j] - r^j| over both templates of both tones, measured by the host in extended precision (pymodem_amd.taps.tone_model).
+ * Fails with PM_ERR_ARG if tap_dev >= 1e-6: such templates are not tones, use pm_afsk_sweep_signs. */
+typedef struct pm_afsk_tones {
+    double mark_rot[2], mark_end[2];
+    double space_rot[2], space_end[2];     /* of the unit-gain space templates */
+    double tap_dev;
+} pm_afsk_tones;
+int pm_afsk_sweep_signs_tones(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound, const double *d_mark_i, const double *d_mark_q,
+                              const double *d_unit_i, const double *d_unit_q, const double *d_space, const double *h_gains, int groups,
+                              int m, const double *d_lpf, int ml, double lpf_abs_sum, uint64_t *const *h_bits,
+                              const pm_afsk_tones *h_tones);
+/* The two magnitude streams the sweep works from, on their own (tests, diagnostics): d_mark_mag[k] = sqrt(I^2 + Q^2) of the mark
+ * templates at output k, d_space_mag likewise (n - m + 1 values each; afsk.py:153-160 without the subtraction).  h_tones NULL:
+ * the direct sums in the reference's order.  h_tones given: the sliding sums; *h_bound receives the bound on their distance
+ * from the direct sums that the certified decision uses (0 for the direct sums). */
+int pm_afsk_magnitudes(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound, const double *d_mark_i, const double *d_mark_q,
+                       const double *d_space_i, const double *d_space_q, int m, const pm_afsk_tones *h_tones, double *d_mark_mag,
+                       double *d_space_mag, double *h_bound);
 int pm_afsk_sweep_last(pm_ctx *ctx, int64_t *h_uncertain);
 
 /* Sign bitmap of a float64 stream: bit k of the little-endian uint64 array = (x[k] >= 0), the only

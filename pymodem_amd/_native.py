@@ -50,6 +50,12 @@ class SliceJob(ctypes.Structure):
                 ("h_state", ctypes.POINTER(SlicerState))]
 
 
+class AfskTones(ctypes.Structure):
+    """pm_afsk_tones"""
+    _fields_ = [("mark_rot", ctypes.c_double * 2), ("mark_end", ctypes.c_double * 2), ("space_rot", ctypes.c_double * 2),
+                ("space_end", ctypes.c_double * 2), ("tap_dev", ctypes.c_double)]
+
+
 class HostJob(ctypes.Structure):
     """pm_host_job"""
     _fields_ = [("codec", ctypes.c_void_p), ("h_data", ctypes.c_void_p), ("h_addr", ctypes.c_void_p), ("n", ctypes.c_int64),
@@ -135,6 +141,9 @@ _SIGS = {
     "pm_afsk_correlate_group": ([_vp, _vp, _i64, _vp, _vp, _vp, _int, _int, _vp, _i64], _int),
     "pm_afsk_sweep_signs": ([_vp, _vp, _i64, _dbl, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(_dbl), _int, _int, _vp, _int, _dbl,
                             ctypes.POINTER(_vp)], _int),
+    "pm_afsk_sweep_signs_tones": ([_vp, _vp, _i64, _dbl, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(_dbl), _int, _int, _vp, _int, _dbl,
+                            ctypes.POINTER(_vp)] + [ctypes.POINTER(AfskTones)], _int),
+    "pm_afsk_magnitudes": ([_vp, _vp, _i64, _dbl, _vp, _vp, _vp, _vp, _int, ctypes.POINTER(AfskTones), _vp, _vp, ctypes.POINTER(_dbl)], _int),
     "pm_afsk_sweep_last": ([_vp, ctypes.POINTER(_i64)], _int),
     "pm_signs_f64": ([_vp, _vp, _i64, _vp], _int),
     "pm_agc_apply": ([_vp, _vp, _i64, ctypes.POINTER(AGCParams), ctypes.POINTER(_dbl)], _int),

@@ -15,6 +15,7 @@
 // (18 dwords: conflict-free for ds_read_b64).  Results go back through the same LDS image so that
 // the global stores are coalesced (lane-contiguous 8 B).
 #include "pm_common.h"
+#include <type_traits>
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -360,6 +361,147 @@ __global__ __launch_bounds__(kThreads) void afsk_correlate_kernel(const double *
         for (int r = 0; r < R; ++r) diff[r] = markv[r] - spacev[r];
         emit(diff, y);
     }
+}
+
+// Mark and unit-space magnitudes by a sliding sum (pm_afsk_sweep_signs_tones): the correlator taps of afsk.py:134-144 are the
+// powers of one rotation, h[j] = r^j with r = e^{iw} (real part = the cos template, imaginary part = the sin template), so the
+// complex correlator sum Z(k) = sum_j r^j x[k + m - 1 - j] obeys
+//     Z(k + 1) = x[k + m] + r Z(k) - r^m x[k]
+// -- 6 fused operations per tone and sample instead of 2m.  The result is NOT the reference's sum, only within a bound of it
+// (L steps of rounding, r^m rounded once, the taps' own deviation from exact powers, measured by the host), which is
+// all a certified-sign path needs.  A thread starts its run of L consecutive outputs from the direct sum with the real taps and
+// slides from there; runs are short so that the error does not build up and so that the 4m fmas of a start are spread over L
+// outputs.  x is staged through LDS with one pad slot per L (lane t's run starts at slot t(L+1)).
+struct SlideTones {
+    double mr, ms, mer, mes;       // mark:  r = mr + i ms,  r^m = mer + i mes
+    double sr, ss, ser, ses;       // space (unit gain)
+};
+constexpr int kSlideThreads = 128;
+template <int L>
+__host__ __device__ __forceinline__ int slide_slot(int p) { return p + p / L; }
+template <int L>
+size_t slide_lds_bytes(int m) { return (size_t)(slide_slot<L>(kSlideThreads * L + m - 1) + 2 + 4 * m) * sizeof(double); }
+
+// sqrt for the sliding sums: reciprocal-square-root seed and two coupled Newton steps, within 2 units in the last place of the
+// root for every v that is not so small that v itself underflows in the seed's square (those come out as 0: an absolute error
+// below 1e-150, nothing against the bound of the certified decision).  The IEEE sqrt costs twice the instructions (scaling of
+// subnormal and huge arguments, class checks), which matters here: two roots are half of a sliding step.
+__device__ __forceinline__ double slide_sqrt(double v)
+{
+    const double y = __builtin_amdgcn_rsq(v);
+    double g = v * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double e = __builtin_fma(-g, g, v);
+    g = __builtin_fma(e, h, g);
+    return v > 1e-300 ? g : 0.0;
+}
+
+template <int L>
+__global__ __launch_bounds__(kSlideThreads) void afsk_slide_kernel(const double *__restrict__ x, int64_t n, const double *__restrict__ mi,
+                                                                   const double *__restrict__ mq, const double *__restrict__ ui,
+                                                                   const double *__restrict__ uq, int m, SlideTones T,
+                                                                   double *__restrict__ M, double *__restrict__ S, int64_t nout)
+{
+    extern __shared__ double xs[];
+    constexpr int TILE = kSlideThreads * L;
+    const int t = threadIdx.x;
+    const int span = TILE + m - 1;
+    const int64_t tile0 = (int64_t)blockIdx.x * TILE;
+    double *tp = xs + (slide_slot<L>(span) + 2) / 2 * 2;   // the four templates, reversed and interleaved: tp[4i + f] = h_f[m - 1 - i]
+    if (((uintptr_t)x & 15) == 0 && tile0 + TILE <= n) {
+        // the tile's own TILE inputs: L / 2 independent 16-byte loads per lane, all in flight before the first LDS write
+        double2v v[L / 2];
+#pragma unroll
+        for (int q = 0; q < L / 2; ++q) v[q] = *reinterpret_cast<const double2v *>(x + tile0 + 2 * (q * kSlideThreads + t));
+#pragma unroll
+        for (int q = 0; q < L / 2; ++q) {
+            const int s0 = slide_slot<L>(2 * (q * kSlideThreads + t));     // even position: its pair never straddles a pad slot
+            xs[s0] = v[q].x;
+            xs[s0 + 1] = v[q].y;
+        }
+        for (int p = TILE + t; p < span; p += kSlideThreads) {
+            const int64_t gi = tile0 + p;
+            xs[slide_slot<L>(p)] = gi < n ? x[gi] : 0.0;
+        }
+    } else {
+        for (int p = t; p < span; p += kSlideThreads) {
+            const int64_t gi = tile0 + p;
+            xs[slide_slot<L>(p)] = gi < n ? x[gi] : 0.0;
+        }
+    }
+    for (int i = t; i < m; i += kSlideThreads) {
+        tp[4 * i + 0] = mi[m - 1 - i];
+        tp[4 * i + 1] = mq[m - 1 - i];
+        tp[4 * i + 2] = ui[m - 1 - i];
+        tp[4 * i + 3] = uq[m - 1 - i];
+    }
+    lds_barrier();
+    const int k0 = t * L;
+    // direct start: the four sums of output tile0 + k0 with the real taps, ascending input index (afsk.py:153-160); every lane
+    // reads the same four taps per step (an LDS broadcast)
+    double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+    {
+        const double2v *tq = reinterpret_cast<const double2v *>(tp);
+        int i = 0;
+        for (; i + 4 <= m; i += 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double v = xs[slide_slot<L>(k0 + i + q)];
+                const double2v h01 = tq[2 * (i + q)], h23 = tq[2 * (i + q) + 1];
+                a = __builtin_fma(h01.x, v, a);
+                b = __builtin_fma(h01.y, v, b);
+                c = __builtin_fma(h23.x, v, c);
+                d = __builtin_fma(h23.y, v, d);
+            }
+        }
+        for (; i < m; ++i) {
+            const double v = xs[slide_slot<L>(k0 + i)];
+            const double2v h01 = tq[2 * i], h23 = tq[2 * i + 1];
+            a = __builtin_fma(h01.x, v, a);
+            b = __builtin_fma(h01.y, v, b);
+            c = __builtin_fma(h23.x, v, c);
+            d = __builtin_fma(h23.y, v, d);
+        }
+    }
+    // The run's 2 x L results stay in registers; once every lane is done with the staged inputs, the LDS image is reused to turn
+    // "L consecutive outputs per lane" into coalesced stores, one stream after the other.
+    double mv[L], sv[L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        mv[i] = slide_sqrt(a * a + b * b);                   // afsk.py:157
+        sv[i] = slide_sqrt(c * c + d * d);
+        if (i + 1 < L) {
+            const double xk = xs[slide_slot<L>(k0 + i)], xn = xs[slide_slot<L>(k0 + i + m)];
+            const double a2 = __builtin_fma(T.mr, a, __builtin_fma(-T.ms, b, __builtin_fma(-T.mer, xk, xn)));
+            const double b2 = __builtin_fma(T.ms, a, __builtin_fma(T.mr, b, -T.mes * xk));
+            const double c2 = __builtin_fma(T.sr, c, __builtin_fma(-T.ss, d, __builtin_fma(-T.ser, xk, xn)));
+            const double d2 = __builtin_fma(T.ss, c, __builtin_fma(T.sr, d, -T.ses * xk));
+            a = a2; b = b2; c = c2; d = d2;
+        }
+    }
+    const bool full = tile0 + TILE <= nout && ((((uintptr_t)M) | ((uintptr_t)S)) & 15) == 0;      // uniform over the workgroup
+    auto emit = [&](const double (&v)[L], double *__restrict__ dst) {
+        lds_barrier();
+        double *op = xs + t * (L + 1);                       // = slide_slot(k0): this lane's L results in L consecutive slots
+#pragma unroll
+        for (int i = 0; i < L; ++i) op[i] = v[i];
+        lds_barrier();
+        if (full) {
+#pragma unroll
+            for (int q = 0; q < L / 2; ++q) {
+                const int p = 2 * (q * kSlideThreads + t);
+                const int s0 = slide_slot<L>(p);
+                *reinterpret_cast<double2v *>(dst + tile0 + p) = double2v{xs[s0], xs[s0 + 1]};
+            }
+        } else {
+            for (int p = t; p < TILE; p += kSlideThreads)
+                if (tile0 + p < nout) dst[tile0 + p] = xs[slide_slot<L>(p)];
+        }
+    };
+    emit(mv, M);
+    emit(sv, S);
 }
 
 // G correlator banks that share their mark filters (the chains of afsk_1200_ax25_super_opt.json differ in space gain only):
@@ -772,9 +914,61 @@ static int afsk_group_dispatch(pm_ctx *ctx, int groups, const double *d_x, int64
     }
 }
 
-int pm_afsk_sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound, const double *d_mark_i, const double *d_mark_q,
-                        const double *d_unit_i, const double *d_unit_q, const double *d_space, const double *h_gains, int groups, int m,
-                        const double *d_lpf, int ml, double lpf_abs_sum, uint64_t *const *h_bits)
+// M = |mark correlators|, S = |unit-gain space correlators| over x, one stream each (nc = n - m + 1 values): by the sliding sum when
+// `tones` describes the templates, else by the direct sums.  *e_slide = bound on |sliding value - direct value| (0 for the direct sums).
+static int afsk_magnitudes(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound, const double *d_mark_i, const double *d_mark_q,
+                           const double *d_unit_i, const double *d_unit_q, int m, const pm_afsk_tones *tones, double *M, double *S,
+                           double *e_slide)
+{
+    const int64_t nc = n - m + 1;
+    constexpr int kRun = 16;
+    *e_slide = 0.0;
+    if (tones && m >= 2) {
+        PM_ARG(tones->tap_dev >= 0.0 && tones->tap_dev < 1e-6);
+        const double u = 1.1102230246251565e-16;
+        // |sliding value - the reference's computed sum| at step i of a run that started from the reference's own sum (same taps,
+        // same order: no difference at i = 0).  With Z_model the exact sums of the power filter r^j:  the run follows Z_model from a
+        // start that is off it by (tap deviation + the start sum's rounding), rotated, and the reference's sum at step i is off
+        // Z_model by the same two kinds of term:  2 sqrt2 m tap_dev X  +  2 sqrt2 m^2 u X.  On top, per step, 6 roundings of
+        // sums bounded by (m + 2) X and r^m being off by sqrt2 u:  < 16 u (m + 1) X, over at most kRun steps.  The magnitude is
+        // 1-Lipschitz in the pair of sums and its own three roundings are the same on both sides up to 3 u m X.
+        *e_slide = (16.0 * kRun * u * (m + 1) + 3.0 * m * tones->tap_dev + 3.0 * u * m * m + 6.0 * u * m) * x_bound;
+        SlideTones T{tones->mark_rot[0], tones->mark_rot[1], tones->mark_end[0], tones->mark_end[1],
+                     tones->space_rot[0], tones->space_rot[1], tones->space_end[0], tones->space_end[1]};
+        const int64_t ntiles = pm_cdiv(nc, (int64_t)kSlideThreads * kRun);
+        PM_ARG(ntiles < (1LL << 31));
+        const size_t lds = slide_lds_bytes<kRun>(m);
+        if (lds > 160 * 1024) return pm_set_error(PM_ERR_ARG, "sliding correlator sums: %d taps do not fit the LDS tile", m);
+        PmProf prof(ctx, PM_K_AFSK_CORR);
+        prof.work((double)n * 8 + 2.0 * nc * 8, (4.0 * m / kRun + 18.0) * (double)nc);
+        if (int rc = allow_lds(afsk_slide_kernel<kRun>, lds)) return rc;
+        hipLaunchKernelGGL((afsk_slide_kernel<kRun>), dim3((unsigned)ntiles), dim3(kSlideThreads), lds, ctx->stream, d_x, n, d_mark_i, d_mark_q,
+                           d_unit_i, d_unit_q, m, T, M, S, nc);
+        PM_HIP(hipGetLastError());
+        return PM_OK;
+    }
+    constexpr int R = 4;
+    const int64_t ntiles = pm_cdiv(nc, (int64_t)kThreads * R);
+    PM_ARG(ntiles < (1LL << 31));
+    const size_t lds = lds_bytes<R>(m);
+    PmProf prof(ctx, PM_K_AFSK_CORR);
+    prof.work((double)n * 8 + 2.0 * nc * 8, 2.0 * 4 * m * (double)nc);
+    if ((((uintptr_t)d_x) & 15) == 0) {
+        if (int rc = allow_lds(afsk_correlate_kernel<R, true, true>, lds)) return rc;
+        hipLaunchKernelGGL((afsk_correlate_kernel<R, true, true>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, d_x, n, d_mark_i,
+                           d_mark_q, d_unit_i, d_unit_q, m, M, nc, S);
+    } else {
+        if (int rc = allow_lds(afsk_correlate_kernel<R, false, true>, lds)) return rc;
+        hipLaunchKernelGGL((afsk_correlate_kernel<R, false, true>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, d_x, n, d_mark_i,
+                           d_mark_q, d_unit_i, d_unit_q, m, M, nc, S);
+    }
+    PM_HIP(hipGetLastError());
+    return PM_OK;
+}
+
+static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound, const double *d_mark_i, const double *d_mark_q,
+                       const double *d_unit_i, const double *d_unit_q, const double *d_space, const double *h_gains, int groups, int m,
+                       const double *d_lpf, int ml, double lpf_abs_sum, uint64_t *const *h_bits, const pm_afsk_tones *tones)
 {
     PM_CTX(ctx);
     PM_ARG(d_x && d_mark_i && d_mark_q && d_unit_i && d_unit_q && d_space && h_gains && d_lpf && h_bits);
@@ -805,26 +999,10 @@ int pm_afsk_sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_boun
     double *d_w = (double *)(base + 2 * b_m + b_a + b_list + 256);
     double *C = (double *)(base + 2 * b_m + b_a + b_list + 256 + b_w);
     ctx->sweep_count = count;
-    {   // mark and unit-gain space magnitudes, one pass over the band-passed stream
-        constexpr int R = 4;
-        const int64_t ntiles = pm_cdiv(nc, (int64_t)kThreads * R);
-        PM_ARG(ntiles < (1LL << 31));
-        const size_t lds = lds_bytes<R>(m);
-        PmProf prof(ctx, PM_K_AFSK_CORR);
-        prof.work((double)n * 8 + 2.0 * nc * 8, 2.0 * 4 * m * (double)nc);
-        if ((((uintptr_t)d_x) & 15) == 0) {
-            if (int rc = allow_lds(afsk_correlate_kernel<R, true, true>, lds)) return rc;
-            hipLaunchKernelGGL((afsk_correlate_kernel<R, true, true>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, d_x, n, d_mark_i,
-                               d_mark_q, d_unit_i, d_unit_q, m, M, nc, S);
-        } else {
-            if (int rc = allow_lds(afsk_correlate_kernel<R, false, true>, lds)) return rc;
-            hipLaunchKernelGGL((afsk_correlate_kernel<R, false, true>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, d_x, n, d_mark_i,
-                               d_mark_q, d_unit_i, d_unit_q, m, M, nc, S);
-        }
-        PM_HIP(hipGetLastError());
-    }
+    double e_slide = 0.0;
+    if (int rc = afsk_magnitudes(ctx, d_x, n, x_bound, d_mark_i, d_mark_q, d_unit_i, d_unit_q, m, tones, M, S, &e_slide)) return rc;
     if (int rc = fir_launch<double>(ctx, M, nc, d_lpf, ml, A, nullptr, 0)) return rc;
-    const double E = 1e-10 * lpf_abs_sum * (1.0 + gmax) * (double)m * 1.4143 * x_bound;
+    const double E = 1e-10 * lpf_abs_sum * (1.0 + gmax) * (double)m * 1.4143 * x_bound + lpf_abs_sum * (1.0 + gmax) * e_slide;
     PM_HIP(hipMemsetAsync(count, 0, sizeof(int), ctx->stream));
     {   // B = LPF(S) and the combine step in one pass: B never reaches memory
         constexpr int R = 8;
@@ -881,6 +1059,36 @@ int pm_afsk_sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_boun
         }
     }
     PM_HIP(hipGetLastError());
+    return PM_OK;
+}
+
+int pm_afsk_sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound, const double *d_mark_i, const double *d_mark_q,
+                        const double *d_unit_i, const double *d_unit_q, const double *d_space, const double *h_gains, int groups, int m,
+                        const double *d_lpf, int ml, double lpf_abs_sum, uint64_t *const *h_bits)
+{
+    return sweep_signs(ctx, d_x, n, x_bound, d_mark_i, d_mark_q, d_unit_i, d_unit_q, d_space, h_gains, groups, m, d_lpf, ml, lpf_abs_sum, h_bits,
+                       nullptr);
+}
+
+int pm_afsk_sweep_signs_tones(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound, const double *d_mark_i, const double *d_mark_q,
+                              const double *d_unit_i, const double *d_unit_q, const double *d_space, const double *h_gains, int groups, int m,
+                              const double *d_lpf, int ml, double lpf_abs_sum, uint64_t *const *h_bits, const pm_afsk_tones *h_tones)
+{
+    if (!h_tones) return pm_set_error(PM_ERR_ARG, "pm_afsk_sweep_signs_tones: no tones");
+    return sweep_signs(ctx, d_x, n, x_bound, d_mark_i, d_mark_q, d_unit_i, d_unit_q, d_space, h_gains, groups, m, d_lpf, ml, lpf_abs_sum, h_bits,
+                       h_tones);
+}
+
+int pm_afsk_magnitudes(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound, const double *d_mark_i, const double *d_mark_q,
+                       const double *d_space_i, const double *d_space_q, int m, const pm_afsk_tones *h_tones, double *d_mark_mag,
+                       double *d_space_mag, double *h_bound)
+{
+    PM_CTX(ctx);
+    PM_ARG(d_x && d_mark_i && d_mark_q && d_space_i && d_space_q && d_mark_mag && d_space_mag);
+    PM_ARG(m >= 1 && m <= kMaxTaps && n >= m && x_bound > 0.0 && x_bound < 1e300);
+    double e = 0.0;
+    if (int rc = afsk_magnitudes(ctx, d_x, n, x_bound, d_mark_i, d_mark_q, d_space_i, d_space_q, m, h_tones, d_mark_mag, d_space_mag, &e)) return rc;
+    if (h_bound) *h_bound = e;
     return PM_OK;
 }
 

@@ -328,10 +328,15 @@ class AFSKModem(_DeviceStage):
             b = ctx.scratch((md._own_key(), "signs", "output_lpf"), (nout + 63) // 64 + 1, np.uint64)
             bits.append(b)
             ptrs[j] = b.ptr.value
-        check(lib().pm_afsk_sweep_signs(ctx.handle, a.ptr, a.n, float(x_bound), lead._const("mi", lead.mark_correlator_i).ptr,
-                                        lead._const("mq", lead.mark_correlator_q).ptr, lead._const("unit_i", ui).ptr,
-                                        lead._const("unit_q", uq).ptr, lead._const("space_group", space.reshape(-1)).ptr, gains, g, mc,
-                                        lead._const("output_lpf", lead.output_lpf).ptr, ml, float(np.abs(lead.output_lpf).sum()), ptrs))
+        args = (ctx.handle, a.ptr, a.n, float(x_bound), lead._const("mi", lead.mark_correlator_i).ptr,
+                lead._const("mq", lead.mark_correlator_q).ptr, lead._const("unit_i", ui).ptr,
+                lead._const("unit_q", uq).ptr, lead._const("space_group", space.reshape(-1)).ptr, gains, g, mc,
+                lead._const("output_lpf", lead.output_lpf).ptr, ml, float(np.abs(lead.output_lpf).sum()), ptrs)
+        tones = lead._tones(ui, uq) if AFSKModem.sliding_sums else None
+        if tones is not None:
+            check(lib().pm_afsk_sweep_signs_tones(*args, ctypes.byref(tones)))
+        else:
+            check(lib().pm_afsk_sweep_signs(*args))
         AFSKModem.sweeps_run += 1
         return [SignBits(b, None, nout) for b in bits]
 
@@ -343,6 +348,25 @@ class AFSKModem(_DeviceStage):
         return v.value
 
     sweeps_run = 0
+    sliding_sums = True        # pm_afsk_sweep_signs_tones where the templates are tones (tests switch it off to compare)
+
+    def _tones(self, ui, uq):
+        """pm_afsk_tones of this modem's mark and unit-space templates, or None if they are not the powers of one rotation each
+        (remembered for as long as the template arrays are the same objects)."""
+        from ._native import AfskTones
+        deps = (self.mark_correlator_i, self.mark_correlator_q, ui, uq)
+        hit = getattr(self, "_tones_memo", None)
+        if hit is not None and all(x is y for x, y in zip(hit[0], deps)):
+            return hit[1]
+        mk, sp = T.tone_model(deps[0], deps[1]), T.tone_model(ui, uq)
+        tones = None
+        if mk is not None and sp is not None and max(mk[2], sp[2]) < 1e-9:
+            tones = AfskTones()
+            tones.mark_rot[:], tones.mark_end[:] = mk[0], mk[1]
+            tones.space_rot[:], tones.space_end[:] = sp[0], sp[1]
+            tones.tap_dev = max(mk[2], sp[2])
+        self._tones_memo = (deps, tones)
+        return tones
 
 
     def back_end(self, a, device_out=False, signs=False, correlated=None):

@@ -126,6 +126,25 @@ def afsk_tone_correlators(sample_rate, symbol_rate, mark_freq, space_freq, space
     return np.cos(mark), np.sin(mark), space_gain * np.cos(space), space_gain * np.sin(space)
 
 
+def tone_model(template_i, template_q):
+    """How well a correlator template pair is the powers of one rotation, template[j] = (r^j).real / .imag with
+    r = (template_i[1], template_q[1]) -> (rot, end, dev): r, r^m rounded to double, and the largest |template[j] - r^j| over both
+    templates, the powers taken in extended precision (pm_afsk_tones; None if the pair is shorter than two taps)."""
+    hi, hq = np.asarray(template_i, dtype=np.float64), np.asarray(template_q, dtype=np.float64)
+    m = len(hi)
+    if m < 2 or len(hq) != m:
+        return None
+    ld = np.longdouble
+    rr, ri = ld(hi[1]), ld(hq[1])
+    zr, zi, dev = ld(1.0), ld(0.0), ld(0.0)
+    for j in range(m):
+        dev = max(dev, abs(zr - ld(hi[j])), abs(zi - ld(hq[j])))
+        zr, zi = zr * rr - zi * ri, zr * ri + zi * rr
+    # the extended-precision powers themselves are off by a few 2^-64 per step; count that in
+    dev = float(dev) + 4.0 * m * float(np.finfo(ld).eps)
+    return (float(hi[1]), float(hq[1])), (float(zr), float(zi)), dev
+
+
 def sine_wavetable(amplitude=1.0, size=256):
     return np.array([amplitude * math.sin(k * 2.0 * math.pi / size) for k in range(size)], dtype=np.float64)
 

@@ -556,7 +556,17 @@ def _exact_afsk_signs(ctx, x, mark, space_pair, lpf):
     return np.unpackbits(bits.download().view(np.uint8), bitorder="little")[:nout].astype(bool)
 
 
-def _sweep(ctx, x, x_bound, mark, unit, gains, lpf):
+def _tones(mark, unit):
+    from pymodem_amd import taps as T
+    from pymodem_amd._native import AfskTones
+    mk, sp = T.tone_model(*mark), T.tone_model(*unit)
+    tones = AfskTones()
+    tones.mark_rot[:], tones.mark_end[:], tones.space_rot[:], tones.space_end[:] = mk[0], mk[1], sp[0], sp[1]
+    tones.tap_dev = max(mk[2], sp[2])
+    return tones
+
+
+def _sweep(ctx, x, x_bound, mark, unit, gains, lpf, sliding=False):
     n, m, ml, g = len(x), len(mark[0]), len(lpf), len(gains)
     nout = n - m - ml + 2
     space = np.stack([np.stack([gn * unit[0], gn * unit[1]]) for gn in gains])
@@ -567,15 +577,20 @@ def _sweep(ctx, x, x_bound, mark, unit, gains, lpf):
     ptrs = (ctypes.c_void_p * g)(*[b.ptr.value for b in bits])
     gs = (ctypes.c_double * g)(*gains)
     redo = ctypes.c_int64()
-    chk(L().pm_afsk_sweep_signs(ctx.handle, dx.ptr, n, float(x_bound), t[0].ptr, t[1].ptr, t[2].ptr, t[3].ptr, ds.ptr, gs, g, m, dl.ptr, ml,
-                                float(np.abs(lpf).sum()), ptrs))
+    args = (ctx.handle, dx.ptr, n, float(x_bound), t[0].ptr, t[1].ptr, t[2].ptr, t[3].ptr, ds.ptr, gs, g, m, dl.ptr, ml,
+            float(np.abs(lpf).sum()), ptrs)
+    if sliding:
+        chk(L().pm_afsk_sweep_signs_tones(*args, ctypes.byref(_tones(mark, unit))))
+    else:
+        chk(L().pm_afsk_sweep_signs(*args))
     chk(L().pm_afsk_sweep_last(ctx.handle, ctypes.byref(redo)))
     out = [np.unpackbits(b.download().view(np.uint8), bitorder="little")[:nout].astype(bool) for b in bits]
     return out, redo.value, space
 
 
-def test_afsk_gain_sweep_signs_are_the_exact_chain_s(ctx):
-    """pm_afsk_sweep_signs: bitmaps of a space_gain sweep from ONE unit space correlator pair and two low-passes, certified against
+@pytest.mark.parametrize("sliding", [False, True])
+def test_afsk_gain_sweep_signs_are_the_exact_chain_s(ctx, sliding):
+    """pm_afsk_sweep_signs / pm_afsk_sweep_signs_tones (sliding correlator sums): bitmaps of a space_gain sweep from ONE unit space correlator pair and two low-passes, certified against
     the exact chain -- every bit must equal pm_afsk_correlate + pm_fir_signs_f64 with that modem's own (gain-scaled) taps, on an
     AFSK-like signal, on noise at several amplitudes (the smaller the amplitude against the caller's bound, the more samples are
     recomputed exactly, and past 65536 of them the exact chains of all modems run instead, decided on the device)."""
@@ -592,7 +607,7 @@ def test_afsk_gain_sweep_signs_are_the_exact_chain_s(ctx):
              ("very quiet", 1e-3 * rng.standard_normal(n), 4.0e4)]
     took_exact_chains = []
     for name, x, bound in cases:
-        got, redo, space = _sweep(ctx, x, bound, (mi, mq), (ui, uq), gains, lpf)
+        got, redo, space = _sweep(ctx, x, bound, (mi, mq), (ui, uq), gains, lpf, sliding)
         if redo > 65536:
             took_exact_chains.append(name)                    # too many uncertain samples: the gated exact chains wrote the bitmaps
         for g, gn in enumerate(gains):
@@ -601,7 +616,43 @@ def test_afsk_gain_sweep_signs_are_the_exact_chain_s(ctx):
             assert np.array_equal(got[g], want), (name, gn, int(np.count_nonzero(got[g] != want)), redo)
     assert "afsk" not in took_exact_chains and "noise" not in took_exact_chains and "very quiet" in took_exact_chains
     z = np.zeros(150000)
-    got, redo, space = _sweep(ctx, z, 4.0e4, (mi, mq), (ui, uq), gains, lpf)
+    got, redo, space = _sweep(ctx, z, 4.0e4, (mi, mq), (ui, uq), gains, lpf, sliding)
     assert redo > 65536                                       # every output is exactly zero: nothing can be certified ...
     for g in range(len(gains)):                               # ... and the exact chains say ">= 0" everywhere
         assert got[g].all()
+
+
+@pytest.mark.parametrize("rate,baud,mark,space,span", [(48000.0, 1200.0, 1300.0, 2100.0, 1.5), (48000.0, 1200.0, 1600.0, 1800.0, 1.0),
+                                                       (8000.0, 300.0, 1600.0, 1800.0, 1.0), (44100.0, 1200.0, 1200.0, 2200.0, 1.5)])
+def test_sliding_correlator_sums_stay_within_their_bound(ctx, rate, baud, mark, space, span):
+    """pm_afsk_magnitudes: the sliding sums (Z(k+1) = x[k+m] + r Z(k) - r^m x[k], restarted every 16 outputs) against the direct sums
+    in the reference's order -- equal at every restart, elsewhere within the bound the certified decision adds for them, and in
+    practice orders of magnitude inside it (the bound is what parity rests on; this pins the error model to the hardware)."""
+    from pymodem_amd import taps as T
+    mi, mq, ui, uq = T.afsk_tone_correlators(rate, baud, mark, space, 1.0, span, 0.0)
+    m = len(mi)
+    rng = np.random.default_rng(int(rate + mark))
+    tones = _tones((mi, mq), (ui, uq))
+    assert tones.tap_dev < 1e-13
+    dt = [ctx.upload(v) for v in (mi, mq, ui, uq)]
+    for n, amp in [(m, 1.0), (m + 15, 3.0e4), (m + 16, 3.0e4), (m + 2047, 1.0e-3), (m + 2048, 3.0e4), (200001, 3.0e4)]:
+        x = amp * rng.standard_normal(n)
+        x[n // 2:n // 2 + 3 * m] = amp * 4.0                                     # a flat stretch: long cancellation in the sums
+        bound_x = float(np.abs(x).max())
+        dx = ctx.upload(x)
+        nc = n - m + 1
+        out = [ctx.empty(nc, np.float64) for _ in range(4)]
+        e = ctypes.c_double(-1.0)
+        chk(L().pm_afsk_magnitudes(ctx.handle, dx.ptr, n, bound_x, dt[0].ptr, dt[1].ptr, dt[2].ptr, dt[3].ptr, m, None, out[0].ptr, out[1].ptr,
+                                   ctypes.byref(e)))
+        assert e.value == 0.0
+        chk(L().pm_afsk_magnitudes(ctx.handle, dx.ptr, n, bound_x, dt[0].ptr, dt[1].ptr, dt[2].ptr, dt[3].ptr, m, ctypes.byref(tones),
+                                   out[2].ptr, out[3].ptr, ctypes.byref(e)))
+        M, S, Ms, Ss = [o.download() for o in out]
+        # the direct sums are the reference's: mark - space is what pm_afsk_correlate gives
+        assert np.array_equal(M - S, O.afsk_correlate_canon(x, mi, mq, ui, uq))
+        # every run starts from the direct sums: there only the root differs (not the IEEE one: within 2 units in the last place)
+        assert np.abs(M[::16] - Ms[::16]).max() <= 4.5e-16 * np.abs(M).max() and np.abs(S[::16] - Ss[::16]).max() <= 4.5e-16 * np.abs(S).max()
+        worst = max(np.abs(M - Ms).max(), np.abs(S - Ss).max())
+        assert 0.0 < e.value < 1e-9 * m * bound_x
+        assert worst <= e.value / 8.0, (n, amp, worst, e.value)
