@@ -356,9 +356,10 @@ def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced
         for part_all in sweeps.values():
             for base in range(0, len(part_all), 8):
                 part = part_all[base:base + 8]
-                if len(part) < 2:
-                    continue
                 mods = [chains[k][1] for k in part]
+                if len(part) < 2 and not (AFSKModem.sliding_sums and mods[0]._tones(*mods[0].unit_space_correlators()) is not None):
+                    continue                     # one chain whose templates are not tones: the exact kernels are cheaper
+
                 bpf = shared_front(mods[0])
                 got = AFSKModem.sweep_signs(mods, bpf, float(np.abs(mods[0].input_bpf).sum()) * 32768.0)
                 for k, sb in zip(part, got):

@@ -402,7 +402,7 @@ template <int L>
 __global__ __launch_bounds__(kSlideThreads) void afsk_slide_kernel(const double *__restrict__ x, int64_t n, const double *__restrict__ mi,
                                                                    const double *__restrict__ mq, const double *__restrict__ ui,
                                                                    const double *__restrict__ uq, int m, SlideTones T,
-                                                                   double *__restrict__ M, double *__restrict__ S, int64_t nout)
+                                                                   double *__restrict__ M, double *__restrict__ S, int64_t nout, double gain)
 {
     extern __shared__ double xs[];
     constexpr int TILE = kSlideThreads * L;
@@ -481,6 +481,10 @@ __global__ __launch_bounds__(kSlideThreads) void afsk_slide_kernel(const double 
             a = a2; b = b2; c = c2; d = d2;
         }
     }
+    if (!S) {                                                // one chain: its mark - space difference (afsk.py:162) in ONE stream
+#pragma unroll
+        for (int i = 0; i < L; ++i) mv[i] = __builtin_fma(-gain, sv[i], mv[i]);
+    }
     const bool full = tile0 + TILE <= nout && ((((uintptr_t)M) | ((uintptr_t)S)) & 15) == 0;      // uniform over the workgroup
     auto emit = [&](const double (&v)[L], double *__restrict__ dst) {
         lds_barrier();
@@ -501,7 +505,7 @@ __global__ __launch_bounds__(kSlideThreads) void afsk_slide_kernel(const double 
         }
     };
     emit(mv, M);
-    emit(sv, S);
+    if (S) emit(sv, S);
 }
 
 // G correlator banks that share their mark filters (the chains of afsk_1200_ax25_super_opt.json differ in space gain only):
@@ -637,13 +641,13 @@ __global__ __launch_bounds__(kThreads) void fir_sweep_kernel(const double *__res
     if (go >= ((nout + 63) >> 6) * 64) return;
     double a[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) a[r] = go + r < nout ? A[go + r] : 0.0;
+    for (int r = 0; r < R; ++r) a[r] = A && go + r < nout ? A[go + r] : 0.0;
     for (int g = 0; g < G; ++g) {
         const double mg = -P.gain[g];
         unsigned byte = 0, unsure = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const double y = __builtin_fma(mg, b[r], a[r]);
+            const double y = A ? __builtin_fma(mg, b[r], a[r]) : b[r];       // no A: the input already is mark - gain * space (one chain)
             const bool in = go + r < nout;
             byte |= (unsigned)(in && y >= 0.0) << r;
             unsure |= (unsigned)(in && !(fabs(y) > E)) << r;                 // cannot be certified (NaN lands here too)
@@ -918,8 +922,9 @@ static int afsk_group_dispatch(pm_ctx *ctx, int groups, const double *d_x, int64
 // `tones` describes the templates, else by the direct sums.  *e_slide = bound on |sliding value - direct value| (0 for the direct sums).
 static int afsk_magnitudes(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound, const double *d_mark_i, const double *d_mark_q,
                            const double *d_unit_i, const double *d_unit_q, int m, const pm_afsk_tones *tones, double *M, double *S,
-                           double *e_slide)
+                           double *e_slide, double diff_gain = 0.0)
 {
+    PM_ARG(S || (tones && m >= 2));                          // the one-stream difference exists for the sliding sums only
     const int64_t nc = n - m + 1;
     constexpr int kRun = 16;
     *e_slide = 0.0;
@@ -940,10 +945,10 @@ static int afsk_magnitudes(pm_ctx *ctx, const double *d_x, int64_t n, double x_b
         const size_t lds = slide_lds_bytes<kRun>(m);
         if (lds > 160 * 1024) return pm_set_error(PM_ERR_ARG, "sliding correlator sums: %d taps do not fit the LDS tile", m);
         PmProf prof(ctx, PM_K_AFSK_CORR);
-        prof.work((double)n * 8 + 2.0 * nc * 8, (4.0 * m / kRun + 18.0) * (double)nc);
+        prof.work((double)n * 8 + (S ? 2.0 : 1.0) * nc * 8, (4.0 * m / kRun + 18.0) * (double)nc);
         if (int rc = allow_lds(afsk_slide_kernel<kRun>, lds)) return rc;
         hipLaunchKernelGGL((afsk_slide_kernel<kRun>), dim3((unsigned)ntiles), dim3(kSlideThreads), lds, ctx->stream, d_x, n, d_mark_i, d_mark_q,
-                           d_unit_i, d_unit_q, m, T, M, S, nc);
+                           d_unit_i, d_unit_q, m, T, M, S, nc, diff_gain);
         PM_HIP(hipGetLastError());
         return PM_OK;
     }
@@ -1000,8 +1005,14 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
     double *C = (double *)(base + 2 * b_m + b_a + b_list + 256 + b_w);
     ctx->sweep_count = count;
     double e_slide = 0.0;
-    if (int rc = afsk_magnitudes(ctx, d_x, n, x_bound, d_mark_i, d_mark_q, d_unit_i, d_unit_q, m, tones, M, S, &e_slide)) return rc;
-    if (int rc = fir_launch<double>(ctx, M, nc, d_lpf, ml, A, nullptr, 0)) return rc;
+    // One chain with tone templates: its mark - gain * space difference leaves the sliding kernel as ONE stream and takes ONE
+    // low-pass (the reference's own dataflow, afsk.py:162-166, on approximate magnitudes); a sweep takes two for all its chains.
+    const bool one = groups == 1 && tones && m >= 2;
+    const double *lp_in = one ? M : S, *lp_a = one ? nullptr : A;
+    if (int rc = afsk_magnitudes(ctx, d_x, n, x_bound, d_mark_i, d_mark_q, d_unit_i, d_unit_q, m, tones, M, one ? nullptr : S, &e_slide, P.gain[0]))
+        return rc;
+    if (!one)
+        if (int rc = fir_launch<double>(ctx, M, nc, d_lpf, ml, A, nullptr, 0)) return rc;
     const double E = 1e-10 * lpf_abs_sum * (1.0 + gmax) * (double)m * 1.4143 * x_bound + lpf_abs_sum * (1.0 + gmax) * e_slide;
     PM_HIP(hipMemsetAsync(count, 0, sizeof(int), ctx->stream));
     {   // B = LPF(S) and the combine step in one pass: B never reaches memory
@@ -1010,15 +1021,15 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
         PM_ARG(ntiles < (1LL << 31));
         const size_t lds = lds_bytes<R>(ml);
         PmProf prof(ctx, PM_K_FIR_F64);
-        prof.work((double)nc * 8 + (double)nl * 8 + (double)groups * nl / 8, 2.0 * ml * (double)nl + 2.0 * groups * (double)nl);
-        if ((((uintptr_t)S) & 15) == 0) {
+        prof.work((double)nc * 8 + (one ? 0.0 : (double)nl * 8) + (double)groups * nl / 8, 2.0 * ml * (double)nl + 2.0 * groups * (double)nl);
+        if ((((uintptr_t)lp_in) & 15) == 0) {
             if (int rc = allow_lds(fir_sweep_kernel<R, true>, lds)) return rc;
-            hipLaunchKernelGGL((fir_sweep_kernel<R, true>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, S, nc, d_lpf, ml, A, nl, groups,
-                               P, E, list, count, cap);
+            hipLaunchKernelGGL((fir_sweep_kernel<R, true>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, lp_in, nc, d_lpf, ml, lp_a, nl,
+                               groups, P, E, list, count, cap);
         } else {
             if (int rc = allow_lds(fir_sweep_kernel<R, false>, lds)) return rc;
-            hipLaunchKernelGGL((fir_sweep_kernel<R, false>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, S, nc, d_lpf, ml, A, nl, groups,
-                               P, E, list, count, cap);
+            hipLaunchKernelGGL((fir_sweep_kernel<R, false>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, lp_in, nc, d_lpf, ml, lp_a, nl,
+                               groups, P, E, list, count, cap);
         }
         PM_HIP(hipGetLastError());
     }

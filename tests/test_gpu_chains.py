@@ -291,26 +291,30 @@ def test_recording_pipeline_prefetch(config_lines):
 
 
 def test_gain_sweep_path_equals_exact_group_path(config_lines):
-    """Group executor on afsk_1200_ax25_super_opt.json with the certified gain-sweep entry (default) and with it switched off (the
-    exact correlator-group + batched low-pass path): identical slicer bytes, addresses and packets for every chain."""
+    """Group executor on afsk_1200_ax25_super_opt.json three ways -- certified signs from sliding correlator sums (default: the seven
+    chains of the gain sweep in one entry, the eighth chain in an entry of its own), certified signs from the direct sums (the
+    sweep only), and the exact correlator-group + batched low-pass path: identical slicer bytes, addresses and packets for every chain."""
     from pymodem_amd import chain_builder as cb, chain_execute as ce, siggen
     from pymodem_amd.modems import AFSKModem
+    import pymodem_amd
     lines = config_lines("afsk_1200_ax25_super_opt.json")
     audio, _ = siggen.recording("afsk1200_ax25", 48000, packets=12, seed=21, noise_sigma=1500.0, payload_len=(20, 80))
     res = {}
-    for on in (True, False):
-        ce._USE_SWEEP = on
+    for name, sweep, sliding in (("sliding", True, True), ("direct", True, False), ("exact", False, True)):
+        ce._USE_SWEEP, AFSKModem.sliding_sums = sweep, sliding
         before = AFSKModem.sweeps_run
         try:
             st = {}
             pk = ce.process_chains_device([cb.build_chain(48000, l) for l in lines], audio, stages=st)
+            if sweep:
+                assert 0 <= AFSKModem.sweep_uncertain(pymodem_amd.Context.default()) < 1000
         finally:
-            ce._USE_SWEEP = True
-        res[on] = (st["sliced"], pk, AFSKModem.sweeps_run - before)
-    assert res[True][2] == 1 and res[False][2] == 0           # the sweep entry ran, and only when enabled
-    import pymodem_amd
-    assert 0 <= AFSKModem.sweep_uncertain(pymodem_amd.Context.default()) < 1000
-    for c in range(len(lines)):
-        a, b = res[True][0][c], res[False][0][c]
-        assert np.array_equal(a.data, b.data) and np.array_equal(a.address, b.address), c
-        assert [(p.streamaddress, bytes(bytearray(p.data))) for p in res[True][1][c]] == [(p.streamaddress, bytes(bytearray(p.data))) for p in res[False][1][c]]
+            ce._USE_SWEEP, AFSKModem.sliding_sums = True, True
+        res[name] = (st["sliced"], pk, AFSKModem.sweeps_run - before)
+    assert [res[k][2] for k in ("sliding", "direct", "exact")] == [2, 1, 0]          # which entries ran
+    for other in ("direct", "exact"):
+        for c in range(len(lines)):
+            a, b = res["sliding"][0][c], res[other][0][c]
+            assert np.array_equal(a.data, b.data) and np.array_equal(a.address, b.address), (other, c)
+            assert [(p.streamaddress, bytes(bytearray(p.data))) for p in res["sliding"][1][c]] == \
+                   [(p.streamaddress, bytes(bytearray(p.data))) for p in res[other][1][c]]

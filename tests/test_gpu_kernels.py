@@ -656,3 +656,23 @@ def test_sliding_correlator_sums_stay_within_their_bound(ctx, rate, baud, mark, 
         worst = max(np.abs(M - Ms).max(), np.abs(S - Ss).max())
         assert 0.0 < e.value < 1e-9 * m * bound_x
         assert worst <= e.value / 8.0, (n, amp, worst, e.value)
+
+
+@pytest.mark.parametrize("gain", [1.0, 2.25])
+@pytest.mark.parametrize("rate,baud,mark,space,span", [(48000.0, 1200.0, 1600.0, 1800.0, 1.0), (8000.0, 300.0, 1600.0, 1800.0, 1.0)])
+def test_one_chain_certified_signs_are_the_exact_chain_s(ctx, rate, baud, mark, space, span, gain):
+    """pm_afsk_sweep_signs_tones with ONE modem: mark - gain * space from the sliding sums as one stream, one low-pass, certified;
+    every bit equals pm_afsk_correlate + pm_fir_signs_f64 (signal, loud and quiet noise, silence -> the gated exact chain)."""
+    from pymodem_amd import taps as T
+    rng = np.random.default_rng(int(rate + 10 * gain))
+    mi, mq, ui, uq = T.afsk_tone_correlators(rate, baud, mark, space, 1.0, span, 0.0)
+    lpf = T.windowed_sinc(round(rate * 2.5 / baud) | 1, 0.75 * baud, rate, pass_zero=True)
+    n = 250001
+    t = np.arange(n)
+    tone = np.where((t // int(rate / baud)) % 3 == 0, mark, space)
+    sig = 8000.0 * np.sin(2 * np.pi * np.cumsum(tone) / rate) + 800.0 * rng.standard_normal(n)
+    for name, x in [("signal", sig), ("noise", 3000.0 * rng.standard_normal(n)), ("quiet", 1e-3 * rng.standard_normal(n)), ("silence", np.zeros(n))]:
+        got, redo, space_taps = _sweep(ctx, x, 4.0e4, (mi, mq), (ui, uq), [gain], lpf, sliding=True)
+        want = _exact_afsk_signs(ctx, x, (mi, mq), (space_taps[0, 0], space_taps[0, 1]), lpf)
+        assert np.array_equal(got[0], want), (name, int(np.count_nonzero(got[0] != want)), redo)
+        assert redo > 65536 if name == "silence" else (redo <= 65536 or name == "quiet"), (name, redo)
