@@ -17,11 +17,14 @@ def short(n):
     return (m.group(1) + (m.group(2) or "")) if m else n[:40]
 
 
-stats = sorted(glob.glob("gpurun_out/prof_stats/*/*_kernel_stats.csv"))[-1]
+import os
+
+# gpurun merges every call's files into gpurun_out/: take the newest, not the highest process id
+stats = max(glob.glob("gpurun_out/prof_stats/*/*_kernel_stats.csv"), key=os.path.getmtime)
 shutil.copyfile(stats, f"profiles/{tag}_{workload}_kernel_stats.csv")
 res = {}
 for name, ctr in [("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")]:
-    f = sorted(glob.glob(f"gpurun_out/{name}/*/*_counter_collection.csv"))[-1]
+    f = max(glob.glob(f"gpurun_out/{name}/*/*_counter_collection.csv"), key=os.path.getmtime)
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         agg[short(r["Kernel_Name"])][0] += 1
