@@ -72,6 +72,9 @@ __device__ __forceinline__ void stage_vec(const int16_t *__restrict__ x, int64_t
     }
 }
 
+template <int R>
+__device__ __forceinline__ void fir_acc_image(const double *__restrict__ xs, const double *__restrict__ h, int m, double (&acc)[R]);
+
 // The sums of one tile: acc[r] = output tile*T + t*R + r of the valid-mode FIR, every sum in ascending input order, one fma per tap.
 template <typename InT, int R, bool VEC>
 __device__ __forceinline__ void fir_tile_acc(const InT *__restrict__ x, int64_t n, const double *__restrict__ h, int m, int64_t tile,
@@ -91,7 +94,14 @@ __device__ __forceinline__ void fir_tile_acc(const InT *__restrict__ x, int64_t 
         }
     }
     lds_barrier();
+    fir_acc_image<R>(xs, h, m, acc);
+}
 
+// The sums over an LDS image of the tile's inputs in the padded layout slot<R>() (thread t's window starts at slot t(R+1)).
+template <int R>
+__device__ __forceinline__ void fir_acc_image(const double *__restrict__ xs, const double *__restrict__ h, int m, double (&acc)[R])
+{
+    const int t = threadIdx.x;
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.0;
     // Window registers: two sets of R that alternate between "carry" (last R-1 values of the previous block) and "new".
@@ -398,6 +408,51 @@ __device__ __forceinline__ double slide_sqrt(double v)
     return v > 1e-300 ? g : 0.0;
 }
 
+// One run: the direct sums of output k0 of the staged tile with the real taps, ascending input index (afsk.py:153-160; every lane
+// reads the same four taps per step, an LDS broadcast), then L - 1 sliding steps; the 2 x L magnitudes stay in registers.
+template <int L>
+__device__ __forceinline__ void slide_run(const double *__restrict__ xs, const double *__restrict__ tp, int k0, int m, const SlideTones &T,
+                                          double (&mv)[L], double (&sv)[L])
+{
+    double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+    {
+        const double2v *tq = reinterpret_cast<const double2v *>(tp);
+        int i = 0;
+        for (; i + 4 <= m; i += 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double v = xs[slide_slot<L>(k0 + i + q)];
+                const double2v h01 = tq[2 * (i + q)], h23 = tq[2 * (i + q) + 1];
+                a = __builtin_fma(h01.x, v, a);
+                b = __builtin_fma(h01.y, v, b);
+                c = __builtin_fma(h23.x, v, c);
+                d = __builtin_fma(h23.y, v, d);
+            }
+        }
+        for (; i < m; ++i) {
+            const double v = xs[slide_slot<L>(k0 + i)];
+            const double2v h01 = tq[2 * i], h23 = tq[2 * i + 1];
+            a = __builtin_fma(h01.x, v, a);
+            b = __builtin_fma(h01.y, v, b);
+            c = __builtin_fma(h23.x, v, c);
+            d = __builtin_fma(h23.y, v, d);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        mv[i] = slide_sqrt(a * a + b * b);                   // afsk.py:157
+        sv[i] = slide_sqrt(c * c + d * d);
+        if (i + 1 < L) {
+            const double xk = xs[slide_slot<L>(k0 + i)], xn = xs[slide_slot<L>(k0 + i + m)];
+            const double a2 = __builtin_fma(T.mr, a, __builtin_fma(-T.ms, b, __builtin_fma(-T.mer, xk, xn)));
+            const double b2 = __builtin_fma(T.ms, a, __builtin_fma(T.mr, b, -T.mes * xk));
+            const double c2 = __builtin_fma(T.sr, c, __builtin_fma(-T.ss, d, __builtin_fma(-T.ser, xk, xn)));
+            const double d2 = __builtin_fma(T.ss, c, __builtin_fma(T.sr, d, -T.ses * xk));
+            a = a2; b = b2; c = c2; d = d2;
+        }
+    }
+}
+
 template <int L>
 __global__ __launch_bounds__(kSlideThreads) void afsk_slide_kernel(const double *__restrict__ x, int64_t n, const double *__restrict__ mi,
                                                                    const double *__restrict__ mq, const double *__restrict__ ui,
@@ -438,49 +493,11 @@ __global__ __launch_bounds__(kSlideThreads) void afsk_slide_kernel(const double 
         tp[4 * i + 3] = uq[m - 1 - i];
     }
     lds_barrier();
-    const int k0 = t * L;
-    // direct start: the four sums of output tile0 + k0 with the real taps, ascending input index (afsk.py:153-160); every lane
-    // reads the same four taps per step (an LDS broadcast)
-    double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
-    {
-        const double2v *tq = reinterpret_cast<const double2v *>(tp);
-        int i = 0;
-        for (; i + 4 <= m; i += 4) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double v = xs[slide_slot<L>(k0 + i + q)];
-                const double2v h01 = tq[2 * (i + q)], h23 = tq[2 * (i + q) + 1];
-                a = __builtin_fma(h01.x, v, a);
-                b = __builtin_fma(h01.y, v, b);
-                c = __builtin_fma(h23.x, v, c);
-                d = __builtin_fma(h23.y, v, d);
-            }
-        }
-        for (; i < m; ++i) {
-            const double v = xs[slide_slot<L>(k0 + i)];
-            const double2v h01 = tq[2 * i], h23 = tq[2 * i + 1];
-            a = __builtin_fma(h01.x, v, a);
-            b = __builtin_fma(h01.y, v, b);
-            c = __builtin_fma(h23.x, v, c);
-            d = __builtin_fma(h23.y, v, d);
-        }
-    }
     // The run's 2 x L results stay in registers; once every lane is done with the staged inputs, the LDS image is reused to turn
     // "L consecutive outputs per lane" into coalesced stores, one stream after the other.
+    const int k0 = t * L;
     double mv[L], sv[L];
-#pragma unroll
-    for (int i = 0; i < L; ++i) {
-        mv[i] = slide_sqrt(a * a + b * b);                   // afsk.py:157
-        sv[i] = slide_sqrt(c * c + d * d);
-        if (i + 1 < L) {
-            const double xk = xs[slide_slot<L>(k0 + i)], xn = xs[slide_slot<L>(k0 + i + m)];
-            const double a2 = __builtin_fma(T.mr, a, __builtin_fma(-T.ms, b, __builtin_fma(-T.mer, xk, xn)));
-            const double b2 = __builtin_fma(T.ms, a, __builtin_fma(T.mr, b, -T.mes * xk));
-            const double c2 = __builtin_fma(T.sr, c, __builtin_fma(-T.ss, d, __builtin_fma(-T.ser, xk, xn)));
-            const double d2 = __builtin_fma(T.ss, c, __builtin_fma(T.sr, d, -T.ses * xk));
-            a = a2; b = b2; c = c2; d = d2;
-        }
-    }
+    slide_run<L>(xs, tp, k0, m, T, mv, sv);
     if (!S) {                                                // one chain: its mark - space difference (afsk.py:162) in ONE stream
 #pragma unroll
         for (int i = 0; i < L; ++i) mv[i] = __builtin_fma(-gain, sv[i], mv[i]);
@@ -648,6 +665,107 @@ __global__ __launch_bounds__(kThreads) void fir_sweep_kernel(const double *__res
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const double y = A ? __builtin_fma(mg, b[r], a[r]) : b[r];       // no A: the input already is mark - gain * space (one chain)
+            const bool in = go + r < nout;
+            byte |= (unsigned)(in && y >= 0.0) << r;
+            unsure |= (unsigned)(in && !(fabs(y) > E)) << r;                 // cannot be certified (NaN lands here too)
+        }
+        reinterpret_cast<uint8_t *>(P.bits[g])[go >> 3] = (uint8_t)byte;     // bits past nout: 0 up to the end of the last word
+        while (unsure) {
+            const int r = __ffs((int)unsure) - 1;
+            unsure &= unsure - 1;
+            const int idx = atomicAdd(count, 1);
+            if (idx < cap) list[idx] = ((unsigned long long)g << 48) | (unsigned long long)(go + r);
+        }
+    }
+}
+
+// Sliding sums, low-pass(es) and the certified combine in ONE kernel: the magnitude streams never reach memory.  A workgroup owns
+// 2048 low-pass outputs; it needs the ml - 1 magnitudes past them too, computes all of them as runs of 16 from one staged window of
+// x (the first ceil((2047 + ml) / 16) lanes do, e.g. 135 of 256 for ml = 100), lays them out as the FIR's padded LDS images -- the
+// space image over the window of x, which is dead by then -- and every thread takes its 8 outputs of each low-pass from there.
+// ONE: a single chain, its mark - gain * space difference as the only image.  Arithmetic and bound: afsk_slide_kernel + fir_valid_kernel
+// + fir_sweep_kernel, value for value.
+constexpr int kFuseRun = 16;
+inline size_t fuse_region0(int m, int ml)
+{
+    const int nmag = kThreads * 8 + ml - 1, nruns = (nmag + kFuseRun - 1) / kFuseRun;
+    const int a = slide_slot<kFuseRun>(nruns * kFuseRun + m - 1) + 2, b = slot<8>(nmag) + 2;
+    return (size_t)((a > b ? a : b) + 1) / 2 * 2;
+}
+inline size_t fuse_image(int ml) { return (size_t)(slot<8>(kThreads * 8 + ml - 1) + 3) / 2 * 2; }
+inline size_t fuse_lds_bytes(int m, int ml) { return (fuse_region0(m, ml) + fuse_image(ml) + 4 * (size_t)m) * sizeof(double); }
+
+template <bool ONE>
+__global__ __launch_bounds__(kThreads) void afsk_slide_lpf_kernel(const double *__restrict__ x, int64_t n, const double *__restrict__ mi,
+                                                                  const double *__restrict__ mq, const double *__restrict__ ui,
+                                                                  const double *__restrict__ uq, int m, SlideTones T,
+                                                                  const double *__restrict__ h, int ml, int64_t nout, int G, SweepArgs P, double E,
+                                                                  unsigned long long *__restrict__ list, int *__restrict__ count, int cap,
+                                                                  int region0, int image)
+{
+    extern __shared__ double xs[];
+    constexpr int R = 8, TILE = kThreads * R, L = kFuseRun;
+    const int t = threadIdx.x;
+    const int64_t tile0 = (int64_t)blockIdx.x * TILE;
+    const int nmag = TILE + ml - 1, nruns = (nmag + L - 1) / L, xspan = nruns * L + m - 1;
+    double *im = xs + region0, *tp = im + image;
+    if (((uintptr_t)x & 15) == 0 && tile0 + TILE <= n) {
+        double2v v[R / 2];
+#pragma unroll
+        for (int q = 0; q < R / 2; ++q) v[q] = *reinterpret_cast<const double2v *>(x + tile0 + 2 * (q * kThreads + t));
+#pragma unroll
+        for (int q = 0; q < R / 2; ++q) {
+            const int s0 = slide_slot<L>(2 * (q * kThreads + t));
+            xs[s0] = v[q].x;
+            xs[s0 + 1] = v[q].y;
+        }
+        for (int p = TILE + t; p < xspan; p += kThreads) {
+            const int64_t gi = tile0 + p;
+            xs[slide_slot<L>(p)] = gi < n ? x[gi] : 0.0;
+        }
+    } else {
+        for (int p = t; p < xspan; p += kThreads) {
+            const int64_t gi = tile0 + p;
+            xs[slide_slot<L>(p)] = gi < n ? x[gi] : 0.0;
+        }
+    }
+    for (int i = t; i < m; i += kThreads) {
+        tp[4 * i + 0] = mi[m - 1 - i];
+        tp[4 * i + 1] = mq[m - 1 - i];
+        tp[4 * i + 2] = ui[m - 1 - i];
+        tp[4 * i + 3] = uq[m - 1 - i];
+    }
+    lds_barrier();
+    double mv[L], sv[L];
+    if (t < nruns) slide_run<L>(xs, tp, t * L, m, T, mv, sv);
+    lds_barrier();                                           // every lane is done with the window of x
+    if (t < nruns) {
+        const double g0 = P.gain[0];
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const int p = t * L + i;
+            if (p < nmag) {
+                if (ONE) {
+                    im[slot<R>(p)] = __builtin_fma(-g0, sv[i], mv[i]);       // afsk.py:162 on the approximate magnitudes
+                } else {
+                    im[slot<R>(p)] = mv[i];
+                    xs[slot<R>(p)] = sv[i];
+                }
+            }
+        }
+    }
+    lds_barrier();
+    double a[R], b[R];
+    fir_acc_image<R>(im, h, ml, a);
+    if (!ONE) fir_acc_image<R>(xs, h, ml, b);
+    const int64_t go = tile0 + (int64_t)t * R;
+    if (go >= ((nout + 63) >> 6) * 64) return;
+    for (int g = 0; g < G; ++g) {
+        const double mg = -P.gain[g];
+        unsigned byte = 0, unsure = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double y = ONE ? a[r] : __builtin_fma(mg, b[r], a[r]);
             const bool in = go + r < nout;
             byte |= (unsigned)(in && y >= 0.0) << r;
             unsure |= (unsigned)(in && !(fabs(y) > E)) << r;                 // cannot be certified (NaN lands here too)
@@ -918,6 +1036,13 @@ static int afsk_group_dispatch(pm_ctx *ctx, int groups, const double *d_x, int64
     }
 }
 
+// Bound on |sliding magnitude - magnitude of the direct sums| for runs of 16 (derivation: afsk_magnitudes).
+static double slide_bound(const pm_afsk_tones *tones, int m, double x_bound)
+{
+    const double u = 1.1102230246251565e-16;
+    return (16.0 * 16 * u * (m + 1) + 3.0 * m * tones->tap_dev + 3.0 * u * m * m + 6.0 * u * m) * x_bound;
+}
+
 // M = |mark correlators|, S = |unit-gain space correlators| over x, one stream each (nc = n - m + 1 values): by the sliding sum when
 // `tones` describes the templates, else by the direct sums.  *e_slide = bound on |sliding value - direct value| (0 for the direct sums).
 static int afsk_magnitudes(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound, const double *d_mark_i, const double *d_mark_q,
@@ -930,14 +1055,13 @@ static int afsk_magnitudes(pm_ctx *ctx, const double *d_x, int64_t n, double x_b
     *e_slide = 0.0;
     if (tones && m >= 2) {
         PM_ARG(tones->tap_dev >= 0.0 && tones->tap_dev < 1e-6);
-        const double u = 1.1102230246251565e-16;
         // |sliding value - the reference's computed sum| at step i of a run that started from the reference's own sum (same taps,
         // same order: no difference at i = 0).  With Z_model the exact sums of the power filter r^j:  the run follows Z_model from a
         // start that is off it by (tap deviation + the start sum's rounding), rotated, and the reference's sum at step i is off
         // Z_model by the same two kinds of term:  2 sqrt2 m tap_dev X  +  2 sqrt2 m^2 u X.  On top, per step, 6 roundings of
         // sums bounded by (m + 2) X and r^m being off by sqrt2 u:  < 16 u (m + 1) X, over at most kRun steps.  The magnitude is
         // 1-Lipschitz in the pair of sums and its own three roundings are the same on both sides up to 3 u m X.
-        *e_slide = (16.0 * kRun * u * (m + 1) + 3.0 * m * tones->tap_dev + 3.0 * u * m * m + 6.0 * u * m) * x_bound;
+        *e_slide = slide_bound(tones, m, x_bound);
         SlideTones T{tones->mark_rot[0], tones->mark_rot[1], tones->mark_end[0], tones->mark_end[1],
                      tones->space_rot[0], tones->space_rot[1], tones->space_end[0], tones->space_end[1]};
         const int64_t ntiles = pm_cdiv(nc, (int64_t)kSlideThreads * kRun);
@@ -1009,13 +1133,43 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
     // low-pass (the reference's own dataflow, afsk.py:162-166, on approximate magnitudes); a sweep takes two for all its chains.
     const bool one = groups == 1 && tones && m >= 2;
     const double *lp_in = one ? M : S, *lp_a = one ? nullptr : A;
-    if (int rc = afsk_magnitudes(ctx, d_x, n, x_bound, d_mark_i, d_mark_q, d_unit_i, d_unit_q, m, tones, M, one ? nullptr : S, &e_slide, P.gain[0]))
-        return rc;
-    if (!one)
-        if (int rc = fir_launch<double>(ctx, M, nc, d_lpf, ml, A, nullptr, 0)) return rc;
+    const bool fused = tones && m >= 2 && (kThreads * 8 + ml - 1 + kFuseRun - 1) / kFuseRun <= kThreads &&
+                       fuse_lds_bytes(m, ml) <= 120 * 1024 && !getenv("PM_AFSK_UNFUSED");
+    if (fused) {
+        // sliding sums, low-pass(es) and combine in one kernel (afsk_slide_lpf_kernel): nothing but the bitmaps is written
+        e_slide = slide_bound(tones, m, x_bound);
+    } else {
+        if (int rc = afsk_magnitudes(ctx, d_x, n, x_bound, d_mark_i, d_mark_q, d_unit_i, d_unit_q, m, tones, M, one ? nullptr : S, &e_slide,
+                                     P.gain[0]))
+            return rc;
+        if (!one)
+            if (int rc = fir_launch<double>(ctx, M, nc, d_lpf, ml, A, nullptr, 0)) return rc;
+    }
     const double E = 1e-10 * lpf_abs_sum * (1.0 + gmax) * (double)m * 1.4143 * x_bound + lpf_abs_sum * (1.0 + gmax) * e_slide;
     PM_HIP(hipMemsetAsync(count, 0, sizeof(int), ctx->stream));
-    {   // B = LPF(S) and the combine step in one pass: B never reaches memory
+    if (fused) {
+        PM_ARG(tones->tap_dev >= 0.0 && tones->tap_dev < 1e-6);
+        SlideTones T{tones->mark_rot[0], tones->mark_rot[1], tones->mark_end[0], tones->mark_end[1],
+                     tones->space_rot[0], tones->space_rot[1], tones->space_end[0], tones->space_end[1]};
+        const int64_t ntiles = pm_cdiv(nl, (int64_t)kThreads * 8);
+        PM_ARG(ntiles < (1LL << 31));
+        const size_t lds = fuse_lds_bytes(m, ml);
+        const int region0 = (int)fuse_region0(m, ml), image = (int)fuse_image(ml);
+        PmProf prof(ctx, PM_K_FIR_F64);
+        const double nlp = one ? 1.0 : 2.0;
+        prof.work((double)n * 8 + (double)groups * nl / 8,
+                  (4.0 * m / kFuseRun + 18.0) * (double)nc + nlp * 2.0 * ml * (double)nl + 2.0 * groups * (double)nl);
+        if (one) {
+            if (int rc = allow_lds(afsk_slide_lpf_kernel<true>, lds)) return rc;
+            hipLaunchKernelGGL((afsk_slide_lpf_kernel<true>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, d_x, n, d_mark_i, d_mark_q,
+                               d_unit_i, d_unit_q, m, T, d_lpf, ml, nl, groups, P, E, list, count, cap, region0, image);
+        } else {
+            if (int rc = allow_lds(afsk_slide_lpf_kernel<false>, lds)) return rc;
+            hipLaunchKernelGGL((afsk_slide_lpf_kernel<false>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, d_x, n, d_mark_i, d_mark_q,
+                               d_unit_i, d_unit_q, m, T, d_lpf, ml, nl, groups, P, E, list, count, cap, region0, image);
+        }
+        PM_HIP(hipGetLastError());
+    } else {   // B = LPF(S) and the combine step in one pass: B never reaches memory
         constexpr int R = 8;
         const int64_t ntiles = pm_cdiv(nl, (int64_t)kThreads * R);
         PM_ARG(ntiles < (1LL << 31));
