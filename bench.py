@@ -421,8 +421,13 @@ def measure(args, env):
                              "frac": round(per_launch_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                              "note": "same kernel class in one extra sequential step after the timed region, no other stream on the GPU"},
                          "note": "achieved = algorithmic bytes of the timed launches / their HIP-event time inside the timed region (where "
-                                 "the slicer streams share the CUs).  Above ~40 taps the kernel is bound by the vector-f64 FMA pipe, not by "
-                                 "HBM: see roofline_fp64 for that fraction (DESIGN.md 4.1-4.2)"},
+                                 "the slicer streams share the CUs).  Above ~40 taps a FIR is bound by the vector-f64 FMA pipe, not by "
+                                 "HBM: see roofline_fp64 for that fraction (DESIGN.md 4.1-4.2).  For the AFSK workloads the class fir_f64 is "
+                                 "the fused certified kernel (sliding correlator sums + two 100-tap low-passes + combine for a whole gain "
+                                 "sweep): it reads the band-passed stream once and writes sign bits only, so its algorithmic bytes are 8 B "
+                                 "per sample for work that is 32 B per sample AND CHAIN stage by stage (SURVEY 8d) -- a low HBM fraction "
+                                 "here means little traffic, not idle hardware; its HBM-bound parts measured on their own: sliding sums "
+                                 "61 % and 8-tap FIR 71-79 % of peak (DESIGN.md 4.2c, 6)"},
             "roofline_fp64": {"bound": "valu_f64", "kernel": dom, "achieved": round(tflops, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(tflops / FP64_PEAK_TFLOPS, 5), "algorithmic_flops_per_launch": round(per_launch_flops),
                               "alone_frac": None if alone_ms is None else round(per_launch_flops / (alone_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5),

@@ -886,7 +886,9 @@ static int afsk_group_go(pm_ctx *ctx, const double *d_x, int64_t n, const double
     PM_ARG(ntiles < (1LL << 31));
     const size_t lds = lds_bytes<R>(m) + 4 * (R + 1) * sizeof(double);        // the last block's look-ahead load
     const bool vec = ((((uintptr_t)d_x | (uintptr_t)d_y) & 15) == 0) && (y_stride % 2 == 0);
-    PmProf prof(ctx, PM_K_AFSK_CORR);
+    // a gated launch (the certified path's overflow fallback, normally every workgroup leaves at once) is booked with the
+    // fallback machinery, not with the correlators
+    PmProf prof(ctx, gate ? PM_K_SIGNS : PM_K_AFSK_CORR);
     if (!gate) prof.work((double)n * 8 + (double)G * nout * 8, 2.0 * (2 + 2 * G) * m * (double)nout);
     if (vec) {
         if (int rc = allow_lds(afsk_group_kernel<G, true>, lds)) return rc;
@@ -1212,7 +1214,7 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
         }
         const int64_t ntiles = pm_cdiv(nl, (int64_t)kThreads * R);
         const size_t lds = lds_bytes<R>(ml);
-        PmProf prof(ctx, PM_K_FIR_F64);
+        PmProf prof(ctx, PM_K_SIGNS);                  // gated fallback, see afsk_group_go
         if (vec) {
             if (int rc = allow_lds(fir_signs_batch_kernel<R, false, true>, lds)) return rc;
             hipLaunchKernelGGL((fir_signs_batch_kernel<R, false, true>), dim3((unsigned)ntiles, (unsigned)groups), dim3(kThreads), lds, ctx->stream, FB,

@@ -32,8 +32,9 @@ for name, ctr in [("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")]:
     for k, (n, v) in agg.items():
         res.setdefault(k, {})[ctr + "_KB_avg_per_launch"] = round(v / n, 1)
         res[k][ctr + "_launches"] = n
-CLASSES = {"fir_i16": ["fir_valid_kernel<short"], "fir_f64": ["fir_valid_kernel<double", "fir_signs_batch_kernel"],
-           "afsk_correlate": ["afsk_correlate_kernel", "afsk_group_kernel"], "signs": ["signs_kernel", "sweep_combine_kernel", "sweep_exact_kernel"],
+CLASSES = {"fir_i16": ["fir_valid_kernel<short"], "fir_f64": ["fir_valid_kernel<double", "fir_sweep_kernel", "afsk_slide_lpf_kernel"],
+           "afsk_correlate": ["afsk_correlate_kernel", "afsk_slide_kernel"],
+           "signs": ["signs_kernel", "sweep_exact_kernel", "afsk_group_kernel", "fir_signs_batch_kernel", "pack_group_taps_kernel"],
            "slice_iter": ["slice_iter_kernel"], "slice_emit": ["slice_count_kernel", "slice_scan_kernel", "slice_pack_kernel"]}
 out = {"workload": workload, "samples": samples,
        "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (two separate passes) --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
