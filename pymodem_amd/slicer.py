@@ -105,6 +105,7 @@ def _slice_group(ctx, slicers, bitmaps, group, out, tight):
     caps, a_off, d_off, at = [], [], [], 0
     for k in group:
         n, sl = bitmaps[k][2], slicers[k]
+        sl._ctx = sl._ctx or ctx                  # bitmaps made elsewhere (another stream, a caller's own kernel): adopt this context
         cap = n * sl.bits_per_symbol // 8 + 5
         if tight:
             cap = min(cap, int(n * sl.bits_per_symbol / (8.0 * sl.samples_per_symbol) * _TIGHT_FACTOR) + 64)
