@@ -83,6 +83,33 @@ __device__ __forceinline__ uint32_t step32(double &clk, uint32_t zc, double thr,
     return sym;
 }
 
+// The same 32 steps with every decision kept in vector registers as a 0 / -1 mask (no compare-to-scalar round trip, fewer
+// instructions: a lone wave already takes most of its SIMD's issue slots, and these waves share SIMDs with FIR waves):
+//     nm   = sign bits of (a - thr) smeared: -1 where the symbol is NOT taken.  a >= thr  <=>  a - thr >= +0: the difference of
+//            two finite doubles is +0, never -0, when they are equal
+//     c    = a + (-sps & ~nm): a + (+0) is a itself (a is never -0: it is a sum with 1.0), a + (-sps) is slicer.py:81
+//     clk  = fma(c, lm1 & cm, c) with lm1 = lock_rate - 1 and cm = -1 on a crossing: c * (lock - 1) + c is c * lock in exact
+//            arithmetic when lock - 1 is exact (the host checks; Sterbenz for 0.5 <= lock <= 2), so the single rounding of the fma
+//            is the rounding of the reference's product (slicer.py:99-104); with a zero multiplier it returns c
+// The symbol flags are gathered as acc = 2 acc + nm; the word is acc - 1 - ... see the caller (sum of (1 + nm_k) 2^(31-k)).
+__device__ __forceinline__ uint32_t step32m(double &clk, uint32_t zc, double thr, double neg_sps, double lm1)
+{
+    const int32_t ns_hi = __double2hiint(neg_sps), ns_lo = __double2loint(neg_sps);
+    const int32_t lm_hi = __double2hiint(lm1), lm_lo = __double2loint(lm1);
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const int32_t cm = (int32_t)(zc << k) >> 31;                     // crossing at this sample: -1
+        const double sel = __hiloint2double(lm_hi & cm, lm_lo & cm);
+        const double a = clk + 1.0;                                      // slicer.py:77
+        const int32_t nm = __double2hiint(a - thr) >> 31;                // slicer.py:79, negated
+        acc = (acc << 1) + (uint32_t)nm;
+        const double c = a + __hiloint2double(ns_hi & ~nm, ns_lo & ~nm);
+        clk = __builtin_fma(c, sel, c);
+    }
+    return acc - 1u;        // sum_k (1 + nm_k) 2^(31-k) = (2^32 - 1) + acc  (mod 2^32)
+}
+
 // One fixed-point iteration.  Work is a list of chunk ids: iteration 0 holds every chunk; a chunk whose run changes its END state
 // writes it into the state array and puts its successor on the next iteration's list.  Lists are dense, so the waves of an iteration
 // are as many as there are chunks to re-run (the thin tail of the iteration costs a handful of waves, not the whole grid) and the
@@ -93,7 +120,7 @@ __device__ __forceinline__ uint32_t step32(double &clk, uint32_t zc, double thr,
 __global__ __launch_bounds__(kBlock) void slice_iter_kernel(const JobDev *__restrict__ jobs, int njobs, int lc_words,
                                                         uint64_t *__restrict__ state, const int32_t *__restrict__ list_in,
                                                         int32_t *__restrict__ list_out, int *__restrict__ counts, int iter,
-                                                        uint64_t *__restrict__ symmap)
+                                                        uint64_t *__restrict__ symmap, int masks)
 {
     // These waves are bound by their own dependent chain; when FIR waves of another stream share the SIMD (pipelined executor)
     // every issue slot they lose lengthens the chain, while the FIR waves only need the slots in between: take issue priority.
@@ -114,6 +141,7 @@ __global__ __launch_bounds__(kBlock) void slice_iter_kernel(const JobDev *__rest
     if (J.quad) lq = w0 == 0 ? (uint64_t)J.lq0 : (J.bq[w0 - 1] >> 63);
     const double thr = J.thr, neg_sps = -J.sps;
     const double lock = J.lock;
+    const double lm1 = lock - 1.0;
     uint64_t *sm = symmap + J.word0;
     for (int64_t w = w0; w < w1; ++w) {
         const uint64_t si = J.bi[w];
@@ -127,8 +155,14 @@ __global__ __launch_bounds__(kBlock) void slice_iter_kernel(const JobDev *__rest
         const int64_t left = J.n - (w << 6);
         uint64_t sym;
         if (left >= 64) {
-            const uint32_t lo = step32(clk, __brev((uint32_t)zc), thr, neg_sps, lock);
-            const uint32_t hi = step32(clk, __brev((uint32_t)(zc >> 32)), thr, neg_sps, lock);
+            uint32_t lo, hi;
+            if (masks) {                             // uniform over the launch
+                lo = step32m(clk, __brev((uint32_t)zc), thr, neg_sps, lm1);
+                hi = step32m(clk, __brev((uint32_t)(zc >> 32)), thr, neg_sps, lm1);
+            } else {
+                lo = step32(clk, __brev((uint32_t)zc), thr, neg_sps, lock);
+                hi = step32(clk, __brev((uint32_t)(zc >> 32)), thr, neg_sps, lock);
+            }
             sym = ((uint64_t)__brev(hi) << 32) | (uint64_t)__brev(lo);
         } else {                                     // the stream's last, partial word
             sym = 0;
@@ -507,6 +541,12 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
     const unsigned grid = (unsigned)pm_cdiv(std::max<int64_t>(total_chunks, ncounts), kBlock);
     hipLaunchKernelGGL(slice_init_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_jobs, nj, total_chunks, state, list_a, counts, ncounts);
 
+    // step32m needs lock_rate - 1 to be exact for every stream of the batch (it is for 0.5 <= lock_rate <= 2) and finite clocks
+    int masks = getenv("PM_SLICER_COMPARE_STEP") ? 0 : 1;
+    for (const JobDev &d : jd) {
+        const volatile double lm1 = d.lock - 1.0;
+        if (!(lm1 + 1.0 == d.lock) || !(d.clk0 - d.clk0 == 0.0) || !(d.sps - d.sps == 0.0)) masks = 0;
+    }
     int *h_flag = (int *)ctx->h_pinned;
     int iters = 0;
     bool converged = false;
@@ -515,7 +555,7 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
         for (int b = 0; b < burst; ++b) {
             PmProf prof(ctx, PM_K_SLICE_ITER);
             hipLaunchKernelGGL(slice_iter_kernel, dim3((unsigned)pm_cdiv(total_chunks, kBlock)), dim3(kBlock), 0, ctx->stream, d_jobs, nj,
-                               (int)lc_words, state, (iters & 1) ? list_b : list_a, (iters & 1) ? list_a : list_b, counts, iters, symmap);
+                               (int)lc_words, state, (iters & 1) ? list_b : list_a, (iters & 1) ? list_a : list_b, counts, iters, symmap, masks);
             ++iters;
         }
         // counts[iters] = chunks the burst's last iteration put on the next list: none means the fixed point is reached
