@@ -92,6 +92,9 @@ __device__ __forceinline__ uint32_t step32(double &clk, uint32_t zc, double thr,
 //            arithmetic when lock - 1 is exact (the host checks; Sterbenz for 0.5 <= lock <= 2), so the single rounding of the fma
 //            is the rounding of the reference's product (slicer.py:99-104); with a zero multiplier it returns c
 // The symbol flags are gathered as acc = 2 acc + nm; the word is acc - 1 - ... see the caller (sum of (1 + nm_k) 2^(31-k)).
+// LM0 / NS0: the low words of lock_rate - 1 / of sps are zero (0.75, 0.875, ...; every sps that is a small integer): one mask
+// operation less each.
+template <bool LM0, bool NS0>
 __device__ __forceinline__ uint32_t step32m(double &clk, uint32_t zc, double thr, double neg_sps, double lm1)
 {
     const int32_t ns_hi = __double2hiint(neg_sps), ns_lo = __double2loint(neg_sps);
@@ -100,11 +103,11 @@ __device__ __forceinline__ uint32_t step32m(double &clk, uint32_t zc, double thr
 #pragma unroll
     for (int k = 0; k < 32; ++k) {
         const int32_t cm = (int32_t)(zc << k) >> 31;                     // crossing at this sample: -1
-        const double sel = __hiloint2double(lm_hi & cm, lm_lo & cm);
+        const double sel = __hiloint2double(lm_hi & cm, LM0 ? 0 : lm_lo & cm);
         const double a = clk + 1.0;                                      // slicer.py:77
         const int32_t nm = __double2hiint(a - thr) >> 31;                // slicer.py:79, negated
         acc = (acc << 1) + (uint32_t)nm;
-        const double c = a + __hiloint2double(ns_hi & ~nm, ns_lo & ~nm);
+        const double c = a + __hiloint2double(ns_hi & ~nm, NS0 ? 0 : ns_lo & ~nm);
         clk = __builtin_fma(c, sel, c);
     }
     return acc - 1u;        // sum_k (1 + nm_k) 2^(31-k) = (2^32 - 1) + acc  (mod 2^32)
@@ -117,10 +120,13 @@ __device__ __forceinline__ uint32_t step32m(double &clk, uint32_t zc, double thr
 // while its predecessor is rewriting it in the same iteration -- either value is a valid 8-byte state, and whenever the
 // predecessor did change it the chunk is on the next list and runs again, so at the fixed point every chunk's last run started
 // from the final end state of its predecessor (the induction of the header comment).
+// STEP: 0 = step32 (compare and selects), 1 = step32m, 2 = step32m with zero low words in lock_rate - 1 and sps.  One kernel per
+// form: with the 64 unrolled steps of several forms in one kernel the loop no longer fits the instruction cache comfortably.
+template <int STEP>
 __global__ __launch_bounds__(kBlock) void slice_iter_kernel(const JobDev *__restrict__ jobs, int njobs, int lc_words,
                                                         uint64_t *__restrict__ state, const int32_t *__restrict__ list_in,
                                                         int32_t *__restrict__ list_out, int *__restrict__ counts, int iter,
-                                                        uint64_t *__restrict__ symmap, int masks)
+                                                        uint64_t *__restrict__ symmap)
 {
     // These waves are bound by their own dependent chain; when FIR waves of another stream share the SIMD (pipelined executor)
     // every issue slot they lose lengthens the chain, while the FIR waves only need the slots in between: take issue priority.
@@ -156,9 +162,12 @@ __global__ __launch_bounds__(kBlock) void slice_iter_kernel(const JobDev *__rest
         uint64_t sym;
         if (left >= 64) {
             uint32_t lo, hi;
-            if (masks) {                             // uniform over the launch
-                lo = step32m(clk, __brev((uint32_t)zc), thr, neg_sps, lm1);
-                hi = step32m(clk, __brev((uint32_t)(zc >> 32)), thr, neg_sps, lm1);
+            if (STEP == 2) {
+                lo = step32m<true, true>(clk, __brev((uint32_t)zc), thr, neg_sps, lm1);
+                hi = step32m<true, true>(clk, __brev((uint32_t)(zc >> 32)), thr, neg_sps, lm1);
+            } else if (STEP == 1) {
+                lo = step32m<false, false>(clk, __brev((uint32_t)zc), thr, neg_sps, lm1);
+                hi = step32m<false, false>(clk, __brev((uint32_t)(zc >> 32)), thr, neg_sps, lm1);
             } else {
                 lo = step32(clk, __brev((uint32_t)zc), thr, neg_sps, lock);
                 hi = step32(clk, __brev((uint32_t)(zc >> 32)), thr, neg_sps, lock);
@@ -542,11 +551,17 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
     hipLaunchKernelGGL(slice_init_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_jobs, nj, total_chunks, state, list_a, counts, ncounts);
 
     // step32m needs lock_rate - 1 to be exact for every stream of the batch (it is for 0.5 <= lock_rate <= 2) and finite clocks
-    int masks = getenv("PM_SLICER_COMPARE_STEP") ? 0 : 1;
+    int masks = getenv("PM_SLICER_COMPARE_STEP") ? 0 : 2;
     for (const JobDev &d : jd) {
         const volatile double lm1 = d.lock - 1.0;
         if (!(lm1 + 1.0 == d.lock) || !(d.clk0 - d.clk0 == 0.0) || !(d.sps - d.sps == 0.0)) masks = 0;
+        uint64_t lb, sb;
+        const double l1 = lm1;
+        memcpy(&lb, &l1, 8);
+        memcpy(&sb, &d.sps, 8);
+        if (masks == 2 && ((uint32_t)lb || (uint32_t)sb)) masks = 1;     // low words not zero: the general mask form
     }
+    auto iter_kernel = masks == 2 ? slice_iter_kernel<2> : masks == 1 ? slice_iter_kernel<1> : slice_iter_kernel<0>;
     int *h_flag = (int *)ctx->h_pinned;
     int iters = 0;
     bool converged = false;
@@ -554,8 +569,8 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
         // a burst of iterations between host checks keeps the launch queue full
         for (int b = 0; b < burst; ++b) {
             PmProf prof(ctx, PM_K_SLICE_ITER);
-            hipLaunchKernelGGL(slice_iter_kernel, dim3((unsigned)pm_cdiv(total_chunks, kBlock)), dim3(kBlock), 0, ctx->stream, d_jobs, nj,
-                               (int)lc_words, state, (iters & 1) ? list_b : list_a, (iters & 1) ? list_a : list_b, counts, iters, symmap, masks);
+            hipLaunchKernelGGL(iter_kernel, dim3((unsigned)pm_cdiv(total_chunks, kBlock)), dim3(kBlock), 0, ctx->stream, d_jobs, nj,
+                               (int)lc_words, state, (iters & 1) ? list_b : list_a, (iters & 1) ? list_a : list_b, counts, iters, symmap);
             ++iters;
         }
         // counts[iters] = chunks the burst's last iteration put on the next list: none means the fixed point is reached
