@@ -167,6 +167,10 @@ def main():
         factory, default_cpg, _ = WORKLOADS[args.workload]
         cpu_line = cpu_baseline(args, [factory(c) for c in range(args.chains_per_gpu or default_cpg)])
 
+    # Libraries print banners on stdout (RCCL's version block when its first communicator comes up): everything but the JSON line
+    # goes to stderr, the line itself to the real stdout.
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     ndev = torch.cuda.device_count()
     if ndev < 1:
@@ -196,7 +200,8 @@ def main():
             out["cpu_baseline"] = cpu_line
         if world == 1 and args.also:
             out["also"] = also_workloads(args, env)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())         # the ONE line of this run's stdout
     if use_dist:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
