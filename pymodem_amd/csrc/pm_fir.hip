@@ -786,29 +786,40 @@ __global__ __launch_bounds__(64) void sweep_exact_kernel(const double *__restric
                                                          const double *__restrict__ space, int mc, const double *__restrict__ lpf, int ml,
                                                          SweepArgs P, const unsigned long long *__restrict__ list, const int *__restrict__ count, int cap)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= min(*count, cap)) return;
-    const int g = (int)(list[i] >> 48);
-    const int64_t k = (int64_t)(list[i] & 0xFFFFFFFFFFFFull);
-    const double *si = space + (size_t)g * 2 * mc, *sq = si + mc;
-    double acc = 0.0;
-    for (int j = 0; j < ml; ++j) {
-        const double *xp = x + k + j;
-        double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
-        for (int t = 0; t < mc; ++t) {
-            const double v = xp[t];
-            a = __builtin_fma(mi[mc - 1 - t], v, a);
-            b = __builtin_fma(mq[mc - 1 - t], v, b);
-            c = __builtin_fma(si[mc - 1 - t], v, c);
-            d = __builtin_fma(sq[mc - 1 - t], v, d);
+    // One wave per listed sample: the ml correlator-bank outputs the low-pass needs are independent of each other and go to the
+    // lanes (each in the canonical tap order); the low-pass sum itself is sequential and stays with lane 0.  (One LANE per sample
+    // took 0.25-0.5 ms for a single entry -- 4 mc ml dependent fmas -- and the demod stream waits for it.)
+    extern __shared__ double dd[];
+    const int lane = threadIdx.x;
+    const int cnt = min(*count, cap);
+    for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
+        const int g = (int)(list[e] >> 48);
+        const int64_t k = (int64_t)(list[e] & 0xFFFFFFFFFFFFull);
+        const double *si = space + (size_t)g * 2 * mc, *sq = si + mc;
+        for (int j = lane; j < ml; j += 64) {
+            const double *xp = x + k + j;
+            double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+            for (int t = 0; t < mc; ++t) {
+                const double v = xp[t];
+                a = __builtin_fma(mi[mc - 1 - t], v, a);
+                b = __builtin_fma(mq[mc - 1 - t], v, b);
+                c = __builtin_fma(si[mc - 1 - t], v, c);
+                d = __builtin_fma(sq[mc - 1 - t], v, d);
+            }
+            const double mark = __builtin_sqrt(a * a + b * b);
+            const double spc = __builtin_sqrt(c * c + d * d);
+            dd[j] = mark - spc;
         }
-        const double mark = __builtin_sqrt(a * a + b * b);
-        const double spc = __builtin_sqrt(c * c + d * d);
-        acc = __builtin_fma(lpf[ml - 1 - j], mark - spc, acc);
+        __syncthreads();
+        if (lane == 0) {
+            double acc = 0.0;
+            for (int j = 0; j < ml; ++j) acc = __builtin_fma(lpf[ml - 1 - j], dd[j], acc);
+            unsigned long long *w = reinterpret_cast<unsigned long long *>(P.bits[g]) + (k >> 6);
+            const unsigned long long bit = 1ull << (k & 63);
+            if (acc >= 0.0) atomicOr(w, bit); else atomicAnd(w, ~bit);
+        }
+        __syncthreads();
     }
-    unsigned long long *w = reinterpret_cast<unsigned long long *>(P.bits[g]) + (k >> 6);
-    const unsigned long long bit = 1ull << (k & 63);
-    if (acc >= 0.0) atomicOr(w, bit); else atomicAnd(w, ~bit);
 }
 
 // One 64-bit word per wave per step: lane l tests sample 64*w + l, the ballot is the word.
@@ -1191,8 +1202,8 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
     }
     {
         PmProf prof(ctx, PM_K_SIGNS);
-        hipLaunchKernelGGL(sweep_exact_kernel, dim3((unsigned)pm_cdiv(cap, 64)), dim3(64), 0, ctx->stream, d_x, d_mark_i, d_mark_q, d_space, m, d_lpf,
-                           ml, P, list, count, cap);
+        hipLaunchKernelGGL(sweep_exact_kernel, dim3(1024), dim3(64), (size_t)ml * sizeof(double), ctx->stream, d_x, d_mark_i, d_mark_q, d_space, m,
+                           d_lpf, ml, P, list, count, cap);
     }
     PM_HIP(hipGetLastError());
     // More uncertain samples than the list holds (degenerate input: silence, amplitudes far below the caller's bound): the exact

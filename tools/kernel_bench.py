@@ -72,6 +72,40 @@ for g, m in [(7, 60), (4, 40)]:
            8.0 * N * (1 + g), (2 + 2 * g) * m * N)
 report("signs", timeit(lambda: check(L.pm_signs_f64(ctx.handle, d_f64.ptr, N, bits.ptr))), 8.125 * N)
 
+# the certified AFSK path on the headline templates: magnitudes by direct and by sliding sums, then the whole sweep
+# entry (7 modems / 1 modem) fused and as separate kernels
+from pymodem_amd import taps as TT  # noqa: E402
+from pymodem_amd._native import AfskTones  # noqa: E402
+mi, mq, ui, uq = TT.afsk_tone_correlators(48000.0, 1200.0, 1300.0, 2100.0, 1.0, 1.5, 0.0)
+mc = len(mi)
+mk, sp = TT.tone_model(mi, mq), TT.tone_model(ui, uq)
+tones = AfskTones()
+tones.mark_rot[:], tones.mark_end[:], tones.space_rot[:], tones.space_end[:], tones.tap_dev = mk[0], mk[1], sp[0], sp[1], max(mk[2], sp[2])
+dt = [ctx.upload(v) for v in (mi, mq, ui, uq)]
+xb = float(np.abs(xi).max()) * 0.01
+for name, tp, fma in (("direct sums", None, 4 * mc), ("sliding sums", ctypes.byref(tones), 4 * mc / 16 + 9)):
+    report(f"afsk_magnitudes {name} m={mc}", timeit(lambda: check(L.pm_afsk_magnitudes(ctx.handle, d_f64.ptr, N, xb, dt[0].ptr, dt[1].ptr, dt[2].ptr,
+                                                                                     dt[3].ptr, mc, tp, d_out.ptr, d_out2.ptr, None))), 24.0 * N, fma * N)
+lpf = TT.windowed_sinc(100, 900.0, 48000.0, pass_zero=True)
+dl = ctx.upload(lpf)
+for gains in ([1.25, 1.5, 1.75, 2.0, 2.25, 2.5, 2.75], [1.0]):
+    g = len(gains)
+    space = np.stack([np.stack([gn * ui, gn * uq]) for gn in gains])
+    ds = ctx.upload(space.reshape(-1))
+    bb = [ctx.empty(N // 64 + 2, np.uint64) for _ in range(g)]
+    ptrs = (ctypes.c_void_p * g)(*[b.ptr.value for b in bb])
+    gs = (ctypes.c_double * g)(*gains)
+    args = (ctx.handle, d_f64.ptr, N, xb, dt[0].ptr, dt[1].ptr, dt[2].ptr, dt[3].ptr, ds.ptr, gs, g, mc, dl.ptr, len(lpf), float(np.abs(lpf).sum()), ptrs)
+    nlp = 1 if g == 1 else 2
+    for label, env in (("fused", None), ("three kernels", "1")):
+        if env:
+            os.environ["PM_AFSK_UNFUSED"] = env
+        report(f"afsk_sweep_signs_tones g={g} {label} (+ gated fallback launches)",
+               timeit(lambda: check(L.pm_afsk_sweep_signs_tones(*args, ctypes.byref(tones)))), (8.0 + g / 8.0) * N, (4 * mc / 16 + 9 + nlp * len(lpf) + g) * N)
+        os.environ.pop("PM_AFSK_UNFUSED", None)
+    report(f"afsk_sweep_signs g={g} direct sums (+ gated fallback launches)", timeit(lambda: check(L.pm_afsk_sweep_signs(*args))), (8.0 + g / 8.0) * N,
+           (4 * mc + 2 * len(lpf) + g) * N)
+
 # a 10-minute buffer is tens of microseconds at roofline, so the HBM-bound short-tap FIR is also timed on 2^28 samples
 # (0.5 GB in, 2.1 GB out per launch) where launch ramp and tail no longer matter
 if os.environ.get("KB_BIG", "1") == "1":
