@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off end-to-end check at BASELINE size: every chain of a bench workload over the full 28.8 M-sample bench buffer, GPU path
 (group executor) against the oracle (canonical FIR order): slicer bytes, addresses and packets must be identical.
-    python tools/fullsize_parity.py [workload] [samples]"""
+    python tests/fullsize_parity.py [workload] [samples]"""
 import json
 import os
 import sys

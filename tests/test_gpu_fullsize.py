@@ -100,7 +100,7 @@ def test_quadrature_slicer_and_agc_at_full_size(ctx):
 def test_headline_workload_end_to_end_at_full_size(ctx):
     """The bench's headline workload (8 AFSK-1200 chains, 28.8 M-sample packet-bearing buffer) through the group executor; three of
     the chains (the one with its own correlators, the first and the last of the shared-mark group) against the oracle: slicer
-    bytes, addresses and every packet identical.  (tools/fullsize_parity.py does all chains of all four workloads.)"""
+    bytes, addresses and every packet identical.  (tests/fullsize_parity.py does all chains of all four workloads.)"""
     import bench
     from pymodem_amd import chain_builder as cb, chain_execute as ce
 
