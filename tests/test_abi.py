@@ -81,3 +81,20 @@ def test_header_is_plain_c_and_ctypes_mirrors_match(tmp_path):
         seen[parts[0]] = True
     assert seen.get("sizeof") and seen.get("offsetof")
     assert out[-1] == "head 40 40"
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under pymodem_amd/ or tools/ may import or load it (only tests/, __graft_entry__'s
+    build()/smoke() and bench.py's cpu_baseline leg do)."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bad = []
+    for path in glob.glob(os.path.join(root, "pymodem_amd", "**", "*"), recursive=True) + glob.glob(os.path.join(root, "tools", "*")):
+        if not os.path.isfile(path) or not path.endswith((".py", ".hip", ".cpp", ".h", ".sh")):
+            continue
+        text = open(path, errors="replace").read()
+        code = re.sub(r"//.*|#.*", "", text)                  # comments may cite the oracle; code may not use it
+        if re.search(r"^\s*(from|import)\s+oracle\b|pm_oracle|pmo_|oracle/_ref|liboracle", code, re.M):
+            bad.append(os.path.relpath(path, root))
+    assert bad == []
