@@ -288,9 +288,12 @@ def measure(args, env):
             return res
         if args.overlap >= 2:
             pipe = ce.RecordingPipeline(slice_workers=args.slice_workers, demod_streams=args.demod_streams)
+            # the exchange runs one recording behind (dist.Exchanger): the copy back of a gather never waits for the collective
+            ex = pdist.Exchanger(nchains, coll_device)
             last = None
             for _ in range(k):
-                last = pipe.submit(build_chains(), d_audio, exchange, dedupe)
+                last = pipe.submit(build_chains(), d_audio, ex.step, dedupe, prepare=lambda rows_list: ex.prepare(dict(zip(my, rows_list))))
+            pipe.flush_finish(ex.flush)
             res = last.result() if last is not None else None
             pipe.close()                                      # every step's de-dup is done, not only the last one's
             stage_ms.clear()
@@ -313,10 +316,12 @@ def measure(args, env):
     def run_steps_uploading(k):
         """The same pipeline, but every step's recording starts in host memory: its copy to HBM runs one step ahead on a copy stream."""
         pipe = ce.RecordingPipeline(slice_workers=args.slice_workers, demod_streams=args.demod_streams)
+        ex = pdist.Exchanger(nchains, coll_device)
         last, nxt = None, (pipe.prefetch(audio) if k else None)
         for i in range(k):
             cur, nxt = nxt, (pipe.prefetch(audio) if i + 1 < k else None)
-            last = pipe.submit(build_chains(), cur, exchange, dedupe)
+            last = pipe.submit(build_chains(), cur, ex.step, dedupe, prepare=lambda rows_list: ex.prepare(dict(zip(my, rows_list))))
+        pipe.flush_finish(ex.flush)
         res = last.result() if last is not None else None
         pipe.close()
         return res

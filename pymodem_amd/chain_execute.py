@@ -187,9 +187,11 @@ class RecordingPipeline:
             return buf, done, k
         return self._upload.submit(copy)
 
-    def submit(self, chains, input_audio, finish=None, post=None):
+    def submit(self, chains, input_audio, finish=None, post=None, prepare=None):
         """Start one recording; returns a Future of post(finish(rows per chain)) (either may be None = identity).  `finish` calls
-        run one at a time in submission order (the place for collectives); `post` calls run in parallel with later recordings."""
+        run one at a time in submission order (the place for collectives); `post` calls run in parallel with later recordings.
+        If finish returns a future itself, post receives its result (and waits for it: see flush_finish).  `prepare(rows)`, if
+        given, runs at the end of the host stage (three recordings at a time) and its result is what finish receives."""
         import time
         acc = self.stage_seconds
         slots = self._slots
@@ -228,6 +230,8 @@ class RecordingPipeline:
             sliced = f_sliced.result()
             t = time.perf_counter()
             rows = _host_rows(chains, sliced)
+            if prepare is not None:                            # e.g. dist.Exchanger.prepare: packing for the wire, off the ordered thread
+                rows = prepare(rows)
             acc["host"] += time.perf_counter() - t
             return rows
         f_rows = self._host.submit(host_stage)
@@ -246,11 +250,18 @@ class RecordingPipeline:
 
         def post_stage():
             x = f_fin.result()
+            if hasattr(x, "result") and hasattr(x, "done"):    # finish handed out a future of its own (dist.Exchanger: resolved a step later)
+                x = x.result()
             t = time.perf_counter()
             out = post(x)
             acc["post"] = acc.get("post", 0.0) + time.perf_counter() - t
             return out
         return self._post.submit(post_stage)
+
+    def flush_finish(self, fn):
+        """Run fn() on the finish thread after every finish submitted so far (e.g. dist.Exchanger.flush, which resolves the last
+        recording's exchange); returns its Future."""
+        return self._finish.submit(fn)
 
     def close(self):
         """Waits for everything submitted."""

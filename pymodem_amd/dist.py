@@ -159,6 +159,146 @@ def exchange_rows(rows_by_chain, nchains, device=None):
     return ("streams", streams, hdrs[:, 2:].sum(axis=0).tolist())
 
 
+class Exchanger:
+    """exchange_rows for a stream of recordings, one step behind: `step(rows)` first collects the PREVIOUS recording's gathered
+    blocks -- their all_gather was enqueued a whole step ago, so the copy back does not wait for the collective to find room on a
+    busy GPU (0.5-0.8 ms inside the pipelined executor) -- then enqueues this recording's all_gather and returns a Future of what
+    exchange_rows would have returned.  `flush()` resolves the last one.  Call both from ONE thread, in the same order on every
+    rank: every collective, including the repeat after a capacity miss (decided from headers all ranks see), is issued there."""
+
+    def __init__(self, nchains, device=None):
+        self.nchains, self.device = nchains, device
+        self._pending = None                   # (future, state of the enqueued collective)
+
+    def prepare(self, rows_by_chain):
+        """What step() takes: the rows packed for the wire when an exchange will really happen (any thread), the rows themselves
+        otherwise."""
+        import os
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not os.environ.get("PYMODEM_AMD_FORCE_GATHER")):
+            return rows_by_chain
+        return pack_rows(rows_by_chain, self.nchains)
+
+    def step(self, rows_by_chain):
+        import os
+        from concurrent.futures import Future
+        import torch.distributed as dist
+        fut = Future()
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not os.environ.get("PYMODEM_AMD_FORCE_GATHER")):
+            fut.set_result(("local", rows_by_chain.rows if isinstance(rows_by_chain, PackedRows) else rows_by_chain))
+            return fut
+        try:
+            self._collect()
+            self._pending = (fut, _exchange_issue(rows_by_chain, self.nchains, self.device))
+        except BaseException as e:
+            fut.set_exception(e)
+        return fut
+
+    def flush(self):
+        self._collect()
+
+    def _collect(self):
+        if self._pending is None:
+            return
+        fut, state = self._pending
+        self._pending = None
+        try:
+            fut.set_result(_exchange_collect(state))
+        except BaseException as e:
+            fut.set_exception(e)
+
+
+class PackedRows:
+    """A rank's rows of one recording in wire form (pack_rows)."""
+    __slots__ = ("rows", "counts", "nrows", "payload")
+
+
+def pack_rows(rows_by_chain, nchains):
+    """{global chain index: pm_packet rows} -> PackedRows: the wire form (40-byte header + len payload bytes per row,
+    pm_packets_pack) ready for Exchanger.step.  Any thread may do this; only step() has to keep the ranks' order."""
+    import ctypes
+    from ._native import check, lib
+    from .packet_meta import PacketTable
+    p = PackedRows()
+    p.rows, p.counts = rows_by_chain, np.zeros(nchains, dtype=np.int64)
+    parts = []
+    for c in sorted(rows_by_chain):
+        r = rows_by_chain[c]
+        if len(r):
+            r["source_decoder"] = c
+            p.counts[c] = len(r)
+            parts.append(r)
+    mine = np.ascontiguousarray(PacketTable._stack(parts))
+    p.nrows = len(mine)
+    need = check(lib().pm_packets_pack(mine.ctypes.data_as(ctypes.c_void_p), len(mine), None, 0))
+    p.payload = np.empty(need, dtype=np.uint8)
+    if need:
+        check(lib().pm_packets_pack(mine.ctypes.data_as(ctypes.c_void_p), len(mine), p.payload.ctypes.data_as(ctypes.c_void_p), need))
+    return p
+
+
+def _exchange_issue(packed, nchains, device, cap=None):
+    """Enqueue the all_gather of this rank's fixed-capacity block (header + packed rows); nothing waits for the GPU."""
+    import torch
+    import torch.distributed as dist
+    if not isinstance(packed, PackedRows):
+        packed = pack_rows(packed, nchains)
+    world = dist.get_world_size()
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    head = 8 * (2 + nchains)
+    need = len(packed.payload)
+    key = (world, nchains)
+    if cap is None:
+        cap = max(_GATHER_CAP.get(key, 1 << 16), 1 << 12)
+    side = None
+    if dev.type == "cuda":
+        side = _SIDE_STREAM.get(dev)
+        if side is None:
+            side = _SIDE_STREAM[dev] = torch.cuda.Stream(device=dev, priority=-1)
+    from .device import _host_block
+    block = _host_block(head + cap)[:head + cap]          # recycled host memory; bytes past the payload are never read by anyone
+    hdr = block[:head].view(np.int64)
+    hdr[0], hdr[1], hdr[2:] = need, packed.nrows, packed.counts
+    if need <= cap:
+        block[head:head + need] = packed.payload
+    with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+        t = torch.from_numpy(block).to(dev)
+        blocks = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(blocks, t)
+    return {"rows": packed, "nchains": nchains, "device": device, "cap": cap, "head": head, "blocks": blocks, "side": side, "key": key,
+            "keep": block}
+
+
+def _exchange_collect(state):
+    """Headers (every rank) and payloads (rank 0) of an enqueued exchange; repeats it once, synchronously, if some rank's payload
+    did not fit the agreed capacity."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    while True:
+        head, cap, blocks, side, nchains = state["head"], state["cap"], state["blocks"], state["side"], state["nchains"]
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            heads = torch.stack([b[:head] for b in blocks]).cpu().numpy()
+        hdrs = heads.copy().view(np.int64).reshape(world, 2 + nchains)
+        most = int(hdrs[:, 0].max())
+        _GATHER_CAP[state["key"]] = max(1 << 16, (most + most // 4 + 4095) // 4096 * 4096)       # same value on every rank
+        if most <= cap:
+            break
+        state = _exchange_issue(state["rows"], nchains, state["device"], cap=_GATHER_CAP[state["key"]])
+    if rank != 0:
+        return None
+    return ("blocks", blocks, hdrs, head, side)          # rank 0: the payloads are copied back by table_from_exchange (any thread)
+
+
+def _streams_from_blocks(blocks, hdrs, head, side):
+    import torch
+    world = len(blocks)
+    used = int(hdrs[:, 0].max())
+    with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+        got = torch.stack([b[head:head + used] for b in blocks]).cpu().numpy()
+    return [got[r, :int(hdrs[r, 0])] for r in range(world)], hdrs[:, 2:].sum(axis=0).tolist()
+
+
 def table_from_exchange(x, names):
     """The local half on rank 0: index the gathered wire streams into a PacketTable of record heads (payloads stay where they are)."""
     from .packet_meta import PacketTable
@@ -166,6 +306,9 @@ def table_from_exchange(x, names):
         return None
     if x[0] == "local":
         return PacketTable(x[1], names)
+    if x[0] == "blocks":
+        streams, counts = _streams_from_blocks(*x[1:])
+        return PacketTable.from_streams(streams, counts, names)
     return PacketTable.from_streams(x[1], x[2], names)
 
 
