@@ -139,7 +139,7 @@ class RecordingPipeline:
               latency bound, so TWO recordings' slicers share the GPU almost for free    one thread each
       host    LFSR + codec (native, GIL released)                                       three threads, each fanning out to the pool
       finish  the caller's `finish(rows per chain)`: the packet exchange                 one thread, submission order (collectives)
-      post    the caller's `post(...)`: rank 0's indexing and de-dup                     two threads
+      post    the caller's `post(...)`: rank 0's payload copy, indexing and de-dup       three threads
 
     While recordings k and k-1 are being sliced, recording k+1 is demodulated and k-2 finished.  The only GPU buffers that cross
     stages are the sign bitmaps (one bit per sample), kept in slice_workers + 2 rotating slots (demod runs one recording ahead); a GPU event, not a host wait,
@@ -152,7 +152,7 @@ class RecordingPipeline:
         self._slice = ThreadPoolExecutor(max_workers=self._workers)
         self._host = ThreadPoolExecutor(max_workers=3)        # LFSR + codec of up to three recordings at a time (each fans out to the pool)
         self._finish = ThreadPoolExecutor(max_workers=1)
-        self._post = ThreadPoolExecutor(max_workers=2)        # whatever follows the ordered step (rank 0's indexing and de-dup)
+        self._post = ThreadPoolExecutor(max_workers=3)        # whatever follows the ordered step (rank 0's payload copy, indexing, de-dup)
         self._inflight = deque()
         self._n = 0
         self._upload = ThreadPoolExecutor(max_workers=1)      # host -> HBM copies of the NEXT recording, on a stream of their own
