@@ -130,7 +130,7 @@ def synth_buffer(n, seed=1234):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="afsk_1200_super_opt", choices=sorted(WORKLOADS))
     ap.add_argument("--samples", type=int, default=28_800_000, help="samples per recording (10 min @ 48 kHz)")
