@@ -318,3 +318,32 @@ def test_gain_sweep_path_equals_exact_group_path(config_lines):
             assert np.array_equal(a.data, b.data) and np.array_equal(a.address, b.address), (other, c)
             assert [(p.streamaddress, bytes(bytearray(p.data))) for p in res["sliding"][1][c]] == \
                    [(p.streamaddress, bytes(bytearray(p.data))) for p in res[other][1][c]]
+
+
+def test_bench_line_contract_with_and_without_the_exchange(tmp_path):
+    """bench.py as the driver runs it: exactly one line on stdout, every field of the contract, the same packets whether the
+    per-recording exchange really runs (one-rank RCCL gather, PYMODEM_AMD_FORCE_GATHER) or not."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = {}
+    for name, extra in (("plain", {}), ("gather", {"PYMODEM_AMD_FORCE_GATHER": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533",
+                                                    "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--also", "0",
+                            "--samples", "4800000"], capture_output=True, text=True, env=env, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = [ln for ln in r.stdout.split("\n") if ln.strip()]
+        assert len(out) == 1, r.stdout[:500]                     # library banners must not reach stdout
+        lines[name] = d = json.loads(out[0])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                    "data", "config", "roofline"):
+            assert key in d, key
+        assert d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 2 and d["higher_is_better"] is True and d["value"] > 0
+        assert d["config"]["workload"].startswith("afsk_1200_super_opt") and "model" not in d["config"]
+        for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert key in d["roofline"], key
+        assert d["roofline"]["bound"] in ("hbm", "mfma") and abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
+    assert lines["plain"]["packets"] == lines["gather"]["packets"] and lines["plain"]["packets"]["unique_good"] > 0
