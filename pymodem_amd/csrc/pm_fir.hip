@@ -23,6 +23,7 @@
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int kGatedGrid = 1024;       // workgroups (per stream) of a gated fallback launch: it walks the tiles if it ever has to run
 constexpr int kMaxTaps = 8192;
 
 // one spare double after every R: lane t's window (R consecutive outputs) starts R+1 doubles after lane t-1's,
@@ -239,8 +240,12 @@ __global__ __launch_bounds__(kThreads) void fir_signs_batch_kernel(FirBatch B, c
     if (gate && *gate <= gate_above) return;                          // a launch that only matters if an earlier kernel said so
     const int s = blockIdx.y;
     const int64_t n = B.n[s], nout = n - m + 1;
-    if ((int64_t)blockIdx.x * (kThreads * R) >= nout) return;          // the grid is sized for the longest stream
-    fir_tile<double, R, NEG, VEC, true>(B.x[s], n, h, m, nullptr, nout, B.bits[s], (int64_t)blockIdx.x);
+    // the grid is sized for the longest stream; a gated launch comes with a small grid and walks the tiles (in the normal case
+    // it only has to leave, and leaving costs by the workgroup)
+    for (int64_t tile = blockIdx.x; tile * (kThreads * R) < nout; tile += gridDim.x) {
+        fir_tile<double, R, NEG, VEC, true>(B.x[s], n, h, m, nullptr, nout, B.bits[s], tile);
+        lds_barrier();                                               // the next tile restages the LDS image
+    }
 }
 
 // Four correlators over one staged window; R outputs x 4 filters = 4R accumulators per thread.
@@ -549,7 +554,10 @@ __global__ __launch_bounds__(kThreads) void afsk_group_kernel(const double *__re
     constexpr int R = 2, F = 2 + 2 * G, T = kThreads * R;
     const int t = threadIdx.x;
     const int span = T + m - 1;
-    const int64_t tile0 = (int64_t)blockIdx.x * T;
+    const double *const w_all = w;
+    for (int64_t tile = blockIdx.x; tile * T < nout; tile += gridDim.x) {     // one trip, except for a gated launch's small grid
+    w = w_all;
+    const int64_t tile0 = tile * T;
     if (VEC) {
         stage_vec<R>(x, n, tile0, span, t, xs);
     } else {
@@ -618,6 +626,8 @@ __global__ __launch_bounds__(kThreads) void afsk_group_kernel(const double *__re
             if (go < nout) yg[go] = o[0];
             if (go + 1 < nout) yg[go + 1] = o[1];
         }
+    }
+    lds_barrier();                                                   // the next tile restages the LDS image
     }
 }
 
@@ -901,13 +911,14 @@ static int afsk_group_go(pm_ctx *ctx, const double *d_x, int64_t n, const double
     // fallback machinery, not with the correlators
     PmProf prof(ctx, gate ? PM_K_SIGNS : PM_K_AFSK_CORR);
     if (!gate) prof.work((double)n * 8 + (double)G * nout * 8, 2.0 * (2 + 2 * G) * m * (double)nout);
+    const unsigned grid = (unsigned)(gate ? std::min<int64_t>(ntiles, kGatedGrid) : ntiles);
     if (vec) {
         if (int rc = allow_lds(afsk_group_kernel<G, true>, lds)) return rc;
-        hipLaunchKernelGGL((afsk_group_kernel<G, true>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, d_x, n, d_w, m, d_y, y_stride, nout,
+        hipLaunchKernelGGL((afsk_group_kernel<G, true>), dim3(grid), dim3(kThreads), lds, ctx->stream, d_x, n, d_w, m, d_y, y_stride, nout,
                            gate, gate_above);
     } else {
         if (int rc = allow_lds(afsk_group_kernel<G, false>, lds)) return rc;
-        hipLaunchKernelGGL((afsk_group_kernel<G, false>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, d_x, n, d_w, m, d_y, y_stride, nout,
+        hipLaunchKernelGGL((afsk_group_kernel<G, false>), dim3(grid), dim3(kThreads), lds, ctx->stream, d_x, n, d_w, m, d_y, y_stride, nout,
                            gate, gate_above);
     }
     PM_HIP(hipGetLastError());
@@ -1228,11 +1239,11 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
         PmProf prof(ctx, PM_K_SIGNS);                  // gated fallback, see afsk_group_go
         if (vec) {
             if (int rc = allow_lds(fir_signs_batch_kernel<R, false, true>, lds)) return rc;
-            hipLaunchKernelGGL((fir_signs_batch_kernel<R, false, true>), dim3((unsigned)ntiles, (unsigned)groups), dim3(kThreads), lds, ctx->stream, FB,
+            hipLaunchKernelGGL((fir_signs_batch_kernel<R, false, true>), dim3((unsigned)std::min<int64_t>(ntiles, kGatedGrid), (unsigned)groups), dim3(kThreads), lds, ctx->stream, FB,
                                d_lpf, ml, count, cap);
         } else {
             if (int rc = allow_lds(fir_signs_batch_kernel<R, false, false>, lds)) return rc;
-            hipLaunchKernelGGL((fir_signs_batch_kernel<R, false, false>), dim3((unsigned)ntiles, (unsigned)groups), dim3(kThreads), lds, ctx->stream, FB,
+            hipLaunchKernelGGL((fir_signs_batch_kernel<R, false, false>), dim3((unsigned)std::min<int64_t>(ntiles, kGatedGrid), (unsigned)groups), dim3(kThreads), lds, ctx->stream, FB,
                                d_lpf, ml, count, cap);
         }
     }
