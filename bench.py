@@ -213,7 +213,7 @@ def also_workloads(args, env):
     at full size -- and fsk_9600 is the shortest-tap FIR path.  Never allowed to break the main line."""
     import copy
     out = {}
-    for name, steps, warm in (("fsk_9600", 10, 2), ("bpsk_300", 1, 0), ("qpsk_2400", 1, 0)):
+    for name, steps, warm in (("fsk_9600", 100, 5), ("bpsk_300", 1, 0), ("qpsk_2400", 1, 0)):
         if name == args.workload:
             continue
         a = copy.copy(args)
