@@ -725,17 +725,25 @@ int pm_lfsr_unscramble(const uint8_t *h_in, int64_t n, uint64_t poly, int invert
     const int64_t nwords = (n + 7) / 8;
     auto load = [&](int64_t w) -> uint64_t {
         if (w < 0) return 0;
-        uint64_t v = 0;
         const int64_t base = w * 8;
-        const int take = (int)std::min<int64_t>(8, n - base);
+        if (base + 8 <= n) {                // a whole word: one unaligned load, big-endian (MSB of byte 0 is stream bit 0)
+            uint64_t v;
+            memcpy(&v, h_in + base, 8);
+            return __builtin_bswap64(v);
+        }
+        uint64_t v = 0;
+        const int take = (int)std::max<int64_t>(0, n - base);
         for (int i = 0; i < take; ++i) v |= (uint64_t)h_in[base + i] << (56 - 8 * i);
         return v;
     };
+    // the taps as shift amounts, once (the inner loop below runs n/8 times)
+    int taps[64], ntaps = 0;
+    for (uint64_t p = poly; p; p &= p - 1) taps[ntaps++] = __builtin_ctzll(p);
     uint64_t prev = 0, cur = load(0);
     for (int64_t w = 0; w < nwords; ++w) {
         uint64_t o = 0;
-        for (uint64_t p = poly; p; p &= p - 1) {
-            const int j = __builtin_ctzll(p);
+        for (int q = 0; q < ntaps; ++q) {
+            const int j = taps[q];
             o ^= j == 0 ? cur : ((cur >> j) | (prev << (64 - j)));
         }
         if (w == 0) {                       // pending contributions of the incoming register: bit t -> stream bit t
@@ -745,8 +753,13 @@ int pm_lfsr_unscramble(const uint8_t *h_in, int64_t n, uint64_t poly, int invert
         }
         if (invert) o = ~o;
         const int64_t base = w * 8;
-        const int take = (int)std::min<int64_t>(8, n - base);
-        for (int i = 0; i < take; ++i) h_out[base + i] = (uint8_t)(o >> (56 - 8 * i));
+        if (base + 8 <= n) {
+            const uint64_t be = __builtin_bswap64(o);
+            memcpy(h_out + base, &be, 8);
+        } else {
+            const int take = (int)(n - base);
+            for (int i = 0; i < take; ++i) h_out[base + i] = (uint8_t)(o >> (56 - 8 * i));
+        }
         prev = cur;
         cur = load(w + 1);
     }
