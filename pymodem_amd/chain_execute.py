@@ -137,7 +137,7 @@ class RecordingPipeline:
       demod   FIR / correlator / loop kernels (vector-f64 ALU and HBM)                 default stream, caller's thread
       slice   chunk-parallel timing recovery: ~1 resident wave per SIMD, dependent-     `slice_workers` high-priority side streams,
               latency bound, so TWO recordings' slicers share the GPU almost for free    one thread each
-      host    LFSR + codec (native, GIL released)                                       three threads, each fanning out to the pool
+      host    LFSR + codec (native, GIL released)                                       five threads (recordings); chains on library threads
       finish  the caller's `finish(rows per chain)`: the packet exchange                 one thread, submission order (collectives)
       post    the caller's `post(...)`: rank 0's payload copy, indexing and de-dup       three threads
 
@@ -150,7 +150,7 @@ class RecordingPipeline:
         self._workers = max(1, int(slice_workers))
         self._demod_streams = int(demod_streams)
         self._slice = ThreadPoolExecutor(max_workers=self._workers)
-        self._host = ThreadPoolExecutor(max_workers=3)        # LFSR + codec of up to three recordings at a time (each fans out to the pool)
+        self._host = ThreadPoolExecutor(max_workers=5)        # LFSR + codec of up to five recordings at a time (IL2P chains take 4-5 ms each)
         self._finish = ThreadPoolExecutor(max_workers=1)
         self._post = ThreadPoolExecutor(max_workers=3)        # whatever follows the ordered step (rank 0's payload copy, indexing, de-dup)
         self._inflight = deque()
