@@ -191,7 +191,7 @@ class RecordingPipeline:
         """Start one recording; returns a Future of post(finish(rows per chain)) (either may be None = identity).  `finish` calls
         run one at a time in submission order (the place for collectives); `post` calls run in parallel with later recordings.
         If finish returns a future itself, post receives its result (and waits for it: see flush_finish).  `prepare(rows)`, if
-        given, runs at the end of the host stage (three recordings at a time) and its result is what finish receives."""
+        given, runs at the end of the host stage (several recordings at a time) and its result is what finish receives."""
         import time
         acc = self.stage_seconds
         slots = self._slots
