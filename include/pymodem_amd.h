@@ -129,7 +129,9 @@ int pm_afsk_sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_boun
  * guaranteed: the sliding sums only feed the certified decision, whose bound grows by their (small) error, and every bit still
  * equals the exact chain's.  rot = r = (template_i[1], template_q[1]); end = r^m rounded to double; tap_dev = the largest
  * |template[j] - r^j| over both templates of both tones, measured by the host in extended precision (pymodem_amd.taps.tone_model).
- * Fails with PM_ERR_ARG if tap_dev >= 1e-6: such templates are not tones, use pm_afsk_sweep_signs. */
+ * Fails with PM_ERR_ARG if tap_dev >= 1e-6: such templates are not tones, use pm_afsk_sweep_signs.  groups == 1 is the lone
+ * chain: its mark - gain * space difference takes ONE low-pass.  Sliding sums, low-pass(es) and the certified combine run as one
+ * kernel (nothing but the bitmaps is written) unless the low-pass is longer than 2049 taps. */
 typedef struct pm_afsk_tones {
     double mark_rot[2], mark_end[2];
     double space_rot[2], space_end[2];     /* of the unit-gain space templates */
