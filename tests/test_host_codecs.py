@@ -228,3 +228,49 @@ def test_batched_host_stage_rejects_a_shared_codec():
         jobs[j].codec = c._handle()
     with pytest.raises(NativeError, match="share a codec"):
         check(lib().pm_host_decode_batch(jobs, 2, 4))
+
+
+def test_recycled_host_blocks_are_never_shared():
+    """device._host_block hands a block out again only when nothing refers to it any more (views keep it alive)."""
+    from pymodem_amd.device import _host_block
+    a = _host_block(3_000_001)
+    view = a[:100].view(np.uint8)
+    b = _host_block(3_000_001)
+    assert b is not a and not np.shares_memory(a, b)
+    ida = a.ctypes.data
+    del a
+    c = _host_block(3_000_001)                      # `view` still refers to the first block
+    assert c.ctypes.data != ida
+    del view, b, c
+    d = _host_block(3_000_001)
+    e = _host_block(2_900_000)                      # a second request while d is held: another block
+    assert not np.shares_memory(d, e) and d.nbytes >= 3_000_001 and e.nbytes >= 2_900_000
+
+
+def test_batched_host_stage_survives_a_fork(tmp_path):
+    """The library's worker threads do not exist in a forked child: the first batch there starts new ones instead of waiting for
+    the parent's (bench.py and the reference's own runner fork)."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+from pymodem_amd import chain_execute as CE
+from pymodem_amd.codecs import AX25Codec
+from pymodem_amd.data_classes import AddressedArray
+from pymodem_amd.lfsr import LFSR
+def group():
+    rng = np.random.default_rng(3)
+    chains = [["c%%d" %% k, None, None, LFSR(poly=0x3, invert=True), AX25Codec(ident="c%%d" %% k)] for k in range(6)]
+    sliced = [AddressedArray(rng.integers(0, 256, 30000, dtype=np.uint8), np.arange(30000, dtype=np.int64) * 7) for _ in range(6)]
+    return chains, sliced
+want = [r.tobytes() for r in CE._host_rows(*group())]          # the parent's pool now exists
+pid = os.fork()
+if pid == 0:
+    got = [r.tobytes() for r in CE._host_rows(*group())]
+    os._exit(0 if got == want else 3)
+_, status = os.waitpid(pid, 0)
+sys.exit(os.waitstatus_to_exitcode(status))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], timeout=120, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
