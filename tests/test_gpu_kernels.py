@@ -681,3 +681,26 @@ def test_one_chain_certified_signs_are_the_exact_chain_s(ctx, rate, baud, mark, 
         want = _exact_afsk_signs(ctx, x, (mi, mq), (space_taps[0, 0], space_taps[0, 1]), lpf)
         assert np.array_equal(got[0], want), (name, int(np.count_nonzero(got[0] != want)), redo)
         assert redo > 65536 if name == "silence" else (redo <= 65536 or name == "quiet"), (name, redo)
+
+
+def test_sweep_tones_rejects_templates_that_are_not_tones(ctx):
+    from pymodem_amd import NativeError
+    from pymodem_amd import taps as T
+    mi, mq, ui, uq = T.afsk_tone_correlators(48000.0, 1200.0, 1300.0, 2100.0, 1.0, 1.5, 0.0)
+    lpf = T.windowed_sinc(100, 900.0, 48000.0, pass_zero=True)
+    x = np.random.default_rng(2).standard_normal(20000) * 100.0
+    dx, dl = ctx.upload(x), ctx.upload(lpf)
+    t = [ctx.upload(v) for v in (mi, mq, ui, uq)]
+    ds = ctx.upload(np.stack([1.5 * ui, 1.5 * uq]).reshape(-1))
+    bits = ctx.empty(len(x) // 64 + 2, np.uint64)
+    ptrs = (ctypes.c_void_p * 1)(bits.ptr.value)
+    gs = (ctypes.c_double * 1)(1.5)
+    args = (ctx.handle, dx.ptr, len(x), 500.0, t[0].ptr, t[1].ptr, t[2].ptr, t[3].ptr, ds.ptr, gs, 1, len(mi), dl.ptr, len(lpf), float(np.abs(lpf).sum()), ptrs)
+    tones = _tones((mi, mq), (ui, uq))
+    tones.tap_dev = 1e-3
+    with pytest.raises(NativeError):
+        chk(L().pm_afsk_sweep_signs_tones(*args, ctypes.byref(tones)))
+    with pytest.raises(NativeError):
+        chk(L().pm_afsk_sweep_signs_tones(*args, None))
+    tones.tap_dev = 2e-15
+    chk(L().pm_afsk_sweep_signs_tones(*args, ctypes.byref(tones)))             # and the same call with honest tones goes through

@@ -67,3 +67,34 @@ def test_factories_mirror_the_reference():
     assert sl.samples_per_symbol == 5.0 and sl.rollover_threshold == 2.0 and sl.lock_rate == 0.88
     q = cb.SlicerConfigurator(48000.0, {"type": "quadrature", "config": "qpsk_2400", "options": {"lock_rate": "0.98"}})
     assert (q.state_mask, q.bits_per_symbol, q.symbol_rate) == (0xF, 2, 1200)
+
+
+def test_tone_model_accepts_tone_templates_only():
+    """taps.tone_model: the correlator templates of afsk.py:134-144 are the powers of one rotation to ~1e-15; anything else is far
+    from that, and AFSKModem then keeps to the direct correlator sums (pm_afsk_sweep_signs_tones refuses tap_dev >= 1e-6)."""
+    import numpy as np
+    from pymodem_amd import taps as T
+    for rate, baud, mark, space, span in [(48000.0, 1200.0, 1300.0, 2100.0, 1.5), (8000.0, 300.0, 1600.0, 1800.0, 1.0), (44100.0, 1200.0, 1200.0, 2200.0, 1.5)]:
+        mi, mq, ui, uq = T.afsk_tone_correlators(rate, baud, mark, space, 1.0, span, 0.0)
+        for hi, hq in ((mi, mq), (ui, uq)):
+            rot, end, dev = T.tone_model(hi, hq)
+            assert dev < 1e-13 and abs(rot[0] ** 2 + rot[1] ** 2 - 1.0) < 1e-15
+            m = len(hi)
+            w = np.arctan2(rot[1], rot[0])
+            assert abs(end[0] - np.cos(m * w)) < 1e-12 and abs(end[1] - np.sin(m * w)) < 1e-12
+    rng = np.random.default_rng(0)
+    assert T.tone_model(rng.standard_normal(40), rng.standard_normal(40))[2] > 1e-3
+    assert T.tone_model(np.ones(1), np.zeros(1)) is None
+    # a gain folded into the templates (what the reference does to the space pair) is not a unit rotation any more
+    assert T.tone_model(2.0 * ui, 2.0 * uq)[2] > 0.5
+
+
+def test_afsk_modem_picks_sliding_sums_only_for_tones():
+    import numpy as np
+    from pymodem_amd.modems import AFSKModem
+    m = AFSKModem(sample_rate=48000, config="1200")
+    ui, uq = m.unit_space_correlators()
+    t = m._tones(ui, uq)
+    assert t is not None and t.tap_dev < 1e-13 and m._tones(ui, uq) is t          # remembered
+    m.mark_correlator_i = m.mark_correlator_i * np.hanning(len(m.mark_correlator_i))   # somebody's windowed template
+    assert m._tones(ui, uq) is None
