@@ -250,7 +250,8 @@ __global__ __launch_bounds__(1024) void slice_scan_kernel(const JobDev *__restri
     const int64_t c0 = min((int64_t)t * per, J.nchunks), c1 = min(c0 + per, J.nchunks);
     uint64_t s = 0;
     int l = -1;
-    for (int64_t c = c0; c < c1; ++c) {
+#pragma unroll 8
+    for (int64_t c = c0; c < c1; ++c) {                    // unrolled: eight independent loads in flight instead of one
         s += cnt[c];
         if (lsym[c] != 0xFF) l = lsym[c];
     }
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(1024) void slice_scan_kernel(const JobDev *__restri
     }
     uint64_t run = before;
     int carry = carry_before;
+#pragma unroll 8
     for (int64_t c = c0; c < c1; ++c) {
         off[c] = run;
         psym[c] = (uint8_t)carry;
@@ -510,7 +512,7 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
     ctx->sl_chunks = total_chunks;
     // The count / scan / pack kernels only read the symbol bitmap the iteration left: they are cut independently of it, finely
     // (throughput kernels: ~4 waves per SIMD), however long the iteration's chunks are.
-    const int64_t le_words = std::max<int64_t>(4, std::min<int64_t>(lc_words, pm_cdiv(total_words, 262144)));
+    const int64_t le_words = std::max<int64_t>(4, std::min<int64_t>(lc_words, pm_cdiv(total_words, 524288)));
     std::vector<JobDev> je = jd;
     int64_t emit_chunks = 0;
     for (JobDev &d : je) {
