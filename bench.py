@@ -171,6 +171,7 @@ def main():
     # goes to stderr, the line itself to the real stdout.
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL between processes needs on these hosts
     import torch
     ndev = torch.cuda.device_count()
     if ndev < 1:
