@@ -446,6 +446,13 @@ def measure(args, env):
                               "alone_frac_of_sustained": None if alone_ms is None else round(per_launch_flops / (alone_ms * 1e-3) / 1e12 / FP64_SUSTAINED_TFLOPS, 5),
                               "note": "2 flops per fma of the FIR sums (epilogue sqrt / sign tests not counted) / the same HIP-event time; "
                                       "sustained_peak_measured is the rate a pure v_fma_f64 register loop holds on this chip (clock under f64 load)"},
+            "roofline_by_class": {k: {"avg_kernel_ms": round(prof[k][0] / prof[k][1], 5), "launches": prof[k][1],
+                                      "algorithmic_bytes_per_launch": round(work[k][0] / prof[k][1]),
+                                      "achieved_GBps": round(work[k][0] / (prof[k][0] * 1e-3) / 1e9, 1),
+                                      "frac_hbm": round(work[k][0] / (prof[k][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                      "tflops_f64": round(work[k][1] / (prof[k][0] * 1e-3) / 1e12, 3),
+                                      "frac_f64_sustained": round(work[k][1] / (prof[k][0] * 1e-3) / 1e12 / FP64_SUSTAINED_TFLOPS, 5)}
+                                  for k in stage if prof[k][0] > 0 and work[k][0] > 0},
             "gpu_kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]},
             "h2d": {"ms": round(h2d_ms, 3), "bytes": int(audio.nbytes),
                     "value_with_h2d": round(float(args.samples) * nchains / (elapsed / args.steps + h2d_ms * 1e-3) / 1e6, 3),
