@@ -153,6 +153,8 @@ def main():
                     "bpsk_300 and qpsk_2400 (BASELINE configs[2], [1], [4]) briefly and attach them under 'also'")
     args = ap.parse_args()
 
+    if os.environ.get("BENCH_SWITCH_INTERVAL"):
+        sys.setswitchinterval(float(os.environ["BENCH_SWITCH_INTERVAL"]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -299,6 +301,9 @@ def measure(args, env):
             pipe.close()                                      # every step's de-dup is done, not only the last one's
             stage_ms.clear()
             stage_ms.update({s: round(v / max(k, 1) * 1e3, 3) for s, v in pipe.stage_seconds.items()})
+            if os.environ.get("BENCH_SLICE_LOG"):
+                t00 = pipe.slice_log[0][1] if pipe.slice_log else 0
+                print("[slice batches] (recordings, start ms, duration ms):", [(n, round((t - t00) * 1e3, 1), round(d * 1e3, 1)) for n, t, d in pipe.slice_log][:60], file=sys.stderr)
             return res
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=1) as worker:       # one worker: host halves (and their collectives) stay in step order
@@ -313,6 +318,8 @@ def measure(args, env):
     sides = [pymodem_amd.Context.side(dev_index, i) for i in range(args.slice_workers)] if args.overlap >= 2 else []
     if args.overlap >= 2 and args.demod_streams >= 2:
         sides.append(pymodem_amd.Context.side(dev_index, 100, high_priority=False))       # the second demod stream
+    if args.overlap >= 2 and int(os.environ.get("PYMODEM_AMD_CU_SPLIT", "0")) > 0:
+        sides.append(pymodem_amd.Context.side(dev_index, 101, high_priority=False))       # the demod stream on the CUs the slicers leave
 
     def run_steps_uploading(k):
         """The same pipeline, but every step's recording starts in host memory: its copy to HBM runs one step ahead on a copy stream."""

@@ -49,11 +49,19 @@ int pm_ctx_create(int device, pm_ctx **out);
  * its own stream, scratch and profiler, device memory is shared.  The pipelined executor runs the slicer (a few resident waves,
  * dependent-latency bound) on a high-priority ctx while the FIR/correlator kernels of the next recording fill the ALUs. */
 int pm_ctx_create_prio(int device, int high_priority, pm_ctx **out);
+/* A context whose stream may only use the compute units whose bit is set in cu_mask (nwords x 32 bits; bit i goes to XCD
+ * i mod 8, so a run of 8 k consecutive bits takes k CUs from every XCD).  The pipelined executor keeps the slicers' few, long-lived,
+ * latency-bound waves on a handful of CUs of their own and the FIR kernels on the rest: a FIR workgroup that shares a SIMD with a
+ * slicer wave runs at the pace of its slowest wave (its barriers couple the four SIMDs of the CU). */
+int pm_ctx_create_cumask(int device, const uint32_t *cu_mask, int nwords, pm_ctx **out);
+int pm_device_cus(int device);      /* compute units of the device (0 if it cannot be queried) */
 int pm_ctx_destroy(pm_ctx *ctx);
 /* Cross-stream ordering without a host wait.  pm_event_record marks the point reached by ctx's stream (creating the event when
  * *event is NULL); pm_event_wait makes everything submitted to ctx AFTER the call wait for that point.  Same device only. */
 int pm_event_record(pm_ctx *ctx, void **event);
 int pm_event_wait(pm_ctx *ctx, void *event);
+int pm_event_query(void *event);     /* 1 = everything before the record has finished, 0 = not yet, < 0 = error */
+int pm_event_sync(void *event);      /* host wait for the event */
 int pm_event_destroy(void *event);
 int pm_ctx_sync(pm_ctx *ctx);                            /* hipStreamSynchronize on the ctx stream */
 void *pm_ctx_stream(pm_ctx *ctx);                        /* the hipStream_t, for interop */

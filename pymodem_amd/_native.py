@@ -116,6 +116,10 @@ _SIGS = {
     "pm_last_error": ([ctypes.c_char_p, ctypes.c_size_t], _int),
     "pm_ctx_create": ([_int, ctypes.POINTER(_vp)], _int),
     "pm_ctx_create_prio": ([_int, _int, ctypes.POINTER(_vp)], _int),
+    "pm_event_query": ([_vp], _int),
+    "pm_event_sync": ([_vp], _int),
+    "pm_ctx_create_cumask": ([_int, ctypes.POINTER(ctypes.c_uint32), _int, ctypes.POINTER(_vp)], _int),
+    "pm_device_cus": ([_int], _int),
     "pm_event_record": ([_vp, ctypes.POINTER(_vp)], _int),
     "pm_event_wait": ([_vp, _vp], _int),
     "pm_event_destroy": ([_vp], _int),

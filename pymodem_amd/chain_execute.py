@@ -131,6 +131,24 @@ def process_chains_split(chains, input_audio):
     return lambda: _host_rows(chains, sliced)
 
 
+class _BatchFetch:
+    """The deferred device-to-host copy of one slicer batch, done once by the first taker."""
+
+    def __init__(self, fetch, ctx, lock):
+        import threading
+        self._fetch, self._ctx, self._copy_lock = fetch, ctx, lock
+        self._lock = threading.Lock()
+        self._out = None
+
+    def get(self, lo, hi):
+        with self._lock:
+            if self._out is None:
+                with self._copy_lock:
+                    self._out = self._fetch(self._ctx)
+                self._fetch = None
+        return self._out[lo:hi]
+
+
 class RecordingPipeline:
     """Successive recordings through chain groups with the stages of the path overlapped, each on its own resource:
 
@@ -145,11 +163,14 @@ class RecordingPipeline:
     stages are the sign bitmaps (one bit per sample), kept in slice_workers + 2 rotating slots (demod runs one recording ahead); a GPU event, not a host wait,
     orders slicer after demod.  Results are identical to process_chains_table on each recording (tests/test_gpu_chains.py)."""
 
-    def __init__(self, slice_workers=2, demod_streams=1):
+    def __init__(self, slice_workers=2, demod_streams=1, slice_group=8, slots=None):
         from collections import deque
+        import os
+        import queue
+        import threading
         self._workers = max(1, int(slice_workers))
         self._demod_streams = int(demod_streams)
-        self._slice = ThreadPoolExecutor(max_workers=self._workers)
+        self._group = max(1, min(int(os.environ.get("PYMODEM_AMD_SLICE_GROUP", slice_group)), 8))
         self._host = ThreadPoolExecutor(max_workers=5)        # LFSR + codec of up to five recordings at a time (IL2P chains take 4-5 ms each)
         self._finish = ThreadPoolExecutor(max_workers=1)
         self._post = ThreadPoolExecutor(max_workers=3)        # whatever follows the ordered step (rank 0's payload copy, indexing, de-dup)
@@ -159,13 +180,71 @@ class RecordingPipeline:
         self._uploads = 0
         self._upload_guard = {}                               # upload slot -> event after which its buffer may be overwritten
         self._upload_done = {}                                # upload slot -> event marking the end of its copy (re-used)
-        import queue
-        self._free_sides = queue.Queue()
-        for i in range(self._workers):
-            self._free_sides.put(Context.side(index=i))
-        self._slots = self._workers + 2                      # bitmaps: one set per slicer in flight, one being written, one ready
-        self._events = [None] * self._slots
+        # The slicer stage: a batch takes ~3 ms of a few hundred long-lived waves however many streams are in it (pm_slice_batch:
+        # one walker per 32 k samples), so a worker takes EVERY recording whose demod has been submitted when it becomes free (up to
+        # `slice_group`, 64 streams per batch): the batch size settles where the slicers keep up with the demod stream, with two or
+        # three streams (HIP maps streams onto a handful of hardware queues; more slicer streams than that end up sharing a queue
+        # with the demod stream and stall it).
+        self._pending = queue.Queue()
+        self._copy_ctx = Context.side(index=201, high_priority=False)     # a copy stream of its own (prefetch() uploads on 200)
+        self._copy_lock = threading.Lock()
+        self._slots = int(slots or os.environ.get("PYMODEM_AMD_BITMAP_SLOTS", 0) or 16)
+        self._events = [None] * self._slots                   # bitmaps: one set per recording between "demod submitted" and "sliced"
         self.stage_seconds = {"demod": 0.0, "slice": 0.0, "host": 0.0, "finish": 0.0}   # busy time per stage, summed over recordings
+        self.slice_batches = 0
+        self.slice_log = []
+        self._slice_threads = [threading.Thread(target=self._slice_loop, args=(Context.side(index=i),), daemon=True) for i in range(self._workers)]
+        for th in self._slice_threads:
+            th.start()
+
+    def _slice_loop(self, side):
+        import queue
+        import time
+        while True:
+            item = self._pending.get()
+            if item is None:
+                self._pending.put(None)                        # one marker ends every worker
+                return
+            # demod runs in submission order: wait (on the host, holding nothing) for this recording's bitmaps, then take along
+            # every later recording whose bitmaps are complete as well
+            Context.event_sync(item[2])
+            items = [item]
+            while len(items) < self._group:
+                try:
+                    nxt = self._pending.get_nowait()
+                except queue.Empty:
+                    break
+                if nxt is None:
+                    self._pending.put(None)
+                    break
+                if not Context.event_done(nxt[2]):
+                    with self._pending.mutex:                  # not ready yet: back to the FRONT of the queue
+                        self._pending.queue.appendleft(nxt)
+                        self._pending.not_empty.notify()
+                    break
+                items.append(nxt)
+            t = time.perf_counter()
+            try:
+                slicers, bitmaps = [], []
+                for chains, bm, ready, _ in items:
+                    slicers += [ch[2] for ch in chains]
+                    bitmaps += bm
+                fetch = slice_batch(slicers, bitmaps, side, defer=True)
+                # The slicers' bytes and addresses are still in device memory: whichever host-stage thread needs them first copies
+                # the whole batch over on the copy stream (this worker's stream is already slicing the next batch).
+                shared = _BatchFetch(fetch, self._copy_ctx, self._copy_lock)
+                at = 0
+                for chains, _, _, fut in items:
+                    fut.set_result((shared, at, at + len(chains)))
+                    at += len(chains)
+            except BaseException as e:                         # noqa: BLE001
+                for _, _, _, fut in items:
+                    if not fut.done():
+                        fut.set_exception(e)
+            dt = time.perf_counter() - t
+            self.stage_seconds["slice"] += dt
+            self.slice_batches += 1
+            self.slice_log.append((len(items), t, dt))
 
     def prefetch(self, host_audio):
         """Start copying a recording (host int16 / float64 array) into HBM on a copy stream; returns a handle for submit().  Call
@@ -202,7 +281,11 @@ class RecordingPipeline:
         t0 = time.perf_counter()
         # two demod streams, alternating: the tail of one recording's FIR launches (the last, partly filled round of workgroups)
         # overlaps the head of the next one's instead of leaving CUs idle
-        dctx = Context.default() if (self._demod_streams < 2 or (self._n & 1)) else Context.side(index=100, high_priority=False)
+        import os
+        if int(os.environ.get("PYMODEM_AMD_CU_SPLIT", "0")) > 0:  # demod on the CUs the slicer streams do not use
+            dctx = Context.side(index=101 if (self._demod_streams < 2 or (self._n & 1)) else 100, high_priority=False)
+        else:
+            dctx = Context.default() if (self._demod_streams < 2 or (self._n & 1)) else Context.side(index=100, high_priority=False)
         upload_slot = None
         if hasattr(input_audio, "result"):                    # a prefetch() handle: the demod stream waits for the copy on the GPU
             input_audio, copied, upload_slot = input_audio.result()
@@ -213,21 +296,18 @@ class RecordingPipeline:
             self._upload_guard[upload_slot] = dctx.record_event(self._upload_guard.get(upload_slot))   # its own event, re-used per slot
         acc["demod"] += time.perf_counter() - t0
 
-        def slice_stage():
-            t = time.perf_counter()
-            side = self._free_sides.get()                      # a slicer stream nobody else is using (a ctx is not thread-safe)
-            try:
-                side.wait_event(ready)
-                sliced = slice_batch([ch[2] for ch in chains], bitmaps, side)
-            finally:
-                self._free_sides.put(side)
-            acc["slice"] += time.perf_counter() - t
-            return sliced
-        f_sliced = self._slice.submit(slice_stage)
-        self._inflight.append(f_sliced)                       # the bitmap slot is free again once the slicer has read it
+        from concurrent.futures import Future
+        f_sliced, f_fetched = Future(), Future()
+        self._pending.put((chains, bitmaps, ready, f_sliced))
+        # the bitmap slot (and the slicers' output block keyed by it) is free again once the slicers' output is on the host
+        self._inflight.append(f_fetched)
 
         def host_stage():
-            sliced = f_sliced.result()
+            try:
+                shared, lo, hi = f_sliced.result()
+                sliced = shared.get(lo, hi)
+            finally:
+                f_fetched.set_result(None)
             t = time.perf_counter()
             rows = _host_rows(chains, sliced)
             if prepare is not None:                            # e.g. dist.Exchanger.prepare: packing for the wire, off the ordered thread
@@ -266,7 +346,14 @@ class RecordingPipeline:
     def close(self):
         """Waits for everything submitted."""
         self._upload.shutdown(wait=True)
-        self._slice.shutdown(wait=True)
+        for f in list(self._inflight):
+            try:
+                f.result()
+            except Exception:                                  # noqa: BLE001  (surfaces through the stage futures)
+                pass
+        self._pending.put(None)
+        for th in self._slice_threads:
+            th.join()
         self._host.shutdown(wait=True)
         self._finish.shutdown(wait=True)
         self._post.shutdown(wait=True)

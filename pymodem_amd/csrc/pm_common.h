@@ -7,12 +7,14 @@
 #include <vector>
 #include "../../include/pymodem_amd.h"
 
+constexpr size_t PM_PINNED_BYTES = 256 * 1024;
+
 struct pm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // small pinned host mailbox + device scratch used by reductions / the slicer fixed point
-    void *h_pinned = nullptr;       // 4 KiB
+    void *h_pinned = nullptr;       // PM_PINNED_BYTES
     void *d_scratch = nullptr;      // grows on demand
     size_t scratch_bytes = 0;
     // optional per-kernel-class timing (pm_prof_*)
@@ -26,7 +28,9 @@ struct pm_ctx {
     // slicer diagnostics
     int32_t sl_iterations = 0, sl_chunk_len = 0;
     int64_t sl_chunks = 0;
-    int64_t sl_target_lanes = 65536;   // chunks a slicer batch is cut into (pm_slicer_tune)
+    int64_t sl_target_lanes = 16384;   // walkers (= chunks) a slicer batch is cut into (pm_slicer_tune)
+    int64_t sl_hint_shape = 0;         // chunk/launch geometry sl_launch_hint was learnt on
+    int32_t sl_launch_hint = 0;        // lockstep launches to enqueue before the emit kernels without asking the device
     int *sweep_count = nullptr;        // device counter of the last pm_afsk_sweep_signs on this ctx (inside d_scratch)
 };
 

@@ -53,9 +53,41 @@ int pm_ctx_create_prio(int device, int high_priority, pm_ctx **out)
     }
     PM_HIP(hipEventCreate(&c->ev0));
     PM_HIP(hipEventCreate(&c->ev1));
-    PM_HIP(hipHostMalloc(&c->h_pinned, 4096, hipHostMallocDefault));
+    PM_HIP(hipHostMalloc(&c->h_pinned, PM_PINNED_BYTES, hipHostMallocDefault));
     *out = c;
     return PM_OK;
+}
+
+int pm_ctx_create_cumask(int device, const uint32_t *cu_mask, int nwords, pm_ctx **out)
+{
+    PM_ARG(out != nullptr && cu_mask != nullptr && nwords >= 1);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return pm_set_error(PM_ERR_NODEV, "no HIP device visible: the HIP path cannot run (there is no CPU fallback)");
+    PM_ARG(device >= 0 && device < n);
+    PM_HIP(hipSetDevice(device));
+    bool any = false;
+    for (int k = 0; k < nwords; ++k) any = any || cu_mask[k] != 0;
+    PM_ARG(any);
+    pm_ctx *c = new pm_ctx();
+    c->device = device;
+    hipError_t e = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)nwords, cu_mask);
+    if (e != hipSuccess) {
+        delete c;
+        return pm_set_error(PM_ERR_HIP, "hipExtStreamCreateWithCUMask failed: %s", hipGetErrorString(e));
+    }
+    PM_HIP(hipEventCreate(&c->ev0));
+    PM_HIP(hipEventCreate(&c->ev1));
+    PM_HIP(hipHostMalloc(&c->h_pinned, PM_PINNED_BYTES, hipHostMallocDefault));
+    *out = c;
+    return PM_OK;
+}
+
+int pm_device_cus(int device)
+{
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return 0;
+    return p.multiProcessorCount;
 }
 
 int pm_ctx_destroy(pm_ctx *c)
@@ -92,6 +124,22 @@ int pm_event_wait(pm_ctx *c, void *event)
     PM_CTX(c);
     PM_ARG(event != nullptr);
     PM_HIP(hipStreamWaitEvent(c->stream, (hipEvent_t)event, 0));
+    return PM_OK;
+}
+
+int pm_event_query(void *event)
+{
+    if (!event) return pm_set_error(PM_ERR_ARG, "bad argument: event (%s:%d)", __FILE__, __LINE__);
+    const hipError_t e = hipEventQuery((hipEvent_t)event);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) return 0;
+    return pm_set_error(PM_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(e));
+}
+
+int pm_event_sync(void *event)
+{
+    PM_ARG(event != nullptr);
+    PM_HIP(hipEventSynchronize((hipEvent_t)event));
     return PM_OK;
 }
 

@@ -4,23 +4,31 @@
 // The reference recurrence, per sample k (1-based address k+1):
 //     clk += 1.0;  if (clk >= sps/2 - 0.5) { clk -= sps;  take a symbol from sign(x[k]) }
 //     if sign(x[k]) != sign(x[k-1]):  clk *= lock_rate
-// is sequential in `clk` only.  Every stream is cut into chunks of L samples, one lane per chunk.
-// An iteration runs the chunks on its work list from the start states handed to them; a chunk whose end
-// state changes hands it to the next chunk and puts that chunk on the next list; chunk 0 of a stream
-// always starts from the true state.  When a list comes up empty, every chunk's last run started from
-// the final end state of its predecessor, so by induction from chunk 0 the per-chunk runs ARE the
-// sequential run, bit for bit: each lane executes the reference's operations in the reference's order,
-// only the starting value is guessed.  Two trajectories that see the same zero crossings contract by lock_rate per
-// crossing, so a few iterations suffice on real signals; the worst case (no crossings at all) degrades
-// to nchunks iterations, i.e. sequential cost, never to a wrong answer.
+// is sequential in `clk` only, and two runs that see the same zero crossings contract towards each other by lock_rate per
+// crossing until they are the same double (~140 crossings at 0.77).  Every stream is cut into chunks of L samples and every
+// chunk gets a WALKER: a lane that starts at the chunk's first sample (walker 0 of a stream from the true state, the others from
+// a cold 0.0), executes the reference's operations in the reference's order, and leaves behind, per 64-sample word, the clock it
+// entered the word with (a checkpoint) and the bitmap of the samples at which it took a symbol.  A walker does not stop at the
+// end of its chunk: it walks on into the next chunk, overwriting what that chunk's own walker left there, until it enters a
+// word with exactly the clock the trail in front of it entered it with -- from there on its future IS that trail, word for word,
+// and it retires.  All walkers advance in lockstep (one launch = the same number of words for every live walker), so a walker
+// is always a whole chunk behind the one in front of it: it only ever reads words that were written by an earlier launch and
+// nobody writes behind it but walkers that started further back.  Walker 0 is the sequential run; by induction the trail it
+// merged into is the sequential run from that word on, and so on down the stream: when no walker is left, checkpoints and symbol
+// bitmaps are those of the sequential run, bit for bit.  The cost is one pass plus the merge lengths (N (1 + m/L) lane-steps
+// instead of one full pass per L/m of merge length), and live walkers are compacted into a dense list after every launch, so a
+// launch has as many waves as there are walkers still on their way.  No crossings at all (digital silence) degrades to every
+// walker reaching the end of its stream: sequential depth, never a wrong answer.
 //
 // A lone wave pays both the loop-carried chain (add -> compare -> select -> multiply, ~45 cycles with the latencies measured
-// by tools/ubench) and the issue of the ~12 VALU instructions of a step (~5.5 cycles each): ~85 cycles per sample.  Each run
-// leaves a bitmap of the samples at which it took a symbol.  After the fixed point a count/scan/pack pipeline, chunked on its
-// own (finely), turns symbol bitmap + sign bitmap(s) into bytes and the 1-based address of each byte's last symbol.  A slicer
-// object's state (clock, last sign, open byte, address count, differential state) enters and leaves through pm_slicer_state.
+// by tools/ubench) and the issue of the ~11 VALU instructions of a step (~5.5 cycles each): ~85 cycles per sample.
+// After the last walker a count/scan/pack pipeline, chunked on its own (finely), turns symbol bitmap + sign bitmap(s) into
+// bytes and the 1-based address of each byte's last symbol.  A slicer object's state (clock, last sign, open byte, address
+// count, differential state) enters and leaves through pm_slicer_state.
 #include "pm_common.h"
+#include "pm_slicer_step.inc"
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -29,6 +37,8 @@ namespace {
 
 constexpr int kMaxJobs = 64;
 constexpr int kBlock = 256;     // four waves: one per SIMD when the grid is one workgroup per CU
+constexpr size_t kPinnedBytes = PM_PINNED_BYTES;
+constexpr int kShortLaunches = 10;    // launches of qwords words after the walkers' own chunks; 4 x qwords from then on
 
 struct JobDev {
     const uint64_t *bi, *bq;       // sign bitmaps (bq null for binary)
@@ -36,6 +46,7 @@ struct JobDev {
     int64_t chunk0, nchunks;       // global chunk range of this stream
     int64_t word0;                 // offset of this stream in the global symbol bitmap
     double thr, sps, lock;
+    double tp;                     // the smallest clock for which fl(clk + 1.0) >= thr (step32c)
     int bps, mask, quad, pad;
     int demap[16];
     uint32_t *data32;
@@ -113,43 +124,100 @@ __device__ __forceinline__ uint32_t step32m(double &clk, uint32_t zc, double thr
     return acc - 1u;        // sum_k (1 + nm_k) 2^(31-k) = (2^32 - 1) + acc  (mod 2^32)
 }
 
-// One fixed-point iteration.  Work is a list of chunk ids: iteration 0 holds every chunk; a chunk whose run changes its END state
-// writes it into the state array and puts its successor on the next iteration's list.  Lists are dense, so the waves of an iteration
-// are as many as there are chunks to re-run (the thin tail of the iteration costs a handful of waves, not the whole grid) and the
-// iteration after the fixed point finds an empty list.  The state array is updated in place: a chunk may read its start state
-// while its predecessor is rewriting it in the same iteration -- either value is a valid 8-byte state, and whenever the
-// predecessor did change it the chunk is on the next list and runs again, so at the fixed point every chunk's last run started
-// from the final end state of its predecessor (the induction of the header comment).
+// The same 32 steps with the symbol decision taken from the clock itself: fl(clk + 1.0) >= thr  <=>  clk >= tp, where tp is the
+// smallest double whose successor-by-one reaches thr (x -> fl(x + 1.0) is monotone, so the clocks that take a symbol are exactly
+// [tp, inf); the host finds tp by stepping through the neighbours of thr - 1).  That takes the compare off the chain behind the
+// addition: compare | a = clk + 1.0 in parallel, then c = a + {0, -sps}, then the crossing's multiplication as one fma (see
+// step32m for why fma(c, lock - 1, c) is the reference's rounded product).  Four dependent operations per sample instead of six,
+// eight vector instructions instead of eleven: compare, select, two additions, fma, the symbol bit shifted in with the compare's
+// carry, and two for the crossing mask.
+template <bool LM0, bool NS0>
+__device__ __forceinline__ uint32_t step32c(double &clk, uint32_t zc, double tp, double neg_sps, double lm1)
+{
+    const int32_t ns_hi = __double2hiint(neg_sps), ns_lo = __double2loint(neg_sps);
+    const int32_t lm_hi = __double2hiint(lm1), lm_lo = __double2loint(lm1);
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const int32_t cm = (int32_t)(zc << k) >> 31;                     // crossing at this sample: -1
+        const double sel = __hiloint2double(lm_hi & cm, LM0 ? 0 : lm_lo & cm);
+        const bool s = clk >= tp;                                        // slicer.py:77-79: (clk + 1.0) >= thr
+        const double a = clk + 1.0;                                      // slicer.py:77
+        acc = acc + acc + (s ? 1u : 0u);
+        const double c = a + __hiloint2double(s ? ns_hi : 0, NS0 ? 0 : (s ? ns_lo : 0));     // slicer.py:81; a + (+0) is a
+        clk = __builtin_fma(c, sel, c);                                  // slicer.py:99-104
+    }
+    return acc;
+}
+
+// step32c as hand-scheduled assembly (tools/gen_slicer_step.py -> pm_slicer_step.inc): the compiler's version of the same
+// source spends 13 instructions per sample (the crossing mask as and + compare + select, a move to rebuild the {0, -sps} pair,
+// the symbol bit as select + shift + or); scheduled by hand it is 8 (10 when -sps and lock_rate - 1 have low words) with the
+// next sample's crossing mask prepared in the shadow of the chain compare -> select -> add -> fma.
+template <bool LM0, bool NS0>
+__device__ __forceinline__ uint32_t step32a(double &clk, uint32_t zc, double tp, double neg_sps, double lm1)
+{
+    const int32_t ns_hi = __double2hiint(neg_sps), ns_lo = __double2loint(neg_sps);
+    const int32_t lm_hi = __double2hiint(lm1), lm_lo = __double2loint(lm1);
+    uint32_t acc = 0;
+#define PM_STEP_ASM(BODY)                                                                                                    \
+    asm volatile(BODY : "+v"(clk), "+v"(acc) : "v"(zc), "v"(tp), "v"(ns_hi), "v"(ns_lo), "v"(lm_hi), "v"(lm_lo)              \
+                 : "vcc", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81")
+    if (LM0 && NS0) PM_STEP_ASM(PM_SLICER_STEP32_LM1_NS1);
+    else if (NS0) PM_STEP_ASM(PM_SLICER_STEP32_LM0_NS1);
+    else if (LM0) PM_STEP_ASM(PM_SLICER_STEP32_LM1_NS0);
+    else PM_STEP_ASM(PM_SLICER_STEP32_LM0_NS0);
+#undef PM_STEP_ASM
+    return acc;
+}
+
+// One lockstep launch of the walkers (see the header): every live walker advances by at most `qwords` words.  Work is a
+// dense list of walker (= chunk) ids; the first launch runs every walker through its own chunk (list_in == nullptr: identity)
+// and needs no comparison -- nobody has been there before.  Beyond its own chunk a walker compares, word by word, the clock it
+// enters the word with against the checkpoint the trail in front of it left: equal means merged, it retires; otherwise it
+// overwrites checkpoint and symbols and walks on.  Lockstep (qwords <= chunk length, the same for every walker of a launch)
+// means the words a walker touches were last written by an EARLIER launch and are touched by nobody else in this one.
+// A walker that reaches the end of its stream leaves the clock there as the stream's end state; walkers from further back
+// arrive in later launches and overwrite it, or merge before the end, in which case what stands there is already theirs.
 // STEP: 0 = step32 (compare and selects), 1 = step32m, 2 = step32m with zero low words in lock_rate - 1 and sps.  One kernel per
 // form: with the 64 unrolled steps of several forms in one kernel the loop no longer fits the instruction cache comfortably.
 template <int STEP>
-__global__ __launch_bounds__(kBlock) void slice_iter_kernel(const JobDev *__restrict__ jobs, int njobs, int lc_words,
-                                                        uint64_t *__restrict__ state, const int32_t *__restrict__ list_in,
-                                                        int32_t *__restrict__ list_out, int *__restrict__ counts, int iter,
-                                                        uint64_t *__restrict__ symmap)
+__global__ __launch_bounds__(kBlock) void slice_walk_kernel(const JobDev *__restrict__ jobs, int njobs, int lc_words, int qwords,
+                                                        uint64_t *__restrict__ wclk, int32_t *__restrict__ wpos,
+                                                        const int32_t *__restrict__ list_in, int32_t *__restrict__ list_out,
+                                                        int *__restrict__ counts, int iter, uint64_t *__restrict__ symmap,
+                                                        uint64_t *__restrict__ ckmap, uint64_t *__restrict__ endstate, int prio)
 {
     // These waves are bound by their own dependent chain; when FIR waves of another stream share the SIMD (pipelined executor)
     // every issue slot they lose lengthens the chain, while the FIR waves only need the slots in between: take issue priority.
-    __builtin_amdgcn_s_setprio(3);
+    if (prio) __builtin_amdgcn_s_setprio(3);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= counts[iter]) return;                   // whole waves beyond the list leave at once
-    const int64_t gc = list_in[i];
+    const int64_t gc = list_in ? list_in[i] : i;
     const int j = find_job(jobs, njobs, gc);
     const JobDev &J = jobs[j];
     const int64_t c = gc - J.chunk0;
-    const int64_t so = gc + j;                       // the state array holds nchunks+1 entries per stream
-    double clk = bitsd(__builtin_nontemporal_load(&state[so]));
-    const int64_t w0 = c * lc_words;
-    const int64_t w1 = min(w0 + (int64_t)lc_words, J.nwords);
+    const int64_t own_end = min((c + 1) * (int64_t)lc_words, J.nwords);
+    int64_t w = wpos[gc];
+    double clk = bitsd(wclk[gc]);
+    const int64_t w_stop = min(w + (int64_t)qwords, J.nwords);
     // last_sample starts at 0.0, i.e. ">= 0" (slicer.py:55,164-165)
-    uint64_t li = w0 == 0 ? (uint64_t)J.li0 : (J.bi[w0 - 1] >> 63);
+    uint64_t li = w == 0 ? (uint64_t)J.li0 : (J.bi[w - 1] >> 63);
     uint64_t lq = 1ull;
-    if (J.quad) lq = w0 == 0 ? (uint64_t)J.lq0 : (J.bq[w0 - 1] >> 63);
-    const double thr = J.thr, neg_sps = -J.sps;
+    if (J.quad) lq = w == 0 ? (uint64_t)J.lq0 : (J.bq[w - 1] >> 63);
+    const double thr = J.thr, neg_sps = -J.sps, tp = J.tp;
     const double lock = J.lock;
     const double lm1 = lock - 1.0;
     uint64_t *sm = symmap + J.word0;
-    for (int64_t w = w0; w < w1; ++w) {
+    uint64_t *ck = ckmap + J.word0;
+    bool alive = true;
+    for (; w < w_stop; ++w) {
+        const uint64_t cb = dbits(clk);
+        if (w >= own_end && __builtin_nontemporal_load(&ck[w]) == cb) {      // merged into the trail in front: retire
+            alive = false;
+            break;
+        }
+        ck[w] = cb;
         const uint64_t si = J.bi[w];
         uint64_t zc = si ^ ((si << 1) | li);
         li = si >> 63;
@@ -162,7 +230,16 @@ __global__ __launch_bounds__(kBlock) void slice_iter_kernel(const JobDev *__rest
         uint64_t sym;
         if (left >= 64) {
             uint32_t lo, hi;
-            if (STEP == 2) {
+            if (STEP >= 5) {                       // 5 + LM0 + 2 NS0: the hand-scheduled form of step32c
+                lo = step32a<((STEP - 5) & 1) != 0, ((STEP - 5) & 2) != 0>(clk, __brev((uint32_t)zc), tp, neg_sps, lm1);
+                hi = step32a<((STEP - 5) & 1) != 0, ((STEP - 5) & 2) != 0>(clk, __brev((uint32_t)(zc >> 32)), tp, neg_sps, lm1);
+            } else if (STEP == 4) {
+                lo = step32c<true, true>(clk, __brev((uint32_t)zc), tp, neg_sps, lm1);
+                hi = step32c<true, true>(clk, __brev((uint32_t)(zc >> 32)), tp, neg_sps, lm1);
+            } else if (STEP == 3) {
+                lo = step32c<false, false>(clk, __brev((uint32_t)zc), tp, neg_sps, lm1);
+                hi = step32c<false, false>(clk, __brev((uint32_t)(zc >> 32)), tp, neg_sps, lm1);
+            } else if (STEP == 2) {
                 lo = step32m<true, true>(clk, __brev((uint32_t)zc), thr, neg_sps, lm1);
                 hi = step32m<true, true>(clk, __brev((uint32_t)(zc >> 32)), thr, neg_sps, lm1);
             } else if (STEP == 1) {
@@ -186,19 +263,23 @@ __global__ __launch_bounds__(kBlock) void slice_iter_kernel(const JobDev *__rest
         }
         sm[w] = sym;
     }
-    const uint64_t e = dbits(clk);
-    const bool ch = e != state[so + 1];
-    if (ch) state[so + 1] = e;
-    // successors of the chunks whose end state moved go on the next list: one atomic per wave
-    const bool add = ch && c + 1 < J.nchunks;
-    const uint64_t mask = __ballot(add);
+    if (alive && w >= J.nwords) {                    // the end of the stream: its end state (later arrivals are the truer ones)
+        endstate[j] = dbits(clk);
+        alive = false;
+    }
+    if (alive) {
+        wpos[gc] = (int32_t)w;
+        wclk[gc] = dbits(clk);
+    }
+    // survivors go on the next launch's list: one atomic per wave
+    const uint64_t mask = __ballot(alive);
     if (mask) {
         const int lane = threadIdx.x & 63;
         const int leader = __ffsll((long long)mask) - 1;
         int base = 0;
         if (lane == leader) base = atomicAdd(&counts[iter + 1], __popcll(mask));
         base = __shfl(base, leader);
-        if (add) list_out[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)(gc + 1);
+        if (alive) list_out[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)gc;
     }
 }
 
@@ -207,8 +288,15 @@ __global__ __launch_bounds__(kBlock) void slice_count_kernel(const JobDev *__res
                                                          const uint64_t *__restrict__ symmap, uint32_t *__restrict__ count,
                                                          uint8_t *__restrict__ lastsym)
 {
-    __builtin_amdgcn_s_setprio(3);          // short kernels on the slicer stream's critical path (see slice_iter_kernel)
+    __builtin_amdgcn_s_setprio(3);          // short kernels on the slicer stream's critical path (see slice_walk_kernel)
     const int64_t gc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // the pack kernel ORs bit fields into the output words of every stream: clear them here, one launch earlier (instead of one
+    // hipMemsetAsync per stream between scan and pack)
+    for (int k = 0; k < njobs; ++k) {
+        uint32_t *d32 = jobs[k].data32;
+        const int64_t nd = (jobs[k].cap + 3) >> 2;
+        for (int64_t d = gc; d < nd; d += (int64_t)gridDim.x * blockDim.x) d32[d] = 0u;
+    }
     if (gc >= total_chunks) return;
     const int j = find_job(jobs, njobs, gc);
     const JobDev &J = jobs[j];
@@ -234,8 +322,7 @@ __global__ __launch_bounds__(kBlock) void slice_count_kernel(const JobDev *__res
 __global__ __launch_bounds__(1024) void slice_scan_kernel(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ count,
                                                           const uint8_t *__restrict__ lastsym, uint64_t *__restrict__ offset,
                                                           uint8_t *__restrict__ prevsym, uint64_t *__restrict__ totals,
-                                                          const uint64_t *__restrict__ s_end, int njobs,
-                                                          const JobDev *__restrict__ iter_jobs)
+                                                          const uint64_t *__restrict__ s_end, int njobs)
 {
     __builtin_amdgcn_s_setprio(3);
     __shared__ uint64_t sums[1024];
@@ -282,8 +369,7 @@ __global__ __launch_bounds__(1024) void slice_scan_kernel(const JobDev *__restri
         off[J.nchunks] = all;
         totals[blockIdx.x] = all;
         // end state for the next call on this slicer object: clock after the last chunk, signs of the last sample, last symbol
-        const JobDev &I = iter_jobs[blockIdx.x];           // the state arrays are laid out by the ITERATION's chunks
-        totals[njobs + blockIdx.x] = s_end[I.chunk0 + blockIdx.x + I.nchunks];
+        totals[njobs + blockIdx.x] = s_end[blockIdx.x];   // left by the last walker to reach the end of the stream
         const int64_t last = J.n - 1;
         uint64_t signs = (J.bi[last >> 6] >> (last & 63)) & 1;
         if (J.quad) signs |= ((J.bq[last >> 6] >> (last & 63)) & 1) << 1;
@@ -315,7 +401,7 @@ __global__ __launch_bounds__(kBlock) void slice_pack_kernel(const JobDev *__rest
 {
     __shared__ uint32_t lb[kPackBytes / 4 + 1];
     __shared__ long long la[kPackBytes + 4];
-    __builtin_amdgcn_s_setprio(3);          // short kernels on the slicer stream's critical path (see slice_iter_kernel)
+    __builtin_amdgcn_s_setprio(3);          // short kernels on the slicer stream's critical path (see slice_walk_kernel)
     const int64_t gc0 = (int64_t)blockIdx.x * kBlock;
     if (gc0 >= total_chunks) return;
     const int j = find_job(jobs, njobs, gc0);
@@ -422,21 +508,43 @@ __global__ __launch_bounds__(kBlock) void slice_pack_kernel(const JobDev *__rest
     }
 }
 
-__global__ void slice_init_kernel(const JobDev *__restrict__ jobs, int njobs, int64_t total_chunks, uint64_t *state, int32_t *list0,
-                                  int *counts, int ncounts)
+__global__ void slice_init_kernel(const JobDev *__restrict__ jobs, int njobs, int lc_words, int64_t total_chunks, uint64_t *wclk,
+                                  int32_t *wpos, int *counts, int ncounts, uint32_t *tails)
 {
-    const int64_t gc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gc < ncounts) counts[gc] = gc == 0 ? (int)total_chunks : 0;       // iteration 0 runs every chunk
-    if (gc >= total_chunks) return;
-    const int j = find_job(jobs, njobs, gc);
-    const int64_t so = gc + j;
-    // cold start everywhere (phase_clock = 0.0); chunk 0 of a stream starts from its true state, carried in or zero (slicer.py:50)
-    state[so] = gc == jobs[j].chunk0 ? dbits(jobs[j].clk0) : 0ull;
-    if (gc - jobs[j].chunk0 == jobs[j].nchunks - 1) state[so + 1] = ~0ull;   // "no end state yet": any first run differs from it
-    list0[gc] = (int32_t)gc;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t k = t; k < ncounts; k += stride) counts[k] = k == 0 ? (int)total_chunks : 0;       // the first launch runs every walker
+    for (int64_t k = t; k < njobs; k += stride) tails[k] = 0u;
+    for (int64_t gc = t; gc < total_chunks; gc += stride) {
+        const int j = find_job(jobs, njobs, gc);
+        const int64_t c = gc - jobs[j].chunk0;
+        // cold start everywhere (phase_clock = 0.0); walker 0 of a stream starts from its true state, carried in or zero (slicer.py:50)
+        wclk[gc] = c == 0 ? dbits(jobs[j].clk0) : 0ull;
+        wpos[gc] = (int32_t)(c * lc_words);
+    }
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// The smallest double x with fl(x + 1.0) >= thr (NaN if it cannot be pinned down: the caller then keeps the compare on the sum).
+double symbol_clock_threshold(double thr)
+{
+    if (!(thr - thr == 0.0)) return NAN;
+    volatile double x = thr - 1.0;
+    for (int k = 0; k < 64; ++k) {                       // down while the predecessor still reaches thr
+        volatile double p = nextafter((double)x, -INFINITY);
+        volatile double sum = p + 1.0;
+        if (!(sum >= thr)) break;
+        x = p;
+        if (k == 63) return NAN;
+    }
+    for (int k = 0; k < 64; ++k) {                       // up until it does
+        volatile double sum = x + 1.0;
+        if (sum >= thr) return x;
+        x = nextafter((double)x, INFINITY);
+    }
+    return NAN;
+}
 
 }  // namespace
 
@@ -458,13 +566,22 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
     }
     if (max_n == 0) return PM_OK;
 
-    // Chunk length (a multiple of 64 samples).  A lone wave is issue bound, so an iteration costs (waves per SIMD) x L x
-    // t_step while the number of iterations falls as 1/L: the best L puts about one wave on each of the 1024 SIMDs
-    // (65536 lanes), but never below 1024 samples.  PM_SLICER_CHUNK_WORDS overrides (tuning).
-    int64_t all_words = 0;
-    for (int j = 0; j < njobs; ++j) all_words += pm_cdiv(jobs[j].n, 64);
+    // Chunk length L (a multiple of 64 samples) = distance between walkers.  Lane-steps are N (1 + m/L) with m the merge length
+    // (10-20 k samples at lock 0.77), the depth is (L + longest merge) x t_step: long chunks are cheap, short ones are quick.
+    // The batch is cut into about sl_target_lanes walkers, between 1024 and 65536 samples each.  PM_SLICER_CHUNK_WORDS overrides.
+    int64_t all_words = 0, max_words = 0;
+    for (int j = 0; j < njobs; ++j) {
+        all_words += pm_cdiv(jobs[j].n, 64);
+        max_words = std::max(max_words, pm_cdiv(jobs[j].n, 64));
+    }
     int64_t lc_words = std::max<int64_t>(16, std::min<int64_t>(pm_cdiv(all_words, ctx->sl_target_lanes), 1024));
     if (const char *e = getenv("PM_SLICER_CHUNK_WORDS")) { if (atoi(e) > 0) lc_words = atoi(e); }
+    // Words per lockstep launch once the walkers are beyond their own chunks (never more than a chunk: see slice_walk_kernel).
+    // A walker that retires mid-launch leaves its lane idle for the rest of it, so short launches waste less; each costs a dispatch.
+    int64_t qwords = 32;
+    if (const char *e = getenv("PM_SLICER_QUANTUM_WORDS")) { if (atoi(e) > 0) qwords = atoi(e); }
+    qwords = std::min(qwords, lc_words);
+    const int64_t qtail = std::min<int64_t>(lc_words, 4 * qwords);
     std::vector<JobDev> jd;
     jd.reserve(njobs);
     std::vector<int> live;
@@ -484,6 +601,7 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
         d.word0 = total_words;
         d.sps = q.params.samples_per_symbol;
         d.thr = (q.params.samples_per_symbol / 2.0) - 0.5;          // slicer.py:52
+        d.tp = symbol_clock_threshold(d.thr);
         d.lock = q.params.lock_rate;
         d.bps = q.params.bits_per_symbol;
         d.mask = q.params.state_mask;
@@ -508,10 +626,11 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
         live.push_back(j);
     }
     const int nj = (int)jd.size();
+    PM_ARG(total_chunks < (1ll << 31) && max_words < (1ll << 31));
     ctx->sl_chunk_len = (int32_t)(lc_words * 64);
     ctx->sl_chunks = total_chunks;
-    // The count / scan / pack kernels only read the symbol bitmap the iteration left: they are cut independently of it, finely
-    // (throughput kernels: ~4 waves per SIMD), however long the iteration's chunks are.
+    // The count / scan / pack kernels only read the symbol bitmap the walkers left: they are cut independently of it, finely
+    // (throughput kernels: ~4 waves per SIMD), however long the walkers' chunks are.
     const int64_t le_words = std::max<int64_t>(4, std::min<int64_t>(lc_words, pm_cdiv(total_words, 524288)));
     std::vector<JobDev> je = jd;
     int64_t emit_chunks = 0;
@@ -521,39 +640,42 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
         emit_chunks += pm_cdiv(d.nchunks, (int64_t)kBlock) * kBlock;      // a workgroup never straddles two streams (slice_pack_kernel)
     }
 
-    const size_t e = (size_t)total_chunks + nj;             // nchunks+1 state entries per stream
+    // No walker walks further than its stream is long: that bounds the launches (reached only without any crossing at all).
+    const int64_t max_launches = pm_cdiv(max_words, qwords) + 2;
+    const int ncounts = (int)std::min<int64_t>(max_launches + 8, 1 << 22);
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t ee = (size_t)emit_chunks + nj;
-    int64_t most_chunks = 0;
-    for (const JobDev &d : jd) most_chunks = std::max(most_chunks, d.nchunks);
-    const int burst = 8;                                   // iterations after the fixed point find an empty list and cost microseconds
-    const int64_t max_iters = most_chunks + 2;
-    const int ncounts = (int)std::min<int64_t>(max_iters + 2 * burst + 8, 1 << 22);
-    const size_t o_jobs = carve(sizeof(JobDev) * nj), o_ejobs = carve(sizeof(JobDev) * nj), o_state = carve(e * 8),
-                 o_la = carve((size_t)total_chunks * 4), o_lb = carve((size_t)total_chunks * 4), o_counts = carve((size_t)ncounts * 4),
+    // one host-to-device block (both job tables) and one device-to-host block (totals | tails | list sizes)
+    const size_t res_tot = (size_t)nj * 8 * 4, res_tail = align_up((size_t)nj * 4, 8);
+    const size_t o_jobs = carve(sizeof(JobDev) * nj * 2), o_wclk = carve((size_t)total_chunks * 8), o_wpos = carve((size_t)total_chunks * 4),
+                 o_la = carve((size_t)total_chunks * 4), o_lb = carve((size_t)total_chunks * 4), o_end = carve((size_t)nj * 8),
+                 o_res = carve(res_tot + res_tail + (size_t)ncounts * 4),
                  o_cnt = carve((size_t)emit_chunks * 4), o_ls = carve(emit_chunks), o_off = carve(ee * 8), o_ps = carve(emit_chunks),
-                 o_sym = carve((size_t)total_words * 8), o_tot = carve((size_t)nj * 8 * 4), o_tail = carve((size_t)nj * 4);
+                 o_sym = carve((size_t)total_words * 8), o_ck = carve((size_t)total_words * 8);
     if (int rc = pm_scratch_reserve(ctx, off)) return rc;
     char *base = (char *)ctx->d_scratch;
-    JobDev *d_jobs = (JobDev *)(base + o_jobs), *d_ejobs = (JobDev *)(base + o_ejobs);
-    uint64_t *state = (uint64_t *)(base + o_state);
+    JobDev *d_jobs = (JobDev *)(base + o_jobs), *d_ejobs = d_jobs + nj;
+    uint64_t *wclk = (uint64_t *)(base + o_wclk), *endstate = (uint64_t *)(base + o_end);
+    int32_t *wpos = (int32_t *)(base + o_wpos);
     int32_t *list_a = (int32_t *)(base + o_la), *list_b = (int32_t *)(base + o_lb);
-    int *counts = (int *)(base + o_counts);
+    uint64_t *totals = (uint64_t *)(base + o_res);
+    uint32_t *tails = (uint32_t *)(base + o_res + res_tot);
+    int *counts = (int *)(base + o_res + res_tot + res_tail);
     uint32_t *cnt = (uint32_t *)(base + o_cnt);
     uint8_t *ls = (uint8_t *)(base + o_ls), *ps = (uint8_t *)(base + o_ps);
-    uint64_t *offs = (uint64_t *)(base + o_off), *symmap = (uint64_t *)(base + o_sym), *totals = (uint64_t *)(base + o_tot);
-    uint32_t *tails = (uint32_t *)(base + o_tail);
+    uint64_t *offs = (uint64_t *)(base + o_off), *symmap = (uint64_t *)(base + o_sym), *ckmap = (uint64_t *)(base + o_ck);
     for (int k = 0; k < nj; ++k) jd[k].tail = je[k].tail = tails + k;
-    PM_HIP(hipMemsetAsync(tails, 0, (size_t)nj * 4, ctx->stream));
 
-    PM_HIP(hipMemcpyAsync(d_jobs, jd.data(), sizeof(JobDev) * nj, hipMemcpyHostToDevice, ctx->stream));
-    PM_HIP(hipMemcpyAsync(d_ejobs, je.data(), sizeof(JobDev) * nj, hipMemcpyHostToDevice, ctx->stream));
-    const unsigned grid = (unsigned)pm_cdiv(std::max<int64_t>(total_chunks, ncounts), kBlock);
-    hipLaunchKernelGGL(slice_init_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_jobs, nj, total_chunks, state, list_a, counts, ncounts);
+    std::vector<JobDev> both(jd);
+    both.insert(both.end(), je.begin(), je.end());
+    PM_HIP(hipMemcpyAsync(d_jobs, both.data(), sizeof(JobDev) * both.size(), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(slice_init_kernel, dim3((unsigned)std::min<int64_t>(pm_cdiv(std::max<int64_t>(total_chunks, ncounts), kBlock), 1024)),
+                       dim3(kBlock), 0, ctx->stream, d_jobs, nj, (int)lc_words, total_chunks, wclk, wpos, counts, ncounts, tails);
 
     // step32m needs lock_rate - 1 to be exact for every stream of the batch (it is for 0.5 <= lock_rate <= 2) and finite clocks
     int masks = getenv("PM_SLICER_COMPARE_STEP") ? 0 : 2;
+    bool lm0 = true, ns0 = true;                     // low words of lock_rate - 1 / of sps zero in every stream
     for (const JobDev &d : jd) {
         const volatile double lm1 = d.lock - 1.0;
         if (!(lm1 + 1.0 == d.lock) || !(d.clk0 - d.clk0 == 0.0) || !(d.sps - d.sps == 0.0)) masks = 0;
@@ -562,44 +684,83 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
         memcpy(&lb, &l1, 8);
         memcpy(&sb, &d.sps, 8);
         if (masks == 2 && ((uint32_t)lb || (uint32_t)sb)) masks = 1;     // low words not zero: the general mask form
+        lm0 = lm0 && (uint32_t)lb == 0;
+        ns0 = ns0 && (uint32_t)sb == 0;
     }
-    auto iter_kernel = masks == 2 ? slice_iter_kernel<2> : masks == 1 ? slice_iter_kernel<1> : slice_iter_kernel<0>;
-    int *h_flag = (int *)ctx->h_pinned;
-    int iters = 0;
-    bool converged = false;
-    while (!converged) {
-        // a burst of iterations between host checks keeps the launch queue full
-        for (int b = 0; b < burst; ++b) {
+    bool direct = masks != 0 && !getenv("PM_SLICER_MASK_STEP");          // step32c: the decision from the clock itself
+    for (const JobDev &d : jd) direct = direct && d.tp == d.tp;
+    const bool hand = direct && !getenv("PM_SLICER_COMPILED_STEP");
+    auto walk_kernel = hand ? (lm0 ? (ns0 ? slice_walk_kernel<8> : slice_walk_kernel<6>) : (ns0 ? slice_walk_kernel<7> : slice_walk_kernel<5>))
+                       : direct ? (masks == 2 ? slice_walk_kernel<4> : slice_walk_kernel<3>)
+                                : masks == 2 ? slice_walk_kernel<2> : masks == 1 ? slice_walk_kernel<1> : slice_walk_kernel<0>;
+    const unsigned wgrid = (unsigned)pm_cdiv(total_chunks, kBlock);
+    const bool trace = getenv("PM_SLICER_TRACE") != nullptr;
+    const int prio = getenv("PM_SLICER_NO_SETPRIO") ? 0 : 1;
+    // How many lockstep launches to enqueue before the emit kernels without asking the device: what the last batches of this
+    // shape needed plus a margin (a launch that finds its list empty costs a dispatch and nothing else).  The list sizes come
+    // back with the results; if walkers were still alive the rest is launched and the emit kernels run again.
+    const int64_t shape = lc_words * 1000003 + qwords;
+    if (ctx->sl_hint_shape != shape) { ctx->sl_hint_shape = shape; ctx->sl_launch_hint = (int32_t)std::min<int64_t>(kShortLaunches + 12, max_launches); }
+    int launches = 0;                                  // walker launches so far; list `launches` is the one the next launch reads
+    int burst = std::max(1, (int)std::min<int64_t>(ctx->sl_launch_hint, max_launches));
+    char *h_res = (char *)ctx->h_pinned;
+    const size_t h_cap_counts = (kPinnedBytes - res_tot - res_tail) / 4;
+    uint64_t *h_tot = (uint64_t *)h_res;
+    uint32_t *h_tail = (uint32_t *)(h_res + res_tot);
+    int *h_counts = (int *)(h_res + res_tot + res_tail);
+    for (;;) {
+        {
             PmProf prof(ctx, PM_K_SLICE_ITER);
-            hipLaunchKernelGGL(iter_kernel, dim3((unsigned)pm_cdiv(total_chunks, kBlock)), dim3(kBlock), 0, ctx->stream, d_jobs, nj,
-                               (int)lc_words, state, (iters & 1) ? list_b : list_a, (iters & 1) ? list_a : list_b, counts, iters, symmap);
-            ++iters;
+            for (int b = 0; b < burst; ++b) {
+                // launch 0: every walker through its own chunk (identity list); then qwords at a time on the compacted lists
+                const int32_t *lin = launches == 0 ? nullptr : ((launches & 1) ? list_a : list_b);
+                int32_t *lout = (launches & 1) ? list_b : list_a;
+                // the first launches after the chunks are short (most walkers retire there: a retired walker's lane idles until
+                // the launch ends); the thin tail afterwards goes in longer launches: fewer dispatches, and few waves to waste
+                const int64_t qw = launches == 0 ? lc_words : launches <= kShortLaunches ? qwords : qtail;
+                hipLaunchKernelGGL(walk_kernel, dim3(wgrid), dim3(kBlock), 0, ctx->stream, d_jobs, nj, (int)lc_words, (int)qw, wclk, wpos,
+                                   lin, lout, counts, launches, symmap, ckmap, endstate, prio);
+                ++launches;
+            }
         }
-        // counts[iters] = chunks the burst's last iteration put on the next list: none means the fixed point is reached
-        PM_HIP(hipMemcpyAsync(h_flag, counts + iters, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        {
+            PmProf prof(ctx, PM_K_SLICE_EMIT);
+            const unsigned egrid = (unsigned)pm_cdiv(emit_chunks, kBlock);
+            hipLaunchKernelGGL(slice_count_kernel, dim3(egrid), dim3(kBlock), 0, ctx->stream, d_ejobs, nj, (int)le_words, emit_chunks, symmap, cnt, ls);
+            hipLaunchKernelGGL(slice_scan_kernel, dim3(nj), dim3(1024), 0, ctx->stream, d_ejobs, cnt, ls, offs, ps, totals, endstate, nj);
+            hipLaunchKernelGGL(slice_pack_kernel, dim3(egrid), dim3(kBlock), 0, ctx->stream, d_ejobs, nj, (int)le_words, emit_chunks, symmap, offs, ps);
+        }
+        const size_t ncopy = std::min<size_t>((size_t)launches + 1, h_cap_counts);
+        PM_HIP(hipMemcpyAsync(h_res, totals, res_tot + res_tail + ncopy * 4, hipMemcpyDeviceToHost, ctx->stream));
+        int *h_last = h_counts + launches;
+        if ((size_t)launches + 1 > ncopy) {               // more launches than the mailbox holds list sizes for: fetch the last one on its own
+            h_last = h_counts + ncopy - 1;
+            PM_HIP(hipMemcpyAsync(h_last, counts + launches, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        }
         PM_HIP(hipStreamSynchronize(ctx->stream));
-        converged = (*h_flag == 0);
-        if (getenv("PM_SLICER_TRACE")) fprintf(stderr, "[slicer] after %d iterations: %d chunks still to re-run\n", iters, *h_flag);
-        if (!converged && (iters > max_iters + burst || iters + burst + 1 >= ncounts))
-            return pm_set_error(PM_ERR_NOCONVERGE, "slicer fixed point not reached after %d iterations (%lld chunks)", iters, (long long)most_chunks);
+        PM_HIP(hipGetLastError());
+        const int alive = *h_last;
+        if (trace) {
+            fprintf(stderr, "[slicer] chunk %lld words, %lld per launch, %lld walkers; alive after each of %d launches:", (long long)lc_words,
+                    (long long)qwords, (long long)total_chunks, launches);
+            for (size_t k = 1; k < ncopy; ++k) fprintf(stderr, " %d", h_counts[k]);
+            fprintf(stderr, "\n");
+        }
+        if (alive == 0) {
+            int used = launches;                        // the first launch that left nobody alive
+            for (size_t k = 1; k < ncopy; ++k)
+                if (h_counts[k] == 0) { used = (int)k; break; }
+            ctx->sl_iterations = used;
+            // next time: what this batch needed and a quarter more; decays slowly when batches get easier
+            const int want = used + std::max(4, used / 4);
+            ctx->sl_launch_hint = want >= ctx->sl_launch_hint ? want : ctx->sl_launch_hint - (ctx->sl_launch_hint - want + 7) / 8;
+            break;
+        }
+        if (launches >= max_launches + 1)
+            return pm_set_error(PM_ERR_NOCONVERGE, "slicer: %d walkers still alive after %d launches (%lld chunks)", alive, launches, (long long)total_chunks);
+        burst = (int)std::min<int64_t>(std::max<int64_t>(8, launches / 2), max_launches + 1 - launches);
     }
-    ctx->sl_iterations = iters;
 
-    {
-        PmProf prof(ctx, PM_K_SLICE_EMIT);
-        const unsigned egrid = (unsigned)pm_cdiv(emit_chunks, kBlock);
-        hipLaunchKernelGGL(slice_count_kernel, dim3(egrid), dim3(kBlock), 0, ctx->stream, d_ejobs, nj, (int)le_words, emit_chunks, symmap, cnt, ls);
-        hipLaunchKernelGGL(slice_scan_kernel, dim3(nj), dim3(1024), 0, ctx->stream, d_ejobs, cnt, ls, offs, ps, totals, state, nj, d_jobs);
-        for (const JobDev &d : jd)
-            if (d.cap > 0) PM_HIP(hipMemsetAsync(d.data32, 0, align_up((size_t)d.cap, 4), ctx->stream));
-        hipLaunchKernelGGL(slice_pack_kernel, dim3(egrid), dim3(kBlock), 0, ctx->stream, d_ejobs, nj, (int)le_words, emit_chunks, symmap, offs, ps);
-    }
-    std::vector<uint64_t> h_tot((size_t)nj * 4);
-    std::vector<uint32_t> h_tail(nj);
-    PM_HIP(hipMemcpyAsync(h_tot.data(), totals, (size_t)nj * 8 * 4, hipMemcpyDeviceToHost, ctx->stream));
-    PM_HIP(hipMemcpyAsync(h_tail.data(), tails, (size_t)nj * 4, hipMemcpyDeviceToHost, ctx->stream));
-    PM_HIP(hipStreamSynchronize(ctx->stream));
-    PM_HIP(hipGetLastError());
     int rc = PM_OK;
     for (int k = 0; k < nj; ++k) {
         pm_slice_job &q = jobs[live[k]];
@@ -662,7 +823,7 @@ int pm_slice_quadrature(pm_ctx *ctx, const uint64_t *d_bits_i, const uint64_t *d
 int pm_slicer_tune(pm_ctx *ctx, int64_t target_lanes)
 {
     PM_ARG(ctx != nullptr && target_lanes >= 0);
-    ctx->sl_target_lanes = target_lanes ? std::max<int64_t>(64, target_lanes) : 65536;
+    ctx->sl_target_lanes = target_lanes ? std::max<int64_t>(64, target_lanes) : 16384;
     return PM_OK;
 }
 

@@ -13,10 +13,29 @@ class Context:
     _default = {}
     _side = {}
 
-    def __init__(self, device=0, high_priority=False):
+    def __init__(self, device=0, high_priority=False, cu_mask=None):
         self._h = ctypes.c_void_p()
         self.device = device
-        check(lib().pm_ctx_create_prio(device, int(bool(high_priority)), ctypes.byref(self._h)))
+        if cu_mask is not None:
+            words = (ctypes.c_uint32 * len(cu_mask))(*cu_mask)
+            check(lib().pm_ctx_create_cumask(device, words, len(cu_mask), ctypes.byref(self._h)))
+        else:
+            check(lib().pm_ctx_create_prio(device, int(bool(high_priority)), ctypes.byref(self._h)))
+
+    @staticmethod
+    def cu_split(device, per_xcd):
+        """(slicer mask, demod mask): the first `per_xcd` CUs of each of the 8 XCDs for the slicers' streams, the rest for the FIR
+        kernels.  Bit i of a CU mask belongs to XCD i mod 8 (pm_ctx_create_cumask)."""
+        cus = lib().pm_device_cus(device) or 256
+        nwords = (cus + 31) // 32
+        low = [0] * nwords
+        for i in range(min(per_xcd * 8, cus)):
+            low[i // 32] |= 1 << (i % 32)
+        high = [0] * nwords
+        for i in range(cus):
+            if not (low[i // 32] >> (i % 32)) & 1:
+                high[i // 32] |= 1 << (i % 32)
+        return low, high
 
     @classmethod
     def side(cls, device=None, index=0, high_priority=True):
@@ -29,9 +48,14 @@ class Context:
         if key not in cls._side:
             if "PYMODEM_AMD_SIDE_PRIORITY" in os.environ:                     # tuning knobs
                 high_priority = os.environ["PYMODEM_AMD_SIDE_PRIORITY"] != "0"
-            cls._side[key] = cls(main.device, high_priority=high_priority)
+            split = int(os.environ.get("PYMODEM_AMD_CU_SPLIT", "0"))
+            if split > 0 and index < 200:                                     # slicer streams (< 100) on their own CUs, demod streams (100..) on the rest
+                low, high = cls.cu_split(main.device, split)
+                cls._side[key] = cls(main.device, cu_mask=low if index < 100 else high)
+            else:
+                cls._side[key] = cls(main.device, high_priority=high_priority)
             # fewer, longer chunks while other streams share the CUs
-            check(lib().pm_slicer_tune(cls._side[key]._h, int(os.environ.get("PYMODEM_AMD_SIDE_LANES", "24576"))))
+            check(lib().pm_slicer_tune(cls._side[key]._h, int(os.environ.get("PYMODEM_AMD_SIDE_LANES", "16384"))))
         return cls._side[key]
 
     @classmethod
@@ -63,6 +87,18 @@ class Context:
     def wait_event(self, event):
         """Work submitted to this context from now on waits (on the GPU) for `event`."""
         check(lib().pm_event_wait(self._h, event))
+
+    @staticmethod
+    def event_done(event):
+        """True once everything submitted before the event's record has finished (no waiting)."""
+        r = lib().pm_event_query(event)
+        if r < 0:
+            check(r)
+        return r == 1
+
+    @staticmethod
+    def event_sync(event):
+        check(lib().pm_event_sync(event))
 
     def empty(self, n, dtype):
         return DeviceBuffer(self, int(n), np.dtype(dtype))
@@ -192,14 +228,14 @@ class DeviceBuffer:
         out._parent = self
         return out
 
-    def download(self, n=None, recycle=False):
+    def download(self, n=None, recycle=False, ctx=None):
         """-> a host array of the first n elements.  recycle=True takes the memory from a small pool of host blocks that are handed
         out again once nothing refers to them any more (views keep their block alive): a fresh 10-40 MB allocation per call costs
         more in first-touch page faults than the copy itself."""
         n = self.n if n is None else int(n)
         out = _host_block(n * self.dtype.itemsize).view(self.dtype)[:n] if recycle else np.empty(n, dtype=self.dtype)
-        if n:
-            check(lib().pm_d2h(self.ctx.handle, out.ctypes.data_as(ctypes.c_void_p), self.ptr, out.nbytes))
+        if n:      # `ctx`: copy on that context's stream instead (the data must be complete: the caller synchronised its producer)
+            check(lib().pm_d2h((ctx or self.ctx).handle, out.ctypes.data_as(ctypes.c_void_p), self.ptr, out.nbytes))
         return out
 
     def free(self):

@@ -72,25 +72,33 @@ class _SlicerBase:
         return slice_batch([self], [(bits_i, bits_q, n)])[0]
 
 
-def slice_batch(slicers, bitmaps, ctx=None):
+def slice_batch(slicers, bitmaps, ctx=None, defer=False):
     """Stage 2 of slice() for many independent streams in ONE pm_slice_batch call (shared iteration launches).
     bitmaps[k] = (bits_i, bits_q | None, n) from slicers[k].sign_bitmaps().  Returns one AddressedArray per stream.
     `ctx`: the context (stream) to run on; the bitmaps must be complete (their producer stream synchronised) if it is not the
-    one that made them."""
+    one that made them.  defer=True: the slicers have run (states updated) but their output is still in device memory; returns
+    fetch(copy_ctx) -> the list, which copies it to the host on copy_ctx's stream (the pipelined executor fetches on another
+    thread while this context already slices the next batch)."""
     ctx = ctx or slicers[0]._ctx or Context.default()
     out = [None] * len(slicers)
+    fetchers = []
     for base in range(0, len(slicers), 64):
         group = list(range(base, min(base + 64, len(slicers))))
         saved = [SlicerState.from_buffer_copy(slicers[k]._state) for k in group]
         try:
-            _slice_group(ctx, slicers, bitmaps, group, out, tight=True)
+            fetchers.append(_slice_group(ctx, slicers, bitmaps, group, out, tight=True))
         except NativeError as e:                      # a stream produced more than twice its nominal symbol count: full-size buffers
             if "capacity" not in str(e):
                 raise
             for k, st in zip(group, saved):
                 ctypes.memmove(ctypes.byref(slicers[k]._state), ctypes.byref(st), ctypes.sizeof(SlicerState))
-            _slice_group(ctx, slicers, bitmaps, group, out, tight=False)
-    return out
+            fetchers.append(_slice_group(ctx, slicers, bitmaps, group, out, tight=False))
+
+    def fetch(copy_ctx=None):
+        for f in fetchers:
+            f(copy_ctx)
+        return out
+    return fetch if defer else fetch()
 
 
 _TIGHT_FACTOR = 1.5
@@ -128,13 +136,17 @@ def _slice_group(ctx, slicers, bitmaps, group, out, tight):
     check(lib().pm_slice_batch(ctx.handle, jobs, len(group)))
     it, cl, nc = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
     lib().pm_slicer_stats(ctx.handle, ctypes.byref(it), ctypes.byref(cl), ctypes.byref(nc))
-    host = block.download(at, recycle=True)
+    counts = [jobs[j].count for j in range(len(group))]
     for j, k in enumerate(group):
-        cnt = jobs[j].count
         slicers[k].last_stats = {"iterations": it.value, "chunk_len": cl.value, "chunks": nc.value}
         slicers[k].phase_clock, slicers[k].streamaddress = slicers[k]._state.phase_clock, slicers[k]._state.streamaddress
-        # views into this call's own download (a fresh array every call): no second copy
-        out[k] = AddressedArray(host[d_off[j]:d_off[j] + cnt], host[a_off[j]:a_off[j] + cnt * 8].view(np.int64))
+
+    def fetch(copy_ctx=None):
+        host = block.download(at, recycle=True, ctx=copy_ctx)
+        for j, k in enumerate(group):
+            # views into this call's own download (a fresh array every call): no second copy
+            out[k] = AddressedArray(host[d_off[j]:d_off[j] + counts[j]], host[a_off[j]:a_off[j] + counts[j] * 8].view(np.int64))
+    return fetch
 
 
 class BinarySlicer(_SlicerBase):
