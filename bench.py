@@ -73,7 +73,8 @@ def wl_bpsk_300(j):
 
 def wl_qpsk_2400(j):
     """BASELINE configs[4]: replicated qpsk_2400 chains at swept tuning offsets (the bundled file sweeps 1475/1500/1525)."""
-    f = 1500.0 + 3.125 * (j - 32)
+    step = (j + 1) // 2 * (1 if j % 2 else -1)      # 0, +1, -1, +2, -2, ...: every prefix of the 64-chain sweep is centred on the carrier
+    f = 1500.0 + 3.125 * step
     return {"object_name": f"QPSK 2400 IL2P+CRC {f:g}", "object_type": "demod_chain",
             "modem": {"type": "mpsk", "config": "qpsk_2400", "options": {"carrier_freq": str(f)}},
             "slicer": {"type": "quadrature", "config": "qpsk_2400", "options": {"lock_rate": "0.98"}},
@@ -149,6 +150,9 @@ def main():
                     help="signal: seeded packet-bearing recording of the workload's mode + AWGN (pymodem_amd.siggen), tiled to --samples; "
                          "noise: BASELINE.md's default_rng(1234) noise buffer")
     ap.add_argument("--cpu-sample", type=int, default=0, help="samples for the CPU baseline leg (0 = auto)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --chains-per-gpu chains on EVERY rank (beyond the config's own chains the sweep continues in finer "
+                         "steps, named in config.workload); strong: the config's own chains (8 for configs[3]) divided over the ranks")
     ap.add_argument("--also", type=int, default=1, help="1 (default, one GPU only): after the headline workload also measure fsk_9600, "
                     "bpsk_300 and qpsk_2400 (BASELINE configs[2], [1], [4]) briefly and attach them under 'also'")
     args = ap.parse_args()
@@ -164,10 +168,18 @@ def main():
         args.gpus = world
 
     # CPU baseline first: it forks one process per chain, which must happen before this process initialises the GPU
-    cpu_line = None
+    cpu_line, cpu_also = None, {}
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         factory, default_cpg, _ = WORKLOADS[args.workload]
         cpu_line = cpu_baseline(args, [factory(c) for c in range(args.chains_per_gpu or default_cpg)])
+        if args.also:                                 # the same oracle leg, shorter, beside every `also` workload
+            import copy
+            for name in ALSO:
+                if name != args.workload:
+                    a = copy.copy(args)
+                    a.workload, a.cpu_sample = name, ALSO_CPU_SAMPLE[name]
+                    f2, cpg2, _ = WORKLOADS[name]
+                    cpu_also[name] = cpu_baseline(a, [f2(c) for c in range(cpg2)], seconds=4.0, max_passes=4)
 
     # Libraries print banners on stdout (RCCL's version block when its first communicator comes up): everything but the JSON line
     # goes to stderr, the line itself to the real stdout.
@@ -202,7 +214,7 @@ def main():
         if cpu_line is not None:
             out["cpu_baseline"] = cpu_line
         if world == 1 and args.also:
-            out["also"] = also_workloads(args, env)
+            out["also"] = also_workloads(args, env, cpu_also)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())         # the ONE line of this run's stdout
     if use_dist:
@@ -210,7 +222,11 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def also_workloads(args, env):
+ALSO = ("fsk_9600", "bpsk_300", "qpsk_2400")
+ALSO_CPU_SAMPLE = {"fsk_9600": 4_800_000, "bpsk_300": 1_440_000, "qpsk_2400": 1_440_000, "afsk_1200_super_opt": 4_800_000}
+
+
+def also_workloads(args, env, cpu_also=None):
     """BASELINE configs[1], [2] and [4] measured after the headline workload in the same process (one GPU only): the single-chain
     BPSK-300 Costas path and the 8-chain QPSK-2400 path are bound by their sequential carrier loops -- one step each
     at full size -- and fsk_9600 is the shortest-tap FIR path.  Never allowed to break the main line."""
@@ -228,8 +244,18 @@ def also_workloads(args, env):
                          "gpu_kernel_ms_per_step": d["gpu_kernel_ms_per_step"], "packets": d["packets"],
                          "roofline_kernel": d["roofline"]["kernel"], "roofline_frac_alone": (d["roofline"]["alone"] or {}).get("frac"),
                          "roofline_fp64_alone_frac": d["roofline_fp64"]["alone_frac"], "dominant_by_time": d["roofline"]["dominant_by_time"]}
+            if cpu_also and name in cpu_also:
+                out[name]["cpu_baseline"] = cpu_also[name]
+            if name == "qpsk_2400":
+                # configs[4] has 64 chains: sharded 8 per GPU each GPU waits for eight sequential carrier loops, which cost what 64 in
+                # ONE launch cost (one lane per loop) -- the whole config on one GPU, one step, for comparison
+                a64 = copy.copy(a)
+                a64.chains_per_gpu, a64.steps, a64.warmup = 64, 1, 0
+                d64 = measure(a64, env)
+                out[name]["all_64_chains_on_one_gpu"] = {"value": d64["value"], "unit": d64["unit"], "ms_per_step": d64["ms_per_step"], "chains_per_gpu": 64,
+                                                         "gpu_kernel_ms_per_step": d64["gpu_kernel_ms_per_step"], "packets": d64["packets"]}
         except Exception as e:                                   # noqa: BLE001
-            out[name] = {"error": repr(e)[:300]}
+            out.setdefault(name, {})["error"] = repr(e)[:300]
     return out
 
 
@@ -243,8 +269,12 @@ def measure(args, env):
 
     factory, default_cpg, desc = WORKLOADS[args.workload]
     cpg = args.chains_per_gpu or default_cpg
-    nchains = cpg * world
-    my = [c for c in range(nchains) if c // cpg == rank]          # contiguous blocks: chains sharing a front end stay together
+    if args.scaling == "strong":                                  # the config's own chains divided over the ranks (contiguous blocks)
+        nchains = cpg
+        my = [c for c in range(nchains) if c * world // nchains == rank] if world <= nchains else ([rank] if rank < nchains else [])
+    else:
+        nchains = cpg * world
+        my = [c for c in range(nchains) if c // cpg == rank]      # contiguous blocks: chains sharing a front end stay together
     lines = {c: factory(c) for c in range(nchains)}
     names = [lines[c]["object_name"] for c in range(nchains)]
 
@@ -423,11 +453,13 @@ def measure(args, env):
         out = {
             "metric": "Msamples/s through demod_chain", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}", "chains_per_gpu": cpg, "chains_total": nchains,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}" + extra_chains_note(args, nchains), "chains_per_gpu": (cpg if args.scaling == "weak" else round(nchains / world, 3)), "chains_total": nchains,
                        "samples_per_recording": args.samples, "sample_rate": args.rate,
                        "buffer": BUFFER_DESC[args.buffer] + ", resident in HBM",
-                       "parallelism": f"chains sharded {cpg}/GPU x {world} GPU, packet gather to rank 0",
+                       "parallelism": (f"chains sharded {cpg}/GPU x {world} GPU, packet gather to rank 0" if args.scaling == "weak" else
+                                       f"the config's {nchains} chains divided over {world} GPU (contiguous blocks), packet gather to rank 0"),
+                       "dist": dist_info(use_dist),
                        "overlap": {0: "none", 1: "host half of step k behind GPU half of step k+1",
                                    2: "3-stage pipeline: demod(k+1) | slice(k) on a side stream | host(k-1)"}[min(args.overlap, 2)]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -477,6 +509,25 @@ def measure(args, env):
     return None
 
 
+def extra_chains_note(args, nchains):
+    """Names the chains a weak-scaling run adds beyond the config's own (they are not in the bundled file)."""
+    own = {"afsk_1200_super_opt": 8, "fsk_9600": 3, "bpsk_300": 1, "qpsk_2400": 64}[args.workload]
+    if nchains <= own:
+        return ""
+    factory = WORKLOADS[args.workload][0]
+    names = [factory(c)["object_name"] for c in range(own, nchains)]
+    shown = ", ".join(names[:4]) + (f", ... ({len(names)} in all)" if len(names) > 4 else "")
+    return f" + {len(names)} chains beyond the config's {own} (same modem, the sweep continued: {shown})"
+
+
+def dist_info(use_dist):
+    """What torch.distributed saw (the exchange's world), or None for a plain one-process run."""
+    if not use_dist:
+        return None
+    import torch.distributed as dist
+    return {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rank0_of": dist.get_world_size()}
+
+
 def pmc_traffic(args, kernel_class):
     """HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes of the same command (profiles/*_pmc.json:
     FETCH_SIZE and WRITE_SIZE in separate passes, x1024, FETCH doubled per the gfx950 note).  PMC counters cannot be read from
@@ -512,7 +563,7 @@ def _cpu_worker(job):
     return done, time.perf_counter() - t0
 
 
-def cpu_baseline(args, lines):
+def cpu_baseline(args, lines, seconds=12.0, max_passes=16):
     """The oracle (CPU restatement of the reference: numpy.convolve FIRs + C loops + Python codecs) on a bounded sample of the same
     workload: one process per chain, one core each, forked BEFORE anything touches the GPU.  A reported baseline, not
     the optimisation target."""
@@ -521,7 +572,7 @@ def cpu_baseline(args, lines):
     n = args.cpu_sample or min(args.samples, 9_600_000)          # 200 s of audio per chain keeps numpy's buffers modest
     _CPU_AUDIO = make_buffer(args)[:n]
     procs = max(1, min(len(lines), (os.cpu_count() or 2) // 2, 8))
-    jobs = [(args.rate, lines[k % len(lines)], 12.0, 16) for k in range(procs)]
+    jobs = [(args.rate, lines[k % len(lines)], seconds, max_passes) for k in range(procs)]
     t0 = time.perf_counter()
     if procs == 1:
         results = [_cpu_worker(jobs[0])]

@@ -265,7 +265,8 @@ int pm_slicer_stats(pm_ctx *ctx, int32_t *iterations, int32_t *chunk_len, int64_
  * hands them over; pointers inside the desc are read during pm_chain_create only.  A chain carries the AGC envelope and the
  * carrier-loop state from one pm_chain_run to the next, like the reference's stage objects; pm_chain_reset returns it to the
  * just-created state.  Output: the slicer's bytes and 1-based stream addresses; when more than `cap` were produced the call
- * returns PM_ERR_CAPACITY with the required size in *h_count. */
+ * returns PM_ERR_CAPACITY with the required size in *h_count -- the run HAS happened (AGC, loop and slicer state have moved on
+ * with the stream) and its output is kept on the device: call pm_chain_fetch with buffers of that size, do not run again. */
 enum { PM_MODEM_AFSK = 0, PM_MODEM_FSK = 1, PM_MODEM_BPSK = 2, PM_MODEM_MPSK = 3, PM_MODEM_AFSK_PLL = 4, PM_MODEM_QPSK = 5 };
 #define PM_CHAIN_INVERT 1       /* FSK: negate the filter output (fsk.py:153-154) */
 typedef struct pm_chain_desc {
@@ -286,6 +287,7 @@ typedef struct pm_chain pm_chain;
 int pm_chain_create(pm_ctx *ctx, const pm_chain_desc *desc, pm_chain **out);
 int pm_chain_run(pm_chain *chain, const int16_t *audio, int64_t n, int audio_on_device,
                  uint8_t *h_data, int64_t *h_addr, int64_t cap, int64_t *h_count);
+int pm_chain_fetch(pm_chain *chain, uint8_t *h_data, int64_t *h_addr, int64_t cap, int64_t *h_count);   /* the last run's output, again */
 int pm_chain_reset(pm_chain *chain);
 int pm_chain_destroy(pm_chain *chain);
 

@@ -162,6 +162,7 @@ _SIGS = {
     "pm_slicer_stats": ([_vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_i64)], _int),
     "pm_chain_create": ([_vp, ctypes.POINTER(ChainDesc), ctypes.POINTER(_vp)], _int),
     "pm_chain_run": ([_vp, _vp, _i64, _int, _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
+    "pm_chain_fetch": ([_vp, _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
     "pm_chain_reset": ([_vp], _int),
     "pm_chain_destroy": ([_vp], _int),
     "pm_lfsr_unscramble": ([_vp, _i64, ctypes.c_uint64, _int, ctypes.POINTER(ctypes.c_uint64), _vp], _int),

@@ -169,7 +169,10 @@ class RecordingPipeline:
         import queue
         import threading
         self._workers = max(1, int(slice_workers))
-        self._demod_streams = int(demod_streams)
+        # One demod stream.  A second one (round 1: alternate recordings on two streams so that the tail of one recording's FIR
+        # launches overlaps the head of the next) never gained anything measurable, and under this executor's host-side hand-off it
+        # showed an intermittent GPU memory fault that was not root-caused: the argument is accepted and ignored.
+        self._demod_streams = 1
         self._group = max(1, min(int(os.environ.get("PYMODEM_AMD_SLICE_GROUP", slice_group)), 8))
         self._host = ThreadPoolExecutor(max_workers=5)        # LFSR + codec of up to five recordings at a time (IL2P chains take 4-5 ms each)
         self._finish = ThreadPoolExecutor(max_workers=1)
@@ -481,12 +484,21 @@ def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced
         for k, sb in zip(members, AFSKModem.lpf_signs_batch([chains[k][1] for k in members], [corr[k] for k in members])):
             bitmaps[k] = chains[k][2].sign_bitmaps(sb)
 
-    # ---- everything else, chain by chain (work buffers shared across the group) ----------------------------------
+    # ---- everything else, chain by chain (work buffers shared across the group); FSK modems that are the same filter (equal taps
+    # and polarity: the chains of fsk_9600.json differ in stream and codec only) share ONE sign bitmap --------------------------------
+    from .modems import FSKModem
+    fsk_done = {}
     for k, ch in enumerate(chains):
         if bitmaps[k] is not None:
             continue
         modem = ch[1]
         modem.scratch_key = (group_key, type(modem).__name__)
+        if isinstance(modem, FSKModem):
+            key = modem.front_end_key()
+            if key not in fsk_done:
+                fsk_done[key] = modem.demod_signs(audio)
+            bitmaps[k] = ch[2].sign_bitmaps(fsk_done[key])
+            continue
         bitmaps[k] = ch[2].sign_bitmaps(modem.demod_signs(audio))
 
     # ---- all slicers in one batch, host stages in parallel ---------------------------------------------------------

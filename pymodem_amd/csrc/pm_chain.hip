@@ -22,6 +22,7 @@ struct pm_chain {
     double *d_a = nullptr, *d_b = nullptr; size_t a_n = 0, b_n = 0;
     uint64_t *d_bits_i = nullptr, *d_bits_q = nullptr; size_t bits_i_n = 0, bits_q_n = 0;
     uint8_t *d_data = nullptr; int64_t *d_addr = nullptr; size_t data_n = 0, addr_n = 0;
+    int64_t last_count = -1;                 // bytes the last pm_chain_run produced (still in d_data / d_addr): pm_chain_fetch
 };
 
 namespace {
@@ -209,9 +210,22 @@ int pm_chain_run(pm_chain *c, const int16_t *audio, int64_t n, int audio_on_devi
     job.cap = need;
     job.h_state = &c->slicer_state;                        // the slicer continues from run to run like the reference's object
     if (int rc = pm_slice_batch(ctx, &job, 1)) return rc;
-    const int64_t count = job.count;
+    c->last_count = job.count;
+    return pm_chain_fetch(c, h_data, h_addr, cap, h_count);
+}
+
+int pm_chain_fetch(pm_chain *c, uint8_t *h_data, int64_t *h_addr, int64_t cap, int64_t *h_count)
+{
+    PM_ARG(c != nullptr && h_count != nullptr && cap >= 0);
+    if (c->last_count < 0) return pm_set_error(PM_ERR_ARG, "pm_chain_fetch: no run to fetch from");
+    pm_ctx *ctx = c->ctx;
+    PM_CTX(ctx);
+    const int64_t count = c->last_count;
     *h_count = count;
-    if (count > cap) return pm_set_error(PM_ERR_CAPACITY, "pm_chain_run: %lld bytes decoded, caller's buffers hold %lld", (long long)count, (long long)cap);
+    // the chain's state has moved on with the run; its output stays in device memory until the next run, so a caller whose
+    // buffers were too small comes back with larger ones instead of running (and advancing the stream) again
+    if (count > cap) return pm_set_error(PM_ERR_CAPACITY, "pm_chain_run: %lld bytes decoded, caller's buffers hold %lld (pm_chain_fetch with larger ones)", (long long)count, (long long)cap);
+    PM_ARG(count == 0 || (h_data && h_addr));
     if (count) {
         if (int rc = pm_d2h(ctx, h_data, c->d_data, (size_t)count)) return rc;
         if (int rc = pm_d2h(ctx, h_addr, c->d_addr, (size_t)count * sizeof(int64_t))) return rc;

@@ -8,6 +8,7 @@
 #include "../../include/pymodem_amd.h"
 
 constexpr size_t PM_PINNED_BYTES = 256 * 1024;
+constexpr int kSweepRing = 64;
 
 struct pm_ctx {
     int device = 0;
@@ -31,7 +32,9 @@ struct pm_ctx {
     int64_t sl_target_lanes = 16384;   // walkers (= chunks) a slicer batch is cut into (pm_slicer_tune)
     int64_t sl_hint_shape = 0;         // chunk/launch geometry sl_launch_hint was learnt on
     int32_t sl_launch_hint = 0;        // lockstep launches to enqueue before the emit kernels without asking the device
-    int *sweep_count = nullptr;        // device counter of the last pm_afsk_sweep_signs on this ctx (inside d_scratch)
+    int *sweep_count = nullptr;        // device counter of the last pm_afsk_sweep_signs on this ctx (a slot of d_sweep)
+    int *d_sweep = nullptr;            // ring of kSweepRing counters, one per certified sweep in flight (own allocation)
+    int64_t sweep_seq = 0;
 };
 
 int pm_set_error(int code, const char *fmt, ...);

@@ -224,6 +224,87 @@ __global__ __launch_bounds__(kThreads) void fir_valid_kernel(const InT *__restri
     fir_tile<InT, R, NEG, VEC, SIGNS>(x, n, h, m, y, nout, bits, (int64_t)blockIdx.x);
 }
 
+// Short FIR (M <= 8 taps) on int16 audio with only the sign bitmap kept (fsk.py:149-159 feeding slicer.slice: the fsk_9600 chain):
+// the whole window of a lane's 8 outputs is 8 + M - 1 <= 15 samples, i.e. TWO 16-byte loads (its own eight samples and the eight
+// after them, which are the next lane's own: the second load is served by the cache), converted once in registers.  No LDS image, no
+// barrier: per 8 outputs 2 loads, 15 conversions, 8 M fma and one byte stored -- the kernel is bound by HBM (2 B in and 1/8 B out
+// per sample) as long as the conversions keep up.  Sums as everywhere: one fma per tap, ascending input index, from +0.
+typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
+
+// int16 -> binary64 without v_cvt_f64_i32 (a quarter-rate instruction: fifteen of them cost as much as the 64 fma of the sums):
+// u = v + 32768 is the sample with its sign bit flipped, {0x43300000, u} is the double 2^52 + u, and (2^52 + u) - (2^52 + 32768)
+// is exact -- the sample itself, +0 for 0.
+__device__ __forceinline__ double i16_biased_to_f64(uint32_t u) { return __hiloint2double(0x43300000, (int)u) - 4503599627403264.0; }
+
+constexpr int kShortIter = 8;      // bitmap bytes per lane: a wave that lives for one byte costs more to launch than to run
+
+template <int M, bool NEG>
+__global__ __launch_bounds__(kThreads) void fir_short_signs_i16_kernel(const int16_t *__restrict__ x, int64_t n, const double *__restrict__ h,
+                                                                       int64_t nout, uint64_t *__restrict__ bits)
+{
+    const int64_t nbytes = ((nout + 63) >> 6) * 8;                             // the bitmap is written in whole 64-bit words
+    double g[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) g[j] = h[M - 1 - j];                           // uniform: scalar loads
+    // the workgroup's lanes take consecutive bytes (coalesced loads and stores), kShortIter rounds of them
+    const int64_t byte0 = (int64_t)blockIdx.x * (kThreads * kShortIter) + threadIdx.x;
+    uint4v a, b;
+    auto fetch = [&](int64_t by, uint4v &qa, uint4v &qb) {
+        const int64_t go = by * 8;                                             // this byte's first output = its first input
+        qa = uint4v{0, 0, 0, 0};
+        qb = uint4v{0, 0, 0, 0};
+        if (by >= nbytes) return;
+        if (go + 15 < n) {
+            qa = *reinterpret_cast<const uint4v *>(x + go);
+            qb = *reinterpret_cast<const uint4v *>(x + go + 8);
+        } else {                                                               // the last bytes of the stream: sample by sample
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t v = go + k < n ? (uint32_t)(uint16_t)x[go + k] : 0u;
+                if (k < 8) qa[k >> 1] |= v << ((k & 1) * 16);
+                else qb[(k - 8) >> 1] |= v << ((k & 1) * 16);
+            }
+        }
+    };
+    fetch(byte0, a, b);
+#pragma unroll 1
+    for (int it = 0; it < kShortIter; ++it) {
+        const int64_t by = byte0 + (int64_t)it * kThreads;
+        uint4v na, nb;
+        fetch(by + kThreads, na, nb);                                          // the next round's loads fly during this round's sums
+        if (by < nbytes) {
+            double w[16];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const uint32_t q = (d < 4 ? a[d] : b[d - 4]) ^ 0x80008000u;
+                w[2 * d] = i16_biased_to_f64(q & 0xFFFFu);
+                w[2 * d + 1] = i16_biased_to_f64(q >> 16);
+            }
+            uint32_t sign = 0;                                                 // bit r = sign bit of output r
+            uint32_t zero = 0;                                                 // bit r = output r is zero (NEG only)
+            double acc[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] = 0.0;
+            // tap by tap across the eight outputs: eight independent chains in flight, each in ascending input order
+#pragma unroll
+            for (int j = 0; j < M; ++j)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) acc[r] = __builtin_fma(g[j], w[r + j], acc[r]);
+#pragma unroll
+            for (int r = 7; r >= 0; --r) {
+                // a sum is never -0 (it starts from +0), so acc >= 0 is "sign bit clear"; negated (fsk.py:153-154) it is "set, or zero"
+                sign = __builtin_amdgcn_alignbit(sign, (uint32_t)__double2hiint(acc[r]), 31);     // (sign << 1) | sign bit
+                if (NEG) zero = (zero << 1) | (acc[r] == 0.0 ? 1u : 0u);
+            }
+            const int64_t left = nout - by * 8;
+            const uint32_t valid = left >= 8 ? 0xFFu : left <= 0 ? 0u : (1u << left) - 1u;
+            const uint32_t byte = (NEG ? (sign | zero) : ~sign) & valid;
+            reinterpret_cast<uint8_t *>(bits)[by] = (uint8_t)byte;
+        }
+        a = na;
+        b = nb;
+    }
+}
+
 // Several sign-only FIRs with the same taps in ONE launch (blockIdx.y = stream): the output low-passes of a chain group.  One ramp
 // and one tail for the whole stage instead of one per chain.
 constexpr int kFirBatchMax = 16;
@@ -235,8 +316,11 @@ struct FirBatch {
 
 template <int R, bool NEG, bool VEC>
 __global__ __launch_bounds__(kThreads) void fir_signs_batch_kernel(FirBatch B, const double *__restrict__ h, int m,
-                                                                   const int *__restrict__ gate = nullptr, int gate_above = 0)
+                                                                   const int *__restrict__ gate = nullptr, int gate_above = 0,
+                                                                   int *__restrict__ reset = nullptr)
 {
+    // the last launch of a certified sweep clears the counter the NEXT sweep on this context will use (pm_ctx::d_sweep is a ring)
+    if (reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *reset = 0;
     if (gate && *gate <= gate_above) return;                          // a launch that only matters if an earlier kernel said so
     const int s = blockIdx.y;
     const int64_t n = B.n[s], nout = n - m + 1;
@@ -869,6 +953,17 @@ int fir_launch2(pm_ctx *ctx, const InT *d_x, int64_t n, const double *d_taps, in
     PmProf prof(ctx, sizeof(InT) == 2 ? PM_K_FIR_I16 : PM_K_FIR_F64);
     prof.work((double)n * sizeof(InT) + (d_bits ? (double)nout / 8 : (double)nout * 8), 2.0 * m * (double)nout);
     const bool vec = (((uintptr_t)d_x | (uintptr_t)d_y) & 15) == 0;          // 16-byte loads and stores
+    if (sizeof(InT) == 2 && d_bits && !d_y && vec && m >= 2 && m <= 8 && !getenv("PM_FIR_NO_SHORT")) {
+        // the register path for short taps (fir_short_signs_i16_kernel): one lane per bitmap byte
+        const int64_t lanes = ((nout + 63) >> 6) * 8;
+        const unsigned grid = (unsigned)pm_cdiv(lanes, (int64_t)kThreads * kShortIter);
+        const int16_t *xs16 = reinterpret_cast<const int16_t *>(d_x);
+#define PM_FIR_SHORT(MM) case MM: hipLaunchKernelGGL((fir_short_signs_i16_kernel<MM, NEG>), dim3(grid), dim3(kThreads), 0, ctx->stream, xs16, n, d_taps, nout, d_bits); break;
+        switch (m) { PM_FIR_SHORT(2) PM_FIR_SHORT(3) PM_FIR_SHORT(4) PM_FIR_SHORT(5) PM_FIR_SHORT(6) PM_FIR_SHORT(7) PM_FIR_SHORT(8) }
+#undef PM_FIR_SHORT
+        PM_HIP(hipGetLastError());
+        return PM_OK;
+    }
 #define PM_FIR_GO(VECF, SIGNF)                                                                                              \
     {                                                                                                                       \
         if (int rc = allow_lds(fir_valid_kernel<InT, R, NEG, VECF, SIGNF>, lds)) return rc;                                  \
@@ -1148,7 +1243,16 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
     char *base = (char *)ctx->d_scratch;
     double *M = (double *)base, *S = (double *)(base + b_m), *A = (double *)(base + 2 * b_m);
     unsigned long long *list = (unsigned long long *)(base + 2 * b_m + b_a);
-    int *count = (int *)(base + 2 * b_m + b_a + b_list);
+    // The counter of uncertain samples lives in a small ring of its own (not in the scratch block, which the next call on this
+    // context re-carves and may re-allocate: pm_afsk_sweep_last reads it later).  All slots start at zero; the last launch of a
+    // sweep clears the slot the next sweep will use, so there is no memset on the stream.
+    if (!ctx->d_sweep) {
+        PM_HIP(hipMalloc((void **)&ctx->d_sweep, kSweepRing * sizeof(int)));
+        PM_HIP(hipMemset(ctx->d_sweep, 0, kSweepRing * sizeof(int)));
+    }
+    int *count = ctx->d_sweep + (ctx->sweep_seq % kSweepRing);
+    int *count_next = ctx->d_sweep + ((ctx->sweep_seq + 1) % kSweepRing);
+    ctx->sweep_seq++;
     double *d_w = (double *)(base + 2 * b_m + b_a + b_list + 256);
     double *C = (double *)(base + 2 * b_m + b_a + b_list + 256 + b_w);
     ctx->sweep_count = count;
@@ -1170,7 +1274,6 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
             if (int rc = fir_launch<double>(ctx, M, nc, d_lpf, ml, A, nullptr, 0)) return rc;
     }
     const double E = 1e-10 * lpf_abs_sum * (1.0 + gmax) * (double)m * 1.4143 * x_bound + lpf_abs_sum * (1.0 + gmax) * e_slide;
-    PM_HIP(hipMemsetAsync(count, 0, sizeof(int), ctx->stream));
     if (fused) {
         PM_ARG(tones->tap_dev >= 0.0 && tones->tap_dev < 1e-6);
         SlideTones T{tones->mark_rot[0], tones->mark_rot[1], tones->mark_end[0], tones->mark_end[1],
@@ -1240,11 +1343,11 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
         if (vec) {
             if (int rc = allow_lds(fir_signs_batch_kernel<R, false, true>, lds)) return rc;
             hipLaunchKernelGGL((fir_signs_batch_kernel<R, false, true>), dim3((unsigned)std::min<int64_t>(ntiles, kGatedGrid), (unsigned)groups), dim3(kThreads), lds, ctx->stream, FB,
-                               d_lpf, ml, count, cap);
+                               d_lpf, ml, count, cap, count_next);
         } else {
             if (int rc = allow_lds(fir_signs_batch_kernel<R, false, false>, lds)) return rc;
             hipLaunchKernelGGL((fir_signs_batch_kernel<R, false, false>), dim3((unsigned)std::min<int64_t>(ntiles, kGatedGrid), (unsigned)groups), dim3(kThreads), lds, ctx->stream, FB,
-                               d_lpf, ml, count, cap);
+                               d_lpf, ml, count, cap, count_next);
         }
     }
     PM_HIP(hipGetLastError());

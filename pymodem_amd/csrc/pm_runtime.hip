@@ -98,6 +98,7 @@ int pm_ctx_destroy(pm_ctx *c)
     pm_prof_fold(c);
     for (hipEvent_t e : c->prof_free) (void)hipEventDestroy(e);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->d_sweep) (void)hipFree(c->d_sweep);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
@@ -173,7 +174,10 @@ int pm_free(pm_ctx *c, void *p)
     PM_CTX(c);
     PM_ARG(c != nullptr);
     if (!p) return PM_OK;
-    PM_HIP(hipStreamSynchronize(c->stream));
+    // device memory is shared by all contexts of a GPU and a buffer made on one stream is often read on another (sign bitmaps by the
+    // slicer streams, the slicers' output by the copy stream): wait for the whole device, not for this context's stream only.
+    // Nothing is freed in steady state (work buffers are pooled), so this costs nothing where it matters.
+    PM_HIP(hipDeviceSynchronize());
     PM_HIP(hipFree(p));
     return PM_OK;
 }
@@ -292,7 +296,7 @@ extern "C" int pm_prof_work(pm_ctx *c, int cls, double *bytes, double *flops)
 int pm_scratch_reserve(pm_ctx *c, size_t bytes)
 {
     if (bytes <= c->scratch_bytes) return PM_OK;
-    PM_HIP(hipStreamSynchronize(c->stream));
+    PM_HIP(hipDeviceSynchronize());      // see pm_free
     if (c->d_scratch) PM_HIP(hipFree(c->d_scratch));
     c->d_scratch = nullptr;
     c->scratch_bytes = 0;

@@ -574,7 +574,8 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
         all_words += pm_cdiv(jobs[j].n, 64);
         max_words = std::max(max_words, pm_cdiv(jobs[j].n, 64));
     }
-    int64_t lc_words = std::max<int64_t>(16, std::min<int64_t>(pm_cdiv(all_words, ctx->sl_target_lanes), 1024));
+    const int64_t lc_max = getenv("PM_SLICER_MAX_CHUNK_WORDS") ? std::max(16, atoi(getenv("PM_SLICER_MAX_CHUNK_WORDS"))) : 256;
+    int64_t lc_words = std::max<int64_t>(16, std::min<int64_t>(pm_cdiv(all_words, ctx->sl_target_lanes), lc_max));
     if (const char *e = getenv("PM_SLICER_CHUNK_WORDS")) { if (atoi(e) > 0) lc_words = atoi(e); }
     // Words per lockstep launch once the walkers are beyond their own chunks (never more than a chunk: see slice_walk_kernel).
     // A walker that retires mid-launch leaves its lane idle for the rest of it, so short launches waste less; each costs a dispatch.

@@ -434,6 +434,11 @@ class FSKModem(_DeviceStage):
         bits, nout = self._fir_signs(x, is_i16, "input_lpf", self.input_lpf, flags=1 if self.invert else 0)
         return SignBits(bits, None, nout)
 
+    def front_end_key(self):
+        """FSK modems with equal keys are the same filter on the same audio (the three chains of configs/fsk_9600.json:1-3 differ
+        in stream and codec only): the group executor computes their sign bitmap once (chain_execute.process_chains_device)."""
+        return ("fsk", float(self.sample_rate), self.input_lpf.tobytes(), bool(self.invert))
+
 
 # =============================================================================================
 class BPSKModem(_DeviceStage):

@@ -80,6 +80,29 @@ def slice_batch(slicers, bitmaps, ctx=None, defer=False):
     fetch(copy_ctx) -> the list, which copies it to the host on copy_ctx's stream (the pipelined executor fetches on another
     thread while this context already slices the next batch)."""
     ctx = ctx or slicers[0]._ctx or Context.default()
+    # Slicers of the same kind and state on the same bitmap(s) (chains that differ only after the slicer) are one job: run the first,
+    # hand its result and end state to the others.
+    first, dup_of = {}, {}
+    for k, (sl, bm) in enumerate(zip(slicers, bitmaps)):
+        key = (bm[0].ptr.value if bm[0] is not None else None, bm[1].ptr.value if bm[1] is not None else None, bm[2],
+               bytes(sl._params()), bytes(sl._state))
+        if key in first:
+            dup_of[k] = first[key]
+        else:
+            first[key] = k
+    if dup_of:
+        uniq = [k for k in range(len(slicers)) if k not in dup_of]
+        inner = slice_batch([slicers[k] for k in uniq], [bitmaps[k] for k in uniq], ctx, defer=True)
+
+        def fetch_all(copy_ctx=None):
+            got = dict(zip(uniq, inner(copy_ctx)))
+            return [got[dup_of.get(k, k)] for k in range(len(slicers))]
+        for k, src in dup_of.items():
+            ctypes.memmove(ctypes.byref(slicers[k]._state), ctypes.byref(slicers[src]._state), ctypes.sizeof(SlicerState))
+            slicers[k].last_stats = slicers[src].last_stats
+            slicers[k].phase_clock, slicers[k].streamaddress = slicers[src].phase_clock, slicers[src].streamaddress
+            slicers[k]._ctx = slicers[k]._ctx or ctx
+        return fetch_all if defer else fetch_all()
     out = [None] * len(slicers)
     fetchers = []
     for base in range(0, len(slicers), 64):

@@ -242,6 +242,35 @@ def test_whole_chain_entry_point_errors():
     assert len(nc.run(np.zeros(0, np.int16))) == 0
 
 
+def test_whole_chain_capacity_error_keeps_the_run():
+    """Buffers that are too small: PM_ERR_CAPACITY, the chain's state has advanced with the stream, and pm_chain_fetch hands the
+    same run's output over again -- two pieces fed that way equal the single call on the whole input cut in the same place."""
+    import ctypes
+    from pymodem_amd import chain_builder as cb, chain_execute as ce
+    from pymodem_amd._native import lib
+    line = {"object_name": "x", "object_type": "demod_chain", "modem": {"type": "fsk", "config": "9600", "options": {}},
+            "slicer": {"type": "binary", "config": "9600", "options": {}}, "stream": {"type": "lfsr", "options": {}}, "codec": {"type": "ax25"}}
+    audio = noise_i16(96000)
+    ch = cb.build_chain(48000, line)
+    nc = ce.NativeChain(ch[1], ch[2])
+    want = [nc.run(audio[:48000]), nc.run(audio[48000:])]
+    nc.reset()
+    got = []
+    for piece in (audio[:48000], audio[48000:]):
+        a = np.ascontiguousarray(piece)
+        small_d, small_a, count = np.empty(16, np.uint8), np.empty(16, np.int64), ctypes.c_int64()
+        rc = lib().pm_chain_run(nc._h, a.ctypes.data_as(ctypes.c_void_p), len(a), 0, small_d.ctypes.data_as(ctypes.c_void_p),
+                                small_a.ctypes.data_as(ctypes.c_void_p), 16, ctypes.byref(count))
+        assert rc == -4 and count.value > 16                      # PM_ERR_CAPACITY, *h_count = what is needed
+        d, ad, c2 = np.empty(count.value, np.uint8), np.empty(count.value, np.int64), ctypes.c_int64()
+        assert lib().pm_chain_fetch(nc._h, d.ctypes.data_as(ctypes.c_void_p), ad.ctypes.data_as(ctypes.c_void_p), count.value, ctypes.byref(c2)) == 0
+        assert c2.value == count.value
+        got.append((d, ad))
+    for (d, ad), w in zip(got, want):
+        assert np.array_equal(d, w.data) and np.array_equal(ad, w.address)
+    nc.close()
+
+
 @pytest.mark.parametrize("demod_streams", [1, 2])
 def test_recording_pipeline_soak(config_lines, demod_streams):
     """Ninety recordings of three different kinds through one pipeline, several in flight on every stage: each result equals the

@@ -1,0 +1,45 @@
+"""End-to-end parity at BASELINE size under the driver's `-m gpu` run: whole chains of the bench workloads over the full 10-minute
+(28.8 M-sample) packet-bearing bench buffer, group executor on the GPU against the oracle in canonical FIR order -- slicer bytes,
+stream addresses and packets (payload, address, corrected bytes) must be identical.  fsk_9600 = BASELINE configs[2] (three chains
+on one front end), bpsk_300 = configs[1], two chains of the qpsk_2400 sweep = configs[4], two of the AFSK gain sweep = configs[3].
+The oracle side costs about a minute of one host core in all."""
+import numpy as np
+import pytest
+
+import bench
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+N = 28_800_000
+
+
+def _buffer(workload):
+    class A:
+        pass
+    a = A()
+    a.samples, a.rate, a.workload, a.buffer = N, 48000, workload, "signal"
+    return bench.make_buffer(a)
+
+
+@pytest.mark.parametrize("workload,chain_ids", [("fsk_9600", [0, 1, 2]), ("bpsk_300", [0]), ("qpsk_2400", [0, 5]),
+                                                ("afsk_1200_super_opt", [0, 7])])
+def test_chains_at_full_size_match_the_oracle(workload, chain_ids):
+    from pymodem_amd import chain_builder as cb, chain_execute as ce
+    audio = _buffer(workload)
+    factory = bench.WORKLOADS[workload][0]
+    lines = [factory(c) for c in chain_ids]
+    chains = [cb.build_chain(48000, line) for line in lines]
+    stages = {}
+    packets = ce.process_chains_device(chains, audio, stages=stages)
+    total = 0
+    for k, line in enumerate(lines):
+        want = O.run_chain(O.build_chain(48000, line), audio, canon=True)
+        got = stages["sliced"][k]
+        assert len(got.data) > 10000
+        assert np.array_equal(got.data, want["slice_data"]), f"{workload} chain {chain_ids[k]}: slicer bytes differ"
+        assert np.array_equal(got.address, want["slice_addr"]), f"{workload} chain {chain_ids[k]}: stream addresses differ"
+        a = [(p.streamaddress, bytes(bytearray(p.data)), p.BytesCorrected) for p in packets[k]]
+        b = [(p.streamaddress, bytes(bytearray(p.data)), p.BytesCorrected) for p in want["packets"]]
+        assert a == b, f"{workload} chain {chain_ids[k]}: packets differ"
+        total += len(b)
+    assert total > 0            # (the inverted fsk_9600 chain decodes nothing, in the reference too)
