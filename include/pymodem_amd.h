@@ -70,6 +70,7 @@ int pm_malloc(pm_ctx *ctx, size_t bytes, void **d_out);
 int pm_free(pm_ctx *ctx, void *d_ptr);
 int pm_h2d(pm_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);   /* async on the ctx stream */
 int pm_d2h(pm_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);   /* synchronous */
+int pm_d2d(pm_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);        /* device to device, on the context's stream */
 int pm_memset(pm_ctx *ctx, void *d_dst, int value, size_t bytes);
 
 /* HIP-event timer on the ctx stream: start, enqueue work, stop -> elapsed milliseconds. */
@@ -269,6 +270,10 @@ int pm_slicer_stats(pm_ctx *ctx, int32_t *iterations, int32_t *chunk_len, int64_
  * with the stream) and its output is kept on the device: call pm_chain_fetch with buffers of that size, do not run again. */
 enum { PM_MODEM_AFSK = 0, PM_MODEM_FSK = 1, PM_MODEM_BPSK = 2, PM_MODEM_MPSK = 3, PM_MODEM_AFSK_PLL = 4, PM_MODEM_QPSK = 5 };
 #define PM_CHAIN_INVERT 1       /* FSK: negate the filter output (fsk.py:153-154) */
+/* AFSK / FSK only, opt-in: keep the last sum(M - 1) input samples of a run and put them in front of the next run's input, so that a
+ * recording fed in pieces gives the bytes, addresses and packets of the single call on the whole.  Without it every
+ * run starts its FIRs afresh like the reference's per-call numpy.convolve(..., 'valid') (afsk.py:151-166, fsk.py:151). */
+#define PM_CHAIN_CARRY_HISTORY 2
 typedef struct pm_chain_desc {
     int32_t modem;                                   /* PM_MODEM_* */
     int32_t flags;

@@ -78,6 +78,7 @@ class ChainDesc(ctypes.Structure):
 
 MODEM_AFSK, MODEM_FSK, MODEM_BPSK, MODEM_MPSK, MODEM_AFSK_PLL, MODEM_QPSK = range(6)
 CHAIN_INVERT = 1
+CHAIN_CARRY_HISTORY = 2
 KERNEL_CLASSES = ("fir_i16", "fir_f64", "afsk_correlate", "signs", "slice_iter", "slice_emit", "agc", "loop")
 PKT_MAX = 1280
 
@@ -116,6 +117,7 @@ _SIGS = {
     "pm_last_error": ([ctypes.c_char_p, ctypes.c_size_t], _int),
     "pm_ctx_create": ([_int, ctypes.POINTER(_vp)], _int),
     "pm_ctx_create_prio": ([_int, _int, ctypes.POINTER(_vp)], _int),
+    "pm_d2d": ([_vp, _vp, _vp, ctypes.c_size_t], _int),
     "pm_event_query": ([_vp], _int),
     "pm_event_sync": ([_vp], _int),
     "pm_ctx_create_cumask": ([_int, ctypes.POINTER(ctypes.c_uint32), _int, ctypes.POINTER(_vp)], _int),

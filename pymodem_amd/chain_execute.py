@@ -441,7 +441,7 @@ def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced
     afsk_groups, corr = {}, {}
     int16_audio = audio.dtype == np.dtype(np.int16)
     for k, ch in enumerate(chains):
-        if isinstance(ch[1], AFSKModem):
+        if isinstance(ch[1], AFSKModem) and not ch[1].carry_history:      # a modem that carries FIR history runs on its own input
             ch[1].use_context(ctx)
             afsk_groups.setdefault(ch[1].mark_key(), []).append(k)
     gi = 0
@@ -493,7 +493,7 @@ def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced
             continue
         modem = ch[1]
         modem.scratch_key = (group_key, type(modem).__name__)
-        if isinstance(modem, FSKModem):
+        if isinstance(modem, FSKModem) and not modem.carry_history:
             key = modem.front_end_key()
             if key not in fsk_done:
                 fsk_done[key] = modem.demod_signs(audio)
@@ -534,12 +534,13 @@ class NativeChain:
             return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double if dtype == np.float64 else ctypes.c_int32)), len(a)
         if isinstance(modem, AFSKModem):
             d.modem = N.MODEM_AFSK
+            d.flags = N.CHAIN_CARRY_HISTORY if modem.carry_history else 0
             d.input_fir, d.n_input_fir = vec(modem.input_bpf)
             d.mark_i, d.n_corr = vec(modem.mark_correlator_i)
             d.mark_q, d.space_i, d.space_q = vec(modem.mark_correlator_q)[0], vec(modem.space_correlator_i)[0], vec(modem.space_correlator_q)[0]
             d.output_fir, d.n_output_fir = vec(modem.output_lpf)
         elif isinstance(modem, FSKModem):
-            d.modem, d.flags = N.MODEM_FSK, (N.CHAIN_INVERT if modem.invert else 0)
+            d.modem, d.flags = N.MODEM_FSK, (N.CHAIN_INVERT if modem.invert else 0) | (N.CHAIN_CARRY_HISTORY if modem.carry_history else 0)
             d.input_fir, d.n_input_fir = vec(modem.input_lpf)
         else:
             d.modem = {BPSKModem: N.MODEM_BPSK, MPSKModem: N.MODEM_MPSK, AFSKPLLModem: N.MODEM_AFSK_PLL, QPSKModem: N.MODEM_QPSK}[type(modem)]

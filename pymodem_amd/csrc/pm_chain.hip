@@ -23,6 +23,7 @@ struct pm_chain {
     uint64_t *d_bits_i = nullptr, *d_bits_q = nullptr; size_t bits_i_n = 0, bits_q_n = 0;
     uint8_t *d_data = nullptr; int64_t *d_addr = nullptr; size_t data_n = 0, addr_n = 0;
     int64_t last_count = -1;                 // bytes the last pm_chain_run produced (still in d_data / d_addr): pm_chain_fetch
+    std::vector<int16_t> hist;               // PM_CHAIN_CARRY_HISTORY: the last sum(M - 1) input samples of the previous run
 };
 
 namespace {
@@ -64,6 +65,9 @@ int pm_chain_create(pm_ctx *ctx, const pm_chain_desc *desc, pm_chain **out)
     if (d.modem == PM_MODEM_BPSK || d.modem == PM_MODEM_MPSK || d.modem == PM_MODEM_AFSK_PLL || d.modem == PM_MODEM_QPSK)
         PM_ARG(d.wavetable != nullptr);
     PM_ARG((d.quadrature != 0) == (d.modem == PM_MODEM_MPSK || d.modem == PM_MODEM_QPSK));
+    // carried FIR history is defined for the modems whose demod() is FIRs and pointwise operations only (the others normalise by the
+    // maximum of each call's buffer, agc.py:67: pieces cannot be the whole there)
+    PM_ARG(!(d.flags & PM_CHAIN_CARRY_HISTORY) || d.modem == PM_MODEM_AFSK || d.modem == PM_MODEM_FSK);
     pm_chain *c = new pm_chain();
     c->ctx = ctx;
     c->d = d;
@@ -99,6 +103,7 @@ int pm_chain_reset(pm_chain *c)
     c->loop = c->loop0;
     c->agc_state[0] = c->agc_state[1] = 0.0;
     c->slicer_state = pm_slicer_state{};
+    c->hist.clear();
     return PM_OK;
 }
 
@@ -125,7 +130,32 @@ int pm_chain_run(pm_chain *c, const int16_t *audio, int64_t n, int audio_on_devi
     const pm_chain_desc &d = c->d;
     const double *T = c->d_taps;
     const int16_t *x = audio;
-    if (!audio_on_device) {
+    if (d.flags & PM_CHAIN_CARRY_HISTORY) {
+        // seamless pieces: [the previous run's last sum(M - 1) input samples | this run's] goes through the FIR
+        // cascade, whose 'valid' output is then exactly the continuation of the previous run's (see _DeviceStage._with_history)
+        const int64_t hlen = (int64_t)d.n_input_fir - 1 + (d.modem == PM_MODEM_AFSK ? (int64_t)d.n_corr - 1 + d.n_output_fir - 1 : 0);
+        const int64_t nt = (int64_t)c->hist.size();
+        if (int rc = grow(ctx, c->d_audio, c->audio_bytes, (size_t)(nt + n) * 2)) return rc;
+        if (nt) { if (int rc = pm_h2d(ctx, c->d_audio, c->hist.data(), (size_t)nt * 2)) return rc; }
+        if (audio_on_device) { if (int rc = pm_d2d(ctx, c->d_audio + nt * 2, audio, (size_t)n * 2)) return rc; }
+        else { if (int rc = pm_h2d(ctx, c->d_audio + nt * 2, audio, (size_t)n * 2)) return rc; }
+        // the new tail: the last hlen samples of [tail | audio]
+        const int64_t take = std::min(hlen, n), keep = std::min(hlen - take, nt);
+        std::vector<int16_t> next((size_t)(keep + take));
+        if (keep) memcpy(next.data(), c->hist.data() + (nt - keep), (size_t)keep * 2);
+        if (take) {
+            if (audio_on_device) { if (int rc = pm_d2h(ctx, next.data() + keep, audio + (n - take), (size_t)take * 2)) return rc; }
+            else memcpy(next.data() + keep, audio + (n - take), (size_t)take * 2);
+        }
+        if (int rc = pm_ctx_sync(ctx)) return rc;          // the tail's upload has left c->hist before it is replaced
+        c->hist.swap(next);
+        x = (const int16_t *)c->d_audio;
+        n += nt;
+        if (n <= hlen) {                                   // not one output yet: the samples wait in the tail
+            c->last_count = 0;
+            return PM_OK;
+        }
+    } else if (!audio_on_device) {
         if (int rc = grow(ctx, c->d_audio, c->audio_bytes, (size_t)n * 2)) return rc;
         if (int rc = pm_h2d(ctx, c->d_audio, audio, (size_t)n * 2)) return rc;
         x = (const int16_t *)c->d_audio;

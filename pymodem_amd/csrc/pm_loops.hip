@@ -87,8 +87,11 @@ __device__ __forceinline__ double pi_update(LoopRegs &L, double sample)
 {
     L.proportional = L.gain * L.p_rate * sample;                         // pi_control.py:26, (gain*p_rate)*sample
     double in = L.integral + L.gain * (L.i_rate * sample);               // pi_control.py:27
-    in = in > L.i_limit ? L.i_limit : in;                                // pi_control.py:28-31
-    in = in < -L.i_limit ? -L.i_limit : in;
+    // pi_control.py:28-31: `if I > limit: I = limit` / `if I < -limit: I = -limit` are min and max for every value that is not a
+    // NaN (the integral never is: it is a clamped sum of finite products) -- one instruction each instead of compare + two selects,
+    // and they sit on the loop-carried path
+    in = __builtin_fmin(in, L.i_limit);
+    in = __builtin_fmax(in, -L.i_limit);
     L.integral = in;
     return L.proportional + in;                                          // pi_control.py:32
 }

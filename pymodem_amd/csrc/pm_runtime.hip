@@ -200,6 +200,14 @@ int pm_d2h(pm_ctx *c, void *h_dst, const void *d_src, size_t bytes)
     return PM_OK;
 }
 
+int pm_d2d(pm_ctx *c, void *d_dst, const void *d_src, size_t bytes)
+{
+    PM_CTX(c);
+    PM_ARG(bytes == 0 || (d_dst && d_src));
+    if (bytes) PM_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return PM_OK;
+}
+
 int pm_memset(pm_ctx *c, void *d_dst, int value, size_t bytes)
 {
     PM_CTX(c);

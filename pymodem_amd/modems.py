@@ -72,6 +72,52 @@ class _DeviceStage:
             return ctx.upload(a), True
         return ctx.upload(np.ascontiguousarray(a, dtype=np.float64)), False
 
+    # ---- seamless chunked input, opt-in --------------------------------------------------------------
+    # The reference's demod() is numpy.convolve(..., 'valid') per call (afsk.py:151-166, fsk.py:151): every call loses the first
+    # M - 1 outputs of every filter, so a recording fed in pieces is NOT the recording fed at once.  With carry_history = True a
+    # modem whose demod() is a cascade of FIRs and pointwise operations (AFSK correlator, FSK) keeps the last H = sum(M_i - 1)
+    # input samples of a call and puts them in front of the next call's input: the cascade's 'valid' output over [tail | new] is
+    # exactly the continuation of the previous call's output, so the pieces give the slicer the stream -- and, with the slicer's
+    # own carried state, the bytes, addresses and packets -- of the single call on the concatenation.  The first call has no tail
+    # and is the reference's call.  Default off: the reference's per-call behaviour.
+    carry_history = False
+
+    def _history_len(self):
+        return 0
+
+    def _with_history(self, x, is_i16):
+        """x (DeviceBuffer of this call's samples) -> the buffer demod() runs on: [carried tail | x]; remembers the new tail."""
+        if not self.carry_history:
+            return x
+        h = self._history_len()
+        ctx = self._ctx
+        tail = getattr(self, "_hist", None)
+        if tail is not None and tail.dtype != x.dtype:
+            raise ValueError("carry_history: the sample type changed between calls")
+        nt = 0 if tail is None else len(tail)
+        if nt:
+            buf = ctx.scratch((self._own_key(), "hist_in"), nt + x.n, x.dtype)
+            check(lib().pm_h2d(ctx.handle, buf.ptr, tail.ctypes.data_as(ctypes.c_void_p), tail.nbytes))
+            check(lib().pm_d2d(ctx.handle, buf.ptr.value + tail.nbytes, x.ptr, x.n * x.dtype.itemsize))
+        else:
+            buf = x
+        # the new tail: the last h samples of [tail | x]
+        take = min(h, x.n)
+        fresh = x.view(x.n - take, take).download() if take else np.zeros(0, x.dtype)
+        keep = h - take
+        self._hist = np.concatenate([tail[nt - min(keep, nt):], fresh]) if (nt and keep) else fresh
+        return buf
+
+    def _starved(self, x, signs, device_out):
+        """carry_history: [tail | x] is still shorter than the cascade needs for one output -- nothing comes out of this call (the
+        samples wait in the tail).  None when there is enough."""
+        if not self.carry_history or x.n > self._history_len():
+            return None
+        if signs:
+            return SignBits(self._ctx.scratch((self._own_key(), "signs", "starved"), 2, np.uint64), None, 0)
+        y = self._ctx.scratch((self._key(), "starved"), 1, np.float64).view(0, 0)
+        return y if device_out else np.zeros(0, np.float64)
+
     def _fir(self, x, is_i16, taps_name, taps, flags=0, tag=None):
         ctx = self._ctx
         m = len(taps)
@@ -108,6 +154,7 @@ class _DeviceStage:
             self._agc_state[0] = self._agc_state[1] = 0.0
         if hasattr(self, "_loop0"):
             ctypes.memmove(ctypes.byref(self._loop), self._loop0, ctypes.sizeof(Loop))
+        self._hist = None                              # carry_history: the next call starts a new stream
 
     def _finish(self, y, device_out):
         return y if device_out else y.download()
@@ -213,14 +260,31 @@ class AFSKModem(_DeviceStage):
         x, is_i16 = self._input(input_audio)
         return self._fir(x, is_i16, "input_bpf", self.input_bpf)
 
+    def _history_len(self):
+        return len(self.input_bpf) - 1 + len(self.mark_correlator_i) - 1 + len(self.output_lpf) - 1
+
     def front_end_key(self):
         return ("afsk", float(self.sample_rate), self.input_bpf.tobytes())
 
     def demod(self, input_audio, device_out=False):   # afsk.py:148-167
+        if self.carry_history:
+            x, is_i16 = self._input(input_audio)
+            x = self._with_history(x, is_i16)
+            empty = self._starved(x, False, device_out)
+            if empty is not None:
+                return empty
+            return self.back_end(self._fir(x, is_i16, "input_bpf", self.input_bpf), device_out)
         return self.back_end(self.front_end(input_audio), device_out)
 
     def demod_signs(self, input_audio):
         """demod() for a slicer: the output low-pass writes only the sign bitmap.  -> SignBits"""
+        if self.carry_history:
+            x, is_i16 = self._input(input_audio)
+            x = self._with_history(x, is_i16)
+            empty = self._starved(x, True, True)
+            if empty is not None:
+                return empty
+            return self.back_end(self._fir(x, is_i16, "input_bpf", self.input_bpf), signs=True)
         return self.back_end(self.front_end(input_audio), signs=True)
 
     def mark_key(self):
@@ -424,13 +488,24 @@ class FSKModem(_DeviceStage):
         else:
             self.input_lpf = T.windowed_sinc(self.input_lpf_tap_count, [self.input_lpf_cutoff], self.sample_rate, pass_zero=True)
 
+    def _history_len(self):
+        return len(self.input_lpf) - 1
+
     def demod(self, input_audio, device_out=False):   # fsk.py:149-159
         x, is_i16 = self._input(input_audio)
+        x = self._with_history(x, is_i16)
+        empty = self._starved(x, False, device_out)
+        if empty is not None:
+            return empty
         y = self._fir(x, is_i16, "input_lpf", self.input_lpf, flags=1 if self.invert else 0)
         return self._finish(y, device_out)
 
     def demod_signs(self, input_audio):
         x, is_i16 = self._input(input_audio)
+        x = self._with_history(x, is_i16)
+        empty = self._starved(x, True, True)
+        if empty is not None:
+            return empty
         bits, nout = self._fir_signs(x, is_i16, "input_lpf", self.input_lpf, flags=1 if self.invert else 0)
         return SignBits(bits, None, nout)
 

@@ -52,3 +52,56 @@ def test_gpu_chain_continues_like_the_reference(golden, config_lines, tag):
                 sliced = nc.run(seg)                      # the C chain object carries AGC, loop and slicer state itself
             pkts = chain[4].decode(chain[3].stream_unscramble_8bit(sliced))
             check_segment(g, f"{tag}__seg{k}", sliced.data, sliced.address, pkts)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,ci", [("afsk_1200", 0), ("afsk_1200", 2), ("afsk_1200_ax25_super_opt", 5), ("fsk_9600", 0), ("fsk_9600", 2), ("fsk_4800", 0)])
+@pytest.mark.parametrize("run", ["stages", "signs", "group", "native"])
+def test_carried_fir_history_makes_pieces_equal_the_whole(golden, config_lines, cfg, ci, run):
+    """SURVEY 8f-3, opt-in carry_history: the 240 000-sample golden input fed in three uneven pieces gives the reference's SINGLE-CALL
+    slicer bytes, stream addresses, LFSR bytes and packets (tests/golden/synth_chains.npz), for AFSK and FSK chains, through the
+    stage objects, the sign-bitmap path, the group executor and the whole-chain C entry point.  (The first piece is shorter than
+    some filters' history, the second starts mid-word of the bitmap.)"""
+    from conftest import noise_i16
+    from pymodem_amd import chain_builder as cb, chain_execute as ce
+    from pymodem_amd.data_classes import AddressedArray
+    g = golden("synth_chains")
+    prefix = f"{cfg}__c{ci}__48k_l"
+    if prefix + "_slice_data" not in g.files:
+        pytest.skip("no golden for this chain")
+    line = config_lines(cfg + ".json")[ci]
+    audio = noise_i16(240000)
+    cuts = [0, 173, 100003, 240000]
+    chain = cb.build_chain(48000, line)
+    chain[1].carry_history = True
+    nc = ce.NativeChain(chain[1], chain[2]) if run == "native" else None
+    data, addr, pkts, lfsr = [], [], [], []
+    for a, b in zip(cuts, cuts[1:]):
+        seg = audio[a:b]
+        if run == "stages":
+            sliced = chain[2].slice(chain[1].demod(seg))
+        elif run == "signs":
+            sliced = chain[2].slice(chain[1].demod_signs(seg))
+        elif run == "group":
+            st = {}
+            ce.process_chains_device([chain], seg, stages=st)       # (also runs stream and codec: they are fed again below from a copy)
+            sliced = st["sliced"][0]
+            data.append(np.array(sliced.data)); addr.append(np.array(sliced.address))
+            continue
+        else:
+            sliced = nc.run(seg)
+        data.append(np.array(sliced.data)); addr.append(np.array(sliced.address))
+        lf = chain[3].stream_unscramble_8bit(sliced)
+        lfsr.append(np.array(lf.data))
+        pkts += chain[4].decode(lf)
+    data, addr = np.concatenate(data), np.concatenate(addr)
+    assert np.array_equal(data, g[prefix + "_slice_data"]) and np.array_equal(addr, g[prefix + "_slice_addr"])
+    if run == "group":
+        return
+    assert np.array_equal(np.concatenate(lfsr), g[prefix + "_lfsr_data"])
+    assert np.array_equal(np.array([p.streamaddress for p in pkts], dtype=np.int64), g[prefix + "_pkt_addr"])
+    assert np.array_equal(np.array([b for p in pkts for b in p.data], dtype=np.uint8), g[prefix + "_pkt_data"])
+    # without the flag the same pieces are the reference's per-call behaviour: fewer samples reach the slicer
+    plain = cb.build_chain(48000, line)
+    n = sum(len(plain[2].slice(plain[1].demod(audio[a:b]))) for a, b in zip(cuts[1:], cuts[2:]))
+    assert n <= len(data)
