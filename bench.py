@@ -157,8 +157,10 @@ def main():
                     "bpsk_300 and qpsk_2400 (BASELINE configs[2], [1], [4]) briefly and attach them under 'also'")
     args = ap.parse_args()
 
-    if os.environ.get("BENCH_SWITCH_INTERVAL"):
-        sys.setswitchinterval(float(os.environ["BENCH_SWITCH_INTERVAL"]))
+    # A dozen Python threads take turns here (the submitting thread, slicer workers, host, finish and post stages), each mostly inside
+    # native calls that release the interpreter lock; with CPython's default 5 ms switch interval a thread coming back from a 20 us
+    # native call can wait milliseconds for the lock.  0.5 ms keeps the hand-offs short (measured: 1.47 -> 1.33 ms per step).
+    sys.setswitchinterval(float(os.environ.get("BENCH_SWITCH_INTERVAL", "0.0005")))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -70,6 +70,9 @@ int pm_malloc(pm_ctx *ctx, size_t bytes, void **d_out);
 int pm_free(pm_ctx *ctx, void *d_ptr);
 int pm_h2d(pm_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);   /* async on the ctx stream */
 int pm_d2h(pm_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);   /* synchronous */
+/* The context's internal work block (slicer state, sweep intermediates): grow it to at least reserve_bytes now (0: leave it) and
+ * report its size.  A host that knows how large its batches will get reserves once instead of paying a free + malloc on the way. */
+int pm_ctx_scratch(pm_ctx *ctx, size_t reserve_bytes, size_t *h_bytes);
 int pm_d2d(pm_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);        /* device to device, on the context's stream */
 int pm_memset(pm_ctx *ctx, void *d_dst, int value, size_t bytes);
 
@@ -158,6 +161,15 @@ int pm_afsk_magnitudes(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
                        const double *d_space_i, const double *d_space_q, int m, const pm_afsk_tones *h_tones, double *d_mark_mag,
                        double *d_space_mag, double *h_bound);
 int pm_afsk_sweep_last(pm_ctx *ctx, int64_t *h_uncertain);
+/* Deferred fallback for pipelined hosts.  By default every certified sweep ends with three launches that look at its counter of
+ * uncertain samples and -- only if the list overflowed (65536: digital silence, input far below the stated bound) -- run the exact
+ * chains after all; in the normal case they leave at once but still cost the stream three dispatches per sweep.  With
+ * pm_afsk_sweep_mode(ctx, 1) they are not enqueued: take a ticket after the call, and once the sweep has FINISHED (stream or event
+ * synchronised) ask pm_afsk_sweep_result; if *h_uncertain > *h_capacity the sweep's bitmaps are not valid and the caller runs the
+ * exact path for those modems (pm_afsk_correlate + pm_fir_signs_f64).  Tickets stay valid for 63 further sweeps on the context. */
+int pm_afsk_sweep_mode(pm_ctx *ctx, int deferred);
+int pm_afsk_sweep_ticket(pm_ctx *ctx, int64_t *h_ticket);
+int pm_afsk_sweep_result(pm_ctx *ctx, int64_t ticket, pm_ctx *via, int64_t *h_uncertain, int64_t *h_capacity);   /* via: the context whose stream carries the 4-byte copy (NULL: ctx) */
 
 /* Sign bitmap of a float64 stream: bit k of the little-endian uint64 array = (x[k] >= 0), the only
  * property of a sample the slicers read (slicer.py:85,99-102,210-232).  d_bits holds (n+63)/64 words. */

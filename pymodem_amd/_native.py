@@ -118,6 +118,7 @@ _SIGS = {
     "pm_ctx_create": ([_int, ctypes.POINTER(_vp)], _int),
     "pm_ctx_create_prio": ([_int, _int, ctypes.POINTER(_vp)], _int),
     "pm_d2d": ([_vp, _vp, _vp, ctypes.c_size_t], _int),
+    "pm_ctx_scratch": ([_vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)], _int),
     "pm_event_query": ([_vp], _int),
     "pm_event_sync": ([_vp], _int),
     "pm_ctx_create_cumask": ([_int, ctypes.POINTER(ctypes.c_uint32), _int, ctypes.POINTER(_vp)], _int),
@@ -151,6 +152,9 @@ _SIGS = {
                             ctypes.POINTER(_vp)] + [ctypes.POINTER(AfskTones)], _int),
     "pm_afsk_magnitudes": ([_vp, _vp, _i64, _dbl, _vp, _vp, _vp, _vp, _int, ctypes.POINTER(AfskTones), _vp, _vp, ctypes.POINTER(_dbl)], _int),
     "pm_afsk_sweep_last": ([_vp, ctypes.POINTER(_i64)], _int),
+    "pm_afsk_sweep_mode": ([_vp, _int], _int),
+    "pm_afsk_sweep_ticket": ([_vp, ctypes.POINTER(_i64)], _int),
+    "pm_afsk_sweep_result": ([_vp, _i64, _vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)], _int),
     "pm_signs_f64": ([_vp, _vp, _i64, _vp], _int),
     "pm_agc_apply": ([_vp, _vp, _i64, ctypes.POINTER(AGCParams), ctypes.POINTER(_dbl)], _int),
     "pm_costas_bpsk": ([_vp, ctypes.POINTER(Loop), _int, _vp, _vp, _i64, _i64, _vp, _i64], _int),

@@ -163,7 +163,7 @@ class RecordingPipeline:
     stages are the sign bitmaps (one bit per sample), kept in slice_workers + 2 rotating slots (demod runs one recording ahead); a GPU event, not a host wait,
     orders slicer after demod.  Results are identical to process_chains_table on each recording (tests/test_gpu_chains.py)."""
 
-    def __init__(self, slice_workers=2, demod_streams=1, slice_group=8, slots=None):
+    def __init__(self, slice_workers=2, demod_streams=1, slice_group=4, slots=None):
         from collections import deque
         import os
         import queue
@@ -189,6 +189,7 @@ class RecordingPipeline:
         # three streams (HIP maps streams onto a handful of hardware queues; more slicer streams than that end up sharing a queue
         # with the demod stream and stall it).
         self._pending = queue.Queue()
+        self._batch_seq = {}
         self._copy_ctx = Context.side(index=201, high_priority=False)     # a copy stream of its own (prefetch() uploads on 200)
         self._copy_lock = threading.Lock()
         self._slots = int(slots or os.environ.get("PYMODEM_AMD_BITMAP_SLOTS", 0) or 16)
@@ -229,21 +230,30 @@ class RecordingPipeline:
             t = time.perf_counter()
             try:
                 slicers, bitmaps = [], []
-                for chains, bm, ready, _ in items:
+                for chains, bm, ready, _, sweeps, audio in items:
+                    if sweeps:                                 # finished (their event has): overflowed ones are redone exactly, here
+                        resolve_sweeps(chains, bm, sweeps, audio, side)
                     slicers += [ch[2] for ch in chains]
                     bitmaps += bm
                 fetch = slice_batch(slicers, bitmaps, side, defer=True)
+                if not getattr(side, "_slicer_block_reserved", False):
+                    # the stream's work block (checkpoints, symbol bitmaps, lists: ~150 MB per recording) sized for a batch of four from
+                    # the first batch on: growing it later is a free + malloc in the middle of the pipeline (10 ms measured)
+                    side._slicer_block_reserved = True        # once per context (contexts outlive pipelines)
+                    have = ctypes.c_size_t()
+                    check(lib().pm_ctx_scratch(side.handle, 0, ctypes.byref(have)))
+                    check(lib().pm_ctx_scratch(side.handle, int(have.value * min(self._group, 4) / len(items)), None))
                 # The slicers' bytes and addresses are still in device memory: whichever host-stage thread needs them first copies
                 # the whole batch over on the copy stream (this worker's stream is already slicing the next batch).
                 shared = _BatchFetch(fetch, self._copy_ctx, self._copy_lock)
                 at = 0
-                for chains, _, _, fut in items:
+                for chains, _, _, fut, _, _ in items:
                     fut.set_result((shared, at, at + len(chains)))
                     at += len(chains)
             except BaseException as e:                         # noqa: BLE001
-                for _, _, _, fut in items:
-                    if not fut.done():
-                        fut.set_exception(e)
+                for it in items:
+                    if not it[3].done():
+                        it[3].set_exception(e)
             dt = time.perf_counter() - t
             self.stage_seconds["slice"] += dt
             self.slice_batches += 1
@@ -293,7 +303,9 @@ class RecordingPipeline:
         if hasattr(input_audio, "result"):                    # a prefetch() handle: the demod stream waits for the copy on the GPU
             input_audio, copied, upload_slot = input_audio.result()
             dctx.wait_event(copied)
-        bitmaps = process_chains_device(chains, input_audio, _bitmaps_only=True, _slot=slot, _ctx=dctx)
+        st = {}
+        bitmaps = process_chains_device(chains, input_audio, stages=st, _bitmaps_only=True, _slot=slot, _ctx=dctx)
+        sweeps = st.get("sweeps") or []
         self._events[slot] = ready = dctx.record_event(self._events[slot])   # bitmaps complete at this point of the stream
         if upload_slot is not None:
             self._upload_guard[upload_slot] = dctx.record_event(self._upload_guard.get(upload_slot))   # its own event, re-used per slot
@@ -301,7 +313,7 @@ class RecordingPipeline:
 
         from concurrent.futures import Future
         f_sliced, f_fetched = Future(), Future()
-        self._pending.put((chains, bitmaps, ready, f_sliced))
+        self._pending.put((chains, bitmaps, ready, f_sliced, sweeps, input_audio))
         # the bitmap slot (and the slicers' output block keyed by it) is free again once the slicers' output is on the host
         self._inflight.append(f_fetched)
 
@@ -360,6 +372,25 @@ class RecordingPipeline:
         self._host.shutdown(wait=True)
         self._finish.shutdown(wait=True)
         self._post.shutdown(wait=True)
+
+
+def resolve_sweeps(chains, bitmaps, sweeps, audio, ctx):
+    """The certified gain sweeps of one recording have FINISHED: any whose list of uncertain samples overflowed (digital silence,
+    audio far below the stated bound -- never on a signal) did not leave valid bitmaps; its chains are demodulated again with the
+    exact kernels on `ctx` (BPF, correlators, low-pass + sign), which is what the in-call fallback of pm_afsk_sweep_signs would have
+    done.  Returns the number of sweeps redone."""
+    redone = 0
+    for sweep, ks in sweeps:
+        if not AFSKModem.sweep_overflowed(sweep, via=ctx):
+            continue
+        redone += 1
+        for k in ks:
+            modem = chains[k][1]
+            modem.use_context(ctx)
+            modem.scratch_key = ("chain-group", "sweep-fallback")
+            chains[k][2]._ctx = chains[k][2]._ctx or ctx
+            bitmaps[k] = chains[k][2].sign_bitmaps(modem.demod_signs(audio))
+    return redone
 
 
 def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced_only=False, _bitmaps_only=False, _slot=0, _ctx=None):
@@ -439,6 +470,7 @@ def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced
     # ---- AFSK: correlator banks that share their mark filters run as one launch per group of up to 8, the rest one by one;
     # then the output low-passes of all chains with equal taps run as one batched sign-only launch ----------------------------
     afsk_groups, corr = {}, {}
+    sweeps = []                        # certified sweeps run: ((ctx, ticket), chain indices), resolved once they have finished
     int16_audio = audio.dtype == np.dtype(np.int16)
     for k, ch in enumerate(chains):
         if isinstance(ch[1], AFSKModem) and not ch[1].carry_history:      # a modem that carries FIR history runs on its own input
@@ -448,13 +480,15 @@ def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced
     for key, members in afsk_groups.items():
         # a gain sweep (members differ in space_gain only, int16 audio so that |band-passed| <= sum|bpf| * 32768): certified sign
         # bitmaps from two correlator pairs and two low-passes for the whole sweep (pm_afsk_sweep_signs)
-        sweeps = {}
+        sweep_sets = {}
         if int16_audio and _USE_SWEEP:
             for k in members:
                 sk = chains[k][1].sweep_key()
                 if sk is not None:
-                    sweeps.setdefault(sk, []).append(k)
-        for part_all in sweeps.values():
+                    sweep_sets.setdefault(sk, []).append(k)
+        if sweep_sets:                 # the overflow fallback of these sweeps is ours (resolve_sweeps), not three gated launches each
+            check(lib().pm_afsk_sweep_mode(ctx.handle, 1))
+        for part_all in sweep_sets.values():
             for base in range(0, len(part_all), 8):
                 part = part_all[base:base + 8]
                 mods = [chains[k][1] for k in part]
@@ -463,8 +497,11 @@ def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced
 
                 bpf = shared_front(mods[0])
                 got = AFSKModem.sweep_signs(mods, bpf, float(np.abs(mods[0].input_bpf).sum()) * 32768.0)
+                sweeps.append((got[0].sweep, list(part)))
                 for k, sb in zip(part, got):
                     bitmaps[k] = chains[k][2].sign_bitmaps(sb)
+        if sweep_sets:
+            check(lib().pm_afsk_sweep_mode(ctx.handle, 0))
         members = [k for k in members if bitmaps[k] is None]
         for base in range(0, len(members), 8):
             part = members[base:base + 8]
@@ -503,7 +540,12 @@ def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced
 
     # ---- all slicers in one batch, host stages in parallel ---------------------------------------------------------
     if _bitmaps_only:
+        if stages is not None:
+            stages["sweeps"] = sweeps
         return bitmaps
+    if sweeps:
+        ctx.sync()                     # the sweeps have finished: look at their counters
+        resolve_sweeps(chains, bitmaps, sweeps, audio, ctx)
     sliced = slice_batch([ch[2] for ch in chains], bitmaps)
     if _sliced_only:
         return sliced

@@ -35,6 +35,7 @@ struct pm_ctx {
     int *sweep_count = nullptr;        // device counter of the last pm_afsk_sweep_signs on this ctx (a slot of d_sweep)
     int *d_sweep = nullptr;            // ring of kSweepRing counters, one per certified sweep in flight (own allocation)
     int64_t sweep_seq = 0;
+    bool sweep_deferred = false;       // pm_afsk_sweep_mode: the overflow fallback is the caller's (pm_afsk_sweep_result), not three gated launches
 };
 
 int pm_set_error(int code, const char *fmt, ...);

@@ -878,8 +878,11 @@ __global__ __launch_bounds__(kThreads) void afsk_slide_lpf_kernel(const double *
 // sum in the canonical order of afsk_correlate_kernel / fir_valid_kernel.  Runs after fir_sweep_kernel (its bitmap bytes are final).
 __global__ __launch_bounds__(64) void sweep_exact_kernel(const double *__restrict__ x, const double *__restrict__ mi, const double *__restrict__ mq,
                                                          const double *__restrict__ space, int mc, const double *__restrict__ lpf, int ml,
-                                                         SweepArgs P, const unsigned long long *__restrict__ list, const int *__restrict__ count, int cap)
+                                                         SweepArgs P, const unsigned long long *__restrict__ list, const int *__restrict__ count, int cap,
+                                                         int *__restrict__ reset = nullptr)
 {
+    // deferred fallback (pm_afsk_sweep_mode): this is the sweep's last launch and clears the next sweep's counter (see d_sweep)
+    if (reset && blockIdx.x == 0 && threadIdx.x == 0) *reset = 0;
     // One wave per listed sample: the ml correlator-bank outputs the low-pass needs are independent of each other and go to the
     // lanes (each in the canonical tap order); the low-pass sum itself is sequential and stays with lane 0.  (One LANE per sample
     // took 0.25-0.5 ms for a single entry -- 4 mc ml dependent fmas -- and the demod stream waits for it.)
@@ -1317,9 +1320,13 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
     {
         PmProf prof(ctx, PM_K_SIGNS);
         hipLaunchKernelGGL(sweep_exact_kernel, dim3(1024), dim3(64), (size_t)ml * sizeof(double), ctx->stream, d_x, d_mark_i, d_mark_q, d_space, m,
-                           d_lpf, ml, P, list, count, cap);
+                           d_lpf, ml, P, list, count, cap, ctx->sweep_deferred ? count_next : nullptr);
     }
     PM_HIP(hipGetLastError());
+    // Deferred fallback: the caller looks at the counter once the sweep has finished (pm_afsk_sweep_result) and runs the exact
+    // chains itself in the (degenerate) overflow case; the three gated launches below -- which in the normal case only look at
+    // the counter and leave, but cost the demod stream three dispatches per sweep -- are not enqueued.
+    if (ctx->sweep_deferred) return PM_OK;
     // More uncertain samples than the list holds (degenerate input: silence, amplitudes far below the caller's bound): the exact
     // chain of every modem runs after all -- the same launches as pm_afsk_correlate_group + pm_fir_signs_f64_batch, each workgroup
     // of which first looks at the counter and leaves at once in the normal case.  No host round trip either way.
@@ -1394,6 +1401,38 @@ int pm_afsk_sweep_last(pm_ctx *ctx, int64_t *h_uncertain)
     PM_HIP(hipMemcpyAsync(&v, ctx->sweep_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     PM_HIP(hipStreamSynchronize(ctx->stream));
     *h_uncertain = v;
+    return PM_OK;
+}
+
+int pm_afsk_sweep_mode(pm_ctx *ctx, int deferred)
+{
+    PM_ARG(ctx != nullptr);
+    ctx->sweep_deferred = deferred != 0;
+    return PM_OK;
+}
+
+int pm_afsk_sweep_ticket(pm_ctx *ctx, int64_t *h_ticket)
+{
+    PM_ARG(ctx != nullptr && h_ticket != nullptr);
+    *h_ticket = ctx->sweep_seq - 1;                    // -1: no sweep yet
+    return PM_OK;
+}
+
+int pm_afsk_sweep_result(pm_ctx *ctx, int64_t ticket, pm_ctx *via, int64_t *h_uncertain, int64_t *h_capacity)
+{
+    PM_CTX(ctx);
+    PM_ARG(h_uncertain != nullptr && ticket >= 0 && ticket < ctx->sweep_seq && ctx->d_sweep != nullptr);
+    if (ctx->sweep_seq - ticket >= kSweepRing)
+        return pm_set_error(PM_ERR_ARG, "pm_afsk_sweep_result: ticket %lld is %lld sweeps old, the ring holds %d", (long long)ticket,
+                            (long long)(ctx->sweep_seq - ticket), kSweepRing);
+    // the caller knows the sweep has finished; the four bytes come over on `via`'s stream (the caller's own: a slicer worker must not
+    // queue behind the demod stream's next recordings, nor take the device-wide wait of a synchronous copy)
+    pm_ctx *c = via ? via : ctx;
+    int *h = (int *)c->h_pinned + 1;                       // word 1 of the mailbox (word 0: the loops' flag)
+    PM_HIP(hipMemcpyAsync(h, ctx->d_sweep + (ticket % kSweepRing), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PM_HIP(hipStreamSynchronize(c->stream));
+    *h_uncertain = *h;
+    if (h_capacity) *h_capacity = 65536;
     return PM_OK;
 }
 

@@ -174,10 +174,10 @@ int pm_free(pm_ctx *c, void *p)
     PM_CTX(c);
     PM_ARG(c != nullptr);
     if (!p) return PM_OK;
-    // device memory is shared by all contexts of a GPU and a buffer made on one stream is often read on another (sign bitmaps by the
-    // slicer streams, the slicers' output by the copy stream): wait for the whole device, not for this context's stream only.
-    // Nothing is freed in steady state (work buffers are pooled), so this costs nothing where it matters.
-    PM_HIP(hipDeviceSynchronize());
+    // The context's own stream is waited for; a buffer that another context still reads (sign bitmaps by a slicer stream, the slicers'
+    // output by the copy stream) is the CALLER's to keep alive until that reader is done -- the pipelined executor's slot bookkeeping
+    // does.  (A device-wide wait here stalls a worker for as long as the other threads keep their streams busy: 15-25 ms measured.)
+    PM_HIP(hipStreamSynchronize(c->stream));
     PM_HIP(hipFree(p));
     return PM_OK;
 }
@@ -301,14 +301,22 @@ extern "C" int pm_prof_work(pm_ctx *c, int cls, double *bytes, double *flops)
     return PM_OK;
 }
 
+extern "C" int pm_ctx_scratch(pm_ctx *c, size_t reserve_bytes, size_t *h_bytes)
+{
+    PM_CTX(c);
+    if (reserve_bytes) { if (int rc = pm_scratch_reserve(c, reserve_bytes)) return rc; }
+    if (h_bytes) *h_bytes = c->scratch_bytes;
+    return PM_OK;
+}
+
 int pm_scratch_reserve(pm_ctx *c, size_t bytes)
 {
     if (bytes <= c->scratch_bytes) return PM_OK;
-    PM_HIP(hipDeviceSynchronize());      // see pm_free
+    PM_HIP(hipStreamSynchronize(c->stream));
     if (c->d_scratch) PM_HIP(hipFree(c->d_scratch));
     c->d_scratch = nullptr;
     c->scratch_bytes = 0;
-    size_t want = bytes + bytes / 4 + 4096;
+    size_t want = bytes + bytes / 2 + 4096;      // grow in big steps: every growth is a stream wait and a hipFree
     PM_HIP(hipMalloc(&c->d_scratch, want));
     c->scratch_bytes = want;
     return PM_OK;

@@ -139,7 +139,7 @@ class Context:
         if raw is None or raw.n < need:
             if raw is not None:
                 raw.free()
-            raw = DeviceBuffer(self, need + need // 8 + 256, np.uint8)
+            raw = DeviceBuffer(self, need + need // 2 + 256, np.uint8)      # big steps: a growth frees, and a free waits for the stream
             pool[tag] = raw
         out = DeviceBuffer(self, int(n), dtype, ptr=raw.ptr.value)
         out._parent = raw

@@ -402,7 +402,21 @@ class AFSKModem(_DeviceStage):
         else:
             check(lib().pm_afsk_sweep_signs(*args))
         AFSKModem.sweeps_run += 1
-        return [SignBits(b, None, nout) for b in bits]
+        out = [SignBits(b, None, nout) for b in bits]
+        ticket = ctypes.c_int64()
+        check(lib().pm_afsk_sweep_ticket(ctx.handle, ctypes.byref(ticket)))
+        for sb in out:
+            sb.sweep = (ctx, ticket.value)             # for sweep_overflowed() (deferred fallback, pm_afsk_sweep_mode)
+        return out
+
+    @staticmethod
+    def sweep_overflowed(sweep, via=None):
+        """(ctx, ticket) of a FINISHED certified sweep -> True if it had more uncertain samples than its list holds: with the fallback
+        deferred (pm_afsk_sweep_mode) its bitmaps are then not valid and the exact chain has to run for its modems."""
+        ctx, ticket = sweep
+        n, cap = ctypes.c_int64(), ctypes.c_int64()
+        check(lib().pm_afsk_sweep_result(ctx.handle, ticket, via.handle if via is not None else None, ctypes.byref(n), ctypes.byref(cap)))
+        return n.value > cap.value
 
     @staticmethod
     def sweep_uncertain(ctx):

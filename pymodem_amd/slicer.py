@@ -72,7 +72,7 @@ class _SlicerBase:
         return slice_batch([self], [(bits_i, bits_q, n)])[0]
 
 
-def slice_batch(slicers, bitmaps, ctx=None, defer=False):
+def slice_batch(slicers, bitmaps, ctx=None, defer=False, reserve=1.0, out_tag=None):
     """Stage 2 of slice() for many independent streams in ONE pm_slice_batch call (shared iteration launches).
     bitmaps[k] = (bits_i, bits_q | None, n) from slicers[k].sign_bitmaps().  Returns one AddressedArray per stream.
     `ctx`: the context (stream) to run on; the bitmaps must be complete (their producer stream synchronised) if it is not the
@@ -92,7 +92,7 @@ def slice_batch(slicers, bitmaps, ctx=None, defer=False):
             first[key] = k
     if dup_of:
         uniq = [k for k in range(len(slicers)) if k not in dup_of]
-        inner = slice_batch([slicers[k] for k in uniq], [bitmaps[k] for k in uniq], ctx, defer=True)
+        inner = slice_batch([slicers[k] for k in uniq], [bitmaps[k] for k in uniq], ctx, defer=True, reserve=reserve, out_tag=out_tag)
 
         def fetch_all(copy_ctx=None):
             got = dict(zip(uniq, inner(copy_ctx)))
@@ -109,13 +109,13 @@ def slice_batch(slicers, bitmaps, ctx=None, defer=False):
         group = list(range(base, min(base + 64, len(slicers))))
         saved = [SlicerState.from_buffer_copy(slicers[k]._state) for k in group]
         try:
-            fetchers.append(_slice_group(ctx, slicers, bitmaps, group, out, tight=True))
+            fetchers.append(_slice_group(ctx, slicers, bitmaps, group, out, tight=True, reserve=reserve, out_tag=out_tag))
         except NativeError as e:                      # a stream produced more than twice its nominal symbol count: full-size buffers
             if "capacity" not in str(e):
                 raise
             for k, st in zip(group, saved):
                 ctypes.memmove(ctypes.byref(slicers[k]._state), ctypes.byref(st), ctypes.sizeof(SlicerState))
-            fetchers.append(_slice_group(ctx, slicers, bitmaps, group, out, tight=False))
+            fetchers.append(_slice_group(ctx, slicers, bitmaps, group, out, tight=False, reserve=reserve, out_tag=out_tag))
 
     def fetch(copy_ctx=None):
         for f in fetchers:
@@ -127,7 +127,7 @@ def slice_batch(slicers, bitmaps, ctx=None, defer=False):
 _TIGHT_FACTOR = 1.5
 
 
-def _slice_group(ctx, slicers, bitmaps, group, out, tight):
+def _slice_group(ctx, slicers, bitmaps, group, out, tight, reserve=1.0, out_tag=None):
     jobs = (SliceJob * len(group))()
     # One device block for the whole batch's output (addresses first, then bytes) and ONE device-to-host copy per batch.  The
     # hard bound is one symbol per sample; the clock can at most double its nominal rate (every crossing pulls it towards zero,
@@ -146,7 +146,10 @@ def _slice_group(ctx, slicers, bitmaps, group, out, tight):
     for cap in caps:
         d_off.append(at)
         at += (cap + 4 + 7) // 8 * 8
-    block = ctx.scratch((slicers[group[0]]._own_key(), "slice_out"), at, np.uint8)
+    # `reserve`: ask for that many times the bytes (a caller whose batches vary in size asks for the largest once: a growth later is a
+    # free and a malloc in the middle of the pipeline); `out_tag`: the caller's own key for the block (it must stay untouched until
+    # fetched: the pipelined executor rotates sixteen per slicer stream)
+    block = ctx.scratch((out_tag if out_tag is not None else slicers[group[0]]._own_key(), "slice_out"), int(at * max(1.0, reserve)), np.uint8)
     for j, k in enumerate(group):
         sl, (bi, bq, n) = slicers[k], bitmaps[k]
         sl._ctx = sl._ctx or ctx

@@ -349,6 +349,38 @@ def test_gain_sweep_path_equals_exact_group_path(config_lines):
                    [(p.streamaddress, bytes(bytearray(p.data))) for p in res[other][1][c]]
 
 
+@pytest.mark.parametrize("kind", ["silence", "whisper"])
+def test_deferred_sweep_fallback_on_degenerate_input(config_lines, kind, monkeypatch):
+    """The group executor defers the certified sweeps' overflow fallback (pm_afsk_sweep_mode): on digital silence and on audio far below
+    the stated bound every sample is uncertain, the list overflows, and the executor must redo those chains with the exact kernels --
+    sequentially and in the pipelined executor.  Bytes and addresses equal the oracle's for every chain."""
+    from pymodem_amd import chain_builder as cb, chain_execute as ce
+    lines = config_lines("afsk_1200_ax25_super_opt.json")
+    n = 400000
+    audio = np.zeros(n, np.int16) if kind == "silence" else (np.random.default_rng(3).integers(-1, 2, n)).astype(np.int16)
+    want = [O.run_chain(O.build_chain(48000, l), audio, canon=True) for l in lines]
+    redone = []
+    real = ce.resolve_sweeps
+    monkeypatch.setattr(ce, "resolve_sweeps", lambda *a: redone.append(real(*a)) or redone[-1])
+    st = {}
+    ce.process_chains_device([cb.build_chain(48000, l) for l in lines], audio, stages=st)
+    if kind == "silence":
+        assert sum(redone) >= 1                                       # every sample uncertain: the lists overflowed, the chains were redone
+    for c in range(len(lines)):
+        assert np.array_equal(st["sliced"][c].data, want[c]["slice_data"]) and np.array_equal(st["sliced"][c].address, want[c]["slice_addr"]), c
+    del redone[:]
+    pipe = ce.RecordingPipeline()
+    futs = [pipe.submit([cb.build_chain(48000, l) for l in lines], audio) for _ in range(4)]
+    rows = [f.result() for f in futs]
+    pipe.close()
+    if kind == "silence":
+        assert sum(redone) >= 4
+    ref = ce.process_chains_table([cb.build_chain(48000, l) for l in lines], audio)
+    for r in rows:
+        for c in range(len(lines)):
+            assert np.array_equal(r[c], ref[c])
+
+
 def test_bench_line_contract_with_and_without_the_exchange(tmp_path):
     """bench.py as the driver runs it: exactly one line on stdout, every field of the contract, the same packets whether the
     per-recording exchange really runs (one-rank RCCL gather, PYMODEM_AMD_FORCE_GATHER) or not."""
