@@ -34,7 +34,7 @@ typedef enum pm_status {
     PM_ERR_ARG = -2,            /* bad argument (null pointer, n < taps, unsupported size) */
     PM_ERR_NODEV = -3,          /* no gfx950 device visible */
     PM_ERR_CAPACITY = -4,       /* caller's output buffer too small; required size reported */
-    PM_ERR_NOCONVERGE = -5      /* internal: slicer fixed point not reached within the iteration cap */
+    PM_ERR_NOCONVERGE = -5      /* internal: slicer walkers still alive after the launch cap (cannot happen: a walker ends with its stream) */
 } pm_status;
 
 typedef struct pm_ctx pm_ctx;
@@ -221,8 +221,9 @@ int pm_costas_qpsk(pm_ctx *ctx, pm_loop *h_loops, int nloops, const double *d_ta
 /* ---- slicers ----------------------------------------------------------------------------------
  * Symbol-timing PLL + bit decision + byte packing.  Input is the sign bitmap(s) of the demodulated
  * stream.  Output: bytes and their 1-based stream addresses (index of the sample that completed the
- * byte), exactly the AddressedData list of the reference.  Evaluated chunk-parallel as a fixed-point
- * iteration on the per-chunk phase_clock; the fixed point is bitwise the sequential result. */
+ * byte), exactly the AddressedData list of the reference.  Evaluated chunk-parallel: one walker per chunk runs the
+ * reference's recurrence, leaves a clock checkpoint per 64-sample word and walks on into the next chunks until it meets the
+ * trail in front of it; when no walker is left the result is bitwise the sequential run's (pm_slicer.hip). */
 typedef struct pm_slicer_params {
     double samples_per_symbol;       /* sample_rate / symbol_rate              slicer.py:51 */
     double lock_rate;                /*                                         slicer.py:22-33,124-165 */
@@ -264,11 +265,11 @@ typedef struct pm_slice_job {
     pm_slicer_state *h_state;        /* in/out; NULL = start from the just-tuned state and do not report the end state */
 } pm_slice_job;
 int pm_slice_batch(pm_ctx *ctx, pm_slice_job *h_jobs, int njobs);           /* njobs <= 64 */
-/* How many chunks (lanes) a batch is cut into on this ctx; 0 restores the default 65536 = one wave per SIMD, the fastest when the
- * slicer has the GPU to itself.  Fewer, longer chunks mean fewer dependent launches and fewer resident waves: better when other
- * streams keep the CUs busy (the pipelined executor sets 24576 on its slicer streams).  Results do not depend on it. */
+/* How many chunks (= walkers) a batch is cut into on this ctx, within 1024..16384 samples per chunk; 0 restores the default 16384.
+ * Lane-steps are N (1 + m/L) for merge length m (10-20 k samples) and chunk length L, the depth is (L + longest merge) x the
+ * step time: long chunks are cheap, short ones are quick.  Results do not depend on it. */
 int pm_slicer_tune(pm_ctx *ctx, int64_t target_lanes);
-/* Diagnostics of the last slicer call on this ctx: fixed-point iterations used, chunk length, chunks. */
+/* Diagnostics of the last slicer call on this ctx: lockstep launches until no walker was left, chunk length, chunks. */
 int pm_slicer_stats(pm_ctx *ctx, int32_t *iterations, int32_t *chunk_len, int64_t *chunks);
 
 /* ---- whole chain: modem + slicer in one call ---------------------------------------------------

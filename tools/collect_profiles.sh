@@ -14,4 +14,5 @@ cd $GRAFT_REPO_ROOT
 KB_REPS=5 python tools/kernel_bench.py > $OUT/kernel_bench.jsonl 2>/dev/null
 python bench.py --workload fsk_9600 --no-cpu-baseline --also 0 > $OUT/bench_fsk_9600.json 2> $OUT/bench_fsk_9600.err
 python bench.py --overlap 0 --steps 10 --no-cpu-baseline --also 0 > $OUT/bench_overlap0.json 2> $OUT/bench_overlap0.err
+python bench.py --gpus 1 --steps 20 --warmup 5 --also 0 > $OUT/bench_driver_cmd.json 2> $OUT/bench_driver_cmd.err
 cat $OUT/bench_default.json

@@ -32,10 +32,10 @@ for name, ctr in [("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")]:
     for k, (n, v) in agg.items():
         res.setdefault(k, {})[ctr + "_KB_avg_per_launch"] = round(v / n, 1)
         res[k][ctr + "_launches"] = n
-CLASSES = {"fir_i16": ["fir_valid_kernel<short"], "fir_f64": ["fir_valid_kernel<double", "fir_sweep_kernel", "afsk_slide_lpf_kernel"],
+CLASSES = {"fir_i16": ["fir_valid_kernel<short", "fir_short_signs_i16_kernel"], "fir_f64": ["fir_valid_kernel<double", "fir_sweep_kernel", "afsk_slide_lpf_kernel"],
            "afsk_correlate": ["afsk_correlate_kernel", "afsk_slide_kernel"],
            "signs": ["signs_kernel", "sweep_exact_kernel", "afsk_group_kernel", "fir_signs_batch_kernel", "pack_group_taps_kernel"],
-           "slice_iter": ["slice_iter_kernel"], "slice_emit": ["slice_count_kernel", "slice_scan_kernel", "slice_pack_kernel"]}
+           "slice_iter": ["slice_walk_kernel", "slice_iter_kernel"], "slice_emit": ["slice_count_kernel", "slice_scan_kernel", "slice_pack_kernel"]}
 out = {"workload": workload, "samples": samples,
        "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (two separate passes) --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
        "corrections": "bytes = counter * 1024; FETCH_SIZE doubled (gfx950 reports half the bytes of a coalesced streaming read, MI355X_MICROARCH.md "
@@ -57,6 +57,9 @@ for cls, prefixes in CLASSES.items():
 json.dump(out, open(f"profiles/{tag}_{workload}_pmc.json", "w"), indent=1)
 shutil.copyfile("gpurun_out/kernel_bench.jsonl", f"profiles/{tag}_kernel_bench.jsonl")
 shutil.copyfile("gpurun_out/bench_default.json", f"profiles/{tag}_bench_default.json")
+for extra in ("bench_fsk_9600", "bench_overlap0", "bench_driver_cmd"):
+    if os.path.exists(f"gpurun_out/{extra}.json"):
+        shutil.copyfile(f"gpurun_out/{extra}.json", f"profiles/{tag}_{extra}.json")
 for k, v in out["kernels"].items():
     print(f"{k:45s} traffic {v['traffic_bytes_per_launch'] / 1e6:9.1f} MB/launch")
 print(open(f"profiles/{tag}_{workload}_kernel_stats.csv").read()[:1500])
