@@ -169,7 +169,8 @@ int pm_afsk_sweep_last(pm_ctx *ctx, int64_t *h_uncertain);
  * exact path for those modems (pm_afsk_correlate + pm_fir_signs_f64).  Tickets stay valid for 63 further sweeps on the context. */
 int pm_afsk_sweep_mode(pm_ctx *ctx, int deferred);
 int pm_afsk_sweep_ticket(pm_ctx *ctx, int64_t *h_ticket);
-int pm_afsk_sweep_result(pm_ctx *ctx, int64_t ticket, pm_ctx *via, int64_t *h_uncertain, int64_t *h_capacity);   /* via: the context whose stream carries the 4-byte copy (NULL: ctx) */
+int pm_afsk_sweep_result(pm_ctx *ctx, int64_t ticket, pm_ctx *via, int64_t *h_uncertain, int64_t *h_capacity);
+int pm_afsk_sweep_results(pm_ctx *ctx, const int64_t *h_tickets, int n, pm_ctx *via, int64_t *h_uncertain, int64_t *h_capacity);   /* several sweeps of one context, one copy */   /* via: the context whose stream carries the 4-byte copy (NULL: ctx) */
 
 /* Sign bitmap of a float64 stream: bit k of the little-endian uint64 array = (x[k] >= 0), the only
  * property of a sample the slicers read (slicer.py:85,99-102,210-232).  d_bits holds (n+63)/64 words. */

@@ -154,6 +154,7 @@ _SIGS = {
     "pm_afsk_sweep_last": ([_vp, ctypes.POINTER(_i64)], _int),
     "pm_afsk_sweep_mode": ([_vp, _int], _int),
     "pm_afsk_sweep_ticket": ([_vp, ctypes.POINTER(_i64)], _int),
+    "pm_afsk_sweep_results": ([_vp, ctypes.POINTER(_i64), _int, _vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)], _int),
     "pm_afsk_sweep_result": ([_vp, _i64, _vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)], _int),
     "pm_signs_f64": ([_vp, _vp, _i64, _vp], _int),
     "pm_agc_apply": ([_vp, _vp, _i64, ctypes.POINTER(AGCParams), ctypes.POINTER(_dbl)], _int),

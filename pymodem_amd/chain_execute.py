@@ -380,8 +380,19 @@ def resolve_sweeps(chains, bitmaps, sweeps, audio, ctx):
     exact kernels on `ctx` (BPF, correlators, low-pass + sign), which is what the in-call fallback of pm_afsk_sweep_signs would have
     done.  Returns the number of sweeps redone."""
     redone = 0
+    # one copy per producing context for all of the recording's sweeps (pm_afsk_sweep_results)
+    over = {}
+    by_ctx = {}
+    for sweep, _ in sweeps:
+        by_ctx.setdefault(id(sweep[0]), (sweep[0], []))[1].append(sweep[1])
+    for sctx, tickets in by_ctx.values():
+        t = (ctypes.c_int64 * len(tickets))(*tickets)
+        n, cap = (ctypes.c_int64 * len(tickets))(), ctypes.c_int64()
+        check(lib().pm_afsk_sweep_results(sctx.handle, t, len(tickets), ctx.handle, n, ctypes.byref(cap)))
+        for tk, v in zip(tickets, n):
+            over[(id(sctx), tk)] = v > cap.value
     for sweep, ks in sweeps:
-        if not AFSKModem.sweep_overflowed(sweep, via=ctx):
+        if not over[(id(sweep[0]), sweep[1])]:
             continue
         redone += 1
         for k in ks:

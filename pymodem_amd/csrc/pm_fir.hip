@@ -1418,22 +1418,30 @@ int pm_afsk_sweep_ticket(pm_ctx *ctx, int64_t *h_ticket)
     return PM_OK;
 }
 
-int pm_afsk_sweep_result(pm_ctx *ctx, int64_t ticket, pm_ctx *via, int64_t *h_uncertain, int64_t *h_capacity)
+int pm_afsk_sweep_results(pm_ctx *ctx, const int64_t *tickets, int n, pm_ctx *via, int64_t *h_uncertain, int64_t *h_capacity)
 {
     PM_CTX(ctx);
-    PM_ARG(h_uncertain != nullptr && ticket >= 0 && ticket < ctx->sweep_seq && ctx->d_sweep != nullptr);
-    if (ctx->sweep_seq - ticket >= kSweepRing)
-        return pm_set_error(PM_ERR_ARG, "pm_afsk_sweep_result: ticket %lld is %lld sweeps old, the ring holds %d", (long long)ticket,
-                            (long long)(ctx->sweep_seq - ticket), kSweepRing);
-    // the caller knows the sweep has finished; the four bytes come over on `via`'s stream (the caller's own: a slicer worker must not
-    // queue behind the demod stream's next recordings, nor take the device-wide wait of a synchronous copy)
+    PM_ARG(h_uncertain != nullptr && tickets != nullptr && n >= 1 && ctx->d_sweep != nullptr);
+    for (int k = 0; k < n; ++k) {
+        PM_ARG(tickets[k] >= 0 && tickets[k] < ctx->sweep_seq);
+        if (ctx->sweep_seq - tickets[k] >= kSweepRing)
+            return pm_set_error(PM_ERR_ARG, "pm_afsk_sweep_results: ticket %lld is %lld sweeps old, the ring holds %d", (long long)tickets[k],
+                                (long long)(ctx->sweep_seq - tickets[k]), kSweepRing);
+    }
+    // the caller knows the sweeps have finished; the whole ring (256 bytes) comes over in ONE copy on `via`'s stream (the caller's own:
+    // a slicer worker must not queue behind the demod stream's next recordings, nor take the device-wide wait of a synchronous copy)
     pm_ctx *c = via ? via : ctx;
-    int *h = (int *)c->h_pinned + 1;                       // word 1 of the mailbox (word 0: the loops' flag)
-    PM_HIP(hipMemcpyAsync(h, ctx->d_sweep + (ticket % kSweepRing), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    int *h = (int *)c->h_pinned + 16;                      // past the words other entry points use as flags
+    PM_HIP(hipMemcpyAsync(h, ctx->d_sweep, kSweepRing * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     PM_HIP(hipStreamSynchronize(c->stream));
-    *h_uncertain = *h;
+    for (int k = 0; k < n; ++k) h_uncertain[k] = h[tickets[k] % kSweepRing];
     if (h_capacity) *h_capacity = 65536;
     return PM_OK;
+}
+
+int pm_afsk_sweep_result(pm_ctx *ctx, int64_t ticket, pm_ctx *via, int64_t *h_uncertain, int64_t *h_capacity)
+{
+    return pm_afsk_sweep_results(ctx, &ticket, 1, via, h_uncertain, h_capacity);
 }
 
 int pm_signs_f64(pm_ctx *ctx, const double *d_x, int64_t n, uint64_t *d_bits)

@@ -395,12 +395,16 @@ __global__ __launch_bounds__(1024) void slice_scan_kernel(const JobDev *__restri
 // byte range: it is assembled in LDS and written out by the whole workgroup, addresses as coalesced 8-byte stores, data as whole
 // dwords; only the first and the last dword of the range can hold bits of a neighbouring workgroup and go out as atomicOr.
 constexpr int kPackBytes = 2048;
+constexpr int kEmitWordsMax = 8;       // words per emit chunk at most (slice_pack_kernel stages 256 chunks of them in LDS)
 __global__ __launch_bounds__(kBlock) void slice_pack_kernel(const JobDev *__restrict__ jobs, int njobs, int lc_words, int64_t total_chunks,
                                                         const uint64_t *__restrict__ symmap, const uint64_t *__restrict__ offset,
                                                         const uint8_t *__restrict__ prevsym)
 {
     __shared__ uint32_t lb[kPackBytes / 4 + 1];
     __shared__ long long la[kPackBytes + 4];
+    // the workgroup's words of the symbol bitmap and of the (in-phase) sign bitmap, loaded once, coalesced: lane by lane the reads
+    // are 32-64 bytes apart and every cache line is fetched several times (PMC round 1: 6.5 x the algorithmic read)
+    __shared__ uint64_t s_sym[kBlock * kEmitWordsMax], s_bi[kBlock * kEmitWordsMax];
     __builtin_amdgcn_s_setprio(3);          // short kernels on the slicer stream's critical path (see slice_walk_kernel)
     const int64_t gc0 = (int64_t)blockIdx.x * kBlock;
     if (gc0 >= total_chunks) return;
@@ -441,6 +445,15 @@ __global__ __launch_bounds__(kBlock) void slice_pack_kernel(const JobDev *__rest
             if (address) J.addr[idx] = address;
         }
     };
+    const int64_t wg0 = c0 * lc_words, wg1 = min(wg0 + (int64_t)kBlock * lc_words, J.nwords);
+    {
+        const uint64_t *smg = symmap + J.word0;
+        for (int64_t i = t; i < wg1 - wg0; i += kBlock) {
+            s_sym[i] = smg[wg0 + i];
+            s_bi[i] = J.bi[wg0 + i];
+        }
+        __syncthreads();
+    }
     if (live) {
         uint64_t g = off[c];
         if (c == 0 && nb0) {
@@ -450,13 +463,12 @@ __global__ __launch_bounds__(kBlock) void slice_pack_kernel(const JobDev *__rest
         }
         uint32_t prev = prevsym[gc];
         const int64_t w0 = c * lc_words, w1 = min(w0 + (int64_t)lc_words, J.nwords);
-        const uint64_t *sm = symmap + J.word0;
         uint32_t acc = 0;
         bool pending = false;
         for (int64_t w = w0; w < w1; ++w) {
-            uint64_t s = sm[w];
+            uint64_t s = s_sym[w - wg0];
             if (!s) continue;
-            const uint64_t si = J.bi[w];
+            const uint64_t si = s_bi[w - wg0];
             const uint64_t sq = J.quad ? J.bq[w] : 0;
             while (s) {
                 const int b = __ffsll((long long)s) - 1;
@@ -632,7 +644,7 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
     ctx->sl_chunks = total_chunks;
     // The count / scan / pack kernels only read the symbol bitmap the walkers left: they are cut independently of it, finely
     // (throughput kernels: ~4 waves per SIMD), however long the walkers' chunks are.
-    const int64_t le_words = std::max<int64_t>(4, std::min<int64_t>(lc_words, pm_cdiv(total_words, 524288)));
+    const int64_t le_words = std::max<int64_t>(std::min<int64_t>(4, lc_words), std::min<int64_t>({lc_words, pm_cdiv(total_words, 524288), (int64_t)kEmitWordsMax}));
     std::vector<JobDev> je = jd;
     int64_t emit_chunks = 0;
     for (JobDev &d : je) {
