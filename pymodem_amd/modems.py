@@ -383,20 +383,31 @@ class AFSKModem(_DeviceStage):
         if a.n < mc + ml - 1:
             raise ValueError("input shorter than the correlators and the output filter")
         nout = a.n - mc - ml + 2
-        ui, uq = lead.unit_space_correlators()
-        space = np.stack([np.stack([md.space_correlator_i, md.space_correlator_q]) for md in modems])
-        gains = (ctypes.c_double * g)(*[float(md.space_gain) for md in modems])
+        # everything that depends on the modems' taps only is prepared once per set of modems (as long as the tap arrays are the same
+        # objects and the gains the same): the submitting thread of a pipelined host comes through here twice per recording
+        deps = [lead.mark_correlator_i, lead.mark_correlator_q, lead.output_lpf] + [t for md in modems for t in (md.space_correlator_i, md.space_correlator_q)]
+        sig = (tuple(id(md) for md in modems), tuple(float(md.space_gain) for md in modems), AFSKModem.sliding_sums)
+        memo = getattr(lead, "_sweep_prep", None)
+        if memo is None or memo[0] != sig or len(memo[1]) != len(deps) or not all(x is y for x, y in zip(memo[1], deps)):
+            ui, uq = lead.unit_space_correlators()
+            space = np.stack([np.stack([md.space_correlator_i, md.space_correlator_q]) for md in modems])
+            prep = {"gains": (ctypes.c_double * g)(*[float(md.space_gain) for md in modems]),
+                    "consts": [lead._const("mi", lead.mark_correlator_i), lead._const("mq", lead.mark_correlator_q), lead._const("unit_i", ui),
+                               lead._const("unit_q", uq), lead._const("space_group", space.reshape(-1)), lead._const("output_lpf", lead.output_lpf)],
+                    "lpf_abs": float(np.abs(lead.output_lpf).sum()),
+                    "tones": lead._tones(ui, uq) if AFSKModem.sliding_sums else None}
+            memo = lead._sweep_prep = (sig, deps, prep)
+        prep = memo[2]
+        gains = prep["gains"]
         bits, ptrs = [], (ctypes.c_void_p * g)()
         for j, md in enumerate(modems):
             md._context()
             b = ctx.scratch((md._own_key(), "signs", "output_lpf"), (nout + 63) // 64 + 1, np.uint64)
             bits.append(b)
             ptrs[j] = b.ptr.value
-        args = (ctx.handle, a.ptr, a.n, float(x_bound), lead._const("mi", lead.mark_correlator_i).ptr,
-                lead._const("mq", lead.mark_correlator_q).ptr, lead._const("unit_i", ui).ptr,
-                lead._const("unit_q", uq).ptr, lead._const("space_group", space.reshape(-1)).ptr, gains, g, mc,
-                lead._const("output_lpf", lead.output_lpf).ptr, ml, float(np.abs(lead.output_lpf).sum()), ptrs)
-        tones = lead._tones(ui, uq) if AFSKModem.sliding_sums else None
+        k = prep["consts"]
+        args = (ctx.handle, a.ptr, a.n, float(x_bound), k[0].ptr, k[1].ptr, k[2].ptr, k[3].ptr, k[4].ptr, gains, g, mc, k[5].ptr, ml, prep["lpf_abs"], ptrs)
+        tones = prep["tones"]
         if tones is not None:
             check(lib().pm_afsk_sweep_signs_tones(*args, ctypes.byref(tones)))
         else:
