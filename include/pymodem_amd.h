@@ -167,6 +167,20 @@ int pm_afsk_sweep_last(pm_ctx *ctx, int64_t *h_uncertain);
  * pm_afsk_sweep_mode(ctx, 1) they are not enqueued: take a ticket after the call, and once the sweep has FINISHED (stream or event
  * synchronised) ask pm_afsk_sweep_result; if *h_uncertain > *h_capacity the sweep's bitmaps are not valid and the caller runs the
  * exact path for those modems (pm_afsk_correlate + pm_fir_signs_f64).  Tickets stay valid for 63 further sweeps on the context. */
+/* One chain group's demod stage in one call: band-pass on the int16 audio into d_bpf_out (n - mb + 1 doubles), then every sweep of
+ * h_sweeps on it (as pm_afsk_sweep_signs / _tones would run them, fallback deferred), h_tickets[k] = the ticket of sweep k. */
+typedef struct pm_afsk_sweep_desc {
+    const double *d_mark_i, *d_mark_q, *d_unit_i, *d_unit_q, *d_space;
+    const double *h_gains;
+    int32_t groups, m;
+    const double *d_lpf;
+    int32_t ml, reserved;
+    double lpf_abs_sum;
+    uint64_t *const *h_bits;
+    const pm_afsk_tones *h_tones;      /* NULL: direct correlator sums */
+} pm_afsk_sweep_desc;
+int pm_afsk_group_run(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const double *d_bpf, int mb, double *d_bpf_out, double x_bound,
+                      const pm_afsk_sweep_desc *h_sweeps, int nsweeps, int64_t *h_tickets);
 int pm_afsk_sweep_mode(pm_ctx *ctx, int deferred);
 int pm_afsk_sweep_ticket(pm_ctx *ctx, int64_t *h_ticket);
 int pm_afsk_sweep_result(pm_ctx *ctx, int64_t ticket, pm_ctx *via, int64_t *h_uncertain, int64_t *h_capacity);

@@ -31,6 +31,14 @@ class Loop(ctypes.Structure):
         "bb0", "bb1", "ba1", "cx0", "cx1", "cy0", "sx0", "sx1", "sy0")]
 
 
+class AfskSweepDesc(ctypes.Structure):
+    """pm_afsk_sweep_desc"""
+    _fields_ = [("d_mark_i", ctypes.c_void_p), ("d_mark_q", ctypes.c_void_p), ("d_unit_i", ctypes.c_void_p), ("d_unit_q", ctypes.c_void_p),
+                ("d_space", ctypes.c_void_p), ("h_gains", ctypes.c_void_p), ("groups", ctypes.c_int32), ("m", ctypes.c_int32),
+                ("d_lpf", ctypes.c_void_p), ("ml", ctypes.c_int32), ("reserved", ctypes.c_int32), ("lpf_abs_sum", ctypes.c_double),
+                ("h_bits", ctypes.c_void_p), ("h_tones", ctypes.c_void_p)]
+
+
 class SlicerParams(ctypes.Structure):
     _fields_ = [("samples_per_symbol", ctypes.c_double), ("lock_rate", ctypes.c_double),
                 ("bits_per_symbol", ctypes.c_int32), ("state_mask", ctypes.c_int32), ("demap", ctypes.c_int32 * 16)]
@@ -152,6 +160,7 @@ _SIGS = {
                             ctypes.POINTER(_vp)] + [ctypes.POINTER(AfskTones)], _int),
     "pm_afsk_magnitudes": ([_vp, _vp, _i64, _dbl, _vp, _vp, _vp, _vp, _int, ctypes.POINTER(AfskTones), _vp, _vp, ctypes.POINTER(_dbl)], _int),
     "pm_afsk_sweep_last": ([_vp, ctypes.POINTER(_i64)], _int),
+    "pm_afsk_group_run": ([_vp, _vp, _i64, _vp, _int, _vp, ctypes.c_double, _vp, _int, ctypes.POINTER(_i64)], _int),
     "pm_afsk_sweep_mode": ([_vp, _int], _int),
     "pm_afsk_sweep_ticket": ([_vp, ctypes.POINTER(_i64)], _int),
     "pm_afsk_sweep_results": ([_vp, ctypes.POINTER(_i64), _int, _vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)], _int),

@@ -374,6 +374,56 @@ class RecordingPipeline:
         self._post.shutdown(wait=True)
 
 
+def _afsk_group_native(ctx, chains, planned, audio, group_key, front, bitmaps, sweeps):
+    """Band-pass of the group's shared front end and every planned certified sweep on it in ONE native call (pm_afsk_group_run): what
+    modem.front_end() + AFSKModem.sweep_signs() per sweep launch, without ten trips through the C boundary per recording -- the
+    submitting thread of the pipelined executor waits for the interpreter lock after each one."""
+    from ._native import AfskSweepDesc
+    from .data_classes import SignBits
+    lead = planned[0][1][0]
+    lead.scratch_key = (group_key, "front", len(front))
+    mb = len(lead.input_bpf)
+    if audio.n < mb:
+        raise ValueError(f"input of {audio.n} samples is shorter than the {mb}-tap filter input_bpf")
+    nb = audio.n - mb + 1
+    taps = lead._const("input_bpf", lead.input_bpf)
+    bpf = ctx.scratch((lead._key(), "input_bpf"), nb, np.float64)           # the buffer front_end() would have used
+    front[lead.front_end_key()] = bpf
+    bound = getattr(lead, "_bpf_bound", None)
+    if bound is None or bound[0] is not lead.input_bpf:
+        bound = lead._bpf_bound = (lead.input_bpf, float(np.abs(lead.input_bpf).sum()) * 32768.0)
+    descs = (AfskSweepDesc * len(planned))()
+    keep, outs = [], []
+    for j, (part, mods) in enumerate(planned):
+        prep = AFSKModem._sweep_prepare(mods)
+        mc, ml, g = len(mods[0].mark_correlator_i), len(mods[0].output_lpf), len(mods)
+        if nb < mc + ml - 1:
+            raise ValueError("input shorter than the correlators and the output filter")
+        nout = nb - mc - ml + 2
+        ptrs = (ctypes.c_void_p * g)()
+        bits = []
+        for i, md in enumerate(mods):
+            md._context()
+            b = ctx.scratch((md._own_key(), "signs", "output_lpf"), (nout + 63) // 64 + 1, np.uint64)
+            bits.append(b)
+            ptrs[i] = b.ptr.value
+        k, d = prep["consts"], descs[j]
+        d.d_mark_i, d.d_mark_q, d.d_unit_i, d.d_unit_q, d.d_space = (k[i].ptr.value for i in range(5))
+        d.h_gains, d.groups, d.m = ctypes.addressof(prep["gains"]), g, mc
+        d.d_lpf, d.ml, d.lpf_abs_sum = k[5].ptr.value, ml, prep["lpf_abs"]
+        d.h_bits = ctypes.addressof(ptrs)
+        d.h_tones = ctypes.addressof(prep["tones"]) if prep["tones"] is not None else None
+        keep.append(ptrs)
+        outs.append((part, bits, nout))
+    tickets = (ctypes.c_int64 * len(planned))()
+    check(lib().pm_afsk_group_run(ctx.handle, audio.ptr, audio.n, taps.ptr, mb, bpf.ptr, bound[1], descs, len(planned), tickets))
+    AFSKModem.sweeps_run += len(planned)
+    for j, (part, bits, nout) in enumerate(outs):
+        sweeps.append(((ctx, int(tickets[j])), list(part)))
+        for k, b in zip(part, bits):
+            bitmaps[k] = chains[k][2].sign_bitmaps(SignBits(b, None, nout))
+
+
 def resolve_sweeps(chains, bitmaps, sweeps, audio, ctx):
     """The certified gain sweeps of one recording have FINISHED: any whose list of uncertain samples overflowed (digital silence,
     audio far below the stated bound -- never on a signal) did not leave valid bitmaps; its chains are demodulated again with the
@@ -488,31 +538,40 @@ def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced
             ch[1].use_context(ctx)
             afsk_groups.setdefault(ch[1].mark_key(), []).append(k)
     gi = 0
-    for key, members in afsk_groups.items():
-        # a gain sweep (members differ in space_gain only, int16 audio so that |band-passed| <= sum|bpf| * 32768): certified sign
-        # bitmaps from two correlator pairs and two low-passes for the whole sweep (pm_afsk_sweep_signs)
-        sweep_sets = {}
-        if int16_audio and _USE_SWEEP:
+    # a gain sweep (members differ in space_gain only, int16 audio so that |band-passed| <= sum|bpf| * 32768): certified sign
+    # bitmaps from two correlator pairs and two low-passes for the whole sweep (pm_afsk_sweep_signs)
+    planned = []                       # (chain indices, their modems) per certified sweep
+    if int16_audio and _USE_SWEEP:
+        for key, members in afsk_groups.items():
+            sweep_sets = {}
             for k in members:
                 sk = chains[k][1].sweep_key()
                 if sk is not None:
                     sweep_sets.setdefault(sk, []).append(k)
-        if sweep_sets:                 # the overflow fallback of these sweeps is ours (resolve_sweeps), not three gated launches each
+            for part_all in sweep_sets.values():
+                for base in range(0, len(part_all), 8):
+                    part = part_all[base:base + 8]
+                    mods = [chains[k][1] for k in part]
+                    if len(part) < 2 and not (AFSKModem.sliding_sums and AFSKModem._sweep_prepare(mods)["tones"] is not None):
+                        continue                 # one chain whose templates are not tones: the exact kernels are cheaper
+                    planned.append((part, mods))
+    if planned:
+        fe = {mods[0].front_end_key() for _, mods in planned}
+        if len(fe) == 1 and next(iter(fe)) not in front and isinstance(audio, DeviceBuffer):
+            # the usual case (every sweep of the group on ONE band-passed stream): band-pass and all sweeps in one native call
+            _afsk_group_native(ctx, chains, planned, audio, group_key, front, bitmaps, sweeps)
+        else:                          # the overflow fallback of these sweeps is ours (resolve_sweeps), not three gated launches each
             check(lib().pm_afsk_sweep_mode(ctx.handle, 1))
-        for part_all in sweep_sets.values():
-            for base in range(0, len(part_all), 8):
-                part = part_all[base:base + 8]
-                mods = [chains[k][1] for k in part]
-                if len(part) < 2 and not (AFSKModem.sliding_sums and mods[0]._tones(*mods[0].unit_space_correlators()) is not None):
-                    continue                     # one chain whose templates are not tones: the exact kernels are cheaper
-
-                bpf = shared_front(mods[0])
-                got = AFSKModem.sweep_signs(mods, bpf, float(np.abs(mods[0].input_bpf).sum()) * 32768.0)
-                sweeps.append((got[0].sweep, list(part)))
-                for k, sb in zip(part, got):
-                    bitmaps[k] = chains[k][2].sign_bitmaps(sb)
-        if sweep_sets:
-            check(lib().pm_afsk_sweep_mode(ctx.handle, 0))
+            try:
+                for part, mods in planned:
+                    bpf = shared_front(mods[0])
+                    got = AFSKModem.sweep_signs(mods, bpf, float(np.abs(mods[0].input_bpf).sum()) * 32768.0)
+                    sweeps.append((got[0].sweep, list(part)))
+                    for k, sb in zip(part, got):
+                        bitmaps[k] = chains[k][2].sign_bitmaps(sb)
+            finally:
+                check(lib().pm_afsk_sweep_mode(ctx.handle, 0))
+    for key, members in afsk_groups.items():
         members = [k for k in members if bitmaps[k] is None]
         for base in range(0, len(members), 8):
             part = members[base:base + 8]

@@ -15,6 +15,7 @@
 // (18 dwords: conflict-free for ds_read_b64).  Results go back through the same LDS image so that
 // the global stores are coalesced (lane-contiguous 8 B).
 #include "pm_common.h"
+#include <chrono>
 #include <type_traits>
 #include <algorithm>
 #include <cstdlib>
@@ -1402,6 +1403,43 @@ int pm_afsk_sweep_last(pm_ctx *ctx, int64_t *h_uncertain)
     PM_HIP(hipStreamSynchronize(ctx->stream));
     *h_uncertain = v;
     return PM_OK;
+}
+
+int pm_afsk_group_run(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const double *d_bpf, int mb, double *d_bpf_out, double x_bound,
+                      const pm_afsk_sweep_desc *h_sweeps, int nsweeps, int64_t *h_tickets)
+{
+    // The demod stage of a whole AFSK chain group in ONE call: the shared band-pass (afsk.py:151) and every certified sweep on its
+    // output (afsk.py:153-166, sign bitmaps only), overflow fallback deferred to the caller (pm_afsk_sweep_results).  The same
+    // launches pm_fir_valid_i16 + pm_afsk_sweep_signs[_tones] would make -- a pipelined Python host saves nine boundary crossings
+    // per recording, each of which waits for the interpreter lock on the way back.
+    PM_CTX(ctx);
+    PM_ARG(d_audio && d_bpf && d_bpf_out && h_sweeps && nsweeps >= 1 && nsweeps <= 64 && mb >= 1 && n >= mb);
+    static const bool trace = getenv("PM_TRACE_CALLS") != nullptr;
+    static double acc_us[3] = {0, 0, 0};
+    static long calls = 0;
+    const auto t_0 = std::chrono::steady_clock::now();
+    if (int rc = fir_launch<int16_t>(ctx, d_audio, n, d_bpf, mb, d_bpf_out, nullptr, 0)) return rc;
+    const auto t_1 = std::chrono::steady_clock::now();
+    const bool was = ctx->sweep_deferred;
+    ctx->sweep_deferred = true;
+    int rc = PM_OK;
+    for (int k = 0; k < nsweeps && rc == PM_OK; ++k) {
+        const pm_afsk_sweep_desc &w = h_sweeps[k];
+        rc = sweep_signs(ctx, d_bpf_out, n - mb + 1, x_bound, w.d_mark_i, w.d_mark_q, w.d_unit_i, w.d_unit_q, w.d_space, w.h_gains, w.groups, w.m,
+                         w.d_lpf, w.ml, w.lpf_abs_sum, w.h_bits, w.h_tones);
+        if (h_tickets) h_tickets[k] = ctx->sweep_seq - 1;
+    }
+    ctx->sweep_deferred = was;
+    if (trace) {
+        const auto t_2 = std::chrono::steady_clock::now();
+        acc_us[0] += std::chrono::duration<double, std::micro>(t_1 - t_0).count();
+        acc_us[1] += std::chrono::duration<double, std::micro>(t_2 - t_1).count();
+        if (++calls % 100 == 0) {
+            fprintf(stderr, "[pm_afsk_group_run] avg over 100 calls: band-pass launch %.1f us, %d sweeps %.1f us\n", acc_us[0] / 100, nsweeps, acc_us[1] / 100);
+            acc_us[0] = acc_us[1] = 0;
+        }
+    }
+    return rc;
 }
 
 int pm_afsk_sweep_mode(pm_ctx *ctx, int deferred)

@@ -373,18 +373,12 @@ class AFSKModem(_DeviceStage):
         return key
 
     @staticmethod
-    def sweep_signs(modems, a, x_bound):
-        """Sign bitmaps of a gain sweep (equal sweep_key) over the band-passed stream `a`, |a| <= x_bound guaranteed by the caller
-        -> [SignBits per modem].  Never waits for the GPU; `sweep_uncertain(ctx)` tells afterwards how many samples had to be
-        recomputed exactly."""
+    def _sweep_prepare(modems):
+        """Everything of a certified sweep that depends on the modems' taps only, prepared once per set of modems (as long as the tap
+        arrays are the same objects and the gains the same): the submitting thread of a pipelined host comes through here twice per
+        recording."""
         lead = modems[0]
-        ctx = lead._context()
-        mc, ml, g = len(lead.mark_correlator_i), len(lead.output_lpf), len(modems)
-        if a.n < mc + ml - 1:
-            raise ValueError("input shorter than the correlators and the output filter")
-        nout = a.n - mc - ml + 2
-        # everything that depends on the modems' taps only is prepared once per set of modems (as long as the tap arrays are the same
-        # objects and the gains the same): the submitting thread of a pipelined host comes through here twice per recording
+        g = len(modems)
         deps = [lead.mark_correlator_i, lead.mark_correlator_q, lead.output_lpf] + [t for md in modems for t in (md.space_correlator_i, md.space_correlator_q)]
         sig = (tuple(id(md) for md in modems), tuple(float(md.space_gain) for md in modems), AFSKModem.sliding_sums)
         memo = getattr(lead, "_sweep_prep", None)
@@ -397,7 +391,20 @@ class AFSKModem(_DeviceStage):
                     "lpf_abs": float(np.abs(lead.output_lpf).sum()),
                     "tones": lead._tones(ui, uq) if AFSKModem.sliding_sums else None}
             memo = lead._sweep_prep = (sig, deps, prep)
-        prep = memo[2]
+        return memo[2]
+
+    @staticmethod
+    def sweep_signs(modems, a, x_bound):
+        """Sign bitmaps of a gain sweep (equal sweep_key) over the band-passed stream `a`, |a| <= x_bound guaranteed by the caller
+        -> [SignBits per modem].  Never waits for the GPU; `sweep_uncertain(ctx)` tells afterwards how many samples had to be
+        recomputed exactly."""
+        lead = modems[0]
+        ctx = lead._context()
+        mc, ml, g = len(lead.mark_correlator_i), len(lead.output_lpf), len(modems)
+        if a.n < mc + ml - 1:
+            raise ValueError("input shorter than the correlators and the output filter")
+        nout = a.n - mc - ml + 2
+        prep = AFSKModem._sweep_prepare(modems)
         gains = prep["gains"]
         bits, ptrs = [], (ctypes.c_void_p * g)()
         for j, md in enumerate(modems):
