@@ -104,6 +104,7 @@ def _host_rows(chains, sliced):
 
 _POOL = None
 _USE_SWEEP = True          # pm_afsk_sweep_signs for gain sweeps (tests switch it off to compare against the exact group path)
+_USE_GROUP_NATIVE = True   # band-pass + all sweeps of a group in one native call (tests switch it off to compare with the separate calls)
 
 
 def _pool():
@@ -557,7 +558,7 @@ def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced
                     planned.append((part, mods))
     if planned:
         fe = {mods[0].front_end_key() for _, mods in planned}
-        if len(fe) == 1 and next(iter(fe)) not in front and isinstance(audio, DeviceBuffer):
+        if _USE_GROUP_NATIVE and len(fe) == 1 and next(iter(fe)) not in front:
             # the usual case (every sweep of the group on ONE band-passed stream): band-pass and all sweeps in one native call
             _afsk_group_native(ctx, chains, planned, audio, group_key, front, bitmaps, sweeps)
         else:                          # the overflow fallback of these sweeps is ours (resolve_sweeps), not three gated launches each

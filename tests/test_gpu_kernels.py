@@ -6,6 +6,7 @@ import ctypes
 import numpy as np
 import pytest
 
+from conftest import noise_i16
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -704,3 +705,53 @@ def test_sweep_tones_rejects_templates_that_are_not_tones(ctx):
         chk(L().pm_afsk_sweep_signs_tones(*args, None))
     tones.tap_dev = 2e-15
     chk(L().pm_afsk_sweep_signs_tones(*args, ctypes.byref(tones)))             # and the same call with honest tones goes through
+
+
+def test_runtime_additions(ctx):
+    """pm_d2d, pm_event_query / pm_event_sync, pm_ctx_scratch and a CU-masked context (pm_ctx_create_cumask) do what they say."""
+    import pymodem_amd
+    from pymodem_amd._native import check, lib
+    L = lib()
+    a = np.arange(100000, dtype=np.int16)
+    src, dst = ctx.upload(a), ctx.empty(len(a), np.int16)
+    check(L.pm_d2d(ctx.handle, dst.ptr, src.ptr, a.nbytes))
+    ev = ctx.record_event()
+    pymodem_amd.Context.event_sync(ev)
+    assert pymodem_amd.Context.event_done(ev) is True
+    assert np.array_equal(dst.download(), a)
+    have = ctypes.c_size_t()
+    check(L.pm_ctx_scratch(ctx.handle, 0, ctypes.byref(have)))
+    check(L.pm_ctx_scratch(ctx.handle, have.value + (1 << 20), ctypes.byref(have)))
+    assert have.value >= (1 << 20)
+    # a context confined to the first 4 CUs of every XCD runs the same kernels with the same results
+    cus = L.pm_device_cus(0)
+    assert cus >= 64
+    low, high = pymodem_amd.Context.cu_split(0, 4)
+    assert sum(bin(w).count("1") for w in low) == 32 and sum(bin(w).count("1") for w in low + high) == cus
+    masked = pymodem_amd.Context(0, cu_mask=low)
+    x = noise_i16(200000)
+    h = np.random.default_rng(5).standard_normal(40)
+    y = masked.empty(len(x) - 39, np.float64)
+    check(L.pm_fir_valid_i16(masked.handle, masked.upload(x).ptr, len(x), masked.upload(h).ptr, 40, y.ptr, 0))
+    assert np.array_equal(y.download(), O.fir_canon(x, h))
+    masked.close()
+
+
+def test_afsk_group_run_equals_the_separate_calls(ctx, config_lines):
+    """pm_afsk_group_run (band-pass + every certified sweep of a chain group in one call, what the group executor's fast path uses)
+    leaves the bitmaps of modem.front_end() + AFSKModem.sweep_signs() per sweep."""
+    from pymodem_amd import chain_builder as cb, chain_execute as ce, siggen
+    lines = config_lines("afsk_1200_ax25_super_opt.json")
+    audio, _ = siggen.recording("afsk1200_ax25", 48000, packets=6, seed=33, noise_sigma=1500.0, payload_len=(20, 60))
+    res = {}
+    for fast in (True, False):
+        ce._USE_GROUP_NATIVE = fast
+        try:
+            st = {}
+            ce.process_chains_device([cb.build_chain(48000, l) for l in lines], audio, stages=st)
+        finally:
+            ce._USE_GROUP_NATIVE = True
+        res[fast] = [(np.array(st["sliced"][c].data), np.array(st["sliced"][c].address)) for c in range(len(lines))]
+    for c in range(len(lines)):
+        assert len(res[True][c][0]) > 100
+        assert np.array_equal(res[True][c][0], res[False][c][0]) and np.array_equal(res[True][c][1], res[False][c][1]), c
