@@ -333,6 +333,11 @@ def measure(args, env):
             pipe.close()                                      # every step's de-dup is done, not only the last one's
             stage_ms.clear()
             stage_ms.update({s: round(v / max(k, 1) * 1e3, 3) for s, v in pipe.stage_seconds.items()})
+            if os.environ.get("BENCH_TIMELINE"):              # diagnostic: host clock at every stage boundary of every recording
+                t00 = pipe.timeline[0]["submit0"] if pipe.timeline else 0
+                for i, rec in enumerate(pipe.timeline):
+                    print("[timeline]", i, {k2: round((v - t00) * 1e3, 2) for k2, v in rec.items()}, file=sys.stderr)
+                print("[timeline] end of run_steps", round((time.perf_counter() - t00) * 1e3, 2), file=sys.stderr)
             if os.environ.get("BENCH_SLICE_LOG"):
                 t00 = pipe.slice_log[0][1] if pipe.slice_log else 0
                 print("[slice batches] (recordings, start ms, duration ms):", [(n, round((t - t00) * 1e3, 1), round(d * 1e3, 1)) for n, t, d in pipe.slice_log][:60], file=sys.stderr)

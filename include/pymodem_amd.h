@@ -70,6 +70,11 @@ int pm_malloc(pm_ctx *ctx, size_t bytes, void **d_out);
 int pm_free(pm_ctx *ctx, void *d_ptr);
 int pm_h2d(pm_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);   /* async on the ctx stream */
 int pm_d2h(pm_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);   /* synchronous */
+/* Page-lock a host block the caller owns (and release it again before freeing the block): copies to and from pinned memory go
+ * straight over the link instead of through the runtime's bounce buffers.  For blocks that are used many times (the executor's
+ * pool of result blocks); pinning costs about as much as one copy of the block. */
+int pm_host_pin(pm_ctx *ctx, void *h_block, size_t bytes);
+int pm_host_unpin(void *h_block);
 /* The context's internal work block (slicer state, sweep intermediates): grow it to at least reserve_bytes now (0: leave it) and
  * report its size.  A host that knows how large its batches will get reserves once instead of paying a free + malloc on the way. */
 int pm_ctx_scratch(pm_ctx *ctx, size_t reserve_bytes, size_t *h_bytes);
@@ -280,6 +285,14 @@ typedef struct pm_slice_job {
     pm_slicer_state *h_state;        /* in/out; NULL = start from the just-tuned state and do not report the end state */
 } pm_slice_job;
 int pm_slice_batch(pm_ctx *ctx, pm_slice_job *h_jobs, int njobs);           /* njobs <= 64 */
+/* The output of a finished pm_slice_batch in the form that is cheapest to bring to the host (3 bytes per data byte instead of 9, no
+ * unused capacity in between): for job j, at d_block + h_offsets[j]: {first address, last address} (2 x int64), count[j] address steps
+ * as uint16 (address[i] - address[i-1], the first one 0; padded to a multiple of 8 bytes), count[j] data bytes (padded likewise).
+ * *h_used = bytes written; PM_ERR_CAPACITY (with *h_used set) if block_bytes is less.  A step is eight symbol periods; should one
+ * not fit 16 bits it wraps, which shows as first + sum(steps) != last: take that job's addresses from its d_addr instead.  Runs on
+ * the ctx stream, after the batch; h_jobs are the batch's jobs as pm_slice_batch left them (count filled in). */
+int pm_slice_compact(pm_ctx *ctx, const pm_slice_job *h_jobs, int njobs, void *d_block, size_t block_bytes, int64_t *h_offsets,
+                     size_t *h_used);
 /* How many chunks (= walkers) a batch is cut into on this ctx, within 1024..16384 samples per chunk; 0 restores the default 16384.
  * Lane-steps are N (1 + m/L) for merge length m (10-20 k samples) and chunk length L, the depth is (L + longest merge) x the
  * step time: long chunks are cheap, short ones are quick.  Results do not depend on it. */
@@ -379,6 +392,8 @@ typedef struct pm_host_job {
     int64_t pending;              /* out: packets waiting in the codec            */
     int32_t lfsr_invert;
     int32_t status;               /* out */
+    const uint16_t *h_addr_delta; /* with h_addr == NULL: the addresses in pm_slice_compact's form, address[i] = addr_first +  */
+    int64_t addr_first;           /* delta[0] + ... + delta[i] (delta[0] = 0)                                                   */
 } pm_host_job;
 int pm_host_decode_batch(pm_host_job *jobs, int njobs, int threads);
 int pm_codec_fetch_batch(pm_codec *const *codecs, const int64_t *counts, int n, pm_packet *h_out, int threads);

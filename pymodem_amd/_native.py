@@ -68,7 +68,8 @@ class HostJob(ctypes.Structure):
     """pm_host_job"""
     _fields_ = [("codec", ctypes.c_void_p), ("h_data", ctypes.c_void_p), ("h_addr", ctypes.c_void_p), ("n", ctypes.c_int64),
                 ("lfsr_poly", ctypes.c_uint64), ("lfsr_state", ctypes.c_uint64), ("pending", ctypes.c_int64),
-                ("lfsr_invert", ctypes.c_int32), ("status", ctypes.c_int32)]
+                ("lfsr_invert", ctypes.c_int32), ("status", ctypes.c_int32),
+                ("h_addr_delta", ctypes.c_void_p), ("addr_first", ctypes.c_int64)]
 
 
 class ChainDesc(ctypes.Structure):
@@ -126,6 +127,8 @@ _SIGS = {
     "pm_ctx_create": ([_int, ctypes.POINTER(_vp)], _int),
     "pm_ctx_create_prio": ([_int, _int, ctypes.POINTER(_vp)], _int),
     "pm_d2d": ([_vp, _vp, _vp, ctypes.c_size_t], _int),
+    "pm_host_pin": ([_vp, _vp, ctypes.c_size_t], _int),
+    "pm_host_unpin": ([_vp], _int),
     "pm_ctx_scratch": ([_vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)], _int),
     "pm_event_query": ([_vp], _int),
     "pm_event_sync": ([_vp], _int),
@@ -175,6 +178,7 @@ _SIGS = {
     "pm_slice_quadrature": ([_vp, _vp, _vp, _i64, ctypes.POINTER(SlicerParams), _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
     "pm_slice_batch": ([_vp, ctypes.POINTER(SliceJob), _int], _int),
     "pm_slicer_tune": ([_vp, _i64], _int),
+    "pm_slice_compact": ([_vp, _vp, _int, _vp, ctypes.c_size_t, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_size_t)], _int),
     "pm_slicer_stats": ([_vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_i64)], _int),
     "pm_chain_create": ([_vp, ctypes.POINTER(ChainDesc), ctypes.POINTER(_vp)], _int),
     "pm_chain_run": ([_vp, _vp, _i64, _int, _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),

@@ -84,7 +84,12 @@ def _host_rows(chains, sliced):
         src = AddressedArray.coerce(sl)
         keep.append(src)
         jobs[j].codec = ch[4]._handle()
-        jobs[j].h_data, jobs[j].h_addr, jobs[j].n = src.data.ctypes.data, src.address.ctypes.data, len(src)
+        steps = src.address_steps
+        if steps is not None:                   # straight from the slicer's compact block: expanded inside the native call
+            jobs[j].h_data, jobs[j].h_addr, jobs[j].n = src.data.ctypes.data, None, len(src)
+            jobs[j].h_addr_delta, jobs[j].addr_first = steps[0].ctypes.data, steps[1]
+        else:
+            jobs[j].h_data, jobs[j].h_addr, jobs[j].n = src.data.ctypes.data, src.address.ctypes.data, len(src)
         jobs[j].lfsr_poly, jobs[j].lfsr_state, jobs[j].lfsr_invert = ch[3].polynomial, ch[3].shift_register, int(bool(ch[3].invert))
     threads = _host_threads()
     rc = lib().pm_host_decode_batch(jobs, n, threads)
@@ -175,6 +180,8 @@ class RecordingPipeline:
         # showed an intermittent GPU memory fault that was not root-caused: the argument is accepted and ignored.
         self._demod_streams = 1
         self._group = max(1, min(int(os.environ.get("PYMODEM_AMD_SLICE_GROUP", slice_group)), 8))
+        self._fetch_inline = os.environ.get("PYMODEM_AMD_FETCH", "worker") != "copy"
+        self._min_group = max(1, min(int(os.environ.get("PYMODEM_AMD_SLICE_MIN_GROUP", 1)), self._group))
         self._host = ThreadPoolExecutor(max_workers=5)        # LFSR + codec of up to five recordings at a time (IL2P chains take 4-5 ms each)
         self._finish = ThreadPoolExecutor(max_workers=1)
         self._post = ThreadPoolExecutor(max_workers=3)        # whatever follows the ordered step (rank 0's payload copy, indexing, de-dup)
@@ -198,6 +205,18 @@ class RecordingPipeline:
         self.stage_seconds = {"demod": 0.0, "slice": 0.0, "host": 0.0, "finish": 0.0}   # busy time per stage, summed over recordings
         self.slice_batches = 0
         self.slice_log = []
+        self.timeline = []                                    # per recording: host clock at the stage boundaries (diagnostics)
+        self._watch = None
+        if os.environ.get("PYMODEM_AMD_PIPE_WATCH"):          # diagnostic: stamp the moment each recording's demod finished on the GPU
+            self._watch = deque()
+
+            def watch():
+                import time
+                while self._watch is not None:
+                    while self._watch and Context.event_done(self._watch[0][1]):
+                        self._watch.popleft()[0]["demod_done"] = time.perf_counter()
+                    time.sleep(0.0001)
+            threading.Thread(target=watch, daemon=True).start()
         self._slice_threads = [threading.Thread(target=self._slice_loop, args=(Context.side(index=i),), daemon=True) for i in range(self._workers)]
         for th in self._slice_threads:
             th.start()
@@ -213,6 +232,7 @@ class RecordingPipeline:
             # demod runs in submission order: wait (on the host, holding nothing) for this recording's bitmaps, then take along
             # every later recording whose bitmaps are complete as well
             Context.event_sync(item[2])
+            item[6]["ready"] = time.perf_counter()
             items = [item]
             while len(items) < self._group:
                 try:
@@ -223,20 +243,24 @@ class RecordingPipeline:
                     self._pending.put(None)
                     break
                 if not Context.event_done(nxt[2]):
-                    with self._pending.mutex:                  # not ready yet: back to the FRONT of the queue
-                        self._pending.queue.appendleft(nxt)
-                        self._pending.not_empty.notify()
-                    break
+                    if len(items) < self._min_group:           # its demod is already queued on the GPU (<= 1 ms): a batch of three costs
+                        Context.event_sync(nxt[2])             # what a batch of one costs, so a short wait here saves whole batches
+                    else:
+                        with self._pending.mutex:              # not ready yet: back to the FRONT of the queue
+                            self._pending.queue.appendleft(nxt)
+                            self._pending.not_empty.notify()
+                        break
                 items.append(nxt)
             t = time.perf_counter()
             try:
                 slicers, bitmaps = [], []
-                for chains, bm, ready, _, sweeps, audio in items:
+                for chains, bm, ready, _, sweeps, audio, rec in items:
+                    rec["slice0"] = t
                     if sweeps:                                 # finished (their event has): overflowed ones are redone exactly, here
                         resolve_sweeps(chains, bm, sweeps, audio, side)
                     slicers += [ch[2] for ch in chains]
                     bitmaps += bm
-                fetch = slice_batch(slicers, bitmaps, side, defer=True)
+                fetch = slice_batch(slicers, bitmaps, side, defer=True, reserve=self._group / len(items), compact=True)
                 if not getattr(side, "_slicer_block_reserved", False):
                     # the stream's work block (checkpoints, symbol bitmaps, lists: ~150 MB per recording) sized for a batch of four from
                     # the first batch on: growing it later is a free + malloc in the middle of the pipeline (10 ms measured)
@@ -246,9 +270,16 @@ class RecordingPipeline:
                     check(lib().pm_ctx_scratch(side.handle, int(have.value * min(self._group, 4) / len(items)), None))
                 # The slicers' bytes and addresses are still in device memory: whichever host-stage thread needs them first copies
                 # the whole batch over on the copy stream (this worker's stream is already slicing the next batch).
+                if self._fetch_inline:
+                    # the compact output of a batch is a few megabytes: copied here, on the stream that made it and is idle at this
+                    # point, it is on the host a third of a millisecond later; on the copy stream it waits for whatever kernel the
+                    # hardware queue that stream shares is running (1-2 ms measured)
+                    done = fetch(side)
+                    fetch = lambda _ctx, _done=done: _done
                 shared = _BatchFetch(fetch, self._copy_ctx, self._copy_lock)
                 at = 0
-                for chains, _, _, fut, _, _ in items:
+                for chains, _, _, fut, _, _, rec in items:
+                    rec["slice1"] = time.perf_counter()
                     fut.set_result((shared, at, at + len(chains)))
                     at += len(chains)
             except BaseException as e:                         # noqa: BLE001
@@ -314,7 +345,11 @@ class RecordingPipeline:
 
         from concurrent.futures import Future
         f_sliced, f_fetched = Future(), Future()
-        self._pending.put((chains, bitmaps, ready, f_sliced, sweeps, input_audio))
+        rec = {"submit0": t0, "submit1": time.perf_counter()}
+        self.timeline.append(rec)
+        if self._watch is not None:
+            self._watch.append((rec, ready))
+        self._pending.put((chains, bitmaps, ready, f_sliced, sweeps, input_audio, rec))
         # the bitmap slot (and the slicers' output block keyed by it) is free again once the slicers' output is on the host
         self._inflight.append(f_fetched)
 
@@ -322,13 +357,15 @@ class RecordingPipeline:
             try:
                 shared, lo, hi = f_sliced.result()
                 sliced = shared.get(lo, hi)
+                rec["fetched"] = time.perf_counter()
             finally:
                 f_fetched.set_result(None)
-            t = time.perf_counter()
+            t = rec["host0"] = time.perf_counter()
             rows = _host_rows(chains, sliced)
             if prepare is not None:                            # e.g. dist.Exchanger.prepare: packing for the wire, off the ordered thread
                 rows = prepare(rows)
-            acc["host"] += time.perf_counter() - t
+            rec["host1"] = time.perf_counter()
+            acc["host"] += rec["host1"] - t
             return rows
         f_rows = self._host.submit(host_stage)
 
@@ -338,7 +375,8 @@ class RecordingPipeline:
                 return rows
             t = time.perf_counter()
             out = finish(rows)
-            acc["finish"] += time.perf_counter() - t
+            rec["finish1"] = time.perf_counter()
+            acc["finish"] += rec["finish1"] - t
             return out
         f_fin = self._finish.submit(finish_stage)
         if post is None:
@@ -350,7 +388,8 @@ class RecordingPipeline:
                 x = x.result()
             t = time.perf_counter()
             out = post(x)
-            acc["post"] = acc.get("post", 0.0) + time.perf_counter() - t
+            rec["post1"] = time.perf_counter()
+            acc["post"] = acc.get("post", 0.0) + rec["post1"] - t
             return out
         return self._post.submit(post_stage)
 
@@ -362,6 +401,7 @@ class RecordingPipeline:
     def close(self):
         """Waits for everything submitted."""
         self._upload.shutdown(wait=True)
+        w, self._watch = self._watch, None
         for f in list(self._inflight):
             try:
                 f.result()

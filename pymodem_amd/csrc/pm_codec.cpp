@@ -821,7 +821,7 @@ int pm_host_decode_batch(pm_host_job *jobs, int njobs, int threads)
     if (njobs < 0 || (njobs > 0 && !jobs) || threads < 1) return pm_set_error(PM_ERR_ARG, "pm_host_decode_batch: bad argument");
     for (int j = 0; j < njobs; ++j) {
         const pm_host_job &q = jobs[j];
-        if (!q.codec || q.n < 0 || (q.n > 0 && (!q.h_data || !q.h_addr)))
+        if (!q.codec || q.n < 0 || (q.n > 0 && (!q.h_data || (!q.h_addr && !q.h_addr_delta))))
             return pm_set_error(PM_ERR_ARG, "pm_host_decode_batch: job %d: bad argument", j);
         for (int i = 0; i < j; ++i)
             if (jobs[i].codec == q.codec) return pm_set_error(PM_ERR_ARG, "pm_host_decode_batch: jobs %d and %d share a codec", i, j);
@@ -829,9 +829,17 @@ int pm_host_decode_batch(pm_host_job *jobs, int njobs, int threads)
     HostPool::get().run(njobs, threads, [&](int j) {
         pm_host_job &q = jobs[j];
         thread_local std::vector<uint8_t> plain;
+        thread_local std::vector<int64_t> wide;
         if ((int64_t)plain.size() < q.n) plain.resize((size_t)q.n);
+        const int64_t *addr = q.h_addr;
+        if (!addr && q.n > 0) {                 // the compact form of pm_slice_compact: first address + 16-bit steps
+            if ((int64_t)wide.size() < q.n) wide.resize((size_t)q.n);
+            int64_t a = q.addr_first;
+            for (int64_t i = 0; i < q.n; ++i) wide[(size_t)i] = (a += q.h_addr_delta[i]);
+            addr = wide.data();
+        }
         q.status = pm_lfsr_unscramble(q.h_data, q.n, q.lfsr_poly, q.lfsr_invert, &q.lfsr_state, plain.data());
-        if (q.status == PM_OK) q.status = pm_codec_decode(q.codec, plain.data(), q.h_addr, q.n, &q.pending);
+        if (q.status == PM_OK) q.status = pm_codec_decode(q.codec, plain.data(), addr, q.n, &q.pending);
     });
     for (int j = 0; j < njobs; ++j)
         if (jobs[j].status != PM_OK) return jobs[j].status;

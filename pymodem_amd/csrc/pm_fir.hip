@@ -775,22 +775,23 @@ __global__ __launch_bounds__(kThreads) void fir_sweep_kernel(const double *__res
 }
 
 // Sliding sums, low-pass(es) and the certified combine in ONE kernel: the magnitude streams never reach memory.  A workgroup owns
-// 2048 low-pass outputs; it needs the ml - 1 magnitudes past them too, computes all of them as runs of 16 from one staged window of
-// x (the first ceil((2047 + ml) / 16) lanes do, e.g. 135 of 256 for ml = 100), lays them out as the FIR's padded LDS images -- the
+// 2048 low-pass outputs; it needs the ml - 1 magnitudes past them too, computes all of them as runs of L = 12 from one staged window of
+// x (the first ceil((2047 + ml) / L) lanes do, e.g. 179 of 256 for ml = 100: three waves with short runs beat two with long ones), lays them out as the FIR's padded LDS images -- the
 // space image over the window of x, which is dead by then -- and every thread takes its 8 outputs of each low-pass from there.
 // ONE: a single chain, its mark - gain * space difference as the only image.  Arithmetic and bound: afsk_slide_kernel + fir_valid_kernel
 // + fir_sweep_kernel, value for value.
-constexpr int kFuseRun = 16;
-inline size_t fuse_region0(int m, int ml)
+constexpr int kFuseRun = 12;     // measured (g = 7 / g = 1, 28.8 M samples): runs of 10: 0.416 / 0.289 ms, 12: 0.395 / 0.264, 16: 0.411 / 0.277, 34 (one wave slides): 0.471 / 0.317
+inline size_t fuse_region0(int m, int ml, int L = kFuseRun)
 {
-    const int nmag = kThreads * 8 + ml - 1, nruns = (nmag + kFuseRun - 1) / kFuseRun;
-    const int a = slide_slot<kFuseRun>(nruns * kFuseRun + m - 1) + 2, b = slot<8>(nmag) + 2;
+    const int nmag = kThreads * 8 + ml - 1, nruns = (nmag + L - 1) / L;
+    const int p = nruns * L + m - 1;
+    const int a = p + p / L + 2, b = slot<8>(nmag) + 2;
     return (size_t)((a > b ? a : b) + 1) / 2 * 2;
 }
 inline size_t fuse_image(int ml) { return (size_t)(slot<8>(kThreads * 8 + ml - 1) + 3) / 2 * 2; }
-inline size_t fuse_lds_bytes(int m, int ml) { return (fuse_region0(m, ml) + fuse_image(ml) + 4 * (size_t)m) * sizeof(double); }
+inline size_t fuse_lds_bytes(int m, int ml, int L = kFuseRun) { return (fuse_region0(m, ml, L) + fuse_image(ml) + 4 * (size_t)m) * sizeof(double); }
 
-template <bool ONE>
+template <bool ONE, int L = kFuseRun>
 __global__ __launch_bounds__(kThreads) void afsk_slide_lpf_kernel(const double *__restrict__ x, int64_t n, const double *__restrict__ mi,
                                                                   const double *__restrict__ mq, const double *__restrict__ ui,
                                                                   const double *__restrict__ uq, int m, SlideTones T,
@@ -799,7 +800,7 @@ __global__ __launch_bounds__(kThreads) void afsk_slide_lpf_kernel(const double *
                                                                   int region0, int image)
 {
     extern __shared__ double xs[];
-    constexpr int R = 8, TILE = kThreads * R, L = kFuseRun;
+    constexpr int R = 8, TILE = kThreads * R;
     const int t = threadIdx.x;
     const int64_t tile0 = (int64_t)blockIdx.x * TILE;
     const int nmag = TILE + ml - 1, nruns = (nmag + L - 1) / L, xspan = nruns * L + m - 1;
@@ -1159,11 +1160,11 @@ static int afsk_group_dispatch(pm_ctx *ctx, int groups, const double *d_x, int64
     }
 }
 
-// Bound on |sliding magnitude - magnitude of the direct sums| for runs of 16 (derivation: afsk_magnitudes).
-static double slide_bound(const pm_afsk_tones *tones, int m, double x_bound)
+// Bound on |sliding magnitude - magnitude of the direct sums| for runs of `steps` (derivation: afsk_magnitudes).
+static double slide_bound(const pm_afsk_tones *tones, int m, double x_bound, int steps = 16)
 {
     const double u = 1.1102230246251565e-16;
-    return (16.0 * 16 * u * (m + 1) + 3.0 * m * tones->tap_dev + 3.0 * u * m * m + 6.0 * u * m) * x_bound;
+    return (16.0 * steps * u * (m + 1) + 3.0 * m * tones->tap_dev + 3.0 * u * m * m + 6.0 * u * m) * x_bound;
 }
 
 // M = |mark correlators|, S = |unit-gain space correlators| over x, one stream each (nc = n - m + 1 values): by the sliding sum when
@@ -1265,11 +1266,13 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
     // low-pass (the reference's own dataflow, afsk.py:162-166, on approximate magnitudes); a sweep takes two for all its chains.
     const bool one = groups == 1 && tones && m >= 2;
     const double *lp_in = one ? M : S, *lp_a = one ? nullptr : A;
-    const bool fused = tones && m >= 2 && (kThreads * 8 + ml - 1 + kFuseRun - 1) / kFuseRun <= kThreads &&
-                       fuse_lds_bytes(m, ml) <= 120 * 1024 && !getenv("PM_AFSK_UNFUSED");
+    int frun = getenv("PM_FUSE_RUN") ? atoi(getenv("PM_FUSE_RUN")) : kFuseRun;
+    if (frun != 16) frun = kFuseRun;                         // PM_FUSE_RUN=16: round 1's run length, for comparison
+    const bool fused = tones && m >= 2 && (kThreads * 8 + ml - 1 + frun - 1) / frun <= kThreads &&
+                       fuse_lds_bytes(m, ml, frun) <= 120 * 1024 && !getenv("PM_AFSK_UNFUSED");
     if (fused) {
         // sliding sums, low-pass(es) and combine in one kernel (afsk_slide_lpf_kernel): nothing but the bitmaps is written
-        e_slide = slide_bound(tones, m, x_bound);
+        e_slide = slide_bound(tones, m, x_bound, frun);
     } else {
         if (int rc = afsk_magnitudes(ctx, d_x, n, x_bound, d_mark_i, d_mark_q, d_unit_i, d_unit_q, m, tones, M, one ? nullptr : S, &e_slide,
                                      P.gain[0]))
@@ -1284,21 +1287,24 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
                      tones->space_rot[0], tones->space_rot[1], tones->space_end[0], tones->space_end[1]};
         const int64_t ntiles = pm_cdiv(nl, (int64_t)kThreads * 8);
         PM_ARG(ntiles < (1LL << 31));
-        const size_t lds = fuse_lds_bytes(m, ml);
-        const int region0 = (int)fuse_region0(m, ml), image = (int)fuse_image(ml);
+        const size_t lds = fuse_lds_bytes(m, ml, frun);
+        const int region0 = (int)fuse_region0(m, ml, frun), image = (int)fuse_image(ml);
         PmProf prof(ctx, PM_K_FIR_F64);
         const double nlp = one ? 1.0 : 2.0;
         prof.work((double)n * 8 + (double)groups * nl / 8,
-                  (4.0 * m / kFuseRun + 18.0) * (double)nc + nlp * 2.0 * ml * (double)nl + 2.0 * groups * (double)nl);
-        if (one) {
-            if (int rc = allow_lds(afsk_slide_lpf_kernel<true>, lds)) return rc;
-            hipLaunchKernelGGL((afsk_slide_lpf_kernel<true>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, d_x, n, d_mark_i, d_mark_q,
-                               d_unit_i, d_unit_q, m, T, d_lpf, ml, nl, groups, P, E, list, count, cap, region0, image);
-        } else {
-            if (int rc = allow_lds(afsk_slide_lpf_kernel<false>, lds)) return rc;
-            hipLaunchKernelGGL((afsk_slide_lpf_kernel<false>), dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, d_x, n, d_mark_i, d_mark_q,
-                               d_unit_i, d_unit_q, m, T, d_lpf, ml, nl, groups, P, E, list, count, cap, region0, image);
+                  (4.0 * m / frun + 18.0) * (double)nc + nlp * 2.0 * ml * (double)nl + 2.0 * groups * (double)nl);
+        auto go = [&](auto kernel) -> int {
+            if (int rc = allow_lds(kernel, lds)) return rc;
+            hipLaunchKernelGGL(kernel, dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, d_x, n, d_mark_i, d_mark_q, d_unit_i, d_unit_q, m, T,
+                               d_lpf, ml, nl, groups, P, E, list, count, cap, region0, image);
+            return PM_OK;
+        };
+        int rc;
+        switch (frun) {
+        case 16: rc = one ? go(afsk_slide_lpf_kernel<true, 16>) : go(afsk_slide_lpf_kernel<false, 16>); break;
+        default: rc = one ? go(afsk_slide_lpf_kernel<true, 12>) : go(afsk_slide_lpf_kernel<false, 12>); break;
         }
+        if (rc) return rc;
         PM_HIP(hipGetLastError());
     } else {   // B = LPF(S) and the combine step in one pass: B never reaches memory
         constexpr int R = 8;

@@ -200,6 +200,21 @@ int pm_d2h(pm_ctx *c, void *h_dst, const void *d_src, size_t bytes)
     return PM_OK;
 }
 
+int pm_host_pin(pm_ctx *c, void *h_block, size_t bytes)
+{
+    PM_CTX(c);
+    PM_ARG(c != nullptr && h_block != nullptr && bytes > 0);
+    PM_HIP(hipHostRegister(h_block, bytes, hipHostRegisterDefault));
+    return PM_OK;
+}
+
+int pm_host_unpin(void *h_block)
+{
+    if (!h_block) return PM_OK;
+    PM_HIP(hipHostUnregister(h_block));
+    return PM_OK;
+}
+
 int pm_d2d(pm_ctx *c, void *d_dst, const void *d_src, size_t bytes)
 {
     PM_CTX(c);

@@ -296,6 +296,9 @@ __global__ __launch_bounds__(kBlock) void slice_count_kernel(const JobDev *__res
         uint32_t *d32 = jobs[k].data32;
         const int64_t nd = (jobs[k].cap + 3) >> 2;
         for (int64_t d = gc; d < nd; d += (int64_t)gridDim.x * blockDim.x) d32[d] = 0u;
+        // ... and the stream's trailing partial byte, which the pack kernel ORs together as well: an emission that ran before the
+        // last walker had merged (the launch hint was too short) has left the bits of a not yet final trajectory in it
+        if (gc == 0) *jobs[k].tail = 0u;
     }
     if (gc >= total_chunks) return;
     const int j = find_job(jobs, njobs, gc);
@@ -796,6 +799,50 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
     return rc;
 }
 
+// ---- compact form of a batch's output for the way to the host ------------------------------------------------------------------
+// Per job: {first address, last address} (2 x int64), count deltas as uint16 (address[i] - address[i-1], delta[0] = 0; padded to 8
+// bytes), count data bytes (padded to 8).  A byte's address is the sample at which its eighth bit was taken, so a delta is eight
+// symbol periods (320 samples at 1200 Bd / 48 kHz); one that does not fit 16 bits wraps, and the host sees it because the deltas no
+// longer add up to last - first.
+struct CompactJobs {
+    const uint8_t *data[kMaxJobs];
+    const int64_t *addr[kMaxJobs];
+    int64_t count[kMaxJobs];
+    int64_t off[kMaxJobs];           // byte offset of the job's header in the block
+    int njobs;
+};
+
+__global__ __launch_bounds__(256) void slice_compact_kernel(CompactJobs J, uint8_t *block)
+{
+    const int j = blockIdx.y;
+    const int64_t n = J.count[j];
+    const int64_t *addr = J.addr[j];
+    uint8_t *base = block + J.off[j];
+    uint16_t *delta = reinterpret_cast<uint16_t *>(base + 16);
+    uint8_t *bytes = base + 16 + ((2 * n + 7) & ~int64_t(7));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        reinterpret_cast<int64_t *>(base)[0] = n ? addr[0] : 0;
+        reinterpret_cast<int64_t *>(base)[1] = n ? addr[n - 1] : 0;
+    }
+    // four entries per thread: one 8-byte store of deltas, one 4-byte store of data
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; 4 * q < n; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = 4 * q;
+        int64_t prev = i ? addr[i - 1] : (n ? addr[0] : 0);
+        uint64_t d4 = 0;
+        uint32_t b4 = 0;
+        for (int k = 0; k < 4; ++k) {
+            if (i + k < n) {
+                const int64_t a = addr[i + k];
+                d4 |= (uint64_t)(uint16_t)(a - prev) << (16 * k);
+                b4 |= (uint32_t)J.data[j][i + k] << (8 * k);
+                prev = a;
+            }
+        }
+        *reinterpret_cast<uint64_t *>(delta + i) = d4;       // the padding makes the last, partly filled store legal
+        *reinterpret_cast<uint32_t *>(bytes + i) = b4;
+    }
+}
+
 extern "C" {
 
 int pm_slice_binary(pm_ctx *ctx, const uint64_t *d_bits, int64_t n, const pm_slicer_params *h_params,
@@ -831,6 +878,35 @@ int pm_slice_quadrature(pm_ctx *ctx, const uint64_t *d_bits_i, const uint64_t *d
     const int rc = pm_slice_batch(ctx, &job, 1);
     *h_count = job.count;
     return rc;
+}
+
+int pm_slice_compact(pm_ctx *ctx, const pm_slice_job *h_jobs, int njobs, void *d_block, size_t block_bytes, int64_t *h_offsets,
+                     size_t *h_used)
+{
+    PM_CTX(ctx);
+    PM_ARG(h_jobs && njobs >= 1 && njobs <= kMaxJobs && d_block && h_offsets && h_used);
+    CompactJobs J;
+    memset(&J, 0, sizeof(J));
+    J.njobs = njobs;
+    size_t at = 0;
+    int64_t most = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const pm_slice_job &q = h_jobs[j];
+        PM_ARG(q.count >= 0 && q.count <= q.cap && (q.count == 0 || (q.d_data && q.d_addr)));
+        J.data[j] = q.d_data;
+        J.addr[j] = q.d_addr;
+        J.count[j] = q.count;
+        J.off[j] = h_offsets[j] = (int64_t)at;
+        at += 16 + (size_t)((2 * q.count + 7) & ~int64_t(7)) + (size_t)((q.count + 7) & ~int64_t(7));
+        most = std::max(most, q.count);
+    }
+    *h_used = at;
+    if (at > block_bytes) return pm_set_error(PM_ERR_CAPACITY, "pm_slice_compact: the block holds %zu bytes, the batch needs %zu", block_bytes, at);
+    PmProf prof(ctx, PM_K_SLICE_EMIT);
+    const int bx = (int)std::max<int64_t>(1, std::min<int64_t>(64, (most / 4 + 255) / 256));
+    hipLaunchKernelGGL(slice_compact_kernel, dim3(bx, njobs), dim3(256), 0, ctx->stream, J, static_cast<uint8_t *>(d_block));
+    PM_HIP(hipGetLastError());
+    return PM_OK;
 }
 
 int pm_slicer_tune(pm_ctx *ctx, int64_t target_lanes)

@@ -37,8 +37,32 @@ class AddressedArray:
 
     def __init__(self, data, address):
         self.data = np.ascontiguousarray(data, dtype=np.uint8)
-        self.address = np.ascontiguousarray(address, dtype=np.int64)
-        assert self.data.shape == self.address.shape
+        self._address = np.ascontiguousarray(address, dtype=np.int64)
+        self._steps = None
+        assert self.data.shape == self._address.shape
+
+    @classmethod
+    def from_steps(cls, data, steps, first):
+        """The slicer's compact form (pm_slice_compact): address[i] = first + steps[0] + ... + steps[i] with steps[0] = 0.  The
+        native host stages take it as it is; `.address` expands it when somebody asks."""
+        self = cls.__new__(cls)
+        self.data = np.ascontiguousarray(data, dtype=np.uint8)
+        self._steps = (np.ascontiguousarray(steps, dtype=np.uint16), int(first))
+        self._address = None
+        assert self.data.shape == self._steps[0].shape
+        return self
+
+    @property
+    def address(self):
+        if self._address is None:
+            steps, first = self._steps
+            self._address = np.cumsum(steps, dtype=np.int64) + first
+        return self._address
+
+    @property
+    def address_steps(self):
+        """(uint16 steps, first address) if the addresses are still in compact form, else None."""
+        return self._steps if self._address is None else None
 
     @classmethod
     def coerce(cls, seq):

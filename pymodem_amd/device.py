@@ -1,6 +1,8 @@
 """Device context and buffers on top of the C ABI (pm_ctx_*, pm_malloc, pm_h2d, pm_d2h)."""
 import ctypes
+import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -185,8 +187,10 @@ class Context:
 _HOST_BLOCKS, _HOST_BLOCKS_LOCK, _HOST_BLOCKS_MAX = [], threading.Lock(), 12
 
 
-def _host_block(nbytes):
-    """A uint8 host array of at least nbytes that nobody else refers to (see DeviceBuffer.download)."""
+def _host_block(nbytes, ctx=None):
+    """A uint8 host array of at least nbytes that nobody else refers to (see DeviceBuffer.download).  With `ctx` a new block is
+    page-locked (pm_host_pin) for as long as it lives: the pool's blocks take a copy per recording, and a copy into pageable
+    memory goes through the runtime's bounce buffers at a third of the link's rate."""
     import sys
     with _HOST_BLOCKS_LOCK:
         for blk in _HOST_BLOCKS:
@@ -194,6 +198,11 @@ def _host_block(nbytes):
             if blk.nbytes >= nbytes and blk.nbytes <= 2 * nbytes + (1 << 20) and sys.getrefcount(blk) == 3:
                 return blk
         blk = np.empty(max(nbytes, 1), dtype=np.uint8)
+        if ctx is not None and os.environ.get("PYMODEM_AMD_PIN_HOST", "1") != "0":
+            blk.fill(0)                                        # touch the pages here rather than inside the pin
+            at = blk.ctypes.data
+            if lib().pm_host_pin(ctx.handle, ctypes.c_void_p(at), blk.nbytes) == 0:
+                weakref.finalize(blk, lib().pm_host_unpin, ctypes.c_void_p(at))   # runs before the array's memory is released
         if len(_HOST_BLOCKS) >= _HOST_BLOCKS_MAX:
             for i, old in enumerate(_HOST_BLOCKS):             # drop an idle block rather than grow without bound
                 if sys.getrefcount(old) == 3:
@@ -228,12 +237,13 @@ class DeviceBuffer:
         out._parent = self
         return out
 
-    def download(self, n=None, recycle=False, ctx=None):
+    def download(self, n=None, recycle=False, ctx=None, room=None):
         """-> a host array of the first n elements.  recycle=True takes the memory from a small pool of host blocks that are handed
         out again once nothing refers to them any more (views keep their block alive): a fresh 10-40 MB allocation per call costs
         more in first-touch page faults than the copy itself."""
         n = self.n if n is None else int(n)
-        out = _host_block(n * self.dtype.itemsize).view(self.dtype)[:n] if recycle else np.empty(n, dtype=self.dtype)
+        # `room`: ask the pool for a block of that many elements (callers whose sizes vary name their largest: one size class)
+        out = _host_block(max(n, int(room or 0)) * self.dtype.itemsize, ctx or self.ctx).view(self.dtype)[:n] if recycle else np.empty(n, dtype=self.dtype)
         if n:      # `ctx`: copy on that context's stream instead (the data must be complete: the caller synchronised its producer)
             check(lib().pm_d2h((ctx or self.ctx).handle, out.ctypes.data_as(ctypes.c_void_p), self.ptr, out.nbytes))
         return out

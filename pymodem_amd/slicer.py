@@ -72,13 +72,14 @@ class _SlicerBase:
         return slice_batch([self], [(bits_i, bits_q, n)])[0]
 
 
-def slice_batch(slicers, bitmaps, ctx=None, defer=False, reserve=1.0, out_tag=None):
+def slice_batch(slicers, bitmaps, ctx=None, defer=False, reserve=1.0, out_tag=None, compact=False):
     """Stage 2 of slice() for many independent streams in ONE pm_slice_batch call (shared iteration launches).
     bitmaps[k] = (bits_i, bits_q | None, n) from slicers[k].sign_bitmaps().  Returns one AddressedArray per stream.
     `ctx`: the context (stream) to run on; the bitmaps must be complete (their producer stream synchronised) if it is not the
     one that made them.  defer=True: the slicers have run (states updated) but their output is still in device memory; returns
     fetch(copy_ctx) -> the list, which copies it to the host on copy_ctx's stream (the pipelined executor fetches on another
-    thread while this context already slices the next batch)."""
+    thread while this context already slices the next batch).  compact=True (with defer): the output crosses to the host in
+    pm_slice_compact's form -- exact counts, 16-bit address steps -- a quarter of the bytes; the arrays returned are the same."""
     ctx = ctx or slicers[0]._ctx or Context.default()
     # Slicers of the same kind and state on the same bitmap(s) (chains that differ only after the slicer) are one job: run the first,
     # hand its result and end state to the others.
@@ -92,7 +93,7 @@ def slice_batch(slicers, bitmaps, ctx=None, defer=False, reserve=1.0, out_tag=No
             first[key] = k
     if dup_of:
         uniq = [k for k in range(len(slicers)) if k not in dup_of]
-        inner = slice_batch([slicers[k] for k in uniq], [bitmaps[k] for k in uniq], ctx, defer=True, reserve=reserve, out_tag=out_tag)
+        inner = slice_batch([slicers[k] for k in uniq], [bitmaps[k] for k in uniq], ctx, defer=True, reserve=reserve, out_tag=out_tag, compact=compact)
 
         def fetch_all(copy_ctx=None):
             got = dict(zip(uniq, inner(copy_ctx)))
@@ -109,13 +110,13 @@ def slice_batch(slicers, bitmaps, ctx=None, defer=False, reserve=1.0, out_tag=No
         group = list(range(base, min(base + 64, len(slicers))))
         saved = [SlicerState.from_buffer_copy(slicers[k]._state) for k in group]
         try:
-            fetchers.append(_slice_group(ctx, slicers, bitmaps, group, out, tight=True, reserve=reserve, out_tag=out_tag))
+            fetchers.append(_slice_group(ctx, slicers, bitmaps, group, out, tight=True, reserve=reserve, out_tag=out_tag, compact=compact and defer))
         except NativeError as e:                      # a stream produced more than twice its nominal symbol count: full-size buffers
             if "capacity" not in str(e):
                 raise
             for k, st in zip(group, saved):
                 ctypes.memmove(ctypes.byref(slicers[k]._state), ctypes.byref(st), ctypes.sizeof(SlicerState))
-            fetchers.append(_slice_group(ctx, slicers, bitmaps, group, out, tight=False, reserve=reserve, out_tag=out_tag))
+            fetchers.append(_slice_group(ctx, slicers, bitmaps, group, out, tight=False, reserve=reserve, out_tag=out_tag, compact=compact and defer))
 
     def fetch(copy_ctx=None):
         for f in fetchers:
@@ -127,7 +128,7 @@ def slice_batch(slicers, bitmaps, ctx=None, defer=False, reserve=1.0, out_tag=No
 _TIGHT_FACTOR = 1.5
 
 
-def _slice_group(ctx, slicers, bitmaps, group, out, tight, reserve=1.0, out_tag=None):
+def _slice_group(ctx, slicers, bitmaps, group, out, tight, reserve=1.0, out_tag=None, compact=False):
     jobs = (SliceJob * len(group))()
     # One device block for the whole batch's output (addresses first, then bytes) and ONE device-to-host copy per batch.  The
     # hard bound is one symbol per sample; the clock can at most double its nominal rate (every crossing pulls it towards zero,
@@ -166,6 +167,28 @@ def _slice_group(ctx, slicers, bitmaps, group, out, tight, reserve=1.0, out_tag=
     for j, k in enumerate(group):
         slicers[k].last_stats = {"iterations": it.value, "chunk_len": cl.value, "chunks": nc.value}
         slicers[k].phase_clock, slicers[k].streamaddress = slicers[k]._state.phase_clock, slicers[k]._state.streamaddress
+
+    if compact:
+        # exact counts and 16-bit address steps, packed by a small kernel behind the batch: what crosses to the host is 3 bytes per
+        # data byte instead of 9 and no unused capacity; the dense block is sized for the capacity once (times `reserve`)
+        dense_cap = sum(16 + (2 * c + 7) // 8 * 8 + (c + 7) // 8 * 8 for c in caps)
+        dense = ctx.scratch((out_tag if out_tag is not None else slicers[group[0]]._own_key(), "slice_dense"), int(dense_cap * max(1.0, reserve)), np.uint8)
+        offs, used = (ctypes.c_int64 * len(group))(), ctypes.c_size_t()
+        check(lib().pm_slice_compact(ctx.handle, jobs, len(group), dense.ptr, dense.n, offs, ctypes.byref(used)))
+
+        def fetch_compact(copy_ctx=None):
+            host = dense.download(used.value, recycle=True, ctx=copy_ctx, room=dense.n)
+            for j, k in enumerate(group):
+                c, o = counts[j], offs[j]
+                first, last = (int(v) for v in host[o:o + 16].view(np.int64))
+                steps = host[o + 16:o + 16 + 2 * c].view(np.uint16)
+                data = host[o + 16 + (2 * c + 7) // 8 * 8:o + 16 + (2 * c + 7) // 8 * 8 + c]
+                if c and first + int(steps.sum(dtype=np.int64)) != last:     # a step beyond 16 bits: this stream's addresses in full
+                    full = block.view(a_off[j], c * 8).download(ctx=copy_ctx).view(np.int64)
+                    out[k] = AddressedArray(data, full)
+                else:
+                    out[k] = AddressedArray.from_steps(data, steps, first)
+        return fetch_compact
 
     def fetch(copy_ctx=None):
         host = block.download(at, recycle=True, ctx=copy_ctx)

@@ -494,6 +494,63 @@ def test_slice_batch_many_streams_and_ragged_lengths(ctx):
         assert np.array_equal(g.data, w[0]) and np.array_equal(g.address, w[1]), k
 
 
+def test_slice_batch_compact_form_equals_the_plain_one(ctx):
+    """defer + compact (pm_slice_compact: exact counts, 16-bit address steps; what the pipelined executor brings to the host) gives
+    the arrays of the plain call -- ragged lengths, an empty stream, quadrature and binary mixed, and a symbol rate so low that
+    eight symbol periods do not fit 16 bits (that stream's addresses then come in full)."""
+    from pymodem_amd.data_classes import IQData
+    from pymodem_amd.slicer import BinarySlicer, QuadratureSlicer, slice_batch
+    from pymodem_amd import chain_execute as ce
+    from pymodem_amd import lfsr as L, chain_builder as cb
+
+    def build():
+        rng = np.random.default_rng(77)
+        slicers, inputs = [], []
+        for k in range(12):
+            n = [1, 7, 300001, 4000, 64, 65, 123457, 200000, 9, 50000, 777, 150000][k]
+            xi, xq = slicer_input(n, 40 + k, "smooth"), slicer_input(n, 90 + k, "noise")
+            if k % 4 == 1:
+                s = QuadratureSlicer(sample_rate=48000, config="qpsk_2400")
+                iq = IQData()
+                iq.i_data, iq.q_data = xi, xq
+                inputs.append(iq)
+            else:
+                s = BinarySlicer(sample_rate=48000, config="9600" if k % 2 else "1200")
+                if k == 7:
+                    s.retune(symbol_rate=5.0)            # 9600 samples per symbol: a byte every 76800 samples
+                    xi = np.where((np.arange(n) // 31000) % 2 == 0, 1.0, -1.0)      # few crossings, or the clock never gets there
+                inputs.append(xi)
+            slicers.append(s)
+        return slicers, [s.sign_bitmaps(x) for s, x in zip(slicers, inputs)]
+
+    slicers, bitmaps = build()
+    plain = slice_batch(slicers, bitmaps)
+    slicers2, bitmaps2 = build()
+    fetch = slice_batch(slicers2, bitmaps2, ctx, defer=True, compact=True, reserve=2.0)
+    compact = fetch(ctx)
+    assert sum(len(p) for p in plain) > 3000
+    # stream 7 needs more lockstep launches than a fresh context's first guess: the batch is emitted twice, and the partial byte left
+    # for the next call must be the final trajectory's (it used to keep bits of the first emission)
+    assert slicers[7]._state.working_bits == 5 and slicers[7]._state.working_byte == 3
+    # the native host stage reads the compact form as it is (before anything below asks for .address, which expands it)
+    chain = lambda: ["c", None, None, L.LFSR(poly=0x3, invert=True), cb.CodecConfigurator({"type": "ax25"}, "c")]
+    assert compact[2].address_steps is not None and len(compact[2]) > 900
+    rows_b = ce._host_rows([chain()], [compact[2]])
+    assert compact[2].address_steps is not None
+    rows_a = ce._host_rows([chain()], [plain[2]])
+    assert rows_a[0].tobytes() == rows_b[0].tobytes()
+    for k, (a, b) in enumerate(zip(plain, compact)):
+        assert np.array_equal(a.data, b.data), k
+        if k == 7:
+            assert b.address_steps is None and len(b) >= 2, (len(b), b.address_steps, a.address)      # the wide steps were noticed
+        elif len(b):
+            assert b.address_steps is not None, k
+        assert np.array_equal(a.address, b.address), k
+        sa, sb = slicers[k]._state, slicers2[k]._state
+        for f in ("phase_clock", "last_i_negative", "last_q_negative", "working_byte", "working_bits", "state_register", "streamaddress"):
+            assert getattr(sa, f) == getattr(sb, f), (k, f, getattr(sa, f), getattr(sb, f))
+
+
 def test_slice_batch_rejects_bad_jobs(ctx):
     from pymodem_amd import NativeError
     from pymodem_amd._native import SliceJob
@@ -708,7 +765,7 @@ def test_sweep_tones_rejects_templates_that_are_not_tones(ctx):
 
 
 def test_runtime_additions(ctx):
-    """pm_d2d, pm_event_query / pm_event_sync, pm_ctx_scratch and a CU-masked context (pm_ctx_create_cumask) do what they say."""
+    """pm_d2d, pm_host_pin, pm_event_query / pm_event_sync, pm_ctx_scratch and a CU-masked context (pm_ctx_create_cumask) do what they say."""
     import pymodem_amd
     from pymodem_amd._native import check, lib
     L = lib()
@@ -719,6 +776,13 @@ def test_runtime_additions(ctx):
     pymodem_amd.Context.event_sync(ev)
     assert pymodem_amd.Context.event_done(ev) is True
     assert np.array_equal(dst.download(), a)
+    # a page-locked host block takes the same copy; the executor's recycled result blocks are pinned when they are made
+    blk = np.zeros(a.nbytes, np.uint8)
+    check(L.pm_host_pin(ctx.handle, blk.ctypes.data_as(ctypes.c_void_p), blk.nbytes))
+    check(L.pm_d2h(ctx.handle, blk.ctypes.data_as(ctypes.c_void_p), dst.ptr, blk.nbytes))
+    check(L.pm_host_unpin(blk.ctypes.data_as(ctypes.c_void_p)))
+    assert np.array_equal(blk.view(np.int16), a)
+    assert np.array_equal(dst.download(recycle=True), a) and np.array_equal(dst.download(recycle=True), a)
     have = ctypes.c_size_t()
     check(L.pm_ctx_scratch(ctx.handle, 0, ctypes.byref(have)))
     check(L.pm_ctx_scratch(ctx.handle, have.value + (1 << 20), ctypes.byref(have)))
