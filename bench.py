@@ -143,7 +143,7 @@ def main():
                          "2: three-stage pipeline (chain_execute.RecordingPipeline): demod of step k+1 on the default stream, slicer of "
                          "step k on a high-priority side stream, host half (LFSR, codec, packet gather, de-dup) of step k-1 in threads; "
                          "1: only the host half runs behind the next step's GPU half; 0: strictly one after the other")
-    ap.add_argument("--slice-workers", type=int, default=3, help="--overlap 2: recordings whose slicers may be in flight at once")
+    ap.add_argument("--slice-workers", type=int, default=2, help="--overlap 2: recordings whose slicers may be in flight at once")
     ap.add_argument("--demod-streams", type=int, default=1, help="--overlap 2: streams the demod kernels of successive recordings alternate on")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--buffer", default="signal", choices=["signal", "noise"],
@@ -313,6 +313,7 @@ def measure(args, env):
         return finish(ce.process_chains_split(build_chains(), d_audio)())
 
     stage_ms = {}
+    pipes = {}
 
     def run_steps(k):
         """k steps; with --overlap the host half of each step runs behind the GPU half of the next one."""
@@ -322,7 +323,12 @@ def measure(args, env):
                 res = step()
             return res
         if args.overlap >= 2:
-            pipe = ce.RecordingPipeline(slice_workers=args.slice_workers, demod_streams=args.demod_streams)
+            # the executor (its threads, streams and work blocks) lives across calls, like the process that owns it would keep it;
+            # the timed region ends when every one of its k recordings has left the last stage (drain)
+            pipe = pipes.get("main")
+            if pipe is None:
+                pipe = pipes["main"] = ce.RecordingPipeline(slice_workers=args.slice_workers, demod_streams=args.demod_streams)
+            pipe.reset_stats()
             # the exchange runs one recording behind (dist.Exchanger): the copy back of a gather never waits for the collective
             ex = pdist.Exchanger(nchains, coll_device)
             last = None
@@ -330,7 +336,9 @@ def measure(args, env):
                 last = pipe.submit(build_chains(), d_audio, ex.step, (None if os.environ.get("BENCH_NO_POST") else dedupe), prepare=lambda rows_list: ex.prepare(dict(zip(my, rows_list))))
             pipe.flush_finish(ex.flush)
             res = last.result() if last is not None else None
-            pipe.close()                                      # every step's de-dup is done, not only the last one's
+            pipe.drain()                                      # every step's de-dup is done, not only the last one's
+            if os.environ.get("BENCH_FRESH_PIPE"):            # diagnostic: a new executor per call, torn down inside the timed region
+                pipes.pop("main").close()
             stage_ms.clear()
             stage_ms.update({s: round(v / max(k, 1) * 1e3, 3) for s, v in pipe.stage_seconds.items()})
             if os.environ.get("BENCH_TIMELINE"):              # diagnostic: host clock at every stage boundary of every recording
@@ -386,6 +394,7 @@ def measure(args, env):
         for sc in sides:
             sc.profile(True)
     t0 = time.perf_counter()
+    cpu0 = time.process_time()
     if os.environ.get("BENCH_PYPROFILE"):                     # where the submitting thread's time goes (diagnostic, stderr)
         import cProfile, pstats
         pr = cProfile.Profile()
@@ -395,6 +404,7 @@ def measure(args, env):
         result = run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    host_cpu_ms = (time.process_time() - cpu0) / max(args.steps, 1) * 1e3     # all threads of this process, native ones included
     if os.environ.get("BENCH_NO_PROF"):                   # diagnostic: the step time without the HIP-event bracketing the roofline needs
         print(json.dumps({"ms_per_step_without_profiling": round(elapsed / args.steps * 1e3, 3), "stages": stage_ms}), file=sys.stderr)
         sys.exit(0)
@@ -418,6 +428,9 @@ def measure(args, env):
         alone = ctx.profile_read()
         ctx.profile(False)
         args.overlap = saved
+    for p in pipes.values():
+        p.close()
+    pipes.clear()
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device or "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -512,6 +525,7 @@ def measure(args, env):
                             "step's recording starts in host memory and is copied to HBM one step ahead on a copy stream "
                             "(RecordingPipeline.prefetch).  `value` itself has the recording resident in HBM"},
             "pipeline_stage_ms_per_step": stage_ms or None,
+            "host_cpu_ms_per_step": round(host_cpu_ms, 3), "host_cores_visible": len(os.sched_getaffinity(0)),
             "slicer": chains_ref[0][2].last_stats if chains_ref else None,
             "packets": {"unique_good": result.CountGood() if result is not None else None,
                         "bad": result.CountBad() if result is not None else None},

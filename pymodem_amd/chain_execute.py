@@ -159,15 +159,19 @@ class RecordingPipeline:
     """Successive recordings through chain groups with the stages of the path overlapped, each on its own resource:
 
       demod   FIR / correlator / loop kernels (vector-f64 ALU and HBM)                 default stream, caller's thread
-      slice   chunk-parallel timing recovery: ~1 resident wave per SIMD, dependent-     `slice_workers` high-priority side streams,
-              latency bound, so TWO recordings' slicers share the GPU almost for free    one thread each
+      slice   lockstep walkers (pm_slice_batch): a batch of up to four recordings costs   `slice_workers` high-priority side streams,
+              about what one costs (dependent-latency bound), so a worker waits for       one thread each
+              three finished demods before it starts one; the batch's bytes and address
+              steps come back in compact form on the same stream (pm_slice_compact)
       host    LFSR + codec (native, GIL released)                                       five threads (recordings); chains on library threads
       finish  the caller's `finish(rows per chain)`: the packet exchange                 one thread, submission order (collectives)
       post    the caller's `post(...)`: rank 0's payload copy, indexing and de-dup       three threads
 
-    While recordings k and k-1 are being sliced, recording k+1 is demodulated and k-2 finished.  The only GPU buffers that cross
-    stages are the sign bitmaps (one bit per sample), kept in slice_workers + 2 rotating slots (demod runs one recording ahead); a GPU event, not a host wait,
-    orders slicer after demod.  Results are identical to process_chains_table on each recording (tests/test_gpu_chains.py)."""
+    While recordings k-1..k-3 are being sliced, recording k+1 is demodulated and k-4 finished.  The only GPU buffers that cross
+    stages are the sign bitmaps (one bit per sample), kept in sixteen rotating slots (the submitter runs ahead until they are
+    all in flight); a GPU event, not a host wait, orders slicer after demod.  drain() waits for everything submitted, the executor
+    stays usable (bench.py keeps one across warm-up and timed steps); close() ends its threads.  Results are identical to
+    process_chains_table on each recording (tests/test_gpu_chains.py)."""
 
     def __init__(self, slice_workers=2, demod_streams=1, slice_group=4, slots=None):
         from collections import deque
@@ -181,11 +185,12 @@ class RecordingPipeline:
         self._demod_streams = 1
         self._group = max(1, min(int(os.environ.get("PYMODEM_AMD_SLICE_GROUP", slice_group)), 8))
         self._fetch_inline = os.environ.get("PYMODEM_AMD_FETCH", "worker") != "copy"
-        self._min_group = max(1, min(int(os.environ.get("PYMODEM_AMD_SLICE_MIN_GROUP", 1)), self._group))
+        self._min_group = max(1, min(int(os.environ.get("PYMODEM_AMD_SLICE_MIN_GROUP", 3)), self._group))
         self._host = ThreadPoolExecutor(max_workers=5)        # LFSR + codec of up to five recordings at a time (IL2P chains take 4-5 ms each)
         self._finish = ThreadPoolExecutor(max_workers=1)
         self._post = ThreadPoolExecutor(max_workers=3)        # whatever follows the ordered step (rank 0's payload copy, indexing, de-dup)
         self._inflight = deque()
+        self._tails = deque()                                 # the last stage's future of every recording not yet drained
         self._n = 0
         self._upload = ThreadPoolExecutor(max_workers=1)      # host -> HBM copies of the NEXT recording, on a stream of their own
         self._uploads = 0
@@ -267,7 +272,7 @@ class RecordingPipeline:
                     side._slicer_block_reserved = True        # once per context (contexts outlive pipelines)
                     have = ctypes.c_size_t()
                     check(lib().pm_ctx_scratch(side.handle, 0, ctypes.byref(have)))
-                    check(lib().pm_ctx_scratch(side.handle, int(have.value * min(self._group, 4) / len(items)), None))
+                    check(lib().pm_ctx_scratch(side.handle, int(have.value * self._group / len(items)), None))
                 # The slicers' bytes and addresses are still in device memory: whichever host-stage thread needs them first copies
                 # the whole batch over on the copy stream (this worker's stream is already slicing the next batch).
                 if self._fetch_inline:
@@ -380,6 +385,7 @@ class RecordingPipeline:
             return out
         f_fin = self._finish.submit(finish_stage)
         if post is None:
+            self._tails.append(f_fin)
             return f_fin
 
         def post_stage():
@@ -391,7 +397,22 @@ class RecordingPipeline:
             rec["post1"] = time.perf_counter()
             acc["post"] = acc.get("post", 0.0) + rec["post1"] - t
             return out
-        return self._post.submit(post_stage)
+        f_post = self._post.submit(post_stage)
+        self._tails.append(f_post)
+        return f_post
+
+    def drain(self):
+        """Waits until every recording submitted so far has left its last stage (the pipeline stays usable); re-raises the first
+        stage error."""
+        while self._tails:
+            self._tails.popleft().result()
+
+    def reset_stats(self):
+        for k in list(self.stage_seconds):
+            self.stage_seconds[k] = 0.0
+        self.slice_batches = 0
+        self.slice_log = []
+        self.timeline = []
 
     def flush_finish(self, fn):
         """Run fn() on the finish thread after every finish submitted so far (e.g. dist.Exchanger.flush, which resolves the last

@@ -235,38 +235,66 @@ struct pm_codec {
 
 namespace {
 
-// Per (consecutive-ones count on entry, input byte): the de-stuffed bits this byte appends, provided no flag or abort
-// can occur inside it (the count never reaches 6 before a bit is examined).  Everything else takes the bit-serial path.
-struct Ax25Fast {
-    uint8_t fast, nout, outbits, ones_out;
+// Per (consecutive-ones count on entry, capped at 7, and input byte): what the eight bits do to the decoder, as at most four steps --
+// "append these de-stuffed bits", "flag", "k ones past the sixth (abort)" -- in bit order.  It is the bit-serial code below run on
+// the part of the state that the bit pattern alone decides (the ones counter); what depends on the rest (bit and byte counters, the
+// collected bytes) happens when the steps are carried out.  Streams between packets are far from random bits (long runs of ones on
+// the chains with a strong space gain), so "no flag or abort inside this byte" is not the common case it is on a clean signal.
+struct Ax25Step {
+    uint8_t op, bits;                                    // op: kind << 4 | n; kind 0 append n bits (first appended = bit 0 of `bits`), 1 flag, 2 abort of n ones
+};
+struct Ax25Entry {
+    uint8_t nsteps, ones_out;                            // nsteps 0xFF: more than three steps -> bit-serial
+    Ax25Step step[3];
 };
 
-const Ax25Fast *ax25_table()
+const Ax25Entry *ax25_table()
 {
-    static Ax25Fast t[6][256];
-    static bool built = false;
-    if (!built) {
-        for (int ones0 = 0; ones0 < 6; ++ones0)
+    static Ax25Entry t[8][256];                          // 16 KB
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (int ones0 = 0; ones0 < 8; ++ones0)
             for (int byte = 0; byte < 256; ++byte) {
-                Ax25Fast e{1, 0, 0, 0};
-                int ones = ones0;
-                for (int i = 0; i < 8 && e.fast; ++i) {
+                Ax25Entry e;
+                memset(&e, 0, sizeof(e));
+                int ones = ones0, ns = 0, kind[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0};
+                bool over = false;
+                auto last = [&](int k) -> int {
+                    if (ns && kind[ns - 1] == k && k != 1) return ns - 1;
+                    if (ns == 3) { over = true; return -1; }
+                    kind[ns] = k;
+                    return ns++;
+                };
+                for (int i = 0; i < 8 && !over; ++i) {
                     const int bit = (byte >> (7 - i)) & 1;
-                    if (ones >= 6) { e.fast = 0; break; }            // next bit decides flag / abort: slow path
                     if (bit) {
-                        e.outbits |= (uint8_t)(1u << e.nout);
-                        ++e.nout;
-                        ++ones;
+                        if (ones < 7) ++ones;
+                        if (ones > 6) {                              // seventh one and beyond: shifted in, counters reset
+                            const int q = last(2);
+                            if (q >= 0) ++cnt[q];
+                        } else {
+                            const int q = last(0);
+                            if (q >= 0) {
+                                e.step[q].bits |= (uint8_t)(1u << cnt[q]);
+                                ++cnt[q];
+                            }
+                        }
                     } else {
-                        if (ones < 5) ++e.nout;                      // a data zero (bit already 0 in outbits)
-                        ones = 0;                                    // ones == 5: stuffed zero, dropped
+                        if (ones < 5) {
+                            const int q = last(0);                   // a data zero
+                            if (q >= 0) ++cnt[q];
+                        } else if (ones == 6) {
+                            last(1);                                 // flag
+                        }                                            // ones == 5: stuffed zero, dropped; ones > 6: nothing
+                        ones = 0;
                     }
                 }
+                for (int q = 0; q < ns; ++q) e.step[q].op = (uint8_t)(kind[q] << 4 | cnt[q]);
+                e.nsteps = over ? 0xFF : (uint8_t)ns;
                 e.ones_out = (uint8_t)ones;
                 t[ones0][byte] = e;
             }
-        built = true;
-    }
+    });
     return &t[0][0];
 }
 
@@ -275,33 +303,64 @@ struct Ax25 : pm_codec {
     int nbytes = 0, ones = 0, nbits = 0;
     std::vector<uint8_t> data;
     static constexpr int kMin = 18, kMax = 1023;           // ax25.py:14-15
-    const Ax25Fast *table = ax25_table();
+    const Ax25Entry *table = ax25_table();
     explicit Ax25(int src) { source = src; }
 
     void feed_many(const uint8_t *d, const int64_t *a, int64_t n) override
     {
+        // the collected bytes as a raw buffer while this call runs (one slot of slack: a byte is stored whether or not it is
+        // complete and the length moves on only if it is -- no branch on the data)
+        size_t len = data.size();
+        auto room = [&](size_t want) {
+            if (data.size() < want) data.resize(std::max(want, 2 * data.size() + 64));
+        };
+        room(len + 2);
+        uint8_t *buf = data.data();
         for (int64_t k = 0; k < n; ++k) {
             const uint8_t byte = d[k];
-            if (ones < 6 && nbytes < kMax - 2) {
-                const Ax25Fast e = table[ones * 256 + byte];
-                if (e.fast) {
-                    // wb holds the last 7 appended bits in bits 6..0 (newest at 6); X extends it with this byte's bits
-                    const unsigned x = (wb & 0x7F) | ((unsigned)e.outbits << 7);
-                    const int need = 8 - nbits;
-                    if (e.nout >= need) {
-                        data.push_back((uint8_t)((x >> (need - 1)) & 0xFF));
-                        ++nbytes;                                    // cannot pass kMax here (guard above)
-                        nbits = e.nout - need;
-                    } else {
-                        nbits += e.nout;
+            const Ax25Entry &e = table[(ones < 7 ? ones : 7) * 256 + byte];
+            // near the length limit a completed byte may clear the ones counter in mid-byte (byte_done): bit by bit there
+            if (__builtin_expect(e.nsteps > 3 || nbytes >= kMax - 2, 0)) {
+                data.resize(len);
+                feed(byte, a[k], sink);
+                len = data.size();
+                room(len + 2);
+                buf = data.data();
+                continue;
+            }
+            for (int q = 0; q < e.nsteps; ++q) {
+                const unsigned op = e.step[q].op, cnt = op & 15;
+                if (op < 16) {
+                    // wb holds the last 7 appended bits in bits 6..0 (newest at 6); x extends it with this step's bits
+                    const unsigned x = (wb & 0x7F) | ((unsigned)e.step[q].bits << 7);
+                    const unsigned total = (unsigned)nbits + cnt;                    // <= 15
+                    const unsigned done = total >> 3;                                // 1: this step completes a byte
+                    buf[len] = (uint8_t)(x >> ((7 - nbits) & 7));                    // the byte as of its eighth bit (used if done)
+                    len += done;
+                    nbytes += (int)done;                                             // cannot pass kMax here (guard above)
+                    nbits = (int)(total & 7);
+                    wb = (x >> cnt) & 0x7F;
+                } else if (op < 32) {                                // flag (ax25.py:52-60)
+                    if (nbytes >= kMin && nbits == 7) {
+                        data.resize(len);
+                        sink.push(data, a[k], 0, source);
                     }
-                    wb = (x >> e.nout) & 0x7F;
-                    ones = e.ones_out;
-                    continue;
+                    len = 0;
+                    nbytes = 0;
+                    nbits = 0;
+                } else {                                             // abort: ones shifted in, counters reset, bytes stay (ax25.py:36-39)
+                    wb = cnt >= 7 ? 0x7Fu : (((wb & 0x7F) >> cnt) | ((0x7Fu << (7 - cnt)) & 0x7Fu));
+                    nbits = 0;
+                    nbytes = 0;
                 }
             }
-            feed(byte, a[k], sink);
+            ones = e.ones_out;
+            if (__builtin_expect(len + 2 > data.size(), 0)) {
+                room(len + 2);
+                buf = data.data();
+            }
         }
+        data.resize(len);
     }
 
     void byte_done(bool from_one)
