@@ -1,21 +1,32 @@
+// MFMA32=1 builds the same test with v_mfma_f32_16x16x4_f32 as the matrix instruction.
 // Micro-benchmark: can the f64 matrix pipe (v_mfma_f64_16x16x4_f64) and the f64 vector pipe (v_fma_f64) run at the same time?
 // MODE 0: MFMA only, 1: vector fma only, 2: both from the same wave (1 MFMA : V vector fmas), and modes 0 + 1 on two streams.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 template <int MODE, int V>
 __global__ __launch_bounds__(256) void k(double *out, double c1, double c2, int iters)
 {
+#ifdef MFMA32
+    f4 acc[4];
+    for (int j = 0; j < 4; ++j) acc[j] = f4{0.f, 0.f, 0.f, 0.f};
+#else
     d4 acc[4];
-    double a[16];
     for (int j = 0; j < 4; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
+#endif
+    double a[16];
     for (int j = 0; j < 16; ++j) a[j] = threadIdx.x + j;
     const double x = c1 + threadIdx.x * 1e-9, y = c2;
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+#ifdef MFMA32
+            if (MODE == 0 || MODE == 2) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)x, (float)y, acc[q], 0, 0, 0);
+#else
             if (MODE == 0 || MODE == 2) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc[q], 0, 0, 0);
+#endif
             if (MODE == 1 || MODE == 2) {
 #pragma unroll
                 for (int j = 0; j < V; ++j) a[(q * V + j) & 15] = __builtin_fma(a[(q * V + j) & 15], c2, c1);
