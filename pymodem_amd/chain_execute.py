@@ -173,7 +173,7 @@ class RecordingPipeline:
     stays usable (bench.py keeps one across warm-up and timed steps); close() ends its threads.  Results are identical to
     process_chains_table on each recording (tests/test_gpu_chains.py)."""
 
-    def __init__(self, slice_workers=2, demod_streams=1, slice_group=4, slots=None):
+    def __init__(self, slice_workers=3, demod_streams=1, slice_group=4, slots=None):
         from collections import deque
         import os
         import queue
@@ -186,9 +186,12 @@ class RecordingPipeline:
         self._group = max(1, min(int(os.environ.get("PYMODEM_AMD_SLICE_GROUP", slice_group)), 8))
         self._fetch_inline = os.environ.get("PYMODEM_AMD_FETCH", "worker") != "copy"
         self._min_group = max(1, min(int(os.environ.get("PYMODEM_AMD_SLICE_MIN_GROUP", 3)), self._group))
-        self._host = ThreadPoolExecutor(max_workers=5)        # LFSR + codec of up to five recordings at a time (IL2P chains take 4-5 ms each)
+        # LFSR + codec of several recordings at a time, each on up to one library thread per chain: about two dozen native threads in
+        # all is where it stops paying (8-chain AFSK group: 3 recordings 1.21 ms per step, 5 recordings 1.38-1.41, medians of
+        # interleaved runs; a 3-chain IL2P group at 4-5 ms per chain needs its five).  Made at the first submit, when the group is known.
+        self._host = None
         self._finish = ThreadPoolExecutor(max_workers=1)
-        self._post = ThreadPoolExecutor(max_workers=3)        # whatever follows the ordered step (rank 0's payload copy, indexing, de-dup)
+        self._post = ThreadPoolExecutor(max_workers=int(os.environ.get("PYMODEM_AMD_POST_THREADS", 3)))        # whatever follows the ordered step (rank 0's payload copy, indexing, de-dup)
         self._inflight = deque()
         self._tails = deque()                                 # the last stage's future of every recording not yet drained
         self._n = 0
@@ -372,6 +375,10 @@ class RecordingPipeline:
             rec["host1"] = time.perf_counter()
             acc["host"] += rec["host1"] - t
             return rows
+        if self._host is None:
+            import os
+            n_host = int(os.environ.get("PYMODEM_AMD_HOST_STAGE_THREADS", 0)) or max(2, min(5, 24 // max(len(chains), 1)))
+            self._host = ThreadPoolExecutor(max_workers=n_host)
         f_rows = self._host.submit(host_stage)
 
         def finish_stage():
@@ -431,7 +438,8 @@ class RecordingPipeline:
         self._pending.put(None)
         for th in self._slice_threads:
             th.join()
-        self._host.shutdown(wait=True)
+        if self._host is not None:
+            self._host.shutdown(wait=True)
         self._finish.shutdown(wait=True)
         self._post.shutdown(wait=True)
 

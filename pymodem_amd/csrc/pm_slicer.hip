@@ -589,7 +589,11 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
         all_words += pm_cdiv(jobs[j].n, 64);
         max_words = std::max(max_words, pm_cdiv(jobs[j].n, 64));
     }
-    const int64_t lc_max = getenv("PM_SLICER_MAX_CHUNK_WORDS") ? std::max(16, atoi(getenv("PM_SLICER_MAX_CHUNK_WORDS"))) : 256;
+    // chunk length of a large batch: 384 words (24.6 k samples).  Longer chunks mean fewer walkers and fewer lane-steps per sample
+    // (N (1 + m/L)), i.e. less of the vector ALU taken from the demod kernels beside them, shorter ones a shallower first launch;
+    // measured in the pipelined executor (medians of interleaved runs, 20 / 400 steps): 256 words 1.52 / 1.17 ms per step, 384 words
+    // 1.45 / 1.16, 512 words 1.48 / 1.25
+    const int64_t lc_max = getenv("PM_SLICER_MAX_CHUNK_WORDS") ? std::max(16, atoi(getenv("PM_SLICER_MAX_CHUNK_WORDS"))) : 384;
     int64_t lc_words = std::max<int64_t>(16, std::min<int64_t>(pm_cdiv(all_words, ctx->sl_target_lanes), lc_max));
     if (const char *e = getenv("PM_SLICER_CHUNK_WORDS")) { if (atoi(e) > 0) lc_words = atoi(e); }
     // Words per lockstep launch once the walkers are beyond their own chunks (never more than a chunk: see slice_walk_kernel).
