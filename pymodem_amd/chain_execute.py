@@ -188,7 +188,7 @@ class RecordingPipeline:
         self._min_group = max(1, min(int(os.environ.get("PYMODEM_AMD_SLICE_MIN_GROUP", 3)), self._group))
         # LFSR + codec of several recordings at a time, each on up to one library thread per chain: about two dozen native threads in
         # all is where it stops paying (8-chain AFSK group: 3 recordings 1.21 ms per step, 5 recordings 1.38-1.41, medians of
-        # interleaved runs; a 3-chain IL2P group at 4-5 ms per chain needs its five).  Made at the first submit, when the group is known.
+        # interleaved runs; a 3-chain IL2P group at 4-5 ms per chain takes eight).  Made at the first submit, when the group is known.
         self._host = None
         self._finish = ThreadPoolExecutor(max_workers=1)
         self._post = ThreadPoolExecutor(max_workers=int(os.environ.get("PYMODEM_AMD_POST_THREADS", 3)))        # whatever follows the ordered step (rank 0's payload copy, indexing, de-dup)
@@ -377,7 +377,7 @@ class RecordingPipeline:
             return rows
         if self._host is None:
             import os
-            n_host = int(os.environ.get("PYMODEM_AMD_HOST_STAGE_THREADS", 0)) or max(2, min(5, 24 // max(len(chains), 1)))
+            n_host = int(os.environ.get("PYMODEM_AMD_HOST_STAGE_THREADS", 0)) or max(2, min(8, 24 // max(len(chains), 1)))
             self._host = ThreadPoolExecutor(max_workers=n_host)
         f_rows = self._host.submit(host_stage)
 
