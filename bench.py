@@ -395,7 +395,31 @@ def measure(args, env):
             sc.profile(True)
     t0 = time.perf_counter()
     cpu0 = time.process_time()
-    if os.environ.get("BENCH_PYPROFILE"):                     # where the submitting thread's time goes (diagnostic, stderr)
+    if os.environ.get("BENCH_PYPROFILE") == "all":            # every thread's interpreter time (diagnostic, stderr): one profiler per thread
+        import cProfile, pstats, threading
+        profs = []
+
+        def boot(*_a):
+            pr = cProfile.Profile()
+            profs.append(pr)
+            sys.setprofile(None)
+            pr.enable()
+        for p_ in list(pipes.values()):                       # threads are made when the executor is: start a fresh one under the hook
+            p_.close()
+        pipes.clear()
+        threading.setprofile(boot)
+        pr0 = cProfile.Profile()
+        result = pr0.runcall(run_steps, args.steps)
+        threading.setprofile(None)
+        st = pstats.Stats(pr0, stream=sys.stderr)
+        for pr in profs:
+            try:
+                pr.create_stats()
+                st.add(pr)
+            except Exception:                                 # noqa: BLE001
+                pass
+        st.sort_stats("tottime").print_stats(45)
+    elif os.environ.get("BENCH_PYPROFILE"):                   # where the submitting thread's time goes (diagnostic, stderr)
         import cProfile, pstats
         pr = cProfile.Profile()
         result = pr.runcall(run_steps, args.steps)

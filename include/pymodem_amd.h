@@ -286,11 +286,13 @@ typedef struct pm_slice_job {
 } pm_slice_job;
 int pm_slice_batch(pm_ctx *ctx, pm_slice_job *h_jobs, int njobs);           /* njobs <= 64 */
 /* The output of a finished pm_slice_batch in the form that is cheapest to bring to the host (3 bytes per data byte instead of 9, no
- * unused capacity in between): for job j, at d_block + h_offsets[j]: {first address, last address} (2 x int64), count[j] address steps
- * as uint16 (address[i] - address[i-1], the first one 0; padded to a multiple of 8 bytes), count[j] data bytes (padded likewise).
- * *h_used = bytes written; PM_ERR_CAPACITY (with *h_used set) if block_bytes is less.  A step is eight symbol periods; should one
- * not fit 16 bits it wraps, which shows as first + sum(steps) != last: take that job's addresses from its d_addr instead.  Runs on
- * the ctx stream, after the batch; h_jobs are the batch's jobs as pm_slice_batch left them (count filled in). */
+ * unused capacity in between): for job j, at d_block + h_offsets[j]: {first address, last address} (2 x int64), 64 flag bytes,
+ * count[j] address steps as uint16 (address[i] - address[i-1], the first one 0; padded to a multiple of 8 bytes), count[j] data
+ * bytes (padded likewise) -- PM_COMPACT_HEAD = 80 bytes before the steps.  *h_used = bytes written; PM_ERR_CAPACITY (with *h_used
+ * set) if block_bytes is less.  A step is eight symbol periods unless the input keeps the clock from its threshold; if any of the
+ * flag bytes is non-zero a step of that stream did not fit 16 bits: take its addresses from its d_addr instead.  Runs on the ctx
+ * stream, after the batch; h_jobs are the batch's jobs as pm_slice_batch left them (count filled in). */
+#define PM_COMPACT_HEAD 80
 int pm_slice_compact(pm_ctx *ctx, const pm_slice_job *h_jobs, int njobs, void *d_block, size_t block_bytes, int64_t *h_offsets,
                      size_t *h_used);
 /* How many chunks (= walkers) a batch is cut into on this ctx, within 1024..16384 samples per chunk; 0 restores the default 16384.

@@ -4,7 +4,7 @@ import ctypes
 
 import numpy as np
 
-from ._native import check, lib, packet_dtype
+from ._native import check, lib, packet_dtype, quick
 from .data_classes import AddressedArray
 from .packet_meta import rows_to_packets
 from .string_ops import check_boolean
@@ -17,7 +17,7 @@ class _NativeCodec:
     def _handle(self):
         if self._h is None:
             h = ctypes.c_void_p()
-            check(lib().pm_codec_create(self._kind, int(self.collect_trailing_crc), int(self.disable_rs), int(self.min_distance),
+            check(quick().pm_codec_create(self._kind, int(self.collect_trailing_crc), int(self.disable_rs), int(self.min_distance),
                                         int(self.sync_tolerance), 0, ctypes.byref(h)))
             self._h = h
         return self._h
@@ -51,7 +51,7 @@ class _NativeCodec:
     def __del__(self):
         try:
             if self._h is not None:
-                lib().pm_codec_destroy(self._h)
+                quick().pm_codec_destroy(self._h)
         except Exception:
             pass
 

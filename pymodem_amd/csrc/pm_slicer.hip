@@ -804,10 +804,13 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
 }
 
 // ---- compact form of a batch's output for the way to the host ------------------------------------------------------------------
-// Per job: {first address, last address} (2 x int64), count deltas as uint16 (address[i] - address[i-1], delta[0] = 0; padded to 8
-// bytes), count data bytes (padded to 8).  A byte's address is the sample at which its eighth bit was taken, so a delta is eight
-// symbol periods (320 samples at 1200 Bd / 48 kHz); one that does not fit 16 bits wraps, and the host sees it because the deltas no
-// longer add up to last - first.
+// Per job: {first address, last address} (2 x int64), 64 flag bytes (one per workgroup of the packing launch: a step it packed did
+// not fit 16 bits), count deltas as uint16 (address[i] - address[i-1], delta[0] = 0; padded to 8 bytes), count data bytes (padded
+// to 8).  A byte's address is the sample at which its eighth bit was taken, so a delta is eight symbol periods (320 samples at
+// 1200 Bd / 48 kHz) -- unless the input keeps the clock from ever reaching its threshold (a zero crossing at every sample does),
+// so the check is a real one: a stream with a flag set has its addresses copied in full.  Every workgroup writes its own flag byte,
+// set or not: nothing has to be cleared beforehand.
+constexpr int kCompactHead = 16 + 64;
 struct CompactJobs {
     const uint8_t *data[kMaxJobs];
     const int64_t *addr[kMaxJobs];
@@ -822,12 +825,13 @@ __global__ __launch_bounds__(256) void slice_compact_kernel(CompactJobs J, uint8
     const int64_t n = J.count[j];
     const int64_t *addr = J.addr[j];
     uint8_t *base = block + J.off[j];
-    uint16_t *delta = reinterpret_cast<uint16_t *>(base + 16);
-    uint8_t *bytes = base + 16 + ((2 * n + 7) & ~int64_t(7));
+    uint16_t *delta = reinterpret_cast<uint16_t *>(base + kCompactHead);
+    uint8_t *bytes = base + kCompactHead + ((2 * n + 7) & ~int64_t(7));
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         reinterpret_cast<int64_t *>(base)[0] = n ? addr[0] : 0;
         reinterpret_cast<int64_t *>(base)[1] = n ? addr[n - 1] : 0;
     }
+    int wide = 0;
     // four entries per thread: one 8-byte store of deltas, one 4-byte store of data
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; 4 * q < n; q += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = 4 * q;
@@ -837,6 +841,7 @@ __global__ __launch_bounds__(256) void slice_compact_kernel(CompactJobs J, uint8
         for (int k = 0; k < 4; ++k) {
             if (i + k < n) {
                 const int64_t a = addr[i + k];
+                wide |= (uint64_t)(a - prev) > 65535u;
                 d4 |= (uint64_t)(uint16_t)(a - prev) << (16 * k);
                 b4 |= (uint32_t)J.data[j][i + k] << (8 * k);
                 prev = a;
@@ -845,6 +850,9 @@ __global__ __launch_bounds__(256) void slice_compact_kernel(CompactJobs J, uint8
         *reinterpret_cast<uint64_t *>(delta + i) = d4;       // the padding makes the last, partly filled store legal
         *reinterpret_cast<uint32_t *>(bytes + i) = b4;
     }
+    wide = __syncthreads_or(wide);
+    if (threadIdx.x == 0) base[16 + blockIdx.x] = (uint8_t)(wide != 0);      // gridDim.x <= 64
+    if (blockIdx.x == 0 && threadIdx.x >= gridDim.x && threadIdx.x < 64) base[16 + threadIdx.x] = 0;
 }
 
 extern "C" {
@@ -901,7 +909,7 @@ int pm_slice_compact(pm_ctx *ctx, const pm_slice_job *h_jobs, int njobs, void *d
         J.addr[j] = q.d_addr;
         J.count[j] = q.count;
         J.off[j] = h_offsets[j] = (int64_t)at;
-        at += 16 + (size_t)((2 * q.count + 7) & ~int64_t(7)) + (size_t)((q.count + 7) & ~int64_t(7));
+        at += kCompactHead + (size_t)((2 * q.count + 7) & ~int64_t(7)) + (size_t)((q.count + 7) & ~int64_t(7));
         most = std::max(most, q.count);
     }
     *h_used = at;

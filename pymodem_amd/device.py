@@ -6,7 +6,7 @@ import weakref
 
 import numpy as np
 
-from ._native import NativeError, check, lib
+from ._native import NativeError, check, lib, quick
 
 
 class Context:
@@ -83,17 +83,17 @@ class Context:
     def record_event(self, event=None):
         """Mark the point this context's stream has reached; returns the (re-usable) event handle."""
         ev = event if event is not None else ctypes.c_void_p()
-        check(lib().pm_event_record(self._h, ctypes.byref(ev)))
+        check(quick().pm_event_record(self._h, ctypes.byref(ev)))
         return ev
 
     def wait_event(self, event):
         """Work submitted to this context from now on waits (on the GPU) for `event`."""
-        check(lib().pm_event_wait(self._h, event))
+        check(quick().pm_event_wait(self._h, event))
 
     @staticmethod
     def event_done(event):
         """True once everything submitted before the event's record has finished (no waiting)."""
-        r = lib().pm_event_query(event)
+        r = quick().pm_event_query(event)
         if r < 0:
             check(r)
         return r == 1

@@ -126,6 +126,7 @@ def slice_batch(slicers, bitmaps, ctx=None, defer=False, reserve=1.0, out_tag=No
 
 
 _TIGHT_FACTOR = 1.5
+_COMPACT_HEAD = 80        # PM_COMPACT_HEAD: first and last address, 64 flag bytes
 
 
 def _slice_group(ctx, slicers, bitmaps, group, out, tight, reserve=1.0, out_tag=None, compact=False):
@@ -171,7 +172,7 @@ def _slice_group(ctx, slicers, bitmaps, group, out, tight, reserve=1.0, out_tag=
     if compact:
         # exact counts and 16-bit address steps, packed by a small kernel behind the batch: what crosses to the host is 3 bytes per
         # data byte instead of 9 and no unused capacity; the dense block is sized for the capacity once (times `reserve`)
-        dense_cap = sum(16 + (2 * c + 7) // 8 * 8 + (c + 7) // 8 * 8 for c in caps)
+        dense_cap = sum(_COMPACT_HEAD + (2 * c + 7) // 8 * 8 + (c + 7) // 8 * 8 for c in caps)
         dense = ctx.scratch((out_tag if out_tag is not None else slicers[group[0]]._own_key(), "slice_dense"), int(dense_cap * max(1.0, reserve)), np.uint8)
         offs, used = (ctypes.c_int64 * len(group))(), ctypes.c_size_t()
         check(lib().pm_slice_compact(ctx.handle, jobs, len(group), dense.ptr, dense.n, offs, ctypes.byref(used)))
@@ -180,10 +181,10 @@ def _slice_group(ctx, slicers, bitmaps, group, out, tight, reserve=1.0, out_tag=
             host = dense.download(used.value, recycle=True, ctx=copy_ctx, room=dense.n)
             for j, k in enumerate(group):
                 c, o = counts[j], offs[j]
-                first, last = (int(v) for v in host[o:o + 16].view(np.int64))
-                steps = host[o + 16:o + 16 + 2 * c].view(np.uint16)
-                data = host[o + 16 + (2 * c + 7) // 8 * 8:o + 16 + (2 * c + 7) // 8 * 8 + c]
-                if c and first + int(steps.sum(dtype=np.int64)) != last:     # a step beyond 16 bits: this stream's addresses in full
+                first = int(host[o:o + 8].view(np.int64)[0])
+                steps = host[o + _COMPACT_HEAD:o + _COMPACT_HEAD + 2 * c].view(np.uint16)
+                data = host[o + _COMPACT_HEAD + (2 * c + 7) // 8 * 8:o + _COMPACT_HEAD + (2 * c + 7) // 8 * 8 + c]
+                if c and host[o + 16:o + _COMPACT_HEAD].any():               # a step beyond 16 bits: this stream's addresses in full
                     full = block.view(a_off[j], c * 8).download(ctx=copy_ctx).view(np.int64)
                     out[k] = AddressedArray(data, full)
                 else:
