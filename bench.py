@@ -333,7 +333,7 @@ def measure(args, env):
             ex = pdist.Exchanger(nchains, coll_device)
             last = None
             for _ in range(k):
-                last = pipe.submit(build_chains(), d_audio, ex.step, (None if os.environ.get("BENCH_NO_POST") else dedupe), prepare=lambda rows_list: ex.prepare(dict(zip(my, rows_list))))
+                last = pipe.submit(build_chains(), d_audio, ex.step, (None if os.environ.get("BENCH_NO_POST") else dedupe), prepare=lambda rows_list: ex.prepare(dict(zip(my, rows_list))), chain_ids=my)
             pipe.flush_finish(ex.flush)
             res = last.result() if last is not None else None
             pipe.drain()                                      # every step's de-dup is done, not only the last one's

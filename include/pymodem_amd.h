@@ -373,6 +373,9 @@ typedef struct pm_codec pm_codec;
 /* kind 0 = AX25Codec (ax25.py:11-93), 1 = IL2PCodec (il2p.py:110-519). */
 int pm_codec_create(int kind, int crc, int disable_rs, int min_dist, int sync_tol, int source_decoder, pm_codec **out);
 int pm_codec_destroy(pm_codec *c);
+/* The index pm_codec_fetch writes into pm_packet.source_decoder from now on (the chain's place in the config: what the reference's
+ * SourceDecoder name stands for, packet_meta.py:181). */
+int pm_codec_set_source(pm_codec *c, int32_t source_decoder);
 /* Feed n descrambled bytes with their stream addresses (state carries over between calls, like the reference's
  * codec objects); decoded packets queue inside the codec, *h_pending = packets waiting.  pm_codec_fetch moves up to
  * cap of them out, oldest first, with CRC and header validity filled (packet_meta.py:197-208). */

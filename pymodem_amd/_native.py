@@ -188,6 +188,7 @@ _SIGS = {
     "pm_lfsr_unscramble": ([_vp, _i64, ctypes.c_uint64, _int, ctypes.POINTER(ctypes.c_uint64), _vp], _int),
     "pm_codec_create": ([_int, _int, _int, _int, _int, _int, ctypes.POINTER(_vp)], _int),
     "pm_codec_destroy": ([_vp], _int),
+    "pm_codec_set_source": ([_vp, ctypes.c_int32], _int),
     "pm_codec_decode": ([_vp, _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
     "pm_codec_fetch": ([_vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
     "pm_host_decode_batch": ([ctypes.POINTER(HostJob), _int, _int], _int),
@@ -220,7 +221,7 @@ def lib():
 
 
 _QUICK = None
-QUICK_CALLS = ("pm_codec_create", "pm_codec_destroy", "pm_event_record", "pm_event_wait", "pm_event_query", "pm_last_error")
+QUICK_CALLS = ("pm_codec_create", "pm_codec_destroy", "pm_codec_set_source", "pm_event_record", "pm_event_wait", "pm_event_query", "pm_last_error")
 
 
 def quick():

@@ -57,13 +57,13 @@ def _host_threads():
     return max(1, min(int(os.environ.get("PYMODEM_AMD_HOST_THREADS", "16")), (os.cpu_count() or 2)))
 
 
-def _host_rows(chains, sliced):
+def _host_rows(chains, sliced, chain_ids=None):
     """LFSR + codec of every chain -> one pm_packet row block per chain, all of them consecutive slices of ONE array the codecs
     wrote straight into (PacketTable then takes the whole array without a copy).  Two native calls per recording
     (pm_host_decode_batch, pm_codec_fetch_batch): the library's own threads take one chain each, the interpreter lock is
     released throughout."""
     import ctypes
-    from ._native import HostJob, check, lib, packet_dtype
+    from ._native import HostJob, check, lib, packet_dtype, quick
     from .data_classes import AddressedArray
     from .lfsr import LFSR
     n = len(chains)
@@ -84,6 +84,8 @@ def _host_rows(chains, sliced):
         src = AddressedArray.coerce(sl)
         keep.append(src)
         jobs[j].codec = ch[4]._handle()
+        if chain_ids is not None:               # the codec stamps its packets with the chain's place in the config as it writes them
+            quick().pm_codec_set_source(jobs[j].codec, int(chain_ids[j]))
         steps = src.address_steps
         if steps is not None:                   # straight from the slicer's compact block: expanded inside the native call
             jobs[j].h_data, jobs[j].h_addr, jobs[j].n = src.data.ctypes.data, None, len(src)
@@ -319,11 +321,12 @@ class RecordingPipeline:
             return buf, done, k
         return self._upload.submit(copy)
 
-    def submit(self, chains, input_audio, finish=None, post=None, prepare=None):
+    def submit(self, chains, input_audio, finish=None, post=None, prepare=None, chain_ids=None):
         """Start one recording; returns a Future of post(finish(rows per chain)) (either may be None = identity).  `finish` calls
         run one at a time in submission order (the place for collectives); `post` calls run in parallel with later recordings.
         If finish returns a future itself, post receives its result (and waits for it: see flush_finish).  `prepare(rows)`, if
-        given, runs at the end of the host stage (several recordings at a time) and its result is what finish receives."""
+        given, runs at the end of the host stage (several recordings at a time) and its result is what finish receives.  `chain_ids`:
+        each chain's place in the config (its key in the packet table); the codecs then stamp their packets with it as they write them."""
         import time
         acc = self.stage_seconds
         slots = self._slots
@@ -369,7 +372,7 @@ class RecordingPipeline:
             finally:
                 f_fetched.set_result(None)
             t = rec["host0"] = time.perf_counter()
-            rows = _host_rows(chains, sliced)
+            rows = _host_rows(chains, sliced, chain_ids)
             if prepare is not None:                            # e.g. dist.Exchanger.prepare: packing for the wire, off the ordered thread
                 rows = prepare(rows)
             rec["host1"] = time.perf_counter()

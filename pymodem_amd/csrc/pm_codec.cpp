@@ -845,6 +845,13 @@ int pm_codec_destroy(pm_codec *c)
     return PM_OK;
 }
 
+int pm_codec_set_source(pm_codec *c, int32_t source_decoder)
+{
+    if (!c) return pm_set_error(PM_ERR_ARG, "pm_codec_set_source: no codec");
+    c->source = source_decoder;
+    return PM_OK;
+}
+
 int pm_codec_decode(pm_codec *c, const uint8_t *h_data, const int64_t *h_addr, int64_t n, int64_t *h_pending)
 {
     if (!c || n < 0 || (n > 0 && (!h_data || !h_addr)) || !h_pending)

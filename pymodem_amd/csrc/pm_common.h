@@ -35,6 +35,8 @@ struct pm_ctx {
     int *sweep_count = nullptr;        // device counter of the last pm_afsk_sweep_signs on this ctx (a slot of d_sweep)
     int *d_sweep = nullptr;            // ring of kSweepRing counters, one per certified sweep in flight (own allocation)
     int64_t sweep_seq = 0;
+    int *h_sweep = nullptr;            // pinned mailbox ring: the deferred sweep's last launch writes its counter here too
+    int64_t sweep_mail[64] = {0};      // ticket + 1 whose counter mailbox slot [ticket % ring] will hold (0: none)
     bool sweep_deferred = false;       // pm_afsk_sweep_mode: the overflow fallback is the caller's (pm_afsk_sweep_result), not three gated launches
 };
 

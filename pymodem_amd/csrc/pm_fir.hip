@@ -881,10 +881,16 @@ __global__ __launch_bounds__(kThreads) void afsk_slide_lpf_kernel(const double *
 __global__ __launch_bounds__(64) void sweep_exact_kernel(const double *__restrict__ x, const double *__restrict__ mi, const double *__restrict__ mq,
                                                          const double *__restrict__ space, int mc, const double *__restrict__ lpf, int ml,
                                                          SweepArgs P, const unsigned long long *__restrict__ list, const int *__restrict__ count, int cap,
-                                                         int *__restrict__ reset = nullptr)
+                                                         int *__restrict__ reset = nullptr, int *__restrict__ mail = nullptr)
 {
-    // deferred fallback (pm_afsk_sweep_mode): this is the sweep's last launch and clears the next sweep's counter (see d_sweep)
+    // deferred fallback (pm_afsk_sweep_mode): this is the sweep's last launch and clears the next sweep's counter (see d_sweep);
+    // it also leaves the counter in a page-locked host word, so that the caller who waits for the recording's event anyway reads it
+    // without a copy and a stream wait of its own
     if (reset && blockIdx.x == 0 && threadIdx.x == 0) *reset = 0;
+    if (mail && blockIdx.x == 0 && threadIdx.x == 0) {
+        *mail = *count;
+        __threadfence_system();
+    }
     // One wave per listed sample: the ml correlator-bank outputs the low-pass needs are independent of each other and go to the
     // lanes (each in the canonical tap order); the low-pass sum itself is sequential and stays with lane 0.  (One LANE per sample
     // took 0.25-0.5 ms for a single entry -- 4 mc ml dependent fmas -- and the demod stream waits for it.)
@@ -1254,9 +1260,13 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
     if (!ctx->d_sweep) {
         PM_HIP(hipMalloc((void **)&ctx->d_sweep, kSweepRing * sizeof(int)));
         PM_HIP(hipMemset(ctx->d_sweep, 0, kSweepRing * sizeof(int)));
+        PM_HIP(hipHostMalloc((void **)&ctx->h_sweep, kSweepRing * sizeof(int), hipHostMallocDefault));
+        memset(ctx->h_sweep, 0, kSweepRing * sizeof(int));
     }
     int *count = ctx->d_sweep + (ctx->sweep_seq % kSweepRing);
     int *count_next = ctx->d_sweep + ((ctx->sweep_seq + 1) % kSweepRing);
+    int *mail = ctx->sweep_deferred ? ctx->h_sweep + (ctx->sweep_seq % kSweepRing) : nullptr;
+    ctx->sweep_mail[ctx->sweep_seq % kSweepRing] = mail ? ctx->sweep_seq + 1 : 0;
     ctx->sweep_seq++;
     double *d_w = (double *)(base + 2 * b_m + b_a + b_list + 256);
     double *C = (double *)(base + 2 * b_m + b_a + b_list + 256 + b_w);
@@ -1327,7 +1337,7 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
     {
         PmProf prof(ctx, PM_K_SIGNS);
         hipLaunchKernelGGL(sweep_exact_kernel, dim3(1024), dim3(64), (size_t)ml * sizeof(double), ctx->stream, d_x, d_mark_i, d_mark_q, d_space, m,
-                           d_lpf, ml, P, list, count, cap, ctx->sweep_deferred ? count_next : nullptr);
+                           d_lpf, ml, P, list, count, cap, ctx->sweep_deferred ? count_next : nullptr, mail);
     }
     PM_HIP(hipGetLastError());
     // Deferred fallback: the caller looks at the counter once the sweep has finished (pm_afsk_sweep_result) and runs the exact
@@ -1471,6 +1481,14 @@ int pm_afsk_sweep_results(pm_ctx *ctx, const int64_t *tickets, int n, pm_ctx *vi
         if (ctx->sweep_seq - tickets[k] >= kSweepRing)
             return pm_set_error(PM_ERR_ARG, "pm_afsk_sweep_results: ticket %lld is %lld sweeps old, the ring holds %d", (long long)tickets[k],
                                 (long long)(ctx->sweep_seq - tickets[k]), kSweepRing);
+    }
+    // deferred sweeps have left their counters in the page-locked mailbox (sweep_exact_kernel): the caller knows they have finished
+    bool mailed = ctx->h_sweep != nullptr;
+    for (int k = 0; k < n && mailed; ++k) mailed = ctx->sweep_mail[tickets[k] % kSweepRing] == tickets[k] + 1;
+    if (mailed) {
+        for (int k = 0; k < n; ++k) h_uncertain[k] = ((volatile int *)ctx->h_sweep)[tickets[k] % kSweepRing];
+        if (h_capacity) *h_capacity = 65536;
+        return PM_OK;
     }
     // the caller knows the sweeps have finished; the whole ring (256 bytes) comes over in ONE copy on `via`'s stream (the caller's own:
     // a slicer worker must not queue behind the demod stream's next recordings, nor take the device-wide wait of a synchronous copy)

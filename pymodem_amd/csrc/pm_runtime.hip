@@ -99,6 +99,7 @@ int pm_ctx_destroy(pm_ctx *c)
     for (hipEvent_t e : c->prof_free) (void)hipEventDestroy(e);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_sweep) (void)hipFree(c->d_sweep);
+    if (c->h_sweep) (void)hipHostFree(c->h_sweep);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);

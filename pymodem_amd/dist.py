@@ -96,7 +96,7 @@ def exchange_rows(rows_by_chain, nchains, device=None):
     import torch
     import torch.distributed as dist
     from ._native import check, lib
-    from .packet_meta import PacketTable
+    from .packet_meta import PacketTable, _stamp
     # PYMODEM_AMD_FORCE_GATHER=1 runs the collective even with one rank (rehearses the RCCL path on a one-GPU box)
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not os.environ.get("PYMODEM_AMD_FORCE_GATHER")):
         return ("local", rows_by_chain)
@@ -111,7 +111,7 @@ def exchange_rows(rows_by_chain, nchains, device=None):
     for c in sorted(rows_by_chain):
         r = rows_by_chain[c]
         if len(r):
-            r["source_decoder"] = c
+            _stamp(r, c)
             counts[c] = len(r)
             parts.append(r)
     mine = PacketTable._stack(parts)
@@ -218,14 +218,14 @@ def pack_rows(rows_by_chain, nchains):
     pm_packets_pack) ready for Exchanger.step.  Any thread may do this; only step() has to keep the ranks' order."""
     import ctypes
     from ._native import check, lib
-    from .packet_meta import PacketTable
+    from .packet_meta import PacketTable, _stamp
     p = PackedRows()
     p.rows, p.counts = rows_by_chain, np.zeros(nchains, dtype=np.int64)
     parts = []
     for c in sorted(rows_by_chain):
         r = rows_by_chain[c]
         if len(r):
-            r["source_decoder"] = c
+            _stamp(r, c)
             p.counts[c] = len(r)
             parts.append(r)
     mine = np.ascontiguousarray(PacketTable._stack(parts))
@@ -301,7 +301,7 @@ def _streams_from_blocks(blocks, hdrs, head, side):
 
 def table_from_exchange(x, names):
     """The local half on rank 0: index the gathered wire streams into a PacketTable of record heads (payloads stay where they are)."""
-    from .packet_meta import PacketTable
+    from .packet_meta import PacketTable, _stamp
     if x is None:
         return None
     if x[0] == "local":

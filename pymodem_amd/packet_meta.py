@@ -89,6 +89,14 @@ def rows_to_packets(rows, decoder_name):
     return [PacketMeta.from_bytes(data[k, :lens[k]].tobytes(), addrs[k], decoder_name, corr[k]) for k in range(len(rows))]
 
 
+def _stamp(rows, c):
+    """rows['source_decoder'] = c unless the codec has written it already (pm_codec_set_source; one chain's rows come from one codec,
+    so the first and the last say it all): a strided pass over rows that another core has just written costs ~1 ms per recording."""
+    sd = rows["source_decoder"]
+    if len(sd) and (sd[0] != c or sd[-1] != c):
+        sd[...] = c
+
+
 class PacketTable:
     """All chains' packets in config order (chain c's records are contiguous, source_decoder = chain index).  The fast path of
     the group executor and of the multi-GPU gather: CRC/header validity come from the native codec, Correlate runs natively,
@@ -107,7 +115,7 @@ class PacketTable:
         for c in range(len(names)):
             r = rows_by_chain.get(c)
             if r is not None and len(r):
-                r["source_decoder"] = c          # in place: the rows are the executor's own, fresh from the codec
+                _stamp(r, c)                     # in place: the rows are the executor's own, fresh from the codec
                 parts.append(r)
         self._rows = self._stack(parts)
         self.heads = self._rows
