@@ -184,32 +184,36 @@ class Context:
             self._h = ctypes.c_void_p()
 
 
-_HOST_BLOCKS, _HOST_BLOCKS_LOCK, _HOST_BLOCKS_MAX = [], threading.Lock(), 12
+_HOST_BLOCKS, _HOST_BLOCKS_LOCK, _HOST_BLOCKS_MAX = {False: [], True: []}, threading.Lock(), 12
 
 
 def _host_block(nbytes, ctx=None):
     """A uint8 host array of at least nbytes that nobody else refers to (see DeviceBuffer.download).  With `ctx` a new block is
     page-locked (pm_host_pin) for as long as it lives: the pool's blocks take a copy per recording, and a copy into pageable
-    memory goes through the runtime's bounce buffers at a third of the link's rate."""
+    memory goes through the runtime's bounce buffers at a third of the link's rate.  Page-locked and plain blocks are pooled
+    apart: a stream of small plain blocks (the packet exchange's) must not push the large page-locked ones out -- making and
+    releasing one of those costs 8 ms (fill, pin, unpin)."""
     import sys
+    pinned = ctx is not None and os.environ.get("PYMODEM_AMD_PIN_HOST", "1") != "0"
     with _HOST_BLOCKS_LOCK:
-        for blk in _HOST_BLOCKS:
+        pool = _HOST_BLOCKS[pinned]
+        for blk in pool:
             # references: the pool's list, the loop variable, getrefcount's argument
             if blk.nbytes >= nbytes and blk.nbytes <= 2 * nbytes + (1 << 20) and sys.getrefcount(blk) == 3:
                 return blk
         blk = np.empty(max(nbytes, 1), dtype=np.uint8)
-        if ctx is not None and os.environ.get("PYMODEM_AMD_PIN_HOST", "1") != "0":
+        if pinned:
             blk.fill(0)                                        # touch the pages here rather than inside the pin
             at = blk.ctypes.data
             if lib().pm_host_pin(ctx.handle, ctypes.c_void_p(at), blk.nbytes) == 0:
                 weakref.finalize(blk, lib().pm_host_unpin, ctypes.c_void_p(at))   # runs before the array's memory is released
-        if len(_HOST_BLOCKS) >= _HOST_BLOCKS_MAX:
-            for i, old in enumerate(_HOST_BLOCKS):             # drop an idle block rather than grow without bound
+        if len(pool) >= _HOST_BLOCKS_MAX:
+            for i, old in enumerate(pool):                     # drop an idle block rather than grow without bound
                 if sys.getrefcount(old) == 3:
-                    del _HOST_BLOCKS[i]
+                    del pool[i]
                     break
-        if len(_HOST_BLOCKS) < _HOST_BLOCKS_MAX:
-            _HOST_BLOCKS.append(blk)
+        if len(pool) < _HOST_BLOCKS_MAX:
+            pool.append(blk)
         return blk
 
 

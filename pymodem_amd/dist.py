@@ -160,15 +160,22 @@ def exchange_rows(rows_by_chain, nchains, device=None):
 
 
 class Exchanger:
-    """exchange_rows for a stream of recordings, one step behind: `step(rows)` first collects the PREVIOUS recording's gathered
-    blocks -- their all_gather was enqueued a whole step ago, so the copy back does not wait for the collective to find room on a
-    busy GPU (0.5-0.8 ms inside the pipelined executor) -- then enqueues this recording's all_gather and returns a Future of what
-    exchange_rows would have returned.  `flush()` resolves the last one.  Call both from ONE thread, in the same order on every
-    rank: every collective, including the repeat after a capacity miss (decided from headers all ranks see), is issued there."""
+    """exchange_rows for a stream of recordings, behind: `step(rows)` first collects the gathered blocks of the exchange enqueued
+    before -- a step or more ago, so the copy back does not wait for the collective to find room on a busy GPU -- then, once
+    `batch` recordings have come in, enqueues ONE all_gather for them, and returns a Future of what exchange_rows would have
+    returned.  `flush()` resolves what is left.  Call both from ONE thread, in the same order on every rank: every collective,
+    including the repeat after a capacity miss (decided from headers all ranks see), is issued there.  `batch` (default 1,
+    PYMODEM_AMD_EXCHANGE_BATCH): several recordings per collective.  Measured with a forced one-rank exchange in the pipelined
+    executor: the ordered stage costs ~1 ms per RECORDING whether they go one, two or four to a collective (0.9 / 2.5 / 3.6 ms per
+    call) -- it is the host's share of a 16-core quota that the packing, indexing and de-dup of the exchange load further, not the
+    number of calls -- so the default stays at the lowest latency."""
 
-    def __init__(self, nchains, device=None):
+    def __init__(self, nchains, device=None, batch=None):
+        import os
         self.nchains, self.device = nchains, device
-        self._pending = None                   # (future, state of the enqueued collective)
+        self.batch = max(1, int(batch or os.environ.get("PYMODEM_AMD_EXCHANGE_BATCH", 1)))
+        self._pending = None                   # (futures, state of the enqueued collective)
+        self._waiting = []                     # (future, rows) not yet enqueued
 
     def prepare(self, rows_by_chain):
         """What step() takes: the rows packed for the wire when an exchange will really happen (any thread), the rows themselves
@@ -177,7 +184,7 @@ class Exchanger:
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not os.environ.get("PYMODEM_AMD_FORCE_GATHER")):
             return rows_by_chain
-        return pack_rows(rows_by_chain, self.nchains)
+        return pack_rows(rows_by_chain, self.nchains, pinned=self.device is not None and str(self.device).startswith("cuda"))
 
     def step(self, rows_by_chain):
         import os
@@ -187,33 +194,46 @@ class Exchanger:
         if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not os.environ.get("PYMODEM_AMD_FORCE_GATHER")):
             fut.set_result(("local", rows_by_chain.rows if isinstance(rows_by_chain, PackedRows) else rows_by_chain))
             return fut
-        try:
-            self._collect()
-            self._pending = (fut, _exchange_issue(rows_by_chain, self.nchains, self.device))
-        except BaseException as e:
-            fut.set_exception(e)
+        self._waiting.append((fut, rows_by_chain))
+        if len(self._waiting) >= self.batch:
+            self._issue()
         return fut
 
+    def _issue(self):
+        waiting, self._waiting = self._waiting, []
+        try:
+            self._collect()
+            self._pending = ([f for f, _ in waiting], _exchange_issue([r for _, r in waiting], self.nchains, self.device))
+        except BaseException as e:
+            for f, _ in waiting:
+                if not f.done():
+                    f.set_exception(e)
+
     def flush(self):
+        if self._waiting:
+            self._issue()
         self._collect()
 
     def _collect(self):
         if self._pending is None:
             return
-        fut, state = self._pending
+        futs, state = self._pending
         self._pending = None
         try:
-            fut.set_result(_exchange_collect(state))
+            for f, res in zip(futs, _exchange_collect(state)):
+                f.set_result(res)
         except BaseException as e:
-            fut.set_exception(e)
+            for f in futs:
+                if not f.done():
+                    f.set_exception(e)
 
 
 class PackedRows:
     """A rank's rows of one recording in wire form (pack_rows)."""
-    __slots__ = ("rows", "counts", "nrows", "payload")
+    __slots__ = ("rows", "counts", "nrows", "payload", "block", "block_cap")
 
 
-def pack_rows(rows_by_chain, nchains):
+def pack_rows(rows_by_chain, nchains, pinned=False):
     """{global chain index: pm_packet rows} -> PackedRows: the wire form (40-byte header + len payload bytes per row,
     pm_packets_pack) ready for Exchanger.step.  Any thread may do this; only step() has to keep the ranks' order."""
     import ctypes
@@ -230,23 +250,50 @@ def pack_rows(rows_by_chain, nchains):
             parts.append(r)
     mine = np.ascontiguousarray(PacketTable._stack(parts))
     p.nrows = len(mine)
-    need = check(lib().pm_packets_pack(mine.ctypes.data_as(ctypes.c_void_p), len(mine), None, 0))
+    # straight into the fixed-capacity wire block (header | payload) if the capacity the ranks agreed on holds it: the ordered
+    # thread then has nothing to copy
+    head = 8 * (2 + nchains)
+    cap = _wire_cap(nchains)
+    p.block = p.block_cap = None
+    rows_p = mine.ctypes.data_as(ctypes.c_void_p)
+    if cap is not None:
+        # one call: it returns the size it needs and has written the rows if that is within the capacity
+        from .device import _host_block
+        block = _pinned_block(head + cap) if pinned else _host_block(head + cap)[:head + cap]
+        need = check(lib().pm_packets_pack(rows_p, len(mine), block[head:].ctypes.data_as(ctypes.c_void_p), cap)) if len(mine) else 0
+        if need <= cap:
+            p.block, p.block_cap = block, cap
+            hdr = block[:head].view(np.int64)
+            hdr[0], hdr[1], hdr[2:] = need, p.nrows, p.counts
+            p.payload = block[head:head + need]
+            return p
+    need = check(lib().pm_packets_pack(rows_p, len(mine), None, 0)) if len(mine) else 0
     p.payload = np.empty(need, dtype=np.uint8)
     if need:
-        check(lib().pm_packets_pack(mine.ctypes.data_as(ctypes.c_void_p), len(mine), p.payload.ctypes.data_as(ctypes.c_void_p), need))
+        check(lib().pm_packets_pack(rows_p, len(mine), p.payload.ctypes.data_as(ctypes.c_void_p), need))
     return p
 
 
-def _exchange_issue(packed, nchains, device, cap=None):
-    """Enqueue the all_gather of this rank's fixed-capacity block (header + packed rows); nothing waits for the GPU."""
+def _wire_cap(nchains):
+    """The exchange capacity per rank currently agreed on (None before the process group exists)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    return max(_GATHER_CAP.get((dist.get_world_size(), nchains), 1 << 16), 1 << 12)
+
+
+def _exchange_issue(packed_list, nchains, device, cap=None):
+    """Enqueue ONE all_gather carrying this rank's fixed-capacity blocks (header + packed rows) of len(packed_list) recordings;
+    nothing waits for the GPU."""
     import torch
     import torch.distributed as dist
-    if not isinstance(packed, PackedRows):
-        packed = pack_rows(packed, nchains)
+    if not isinstance(packed_list, (list, tuple)):
+        packed_list = [packed_list]
+    packed_list = [p if isinstance(p, PackedRows) else pack_rows(p, nchains) for p in packed_list]
+    k_rec = len(packed_list)
     world = dist.get_world_size()
     dev = torch.device(device) if device is not None else torch.device("cpu")
     head = 8 * (2 + nchains)
-    need = len(packed.payload)
     key = (world, nchains)
     if cap is None:
         cap = max(_GATHER_CAP.get(key, 1 << 16), 1 << 12)
@@ -256,38 +303,121 @@ def _exchange_issue(packed, nchains, device, cap=None):
         if side is None:
             side = _SIDE_STREAM[dev] = torch.cuda.Stream(device=dev, priority=-1)
     from .device import _host_block
-    block = _host_block(head + cap)[:head + cap]          # recycled host memory; bytes past the payload are never read by anyone
-    hdr = block[:head].view(np.int64)
-    hdr[0], hdr[1], hdr[2:] = need, packed.nrows, packed.counts
-    if need <= cap:
-        block[head:head + need] = packed.payload
+    one = head + cap
+    if k_rec == 1 and getattr(packed_list[0], "block", None) is not None and packed_list[0].block_cap == cap:
+        block = packed_list[0].block                      # built by pack_rows on a host-stage thread
+    else:
+        # recycled host memory (page-locked when it goes to a GPU); bytes past a payload are never read by anyone
+        block = _pinned_block(k_rec * one, slots=8) if dev.type == "cuda" else _host_block(k_rec * one)[:k_rec * one]
+        for k, packed in enumerate(packed_list):
+            if getattr(packed, "block", None) is not None and packed.block_cap == cap:
+                block[k * one:(k + 1) * one] = packed.block
+                continue
+            need = len(packed.payload)
+            hdr = block[k * one:k * one + head].view(np.int64)
+            hdr[0], hdr[1], hdr[2:] = need, packed.nrows, packed.counts
+            if need <= cap:
+                block[k * one + head:k * one + head + need] = packed.payload
+    heads_host = done = None
     with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-        t = torch.from_numpy(block).to(dev)
-        blocks = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(blocks, t)
-    return {"rows": packed, "nchains": nchains, "device": device, "cap": cap, "head": head, "blocks": blocks, "side": side, "key": key,
-            "keep": block}
+        # nothing here waits for the GPU, and as few calls as possible -- each one that drops the interpreter lock waits for it
+        # again behind a dozen threads (measured in the pipelined executor: 0.4 ms for the copy up, 0.6 for the collective call,
+        # 0.3 for the copy of the headers, per call whatever its size; hence several recordings per call, Exchanger.batch).  The
+        # block goes up asynchronously (it stays alive in the state), ONE output tensor takes every rank's blocks, and the headers
+        # come back into page-locked memory behind the collective: the ordered thread only looks at an event later.
+        if dev.type == "cuda":
+            # device buffers from a ring of sixteen per shape, never from the allocator: a tensor the collective has used on its own
+            # stream goes back to the caching allocator only behind an event, and when the cache runs dry in the middle of the
+            # pipeline the hipMalloc behind it waits for the device.  Sixteen = the executor's depth: a slot comes round again
+            # only after its recording has long left the post stage (which reads the payloads out of `out` on rank 0).
+            rk = (dev, world, k_rec, one)
+            ring = _DEV_RING.setdefault(rk, [])
+            if len(ring) < 16:
+                ring.append((torch.empty(k_rec * one, dtype=torch.uint8, device=dev), torch.empty((world, k_rec * one), dtype=torch.uint8, device=dev)))
+                t, out = ring[-1]
+            else:
+                t, out = ring[_DEV_SEQ[0] % 16]
+            _DEV_SEQ[0] += 1
+            t.copy_(torch.from_numpy(block), non_blocking=True)
+        else:
+            t = torch.from_numpy(block)
+            out = None
+        if hasattr(dist, "all_gather_into_tensor") and dev.type == "cuda":
+            dist.all_gather_into_tensor(out.view(-1), t)
+        else:
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(parts, t)
+            out = torch.stack(parts)
+        if side is not None:
+            ring = _HEADS_RING.setdefault((dev, world, head, k_rec), [])
+            if len(ring) < 4:
+                ring.append((torch.empty((world, k_rec, head), dtype=torch.uint8, pin_memory=True), torch.cuda.Event()))
+                heads_host, done = ring[-1]
+            else:
+                heads_host, done = ring[_HEADS_SEQ[0] % 4]
+            _HEADS_SEQ[0] += 1
+            heads_host.copy_(out.view(world, k_rec, one)[:, :, :head], non_blocking=True)
+            done.record(side)
+    return {"rows": packed_list, "nchains": nchains, "device": device, "cap": cap, "head": head, "out": out, "side": side, "key": key,
+            "keep": block, "heads_host": heads_host, "done": done}
+
+
+_DEV_RING, _DEV_SEQ = {}, [0]
+_PIN_RING, _PIN_LOCK = {}, __import__("threading").Lock()
+
+
+def _pinned_block(nbytes, slots=24):
+    """A page-locked host block of nbytes from a ring of `slots` per size (numpy view of a pinned torch tensor): whoever got a slot
+    may use it until `slots` more have been handed out -- more than the executor has recordings in flight.  A copy to the device out
+    of pageable memory is staged by the runtime in pieces, each of which the calling thread waits for on a busy GPU (measured:
+    ~1 ms per half megabyte in the ordered stage of the pipelined executor); out of page-locked memory it is one asynchronous
+    transfer.  (The general pool of device.py is not used for these: up to sixteen are alive at a time, and pinning and unpinning
+    pool blocks as they come and go costs milliseconds each.)"""
+    import torch
+    with _PIN_LOCK:
+        ring = _PIN_RING.setdefault(nbytes, [[], 0])
+        if len(ring[0]) < slots:
+            ring[0].append(torch.empty(nbytes, dtype=torch.uint8, pin_memory=True))
+            t = ring[0][-1]
+        else:
+            t = ring[0][ring[1] % slots]
+        ring[1] += 1
+    return t.numpy()
+
+_HEADS_RING, _HEADS_SEQ = {}, [0]       # four page-locked header blocks + events per (device, world, batch): one is in use for a step or two
 
 
 def _exchange_collect(state):
-    """Headers (every rank) and payloads (rank 0) of an enqueued exchange; repeats it once, synchronously, if some rank's payload
-    did not fit the agreed capacity."""
+    """Headers (every rank) and payloads (rank 0) of an enqueued exchange, one result per recording in it; a recording whose payload
+    did not fit the agreed capacity on some rank is exchanged again, on its own and synchronously."""
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
-    while True:
-        head, cap, blocks, side, nchains = state["head"], state["cap"], state["blocks"], state["side"], state["nchains"]
+    head, cap, out, side, nchains = state["head"], state["cap"], state["out"], state["side"], state["nchains"]
+    k_rec, one = len(state["rows"]), state["head"] + state["cap"]
+    if state.get("done") is not None:
+        if not state["done"].query():                     # enqueued a step or more ago: normally long finished
+            state["done"].synchronize()
+        heads = state["heads_host"].numpy().copy()
+    else:
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-            heads = torch.stack([b[:head] for b in blocks]).cpu().numpy()
-        hdrs = heads.copy().view(np.int64).reshape(world, 2 + nchains)
-        most = int(hdrs[:, 0].max())
-        _GATHER_CAP[state["key"]] = max(1 << 16, (most + most // 4 + 4095) // 4096 * 4096)       # same value on every rank
-        if most <= cap:
-            break
-        state = _exchange_issue(state["rows"], nchains, state["device"], cap=_GATHER_CAP[state["key"]])
-    if rank != 0:
-        return None
-    return ("blocks", blocks, hdrs, head, side)          # rank 0: the payloads are copied back by table_from_exchange (any thread)
+            heads = out.view(world, k_rec, one)[:, :, :head].cpu().numpy().copy()
+    hdrs_all = heads.view(np.int64).reshape(world, k_rec, 2 + nchains)
+    most = int(hdrs_all[:, :, 0].max())
+    _GATHER_CAP[state["key"]] = max(1 << 16, (most + most // 4 + 4095) // 4096 * 4096)           # same value on every rank
+    results = []
+    for k in range(k_rec):
+        hdrs = np.ascontiguousarray(hdrs_all[:, k, :])
+        if int(hdrs[:, 0].max()) > cap:                   # every rank sees this and repeats, in the same order
+            sub = _exchange_issue([state["rows"][k]], nchains, state["device"], cap=_GATHER_CAP[state["key"]])
+            results.append(_exchange_collect(sub)[0])
+            continue
+        if rank != 0:
+            results.append(None)
+            continue
+        blocks = [out[r, k * one:(k + 1) * one] for r in range(world)]
+        results.append(("blocks", blocks, hdrs, head, side))      # rank 0: the payloads are copied back by table_from_exchange (any thread)
+    return results
 
 
 def _streams_from_blocks(blocks, hdrs, head, side):

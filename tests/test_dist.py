@@ -56,18 +56,22 @@ else:
     assert table is None
 # the deferred form: three recordings through an Exchanger, the first against a capacity that is too small; every future must give
 # what the synchronous exchange gave
-pdist._GATHER_CAP[(world, len(names))] = 4096
-ex = pdist.Exchanger(len(names))
-futs = [ex.step({c: r.copy() for c, r in rows.items()}) for _ in range(3)]
-assert futs[0].done() and futs[1].done() and not futs[2].done()        # each step resolves the one before it
-ex.flush()
-for f in futs:
-    t2 = pdist.table_from_exchange(f.result(), names)
-    if rank == 0:
-        assert np.array_equal(t2.rows, first.rows) and t2.counts == first.counts        # (`table` has been through correlate() since)
+for batch in (1, 2):
+    pdist._GATHER_CAP[(world, len(names))] = 4096
+    ex = pdist.Exchanger(len(names), batch=batch)
+    futs = [ex.step({c: r.copy() for c, r in rows.items()}) for _ in range(3)]
+    if batch == 1:
+        assert futs[0].done() and futs[1].done() and not futs[2].done()        # each step resolves the one before it
     else:
-        assert t2 is None
-assert pdist._GATHER_CAP[(world, len(names))] > 4096
+        assert not any(f.done() for f in futs)                                 # two recordings per collective: enqueued at the second step
+    ex.flush()
+    for f in futs:
+        t2 = pdist.table_from_exchange(f.result(), names)
+        if rank == 0:
+            assert np.array_equal(t2.rows, first.rows) and t2.counts == first.counts        # (`table` has been through correlate() since)
+        else:
+            assert t2 is None
+    assert pdist._GATHER_CAP[(world, len(names))] > 4096
 for _ in range(2):                       # twice: the exchange must be repeatable
     got = pdist.gather_packets(pk, names)
 if rank == 0:
