@@ -159,8 +159,10 @@ def main():
 
     # A dozen Python threads take turns here (the submitting thread, slicer workers, host, finish and post stages), each mostly inside
     # native calls that release the interpreter lock; with CPython's default 5 ms switch interval a thread coming back from a 20 us
-    # native call can wait milliseconds for the lock.  0.5 ms keeps the hand-offs short (measured: 1.47 -> 1.33 ms per step).
-    sys.setswitchinterval(float(os.environ.get("BENCH_SWITCH_INTERVAL", "0.0005")))
+    # native call can wait milliseconds for the lock.  Round 1: 0.5 ms (1.47 -> 1.33 ms per step).  With round 2's executor (fewer,
+    # longer-running threads; the tiny calls no longer drop the lock at all) interleaved runs give, 20 steps / 400 steps, medians:
+    # 0.5 ms 1.52 / 1.11, 1 ms 1.41 / 1.09, 2 ms 1.35 / 1.09, 5 ms 1.44 / 1.03 ms per step.
+    sys.setswitchinterval(float(os.environ.get("BENCH_SWITCH_INTERVAL", "0.002")))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
