@@ -123,6 +123,7 @@ class Context:
         return key
 
     def _release(self, key):
+        self.__dict__.get("_pool_views", {}).clear()
         pool = self.__dict__.get("_pool", {})
         for tag in [t for t in pool if isinstance(t, tuple) and t and t[0] == key]:
             try:
@@ -143,8 +144,15 @@ class Context:
                 raw.free()
             raw = DeviceBuffer(self, need + need // 2 + 256, np.uint8)      # big steps: a growth frees, and a free waits for the stream
             pool[tag] = raw
-        out = DeviceBuffer(self, int(n), dtype, ptr=raw.ptr.value)
-        out._parent = raw
+        views = self.__dict__.setdefault("_pool_views", {})
+        vk = (tag, int(n), dtype)
+        out = views.get(vk)
+        if out is None or out._parent is not raw:           # the same borrowed view for the same request (ten per recording)
+            out = DeviceBuffer(self, int(n), dtype, ptr=raw.ptr.value)
+            out._parent = raw
+            if len(views) > 4096:
+                views.clear()
+            views[vk] = out
         return out
 
     def profile(self, on=True):

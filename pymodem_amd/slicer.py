@@ -10,6 +10,9 @@ from .data_classes import AddressedArray, DeviceIQ, IQData, SignBits
 from .device import Context, DeviceBuffer, NativeError
 
 
+_PARAMS_CACHE = {}          # (sps, lock, bits, mask, demap) -> (SlicerParams, its bytes): shared, read-only
+
+
 class _SlicerBase:
     _ctx = None
     last_stats = None
@@ -38,14 +41,25 @@ class _SlicerBase:
         self._state = SlicerState()        # phase clock, last sample sign(s), partial byte, address: carried from slice() to slice()
 
     def _params(self):
-        p = SlicerParams()
-        p.samples_per_symbol = self.samples_per_symbol
-        p.lock_rate = self.lock_rate
-        p.bits_per_symbol = self.bits_per_symbol
-        p.state_mask = self.state_mask
-        for k, v in enumerate(self.demap):
-            p.demap[k] = v
-        return p
+        # built once per set of values (a batch asks every slicer twice; the executor makes eight slicers per recording)
+        key = (self.samples_per_symbol, self.lock_rate, self.bits_per_symbol, self.state_mask, tuple(self.demap))
+        hit = _PARAMS_CACHE.get(key)
+        if hit is None:
+            p = SlicerParams()
+            p.samples_per_symbol = self.samples_per_symbol
+            p.lock_rate = self.lock_rate
+            p.bits_per_symbol = self.bits_per_symbol
+            p.state_mask = self.state_mask
+            for k, v in enumerate(self.demap):
+                p.demap[k] = v
+            if len(_PARAMS_CACHE) > 256:
+                _PARAMS_CACHE.clear()
+            hit = _PARAMS_CACHE[key] = (p, bytes(p))
+        return hit[0]
+
+    def _params_bytes(self):
+        self._params()
+        return _PARAMS_CACHE[(self.samples_per_symbol, self.lock_rate, self.bits_per_symbol, self.state_mask, tuple(self.demap))][1]
 
     def _bits(self, ctx, x, tag):
         if not isinstance(x, DeviceBuffer):
@@ -86,7 +100,7 @@ def slice_batch(slicers, bitmaps, ctx=None, defer=False, reserve=1.0, out_tag=No
     first, dup_of = {}, {}
     for k, (sl, bm) in enumerate(zip(slicers, bitmaps)):
         key = (bm[0].ptr.value if bm[0] is not None else None, bm[1].ptr.value if bm[1] is not None else None, bm[2],
-               bytes(sl._params()), bytes(sl._state))
+               sl._params_bytes(), bytes(sl._state))
         if key in first:
             dup_of[k] = first[key]
         else:
