@@ -236,7 +236,7 @@ def also_workloads(args, env, cpu_also=None):
     at full size -- and fsk_9600 is the shortest-tap FIR path.  Never allowed to break the main line."""
     import copy
     out = {}
-    for name, steps, warm in (("fsk_9600", 100, 5), ("bpsk_300", 1, 0), ("qpsk_2400", 1, 0)):
+    for name, steps, warm in (("fsk_9600", 300, 10), ("bpsk_300", 1, 0), ("qpsk_2400", 1, 0)):
         if name == args.workload:
             continue
         a = copy.copy(args)
@@ -420,7 +420,7 @@ def measure(args, env):
                 st.add(pr)
             except Exception:                                 # noqa: BLE001
                 pass
-        st.sort_stats("tottime").print_stats(45)
+        st.sort_stats("tottime").print_stats(int(os.environ.get("BENCH_PYPROFILE_LINES", 45)))
     elif os.environ.get("BENCH_PYPROFILE"):                   # where the submitting thread's time goes (diagnostic, stderr)
         import cProfile, pstats
         pr = cProfile.Profile()
