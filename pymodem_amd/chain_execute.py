@@ -186,6 +186,7 @@ class RecordingPipeline:
         # showed an intermittent GPU memory fault that was not root-caused: the argument is accepted and ignored.
         self._demod_streams = 1
         self._group = max(1, min(int(os.environ.get("PYMODEM_AMD_SLICE_GROUP", slice_group)), 8))
+        self._host_blocks_warm = False
         self._fetch_inline = os.environ.get("PYMODEM_AMD_FETCH", "worker") != "copy"
         self._min_group = max(1, min(int(os.environ.get("PYMODEM_AMD_SLICE_MIN_GROUP", 3)), self._group))
         # LFSR + codec of several recordings at a time, each on up to one library thread per chain: about two dozen native threads in
@@ -278,6 +279,13 @@ class RecordingPipeline:
                     have = ctypes.c_size_t()
                     check(lib().pm_ctx_scratch(side.handle, 0, ctypes.byref(have)))
                     check(lib().pm_ctx_scratch(side.handle, int(have.value * self._group / len(items)), None))
+                    # ... and the page-locked host blocks the compact output is copied into (two batches' worth per worker may be
+                    # alive at a time: one being decoded, one being copied)
+                    rooms = [f.room for f in getattr(fetch, "fetchers", []) if getattr(f, "room", 0)]
+                    if rooms and self._fetch_inline and not self._host_blocks_warm:
+                        from .device import DeviceBuffer
+                        self._host_blocks_warm = True         # the pool is the process's: once, by whichever worker has the first batch
+                        DeviceBuffer.prewarm_host_blocks(side, max(rooms), 2 * self._workers)
                 # The slicers' bytes and addresses are still in device memory: whichever host-stage thread needs them first copies
                 # the whole batch over on the copy stream (this worker's stream is already slicing the next batch).
                 if self._fetch_inline:

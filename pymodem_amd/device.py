@@ -249,6 +249,13 @@ class DeviceBuffer:
         out._parent = self
         return out
 
+    @staticmethod
+    def prewarm_host_blocks(ctx, nbytes, count):
+        """Make sure the pool holds `count` idle page-locked blocks of nbytes: making one costs ~8 ms (touch, pin), which belongs in a
+        warm-up, not in front of a batch's copy."""
+        held = [_host_block(nbytes, ctx) for _ in range(count)]      # each call returns a different block while the others are held
+        del held
+
     def download(self, n=None, recycle=False, ctx=None, room=None):
         """-> a host array of the first n elements.  recycle=True takes the memory from a small pool of host blocks that are handed
         out again once nothing refers to them any more (views keep their block alive): a fresh 10-40 MB allocation per call costs

@@ -112,6 +112,7 @@ def slice_batch(slicers, bitmaps, ctx=None, defer=False, reserve=1.0, out_tag=No
         def fetch_all(copy_ctx=None):
             got = dict(zip(uniq, inner(copy_ctx)))
             return [got[dup_of.get(k, k)] for k in range(len(slicers))]
+        fetch_all.fetchers = getattr(inner, "fetchers", [])
         for k, src in dup_of.items():
             ctypes.memmove(ctypes.byref(slicers[k]._state), ctypes.byref(slicers[src]._state), ctypes.sizeof(SlicerState))
             slicers[k].last_stats = slicers[src].last_stats
@@ -136,6 +137,7 @@ def slice_batch(slicers, bitmaps, ctx=None, defer=False, reserve=1.0, out_tag=No
         for f in fetchers:
             f(copy_ctx)
         return out
+    fetch.fetchers = fetchers
     return fetch if defer else fetch()
 
 
@@ -203,6 +205,7 @@ def _slice_group(ctx, slicers, bitmaps, group, out, tight, reserve=1.0, out_tag=
                     out[k] = AddressedArray(data, full)
                 else:
                     out[k] = AddressedArray.from_steps(data, steps, first)
+        fetch_compact.room = dense.n
         return fetch_compact
 
     def fetch(copy_ctx=None):
