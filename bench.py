@@ -333,9 +333,11 @@ def measure(args, env):
             pipe.reset_stats()
             # the exchange runs one recording behind (dist.Exchanger): the copy back of a gather never waits for the collective
             ex = pdist.Exchanger(nchains, coll_device)
+            # one rank and no forced exchange: nothing behind the host stage has to keep the recordings' order
+            local_only = not use_dist and not os.environ.get("PYMODEM_AMD_FORCE_GATHER") and not os.environ.get("BENCH_ORDERED_TAIL")
             last = None
             for _ in range(k):
-                last = pipe.submit(build_chains(), d_audio, ex.step, (None if os.environ.get("BENCH_NO_POST") else dedupe), prepare=lambda rows_list: ex.prepare(dict(zip(my, rows_list))), chain_ids=my)
+                last = pipe.submit(build_chains(), d_audio, ex.step, (None if os.environ.get("BENCH_NO_POST") else dedupe), prepare=lambda rows_list: ex.prepare(dict(zip(my, rows_list))), chain_ids=my, unordered=local_only)
             pipe.flush_finish(ex.flush)
             res = last.result() if last is not None else None
             pipe.drain()                                      # every step's de-dup is done, not only the last one's
@@ -391,10 +393,19 @@ def measure(args, env):
 
     run_steps(args.warmup)
     fence()
+    # The cyclic collector stops every thread (it runs under the interpreter lock): a full collection over the millions of objects
+    # torch and numpy bring along took 7-15 ms and landed inside about one 20-step run in three (two slicer batches and the submitting
+    # thread stalled together in the per-recording timeline).  Everything alive after the warm-up goes to the permanent generation;
+    # what the steps allocate is still collected, in collections that only have those objects to look at.
+    import gc
+    gc.collect()
+    gc.freeze()
     if not os.environ.get("BENCH_NO_PROF"):
         ctx.profile(True)
         for sc in sides:
             sc.profile(True)
+    if os.environ.get("BENCH_TIMELINE"):
+        print("[timeline] timed region begins", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     cpu0 = time.process_time()
     if os.environ.get("BENCH_PYPROFILE") == "all":            # every thread's interpreter time (diagnostic, stderr): one profiler per thread
@@ -430,6 +441,8 @@ def measure(args, env):
         result = run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("BENCH_TIMELINE"):
+        print("[timeline] timed region ends", file=sys.stderr, flush=True)
     host_cpu_ms = (time.process_time() - cpu0) / max(args.steps, 1) * 1e3     # all threads of this process, native ones included
     if os.environ.get("BENCH_NO_PROF"):                   # diagnostic: the step time without the HIP-event bracketing the roofline needs
         print(json.dumps({"ms_per_step_without_profiling": round(elapsed / args.steps * 1e3, 3), "stages": stage_ms}), file=sys.stderr)

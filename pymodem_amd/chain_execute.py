@@ -233,6 +233,7 @@ class RecordingPipeline:
             th.start()
 
     def _slice_loop(self, side):
+        import os
         import queue
         import time
         while True:
@@ -271,7 +272,12 @@ class RecordingPipeline:
                         resolve_sweeps(chains, bm, sweeps, audio, side)
                     slicers += [ch[2] for ch in chains]
                     bitmaps += bm
-                fetch = slice_batch(slicers, bitmaps, side, defer=True, reserve=self._group / len(items), compact=True)
+                # (copied to the host by this worker before its next batch: ONE output block per worker will do -- keyed by the first
+                # recording's slot there would be sixteen of them, 1.9 GB per worker, allocated as the slots come round for the first time)
+                t_a = time.perf_counter()
+                fetch = slice_batch(slicers, bitmaps, side, defer=True, reserve=self._group / len(items), compact=True,
+                                    out_tag=("pipeline-out",) if self._fetch_inline else None)
+                t_b = time.perf_counter()
                 if not getattr(side, "_slicer_block_reserved", False):
                     # the stream's work block (checkpoints, symbol bitmaps, lists: ~150 MB per recording) sized for a batch of four from
                     # the first batch on: growing it later is a free + malloc in the middle of the pipeline (10 ms measured)
@@ -279,21 +285,27 @@ class RecordingPipeline:
                     have = ctypes.c_size_t()
                     check(lib().pm_ctx_scratch(side.handle, 0, ctypes.byref(have)))
                     check(lib().pm_ctx_scratch(side.handle, int(have.value * self._group / len(items)), None))
-                    # ... and the page-locked host blocks the compact output is copied into (two batches' worth per worker may be
-                    # alive at a time: one being decoded, one being copied)
+                    # ... and the page-locked host blocks the compact output is copied into: a block stays referenced until the host
+                    # stages of all its recordings are through, and with sixteen recordings in flight that can be more than two batches
+                    # per worker; one made in front of a copy costs 8-20 ms there (touch, pin, under load)
                     rooms = [f.room for f in getattr(fetch, "fetchers", []) if getattr(f, "room", 0)]
                     if rooms and self._fetch_inline and not self._host_blocks_warm:
                         from .device import DeviceBuffer
                         self._host_blocks_warm = True         # the pool is the process's: once, by whichever worker has the first batch
-                        DeviceBuffer.prewarm_host_blocks(side, max(rooms), 2 * self._workers)
+                        DeviceBuffer.prewarm_host_blocks(side, max(rooms), 4 * self._workers)
                 # The slicers' bytes and addresses are still in device memory: whichever host-stage thread needs them first copies
                 # the whole batch over on the copy stream (this worker's stream is already slicing the next batch).
                 if self._fetch_inline:
                     # the compact output of a batch is a few megabytes: copied here, on the stream that made it and is idle at this
                     # point, it is on the host a third of a millisecond later; on the copy stream it waits for whatever kernel the
                     # hardware queue that stream shares is running (1-2 ms measured)
+                    t_c = time.perf_counter()
                     done = fetch(side)
                     fetch = lambda _ctx, _done=done: _done
+                    if time.perf_counter() - t > 0.008 and os.environ.get("BENCH_TIMELINE"):
+                        import sys
+                        print("[slow batch] %d recordings: before slice_batch %.2f, slice_batch %.2f, between %.2f, fetch %.2f ms" % (
+                            len(items), (t_a - t) * 1e3, (t_b - t_a) * 1e3, (t_c - t_b) * 1e3, (time.perf_counter() - t_c) * 1e3), file=sys.stderr)
                 shared = _BatchFetch(fetch, self._copy_ctx, self._copy_lock)
                 at = 0
                 for chains, _, _, fut, _, _, rec in items:
@@ -329,12 +341,14 @@ class RecordingPipeline:
             return buf, done, k
         return self._upload.submit(copy)
 
-    def submit(self, chains, input_audio, finish=None, post=None, prepare=None, chain_ids=None):
+    def submit(self, chains, input_audio, finish=None, post=None, prepare=None, chain_ids=None, unordered=False):
         """Start one recording; returns a Future of post(finish(rows per chain)) (either may be None = identity).  `finish` calls
         run one at a time in submission order (the place for collectives); `post` calls run in parallel with later recordings.
         If finish returns a future itself, post receives its result (and waits for it: see flush_finish).  `prepare(rows)`, if
         given, runs at the end of the host stage (several recordings at a time) and its result is what finish receives.  `chain_ids`:
-        each chain's place in the config (its key in the packet table); the codecs then stamp their packets with it as they write them."""
+        each chain's place in the config (its key in the packet table); the codecs then stamp their packets with it as they write them.
+        `unordered`: finish does not depend on the recordings' order (no collective behind it): finish and post run at the end of the
+        host stage, on its thread."""
         import time
         acc = self.stage_seconds
         slots = self._slots
@@ -385,12 +399,27 @@ class RecordingPipeline:
                 rows = prepare(rows)
             rec["host1"] = time.perf_counter()
             acc["host"] += rec["host1"] - t
+            if unordered:                                      # nothing needs the recordings' order: finish and post right here,
+                x = rows if finish is None else finish(rows)   # two thread hand-overs (and their waits for the interpreter lock) less
+                rec["finish1"] = time.perf_counter()
+                acc["finish"] += rec["finish1"] - rec["host1"]
+                if post is not None:
+                    if hasattr(x, "result") and hasattr(x, "done"):
+                        x = x.result()
+                    x = post(x)
+                    rec["post1"] = time.perf_counter()
+                    acc["post"] = acc.get("post", 0.0) + rec["post1"] - rec["finish1"]
+                return x
             return rows
         if self._host is None:
             import os
-            n_host = int(os.environ.get("PYMODEM_AMD_HOST_STAGE_THREADS", 0)) or max(2, min(8, 24 // max(len(chains), 1)))
+            # (one more when finish and post run on these threads too)
+            n_host = int(os.environ.get("PYMODEM_AMD_HOST_STAGE_THREADS", 0)) or max(2, min(8, 24 // max(len(chains), 1))) + (1 if unordered else 0)
             self._host = ThreadPoolExecutor(max_workers=n_host)
         f_rows = self._host.submit(host_stage)
+        if unordered:
+            self._tails.append(f_rows)
+            return f_rows
 
         def finish_stage():
             rows = f_rows.result()

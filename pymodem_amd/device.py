@@ -142,7 +142,8 @@ class Context:
         if raw is None or raw.n < need:
             if raw is not None:
                 raw.free()
-            raw = DeviceBuffer(self, need + need // 2 + 256, np.uint8)      # big steps: a growth frees, and a free waits for the stream
+            want = need + need // 2 + 256                                    # big steps: a growth frees, and a free waits for the stream
+            raw = self._arena_alloc(want) or DeviceBuffer(self, want, np.uint8)
             pool[tag] = raw
         views = self.__dict__.setdefault("_pool_views", {})
         vk = (tag, int(n), dtype)
@@ -154,6 +155,32 @@ class Context:
                 views.clear()
             views[vk] = out
         return out
+
+    # Work buffers come out of large device blocks (2 GB; PYMODEM_AMD_ARENA_MB, 0 = a hipMalloc per buffer): the pipelined executor
+    # touches a new set of per-slot buffers with each of its first sixteen recordings, and a hipMalloc in the middle of a full GPU
+    # can hold every queue for milliseconds (seen as an 8 ms hole in the demod stream and two slicer batches at once).  A released
+    # buffer (its owner object gone) is handed out again to the next request of the same size.
+    def _arena_alloc(self, nbytes):
+        mb = int(os.environ.get("PYMODEM_AMD_ARENA_MB", "2048"))
+        nb = (int(nbytes) + 255) & ~255
+        if mb <= 0 or nb > (mb << 20) // 4:
+            return None
+        with self.__dict__.setdefault("_arena_lock", threading.Lock()):
+            free = self.__dict__.setdefault("_arena_free", {})
+            if free.get(nb):
+                return _ArenaBuffer(self, nb, free[nb].pop())
+            chunks = self.__dict__.setdefault("_arena_chunks", [])
+            if not chunks or chunks[-1][1] + nb > chunks[-1][0].n:
+                chunks.append([DeviceBuffer(self, mb << 20, np.uint8), 0])
+            chunk = chunks[-1]
+            ptr = chunk[0].ptr.value + chunk[1]
+            chunk[1] += nb
+            return _ArenaBuffer(self, nb, ptr)
+
+    def _arena_release(self, buf):
+        self.sync()                                        # like pm_free: what this stream still does with it finishes first
+        with self.__dict__.setdefault("_arena_lock", threading.Lock()):
+            self.__dict__.setdefault("_arena_free", {}).setdefault(buf.n, []).append(buf.ptr.value)
 
     def profile(self, on=True):
         check(lib().pm_prof_enable(self._h, int(bool(on))))
@@ -188,11 +215,14 @@ class Context:
 
     def close(self):
         if self._h:
+            for chunk in self.__dict__.pop("_arena_chunks", []):
+                chunk[0].free()
+            self.__dict__.pop("_arena_free", None)
             lib().pm_ctx_destroy(self._h)
             self._h = ctypes.c_void_p()
 
 
-_HOST_BLOCKS, _HOST_BLOCKS_LOCK, _HOST_BLOCKS_MAX = {False: [], True: []}, threading.Lock(), 12
+_HOST_BLOCKS, _HOST_BLOCKS_LOCK, _HOST_BLOCKS_MAX = {False: [], True: []}, threading.Lock(), 32
 
 
 def _host_block(nbytes, ctx=None):
@@ -277,6 +307,20 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+class _ArenaBuffer(DeviceBuffer):
+    """A range of one of a context's large blocks (Context._arena_alloc)."""
+
+    def __init__(self, ctx, nbytes, ptr):
+        super().__init__(ctx, nbytes, np.uint8, ptr=ptr)
+
+    def free(self):
+        if self.ptr:
+            try:
+                self.ctx._arena_release(self)
+            finally:
+                self.ptr = ctypes.c_void_p()
 
 
 __all__ = ["Context", "DeviceBuffer", "NativeError"]
