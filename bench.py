@@ -461,8 +461,10 @@ def measure(args, env):
     alone = {}
     if args.overlap:
         saved, args.overlap = args.overlap, 0
+        run_steps(1)                                          # (the sequential path's own buffers and first launches)
+        fence()
         ctx.profile(True)
-        run_steps(1)
+        run_steps(3 if args.steps > 1 else 1)                 # a 30 us kernel measured once is whatever that one launch happened to be
         fence()
         alone = ctx.profile_read()
         ctx.profile(False)
@@ -532,7 +534,7 @@ def measure(args, env):
                          "alone": None if alone_ms is None else {
                              "avg_kernel_ms": round(alone_ms, 5), "achieved": round(per_launch_bytes / (alone_ms * 1e-3) / 1e9, 2),
                              "frac": round(per_launch_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                             "note": "same kernel class in one extra sequential step after the timed region, no other stream on the GPU"},
+                             "note": "same kernel class in three extra sequential steps after the timed region, no other stream on the GPU"},
                          "note": "achieved = algorithmic bytes of the timed launches / their HIP-event time inside the timed region (where "
                                  "the slicer streams share the CUs).  Above ~40 taps a FIR is bound by the vector-f64 FMA pipe, not by "
                                  "HBM: see roofline_fp64 for that fraction (DESIGN.md 4.1-4.2).  For the AFSK workloads the class fir_f64 is "
