@@ -187,6 +187,7 @@ class RecordingPipeline:
         self._demod_streams = 1
         self._group = max(1, min(int(os.environ.get("PYMODEM_AMD_SLICE_GROUP", slice_group)), 8))
         self._host_blocks_warm = False
+        self._collect_lock = None if os.environ.get("PYMODEM_AMD_SLICE_COLLECT") == "free" else threading.Lock()
         self._fetch_inline = os.environ.get("PYMODEM_AMD_FETCH", "worker") != "copy"
         self._min_group = max(1, min(int(os.environ.get("PYMODEM_AMD_SLICE_MIN_GROUP", 3)), self._group))
         # LFSR + codec of several recordings at a time, each on up to one library thread per chain: about two dozen native threads in
@@ -232,37 +233,52 @@ class RecordingPipeline:
         for th in self._slice_threads:
             th.start()
 
+    def _collect_batch(self):
+        import queue
+        import time
+        item = self._pending.get()
+        if item is None:
+            self._pending.put(None)                            # one marker ends every worker
+            return None
+        # demod runs in submission order: wait (on the host, holding nothing) for this recording's bitmaps, then take along
+        # every later recording whose bitmaps are complete as well
+        Context.event_sync(item[2])
+        item[6]["ready"] = time.perf_counter()
+        items = [item]
+        while len(items) < self._group:
+            try:
+                nxt = self._pending.get_nowait()
+            except queue.Empty:
+                break
+            if nxt is None:
+                self._pending.put(None)
+                break
+            if not Context.event_done(nxt[2]):
+                if len(items) < self._min_group:               # its demod is already queued on the GPU (<= 1 ms): a batch of three costs
+                    Context.event_sync(nxt[2])                 # what a batch of one costs, so a short wait here saves whole batches
+                else:
+                    with self._pending.mutex:                  # not ready yet: back to the FRONT of the queue
+                        self._pending.queue.appendleft(nxt)
+                        self._pending.not_empty.notify()
+                    break
+            items.append(nxt)
+        return items
+
     def _slice_loop(self, side):
         import os
         import queue
         import time
         while True:
-            item = self._pending.get()
-            if item is None:
-                self._pending.put(None)                        # one marker ends every worker
+            # ONE worker at a time puts a batch together, so that a batch is CONSECUTIVE recordings and starts when its third demod is
+            # done; three workers collecting at once took every third recording each, and all three batches started only when the
+            # ninth demod was done (seen in the per-recording timeline).  PYMODEM_AMD_SLICE_COLLECT=free: the old behaviour.
+            if self._collect_lock is not None:
+                with self._collect_lock:
+                    items = self._collect_batch()
+            else:
+                items = self._collect_batch()
+            if items is None:
                 return
-            # demod runs in submission order: wait (on the host, holding nothing) for this recording's bitmaps, then take along
-            # every later recording whose bitmaps are complete as well
-            Context.event_sync(item[2])
-            item[6]["ready"] = time.perf_counter()
-            items = [item]
-            while len(items) < self._group:
-                try:
-                    nxt = self._pending.get_nowait()
-                except queue.Empty:
-                    break
-                if nxt is None:
-                    self._pending.put(None)
-                    break
-                if not Context.event_done(nxt[2]):
-                    if len(items) < self._min_group:           # its demod is already queued on the GPU (<= 1 ms): a batch of three costs
-                        Context.event_sync(nxt[2])             # what a batch of one costs, so a short wait here saves whole batches
-                    else:
-                        with self._pending.mutex:              # not ready yet: back to the FRONT of the queue
-                            self._pending.queue.appendleft(nxt)
-                            self._pending.not_empty.notify()
-                        break
-                items.append(nxt)
             t = time.perf_counter()
             try:
                 slicers, bitmaps = [], []
