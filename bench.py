@@ -143,7 +143,7 @@ def main():
                          "2: three-stage pipeline (chain_execute.RecordingPipeline): demod of step k+1 on the default stream, slicer of "
                          "step k on a high-priority side stream, host half (LFSR, codec, packet gather, de-dup) of step k-1 in threads; "
                          "1: only the host half runs behind the next step's GPU half; 0: strictly one after the other")
-    ap.add_argument("--slice-workers", type=int, default=3, help="--overlap 2: recordings whose slicers may be in flight at once")
+    ap.add_argument("--slice-workers", type=int, default=2, help="--overlap 2: recordings whose slicers may be in flight at once")
     ap.add_argument("--demod-streams", type=int, default=1, help="--overlap 2: streams the demod kernels of successive recordings alternate on")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--buffer", default="signal", choices=["signal", "noise"],

@@ -175,7 +175,7 @@ class RecordingPipeline:
     stays usable (bench.py keeps one across warm-up and timed steps); close() ends its threads.  Results are identical to
     process_chains_table on each recording (tests/test_gpu_chains.py)."""
 
-    def __init__(self, slice_workers=3, demod_streams=1, slice_group=4, slots=None):
+    def __init__(self, slice_workers=2, demod_streams=1, slice_group=4, slots=None):
         from collections import deque
         import os
         import queue
@@ -189,7 +189,7 @@ class RecordingPipeline:
         self._host_blocks_warm = False
         self._collect_lock = None if os.environ.get("PYMODEM_AMD_SLICE_COLLECT") == "free" else threading.Lock()
         self._fetch_inline = os.environ.get("PYMODEM_AMD_FETCH", "worker") != "copy"
-        self._min_group = max(1, min(int(os.environ.get("PYMODEM_AMD_SLICE_MIN_GROUP", 3)), self._group))
+        self._min_group = max(1, min(int(os.environ.get("PYMODEM_AMD_SLICE_MIN_GROUP", 4)), self._group))
         # LFSR + codec of several recordings at a time, each on up to one library thread per chain: about two dozen native threads in
         # all is where it stops paying (8-chain AFSK group: 3 recordings 1.21 ms per step, 5 recordings 1.38-1.41, medians of
         # interleaved runs; a 3-chain IL2P group at 4-5 ms per chain takes eight).  Made at the first submit, when the group is known.
