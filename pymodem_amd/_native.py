@@ -221,7 +221,7 @@ def lib():
 
 
 _QUICK = None
-QUICK_CALLS = ("pm_codec_create", "pm_codec_destroy", "pm_codec_set_source", "pm_event_record", "pm_event_wait", "pm_event_query", "pm_last_error")
+QUICK_CALLS = ("pm_afsk_group_run", "pm_codec_create", "pm_codec_destroy", "pm_codec_set_source", "pm_event_record", "pm_event_wait", "pm_event_query", "pm_last_error")
 
 
 def quick():

@@ -16,7 +16,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
-from ._native import Loop, check, lib
+from ._native import Loop, check, lib, quick
 from .device import Context, DeviceBuffer
 from .modems import AFSKModem, AFSKPLLModem, BPSKModem, MPSKModem, QPSKModem
 from .slicer import slice_batch
@@ -111,6 +111,7 @@ def _host_rows(chains, sliced, chain_ids=None):
 
 _POOL = None
 _USE_SWEEP = True          # pm_afsk_sweep_signs for gain sweeps (tests switch it off to compare against the exact group path)
+_GROUP_RUN_QUICK = [__import__("os").environ.get("PYMODEM_AMD_GROUP_RUN_QUICK", "0") != "0"]     # measured: submit 0.16 ms instead of 0.4, the step unchanged
 _USE_GROUP_NATIVE = True   # band-pass + all sweeps of a group in one native call (tests switch it off to compare with the separate calls)
 
 
@@ -163,7 +164,7 @@ class RecordingPipeline:
       demod   FIR / correlator / loop kernels (vector-f64 ALU and HBM)                 default stream, caller's thread
       slice   lockstep walkers (pm_slice_batch): a batch of up to four recordings costs   `slice_workers` high-priority side streams,
               about what one costs (dependent-latency bound), so a worker waits for       one thread each
-              three finished demods before it starts one; the batch's bytes and address
+              four finished demods before it starts one (one worker collects at a time); the batch's bytes and address
               steps come back in compact form on the same stream (pm_slice_compact)
       host    LFSR + codec (native, GIL released)                                       five threads (recordings); chains on library threads
       finish  the caller's `finish(rows per chain)`: the packet exchange                 one thread, submission order (collectives)
@@ -542,7 +543,10 @@ def _afsk_group_native(ctx, chains, planned, audio, group_key, front, bitmaps, s
         keep.append(ptrs)
         outs.append((part, bits, nout))
     tickets = (ctypes.c_int64 * len(planned))()
-    check(lib().pm_afsk_group_run(ctx.handle, audio.ptr, audio.n, taps.ptr, mb, bpf.ptr, bound[1], descs, len(planned), tickets))
+    # launches only (115 us): without dropping the interpreter lock when the pipelined executor asks for it -- getting it back
+    # behind a dozen threads cost the submitting thread 0.5 ms per recording
+    native = quick() if _GROUP_RUN_QUICK[0] else lib()
+    check(native.pm_afsk_group_run(ctx.handle, audio.ptr, audio.n, taps.ptr, mb, bpf.ptr, bound[1], descs, len(planned), tickets))
     AFSKModem.sweeps_run += len(planned)
     for j, (part, bits, nout) in enumerate(outs):
         sweeps.append(((ctx, int(tickets[j])), list(part)))
