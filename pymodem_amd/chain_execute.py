@@ -166,7 +166,8 @@ class RecordingPipeline:
               about what one costs (dependent-latency bound), so a worker waits for       one thread each
               four finished demods before it starts one (one worker collects at a time); the batch's bytes and address
               steps come back in compact form on the same stream (pm_slice_compact)
-      host    LFSR + codec (native, GIL released)                                       five threads (recordings); chains on library threads
+      host    LFSR + codec (native, GIL released)                                       three to nine threads (recordings), sized to the chain
+                                                                                        group; chains on library threads
       finish  the caller's `finish(rows per chain)`: the packet exchange                 one thread, submission order (collectives)
       post    the caller's `post(...)`: rank 0's payload copy, indexing and de-dup       three threads
 
