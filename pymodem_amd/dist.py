@@ -367,22 +367,31 @@ _PIN_RING, _PIN_LOCK = {}, __import__("threading").Lock()
 
 
 def _pinned_block(nbytes, slots=24):
-    """A page-locked host block of nbytes from a ring of `slots` per size (numpy view of a pinned torch tensor): whoever got a slot
-    may use it until `slots` more have been handed out -- more than the executor has recordings in flight.  A copy to the device out
-    of pageable memory is staged by the runtime in pieces, each of which the calling thread waits for on a busy GPU (measured:
-    ~1 ms per half megabyte in the ordered stage of the pipelined executor); out of page-locked memory it is one asynchronous
-    transfer.  (The general pool of device.py is not used for these: up to sixteen are alive at a time, and pinning and unpinning
-    pool blocks as they come and go costs milliseconds each.)"""
-    import torch
+    """A page-locked host block of nbytes from a ring of `slots` per size: whoever got a slot may use it until `slots` more have been
+    handed out -- more than the executor has recordings in flight.  A copy to the device out of pageable memory is staged by the
+    runtime in pieces, each of which the calling thread waits for on a busy GPU; out of page-locked memory it is one asynchronous
+    transfer.  The blocks are ordinary (cached) memory registered with the runtime once (pm_host_pin), not memory the runtime
+    allocated page-locked: the CPU writes and reads the latter at ~1 GB/s here (2.5 ms to put four half-megabyte blocks together),
+    and the packing and the headers are CPU work.  (The general pool of device.py is not used for these: up to sixteen are alive at a
+    time, and pinning and unpinning pool blocks as they come and go costs milliseconds each.)"""
+    import ctypes
+    from ._native import lib
+    from .device import Context
     with _PIN_LOCK:
         ring = _PIN_RING.setdefault(nbytes, [[], 0])
         if len(ring[0]) < slots:
-            ring[0].append(torch.empty(nbytes, dtype=torch.uint8, pin_memory=True))
-            t = ring[0][-1]
+            blk = np.zeros(nbytes, dtype=np.uint8)
+            try:
+                lib().pm_host_pin(Context.default().handle, blk.ctypes.data_as(ctypes.c_void_p), blk.nbytes)    # for the process's life
+            except Exception:                             # noqa: BLE001  (no GPU: plain memory will do)
+                pass
+            ring[0].append(blk)
+            t = blk
         else:
             t = ring[0][ring[1] % slots]
         ring[1] += 1
-    return t.numpy()
+    return t
+
 
 _HEADS_RING, _HEADS_SEQ = {}, [0]       # four page-locked header blocks + events per (device, world, batch): one is in use for a step or two
 
