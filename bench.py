@@ -461,8 +461,9 @@ def measure(args, env):
     alone = {}
     if args.overlap:
         saved, args.overlap = args.overlap, 0
-        run_steps(1)                                          # (the sequential path's own buffers and first launches)
-        fence()
+        if args.steps > 1:                                    # (not for the one-step carrier-loop workloads: 5-8 s per step)
+            run_steps(1)                                      # the sequential path's own buffers and first launches
+            fence()
         ctx.profile(True)
         run_steps(3 if args.steps > 1 else 1)                 # a 30 us kernel measured once is whatever that one launch happened to be
         fence()
