@@ -201,6 +201,69 @@ def test_recording_pipeline_matches_one_at_a_time(golden, config_lines):
         assert np.array_equal(got[0][ci]["streamaddress"], g[f"afsk_300__c{ci}_pkt_addr"])
 
 
+def test_recording_pipeline_unordered_tail_drain_and_chain_ids(config_lines):
+    """submit(..., unordered=True, chain_ids=...): finish and post run on the host-stage thread and the codecs stamp their packets
+    with the chain's place in the config; drain() waits for everything and leaves the executor usable.  Results as one at a time."""
+    from pymodem_amd import chain_builder as cb, chain_execute as ce, siggen
+    lines = config_lines("afsk_1200_ax25_super_opt.json")
+    kinds = [siggen.recording("afsk1200_ax25", 48000, packets=4, seed=s, noise_sigma=500.0, payload_len=(20, 60))[0] for s in (5, 6)]
+    want = [ce.process_chains_table([cb.build_chain(48000, l) for l in lines], a) for a in kinds]
+    ids = [10 + c for c in range(len(lines))]
+    pipe = ce.RecordingPipeline()
+    try:
+        for rnd in range(2):                                   # two rounds through the same executor with a drain in between
+            futures, fin = [], []
+            for k in range(9):
+                futures.append((k % 2, pipe.submit([cb.build_chain(48000, l) for l in lines], kinds[k % 2], finish=lambda rows: (fin.append(1), rows)[1],
+                                                   post=lambda rows: [r.copy() for r in rows], chain_ids=ids, unordered=True)))
+            pipe.drain()
+            assert len(fin) == 9 and all(f.done() for _, f in futures)
+            for which, f in futures:
+                rows = f.result()
+                for ci in range(len(lines)):
+                    r, w = rows[ci], want[which][ci]
+                    assert len(r) == len(w) and np.array_equal(r["data"], w["data"]) and np.array_equal(r["streamaddress"], w["streamaddress"])
+                    assert (r["source_decoder"] == ids[ci]).all()
+            assert sum(len(r) for r in want[0].values()) > 0
+    finally:
+        pipe.close()
+
+
+def test_work_buffers_come_from_arenas_and_are_reused():
+    """Context.scratch carves its buffers out of large device blocks: distinct tags get distinct ranges, a released owner's range is
+    handed out again for the same size, and what is written through one view is read back through the next."""
+    import gc
+    import pymodem_amd
+    ctx = pymodem_amd.Context(0)
+    try:
+        a = ctx.scratch(("t", 1), 1000, np.float64)
+        b = ctx.scratch(("t", 2), 1000, np.float64)
+        assert a.ptr.value != b.ptr.value and abs(a.ptr.value - b.ptr.value) >= 8000
+        assert ctx.scratch(("t", 1), 1000, np.float64).ptr.value == a.ptr.value
+        chunks = ctx.__dict__["_arena_chunks"]
+        assert len(chunks) == 1 and chunks[0][0].ptr.value <= a.ptr.value < chunks[0][0].ptr.value + chunks[0][0].n
+
+        class Owner:
+            pass
+        o = Owner()
+        c = ctx.scratch((ctx.owner_key(o), "x"), 5000, np.int16)
+        where = c.ptr.value
+        del o, c
+        gc.collect()
+        o2 = Owner()
+        d = ctx.scratch((ctx.owner_key(o2), "x"), 5000, np.int16)
+        assert d.ptr.value == where                            # the released range, same size: handed out again
+        big = ctx.scratch(("t", "big"), (600 << 20), np.uint8)  # beyond a quarter of the block: its own allocation
+        assert not (chunks[0][0].ptr.value <= big.ptr.value < chunks[0][0].ptr.value + chunks[0][0].n)
+        x = np.arange(1000, dtype=np.float64)
+        up = ctx.upload(x)
+        from pymodem_amd._native import check, lib
+        check(lib().pm_d2d(ctx.handle, a.ptr, up.ptr, x.nbytes))
+        assert np.array_equal(ctx.scratch(("t", 1), 1000, np.float64).download(), x)
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("cfg,rate", [("afsk_1200.json", 48000), ("fsk_9600.json", 48000), ("bpsk_300.json", 48000), ("qpsk_2400.json", 48000),
                                       ("afsk_300_pll.json", 8000), ("afsk_300.json", 8000)])
 def test_whole_chain_entry_point_matches_the_stage_path(config_lines, cfg, rate):

@@ -274,3 +274,21 @@ sys.exit(os.waitstatus_to_exitcode(status))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], timeout=120, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-1500:]
+
+
+def test_codec_set_source_stamps_the_rows(golden, config_lines):
+    """pm_codec_set_source: the index pm_codec_fetch writes into pm_packet.source_decoder (the executor gives every codec its chain's
+    place in the config, so that nobody has to walk the rows afterwards)."""
+    from pymodem_amd import chain_builder as cb
+    from pymodem_amd._native import check, quick
+    from pymodem_amd.data_classes import AddressedArray
+    g = golden("wav_chains")
+    line = config_lines("afsk_300.json")[0]
+    for src in (0, 7):
+        stream = cb.StreamConfigurator(line["stream"])
+        codec = cb.CodecConfigurator(line["codec"], line["object_name"])
+        if src:
+            check(quick().pm_codec_set_source(codec._handle(), src))
+        lf = stream.stream_unscramble_8bit(AddressedArray(g["afsk_300__c0_slice_data"], g["afsk_300__c0_slice_addr"]))
+        rows = codec.decode_rows(lf)
+        assert len(rows) == len(g["afsk_300__c0_pkt_addr"]) > 3 and (rows["source_decoder"] == src).all()
