@@ -35,7 +35,7 @@ for name, ctr in [("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")]:
 CLASSES = {"fir_i16": ["fir_valid_kernel<short", "fir_short_signs_i16_kernel"], "fir_f64": ["fir_valid_kernel<double", "fir_sweep_kernel", "afsk_slide_lpf_kernel"],
            "afsk_correlate": ["afsk_correlate_kernel", "afsk_slide_kernel"],
            "signs": ["signs_kernel", "sweep_exact_kernel", "afsk_group_kernel", "fir_signs_batch_kernel", "pack_group_taps_kernel"],
-           "slice_iter": ["slice_walk_kernel", "slice_iter_kernel"], "slice_emit": ["slice_count_kernel", "slice_scan_kernel", "slice_pack_kernel"]}
+           "slice_iter": ["slice_walk_kernel", "slice_iter_kernel"], "slice_emit": ["slice_count_kernel", "slice_scan_kernel", "slice_pack_kernel", "slice_compact_kernel"]}
 out = {"workload": workload, "samples": samples,
        "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (two separate passes) --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
        "corrections": "bytes = counter * 1024; FETCH_SIZE doubled (gfx950 reports half the bytes of a coalesced streaming read, MI355X_MICROARCH.md "
