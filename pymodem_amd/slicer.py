@@ -40,7 +40,7 @@ class _SlicerBase:
         self.streamaddress = 0
         self._state = SlicerState()        # phase clock, last sample sign(s), partial byte, address: carried from slice() to slice()
 
-    def _params(self):
+    def _params_entry(self):
         # built once per set of values (a batch asks every slicer twice; the executor makes eight slicers per recording)
         key = (self.samples_per_symbol, self.lock_rate, self.bits_per_symbol, self.state_mask, tuple(self.demap))
         hit = _PARAMS_CACHE.get(key)
@@ -55,11 +55,13 @@ class _SlicerBase:
             if len(_PARAMS_CACHE) > 256:
                 _PARAMS_CACHE.clear()
             hit = _PARAMS_CACHE[key] = (p, bytes(p))
-        return hit[0]
+        return hit
+
+    def _params(self):
+        return self._params_entry()[0]
 
     def _params_bytes(self):
-        self._params()
-        return _PARAMS_CACHE[(self.samples_per_symbol, self.lock_rate, self.bits_per_symbol, self.state_mask, tuple(self.demap))][1]
+        return self._params_entry()[1]
 
     def _bits(self, ctx, x, tag):
         if not isinstance(x, DeviceBuffer):
