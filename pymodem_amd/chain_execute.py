@@ -199,7 +199,8 @@ class RecordingPipeline:
         self._finish = ThreadPoolExecutor(max_workers=1)
         self._post = ThreadPoolExecutor(max_workers=int(os.environ.get("PYMODEM_AMD_POST_THREADS", 3)))        # whatever follows the ordered step (rank 0's payload copy, indexing, de-dup)
         self._inflight = deque()
-        self._tails = deque()                                 # the last stage's future of every recording not yet drained
+        self._tails = deque()                                 # the last stage's future of every recording not yet through
+        self._failed = []
         self._n = 0
         self._upload = ThreadPoolExecutor(max_workers=1)      # host -> HBM copies of the NEXT recording, on a stream of their own
         self._uploads = 0
@@ -369,6 +370,7 @@ class RecordingPipeline:
         host stage, on its thread."""
         import time
         acc = self.stage_seconds
+        self._forget_finished()
         slots = self._slots
         slot = self._n % slots
         self._n += 1
@@ -471,6 +473,17 @@ class RecordingPipeline:
         stage error."""
         while self._tails:
             self._tails.popleft().result()
+        if self._failed:
+            f, self._failed = self._failed[0], []
+            f.result()
+
+    def _forget_finished(self):
+        # a finished recording's future holds its result (megabytes of packet rows): let go of it as soon as it is through, keeping
+        # only the ones that failed for drain() to report
+        while self._tails and self._tails[0].done():
+            f = self._tails.popleft()
+            if f.exception() is not None:
+                self._failed.append(f)
 
     def reset_stats(self):
         for k in list(self.stage_seconds):
