@@ -141,12 +141,21 @@ int rs_decode(int num_roots, uint8_t *buf, int n, int min_distance)
     const int first_root = 0, half = num_roots / 2;
     int syn[16];
     auto syndromes = [&]() {
-        for (int i = 0; i < num_roots; ++i) {
-            const uint8_t *row = g.row[first_root + i];            // multiplication by the i-th root
-            unsigned v = 0;
-            for (int j = 0; j < n - 1; ++j) v = row[v ^ buf[j]];
-            syn[i] = (int)(v ^ buf[n - 1]);
+        // Horner in every root at once: byte by byte, the roots' chains side by side (each step of one chain is a table lookup that
+        // waits for the one before it: root by root that was 16 x n dependent loads, 2 us for a 100-byte block)
+        unsigned v[16] = {0};
+        if (num_roots == 16) {
+            for (int j = 0; j < n - 1; ++j) {
+                const unsigned b = buf[j];
+                for (int i = 0; i < 16; ++i) v[i] = g.row[first_root + i][v[i] ^ b];     // row[i]: multiplication by the i-th root
+            }
+        } else {
+            for (int j = 0; j < n - 1; ++j) {
+                const unsigned b = buf[j];
+                for (int i = 0; i < num_roots; ++i) v[i] = g.row[first_root + i][v[i] ^ b];
+            }
         }
+        for (int i = 0; i < num_roots; ++i) syn[i] = (int)(v[i] ^ buf[n - 1]);
     };
     syndromes();
     {
@@ -175,11 +184,21 @@ int rs_decode(int num_roots, uint8_t *buf, int n, int min_distance)
         corr[0] = 0;
     }
     int count = 0;
-    for (int j = 0; j < n; ++j) {                            // Chien search
+    // Chien search.  The exponent of term i at position j is ((j + 256 - n) i + index[loc[i]]) mod 255: kept per term and advanced by i
+    // from one position to the next instead of being reduced from scratch (wrap255 subtracts 255 up to eight times per term)
+    int ex[9], ni = 0, which[9];
+    for (int i = 1; i <= half; ++i)
+        if (loc[i]) {
+            ex[ni] = wrap255((256 - n) * i + g.index[loc[i]]);
+            which[ni++] = i;
+        }
+    for (int j = 0; j < n; ++j) {
         int x = 0;
-        const int y = j + 256 - n;
-        for (int i = 1; i <= half; ++i)
-            if (loc[i]) x ^= g.table[wrap255(y * i + g.index[loc[i]])];
+        for (int k = 0; k < ni; ++k) {
+            x ^= g.table[ex[k]];
+            ex[k] += which[k];
+            if (ex[k] > 254) ex[k] -= 255;
+        }
         x ^= loc[0];
         if (x == 0) {
             if (count < 17) where[count] = j;
@@ -504,18 +523,44 @@ struct Il2p : pm_codec {
     }
 
     static void descramble(uint8_t *p, int n)
-    {   // il2p.py:160-163 + lfsr.py:54-92: x^9 + x^4 + 1 (0x211), register preset 0x1F0
-        unsigned reg = 0x1F0, w = 0;
-        for (int k = 0; k < n; ++k) {
-            unsigned b = p[k];
-            for (int i = 0; i < 8; ++i) {
-                w = (w << 1) & 0xFE;
-                if (b & 0x80) reg ^= 0x211;
-                w |= reg & 1;
-                b <<= 1;
-                reg >>= 1;
+    {   // il2p.py:160-163 + lfsr.py:54-92: x^9 + x^4 + 1 (0x211), register preset 0x1F0.  The register step is linear over GF(2), so
+        // a byte's eight steps are (what the register alone does) XOR (what the byte alone does): four small tables built from the
+        // bit-serial loop below, which is the reference's (a 100-byte block took 800 of its iterations).
+        struct Tab {
+            uint8_t out_reg[512], out_in[256];
+            uint16_t nxt_reg[512], nxt_in[256];
+            Tab()
+            {
+                auto run = [](unsigned reg, unsigned b, unsigned &regout) {
+                    unsigned w = 0;
+                    for (int i = 0; i < 8; ++i) {
+                        w = (w << 1) & 0xFE;
+                        if (b & 0x80) reg ^= 0x211;
+                        w |= reg & 1;
+                        b <<= 1;
+                        reg >>= 1;
+                    }
+                    regout = reg;
+                    return w;
+                };
+                for (unsigned r = 0; r < 512; ++r) {
+                    unsigned ro;
+                    out_reg[r] = (uint8_t)run(r, 0, ro);
+                    nxt_reg[r] = (uint16_t)ro;
+                }
+                for (unsigned b = 0; b < 256; ++b) {
+                    unsigned ro;
+                    out_in[b] = (uint8_t)run(0, b, ro);
+                    nxt_in[b] = (uint16_t)ro;
+                }
             }
-            p[k] = (uint8_t)w;
+        };
+        static const Tab t;
+        unsigned reg = 0x1F0;
+        for (int k = 0; k < n; ++k) {
+            const unsigned b = p[k];
+            p[k] = (uint8_t)(t.out_reg[reg] ^ t.out_in[b]);
+            reg = (unsigned)(t.nxt_reg[reg] ^ t.nxt_in[b]);
         }
     }
 
