@@ -347,6 +347,23 @@ struct Ax25 : pm_codec {
                 buf = data.data();
                 continue;
             }
+            if (__builtin_expect(e.nsteps == 1 && e.step[0].op < 16, 1)) {           // nine bytes in ten: eight bits' worth of appends
+                const unsigned cnt = e.step[0].op;
+                const unsigned x = (wb & 0x7F) | ((unsigned)e.step[0].bits << 7);
+                const unsigned total = (unsigned)nbits + cnt;
+                const unsigned done = total >> 3;
+                buf[len] = (uint8_t)(x >> ((7 - nbits) & 7));
+                len += done;
+                nbytes += (int)done;
+                nbits = (int)(total & 7);
+                wb = (x >> cnt) & 0x7F;
+                ones = e.ones_out;
+                if (__builtin_expect(len + 2 > data.size(), 0)) {
+                    room(len + 2);
+                    buf = data.data();
+                }
+                continue;
+            }
             for (int q = 0; q < e.nsteps; ++q) {
                 const unsigned op = e.step[q].op, cnt = op & 15;
                 if (op < 16) {
