@@ -372,15 +372,19 @@ def measure(args, env):
 
     def run_steps_uploading(k):
         """The same pipeline, but every step's recording starts in host memory: its copy to HBM runs one step ahead on a copy stream."""
-        pipe = ce.RecordingPipeline(slice_workers=args.slice_workers, demod_streams=args.demod_streams)
+        pipe = pipes.get("upload")                            # kept across the warm-up and the timed call, like the main one
+        if pipe is None:
+            pipe = pipes["upload"] = ce.RecordingPipeline(slice_workers=args.slice_workers, demod_streams=args.demod_streams)
         ex = pdist.Exchanger(nchains, coll_device)
+        local_only = not use_dist and not os.environ.get("PYMODEM_AMD_FORCE_GATHER") and not os.environ.get("BENCH_ORDERED_TAIL")
         last, nxt = None, (pipe.prefetch(audio) if k else None)
         for i in range(k):
             cur, nxt = nxt, (pipe.prefetch(audio) if i + 1 < k else None)
-            last = pipe.submit(build_chains(), cur, ex.step, dedupe, prepare=lambda rows_list: ex.prepare(dict(zip(my, rows_list))))
+            last = pipe.submit(build_chains(), cur, ex.step, dedupe, prepare=lambda rows_list: ex.prepare(dict(zip(my, rows_list))), chain_ids=my,
+                               unordered=local_only)
         pipe.flush_finish(ex.flush)
         res = last.result() if last is not None else None
-        pipe.close()
+        pipe.drain()
         return res
 
     def fence():
@@ -487,6 +491,9 @@ def measure(args, env):
         run_steps_uploading(args.steps)
         fence()
         h2d_overlapped = time.perf_counter() - t_u
+        for p_ in pipes.values():
+            p_.close()
+        pipes.clear()
         if use_dist:
             tu = torch.tensor([h2d_overlapped], dtype=torch.float64, device=coll_device or "cpu")
             torch.distributed.all_reduce(tu, op=torch.distributed.ReduceOp.MAX)
