@@ -195,38 +195,79 @@ __global__ __launch_bounds__(kBlock) void slice_walk_kernel(const JobDev *__rest
     if (i >= counts[iter]) return;                   // whole waves beyond the list leave at once
     const int64_t gc = list_in ? list_in[i] : i;
     const int j = find_job(jobs, njobs, gc);
-    const JobDev &J = jobs[j];
-    const int64_t c = gc - J.chunk0;
-    const int64_t own_end = min((c + 1) * (int64_t)lc_words, J.nwords);
+    // Everything the loop needs from the job table in registers BEFORE the loop: the walker stores through ck / sm, so a field read
+    // as jobs[j].x inside the loop is re-loaded in every word, and each such load (the pointer, then the word behind it, then n)
+    // is a round trip on the walker's critical path -- a fifth of a word's time alone, and several times that while the FIR
+    // kernels of the demod stream keep L1 and L2 busy.
+    // (The bitmap pointers come out of a table, so the compiler would take them for generic pointers: `flat` loads, which may
+    // return out of order and force a full `s_waitcnt vmcnt(0) lgkmcnt(0)` -- the previous word's stores included -- in front of
+    // every use.  They are device memory: say so, and the wait in front of the next word counts past the two stores.)
+    typedef const uint64_t __attribute__((address_space(1))) *gptr_c;
+    typedef uint64_t __attribute__((address_space(1))) *gptr;
+    const JobDev *Jp = jobs + j;
+    const gptr_c bi = (gptr_c)Jp->bi;
+    const gptr_c bq = (gptr_c)Jp->bq;
+    const int64_t n = Jp->n, nwords = Jp->nwords, chunk0 = Jp->chunk0, word0 = Jp->word0;
+    const bool quad = Jp->quad != 0;
+    const double thr = Jp->thr, sps = Jp->sps, lock = Jp->lock, tp = Jp->tp;
+    const int li0 = Jp->li0, lq0 = Jp->lq0;
+    const int64_t c = gc - chunk0;
+    const int64_t own_end = min((c + 1) * (int64_t)lc_words, nwords);
     int64_t w = wpos[gc];
     double clk = bitsd(wclk[gc]);
-    const int64_t w_stop = min(w + (int64_t)qwords, J.nwords);
+    const int64_t w_stop = min(w + (int64_t)qwords, nwords);
     // last_sample starts at 0.0, i.e. ">= 0" (slicer.py:55,164-165)
-    uint64_t li = w == 0 ? (uint64_t)J.li0 : (J.bi[w - 1] >> 63);
+    uint64_t li = w == 0 ? (uint64_t)li0 : (bi[w - 1] >> 63);
     uint64_t lq = 1ull;
-    if (J.quad) lq = w == 0 ? (uint64_t)J.lq0 : (J.bq[w - 1] >> 63);
-    const double thr = J.thr, neg_sps = -J.sps, tp = J.tp;
-    const double lock = J.lock;
+    if (quad) lq = w == 0 ? (uint64_t)lq0 : (bq[w - 1] >> 63);
+    const double neg_sps = -sps;
     const double lm1 = lock - 1.0;
-    uint64_t *sm = symmap + J.word0;
-    uint64_t *ck = ckmap + J.word0;
+    const gptr sm = (gptr)(symmap + word0);
+    const gptr ck = (gptr)(ckmap + word0);
     bool alive = true;
+    // The next word's sign bits (and, beyond the own chunk, the checkpoint standing there) are loaded one word ahead: the 64 steps
+    // of a word are ~2 us of dependent arithmetic, and a load issued at the top of the word it is needed in puts its whole latency
+    // on top of every word.  Words [w, w_stop) are this walker's alone in this launch (lockstep), so what is read early is what
+    // would have been read late.
+    // Unconditional and branch-free (a binary slicer reads the in-phase word twice, the own chunk reads checkpoints it does not
+    // compare, the last word of a launch reads itself again): with the loads under conditions the compiler cannot count them and
+    // waits for everything outstanding, the previous word's stores included.
+    const gptr_c bqe = quad ? bq : bi;
+    uint64_t si_n = 0, sq_n = 0, ck_n = 0;
+    if (w < w_stop) {
+        si_n = bi[w];
+        sq_n = bqe[w];
+        ck_n = __builtin_nontemporal_load(&ck[w]);
+    }
+    // ... and the symbol word of a word is stored at the top of the NEXT one, together with that word's loads and checkpoint
+    // store: every memory operation of a word then has the word's 64 steps to complete in, and the wait in front of the next
+    // word's first use of a loaded value finds nothing young outstanding (stored at the end of its own word, the symbol store's
+    // acknowledgement was waited for there, once per word).
+    uint64_t sym_late = 0;
+    bool late = false;
     for (; w < w_stop; ++w) {
-        const uint64_t cb = dbits(clk);
-        if (w >= own_end && __builtin_nontemporal_load(&ck[w]) == cb) {      // merged into the trail in front: retire
+        const uint64_t si = si_n, sq = sq_n, ck_here = ck_n;
+        uint64_t cb = dbits(clk);
+        if (w >= own_end && ck_here == cb) {         // merged into the trail in front: retire
             alive = false;
             break;
         }
-        ck[w] = cb;
-        const uint64_t si = J.bi[w];
         uint64_t zc = si ^ ((si << 1) | li);
         li = si >> 63;
-        if (J.quad) {
-            const uint64_t sq = J.bq[w];
+        if (quad) {
             zc |= sq ^ ((sq << 1) | lq);
             lq = sq >> 63;
         }
-        const int64_t left = J.n - (w << 6);
+        // every loaded value has been used above (one wait, for operations issued a whole word ago); now this word's traffic
+        asm volatile("" : "+v"(zc), "+v"(cb) : : "memory");
+        if (late) sm[w - 1] = sym_late;
+        const int64_t wn = min(w + 1, w_stop - 1);
+        si_n = bi[wn];
+        sq_n = bqe[wn];
+        ck_n = __builtin_nontemporal_load(&ck[wn]);
+        ck[w] = cb;
+        asm volatile("" : : : "memory");
+        const int64_t left = n - (w << 6);
         uint64_t sym;
         if (left >= 64) {
             uint32_t lo, hi;
@@ -255,15 +296,17 @@ __global__ __launch_bounds__(kBlock) void slice_walk_kernel(const JobDev *__rest
             for (int b = 0; b < (int)left; ++b) {
                 clk += 1.0;
                 if (clk >= thr) {
-                    clk -= J.sps;
+                    clk -= sps;
                     sym |= 1ull << b;
                 }
-                if ((zc >> b) & 1) clk = clk * J.lock;
+                if ((zc >> b) & 1) clk = clk * lock;
             }
         }
-        sm[w] = sym;
+        sym_late = sym;
+        late = true;
     }
-    if (alive && w >= J.nwords) {                    // the end of the stream: its end state (later arrivals are the truer ones)
+    if (late) sm[w - 1] = sym_late;                  // the last word walked (a walker that retired had not stored it yet either)
+    if (alive && w >= nwords) {                      // the end of the stream: its end state (later arrivals are the truer ones)
         endstate[j] = dbits(clk);
         alive = false;
     }
