@@ -65,11 +65,18 @@ __device__ __forceinline__ uint64_t dbits(double v) { return (uint64_t)__double_
 __device__ __forceinline__ double bitsd(uint64_t v) { return __longlong_as_double((long long)v); }
 __device__ __forceinline__ double mkdouble(uint32_t hi, uint32_t lo) { return __hiloint2double((int)hi, (int)lo); }
 
+// The last job whose first chunk is <= gc (chunk0 ascends along the table; streams without chunks share their successor's).
+// Bisection: every probe is a dependent load at the head of a launch that is itself only tens of microseconds long, and the
+// linear scan needed as many of them as the walker's stream has predecessors in the batch (up to 63).
 __device__ __forceinline__ int find_job(const JobDev *jobs, int njobs, int64_t gc)
 {
-    int j = 0;
-    while (j + 1 < njobs && gc >= jobs[j + 1].chunk0) ++j;
-    return j;
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (gc >= jobs[mid].chunk0) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
 }
 
 // 32 samples, most significant bit first: zc = crossing flags (bit 31 = first sample).  Returns the symbol flags in
