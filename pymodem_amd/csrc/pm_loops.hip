@@ -345,7 +345,43 @@ __global__ __launch_bounds__(256) void agc_iter_kernel(const double *__restrict_
     P.dec = consts[2];
     double env = s_in[c].x, sustain = s_in[c].y;
     const int64_t k0 = c * lc, k1 = min(k0 + (int64_t)lc, n);
-    for (int64_t k = k0; k < k1; ++k) {
+    // Eight samples at a time, the next eight in flight while these are stepped (two register blocks taking turns, every load
+    // unconditional so that the waits can be counted: the block fetched past the end of the chunk is the chunk's last eight
+    // again, and is not used): a load per sample, waited for in front of the ten operations that use it, made the recurrence
+    // wait for memory -- every lane reads a cache line of its own -- for several times as long as it computes.
+    constexpr int kAhead = 8;
+    double cur[kAhead], nxt[kAhead];
+    int64_t k = k0;
+    if (k + kAhead <= k1) {
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) cur[u] = buf[k + u];
+    }
+    for (; k + 2 * kAhead <= k1; k += 2 * kAhead) {
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) nxt[u] = buf[k + kAhead + u];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            agc_step(cur[u], env, sustain, P);
+            if (EMIT) env_out[k + u] = env;
+        }
+        const int64_t ahead = min(k + 2 * kAhead, k1 - kAhead);
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) cur[u] = buf[ahead + u];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            agc_step(nxt[u], env, sustain, P);
+            if (EMIT) env_out[k + kAhead + u] = env;
+        }
+    }
+    if (k + kAhead <= k1) {
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            agc_step(cur[u], env, sustain, P);
+            if (EMIT) env_out[k + u] = env;
+        }
+        k += kAhead;
+    }
+    for (; k < k1; ++k) {
         agc_step(buf[k], env, sustain, P);
         if (EMIT) env_out[k] = env;
     }
