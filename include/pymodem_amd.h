@@ -114,6 +114,20 @@ int pm_fir_signs_f64(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_
 int pm_fir_signs_f64_batch(pm_ctx *ctx, int count, const double *const *h_x, const int64_t *h_n, const double *d_taps, int m,
                            uint64_t *const *h_bits, int flags);
 
+/* The same FIRs over `rows` streams of equal length in ONE launch (the band-pass, Hilbert and matched filters of a batch of
+ * recordings x chains, pm_lbatch below).  Input row r is d_x + r * x_stride (elements), or -- pm_fir_rows_i16_ptrs, rows that are
+ * separate allocations -- d_x_ptrs[r] + x_off with d_x_ptrs a DEVICE array of `rows` device pointers (x_aligned16: every row
+ * pointer + x_off is 16-byte aligned, which the library cannot see).  Output row r is d_y + r * y_stride (n - m + 1 doubles) or
+ * d_bits + r * bits_stride words.  Every row's result is bit-identical to the single-stream call. */
+int pm_fir_rows_i16(pm_ctx *ctx, const int16_t *d_x, int64_t x_stride, int rows, int64_t n, const double *d_taps, int m, double *d_y,
+                    int64_t y_stride, int flags);
+int pm_fir_rows_i16_ptrs(pm_ctx *ctx, const int16_t *const *d_x_ptrs, int64_t x_off, int x_aligned16, int rows, int64_t n, const double *d_taps,
+                         int m, double *d_y, int64_t y_stride, int flags);
+int pm_fir_rows_f64(pm_ctx *ctx, const double *d_x, int64_t x_stride, int rows, int64_t n, const double *d_taps, int m, double *d_y,
+                    int64_t y_stride, int flags);
+int pm_fir_rows_signs_f64(pm_ctx *ctx, const double *d_x, int64_t x_stride, int rows, int64_t n, const double *d_taps, int m, uint64_t *d_bits,
+                          int64_t bits_stride, int flags);
+
 /* AFSK mark/space quadrature correlators fused with magnitude and difference (afsk.py:153-162):
  * y[k] = sqrt(mi*x ^2 + mq*x ^2) - sqrt(si*x ^2 + sq*x ^2), each product a 'valid' convolution. */
 int pm_afsk_correlate(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_mark_i, const double *d_mark_q,
@@ -202,6 +216,15 @@ typedef struct pm_agc_params {       /* AGC.__init__, agc.py:7-24 */
 /* AGC.apply in place (agc.py:61-80): normal = max(buf), envelope follower, buf[i] = target*s/env.
  * h_state[2] = {envelope, sustain_count}, read and written (carried like self.* in the reference). */
 int pm_agc_apply(pm_ctx *ctx, double *d_buf, int64_t n, const pm_agc_params *h_params, double *h_state);
+
+/* The envelope follower and normalisation of AGC.apply (agc.py:68-80) for `rows` streams, each CONTINUED from h_state[2r..] =
+ * {envelope, sustain_count} over n more samples, out of place (y may be x): what a recording processed in time chunks needs, where
+ * `normal` = max(buffer) over the WHOLE buffer (agc.py:67) is known before the first chunk (h_normal[r]; pm_rows_max_f64 gives the
+ * maxima of the rows of a chunk).  Pieces of a buffer run through this one after the other give the bits of pm_agc_apply on the
+ * whole.  One wave per row steps the recurrence; the division is done by all lanes. */
+int pm_agc_rows_apply(pm_ctx *ctx, const double *d_x, int64_t x_stride, double *d_y, int64_t y_stride, int rows, int64_t n,
+                      const pm_agc_params *h_params, const double *h_normal, double *h_state);
+int pm_rows_max_f64(pm_ctx *ctx, const double *d_x, int64_t x_stride, int rows, int64_t n, double *h_max);
 
 typedef struct pm_loop {             /* one carrier loop = NCO (nco.py) + IIR_1 (iir.py) + PI (pi_control.py) */
     double phase_scaling;            /* 2*pi / sample_rate                       nco.py:31 */
@@ -338,6 +361,41 @@ int pm_chain_run(pm_chain *chain, const int16_t *audio, int64_t n, int audio_on_
 int pm_chain_fetch(pm_chain *chain, uint8_t *h_data, int64_t *h_addr, int64_t cap, int64_t *h_count);   /* the last run's output, again */
 int pm_chain_reset(pm_chain *chain);
 int pm_chain_destroy(pm_chain *chain);
+
+/* ---- batch engine for the carrier-loop modems: many recordings x chains in flight -----------------
+ * A carrier loop (psk.py:173-189, psk.py:734-747, afsk_pll.py:153-165) is one dependent chain per sample: a GPU lane cannot make it
+ * faster than a host core, it can only run hundreds at once.  pm_lbatch runs `recordings` recordings of equal length through
+ * `chains` chains that share their front end (band-pass, AGC, Hilbert pair: the chains of configs/qpsk_2400.json differ in
+ * carrier_freq only) in time chunks, all recordings x chains loops in ONE launch per chunk, every sequential state (AGC envelope,
+ * loop registers, FIR histories) carried in device memory from chunk to chunk.  Output: the sign bitmap(s) of every chain's
+ * demodulated stream (what modem.demod() followed by `>= 0` gives: psk.py:162-195, psk.py:705-773, afsk_pll.py:140-170,
+ * psk.py:426-476), stream s = recording * chains + chain at d_bits_i + s * bits_stride words (and d_bits_q for the quadrature
+ * modems), ready for pm_slice_batch.  Bit-identical to the per-recording entry points for every chunk length. */
+typedef struct pm_lbatch_desc {
+    int32_t modem;                                   /* PM_MODEM_BPSK | PM_MODEM_MPSK | PM_MODEM_AFSK_PLL | PM_MODEM_QPSK */
+    int32_t recordings;                              /* most recordings a run will bring */
+    int32_t chains;                                  /* carrier loops per recording */
+    int32_t chunk;                                   /* final-filter outputs per chunk (rounded up to 2048s; 0 = 262144) */
+    const double *input_fir;  int32_t n_input_fir;   /* input_bpf */
+    const double *hilbert;    int32_t n_hilbert, hilbert_delay;             /* mpsk */
+    const double *output_fir; int32_t n_output_fir;  /* RRC matched filter (bpsk, qpsk; mpsk both arms) or output_lpf (afsk_pll) */
+    pm_agc_params agc;
+    const pm_loop *loops;                            /* `chains` loops: parameters and initial state (the same for every recording) */
+    const double *wavetable;                         /* 256 entries (nco.py:22-24) */
+    const int32_t *pd_table;                         /* 64 x 64 (phase_detector.py:36-44), mpsk */
+} pm_lbatch_desc;
+typedef struct pm_lbatch pm_lbatch;
+int pm_lbatch_create(pm_ctx *ctx, const pm_lbatch_desc *desc, pm_lbatch **out);      /* pointers inside desc are read here only */
+/* samples per demodulated stream, outputs per chunk and chunks for recordings of n samples */
+int pm_lbatch_geometry(pm_lbatch *batch, int64_t n, int64_t *h_nout, int64_t *h_chunk, int64_t *h_chunks);
+/* h_d_audio: HOST array of `recordings` device pointers to int16 recordings of n samples each (they may be the same buffer).
+ * Everything is enqueued (two streams: the context's and one of the engine's own); nothing waits for the GPU: the bitmaps are
+ * complete when the context's stream has reached the end of the call.  Every run starts from fresh AGC and loop states.
+ * bits_stride >= (nout + 63) / 64 + 1 words. */
+int pm_lbatch_run(pm_lbatch *batch, const int16_t *const *h_d_audio, int recordings, int64_t n, uint64_t *d_bits_i, uint64_t *d_bits_q,
+                  int64_t bits_stride, int64_t *h_nout);
+pm_ctx *pm_lbatch_front_ctx(pm_lbatch *batch);       /* the engine's own context (band-pass, AGC, Hilbert): for pm_prof_* */
+int pm_lbatch_destroy(pm_lbatch *batch);
 
 /* ---- host-integer stages (native C++, no GPU) --------------------------------------------------
  * These consume the slicer's byte stream; they are bit-serial state machines over KBs of data. */

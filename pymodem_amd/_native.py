@@ -85,6 +85,16 @@ class ChainDesc(ctypes.Structure):
                 ("quadrature", _i32), ("slicer", SlicerParams)]
 
 
+class LBatchDesc(ctypes.Structure):
+    """pm_lbatch_desc"""
+    _dp, _i32 = ctypes.POINTER(ctypes.c_double), ctypes.c_int32
+    _fields_ = [("modem", _i32), ("recordings", _i32), ("chains", _i32), ("chunk", _i32),
+                ("input_fir", _dp), ("n_input_fir", _i32),
+                ("hilbert", _dp), ("n_hilbert", _i32), ("hilbert_delay", _i32),
+                ("output_fir", _dp), ("n_output_fir", _i32),
+                ("agc", AGCParams), ("loops", ctypes.POINTER(Loop)), ("wavetable", _dp), ("pd_table", ctypes.POINTER(ctypes.c_int32))]
+
+
 MODEM_AFSK, MODEM_FSK, MODEM_BPSK, MODEM_MPSK, MODEM_AFSK_PLL, MODEM_QPSK = range(6)
 CHAIN_INVERT = 1
 CHAIN_CARRY_HISTORY = 2
@@ -155,6 +165,10 @@ _SIGS = {
     "pm_fir_signs_i16": ([_vp, _vp, _i64, _vp, _int, _vp, _int], _int),
     "pm_fir_signs_f64": ([_vp, _vp, _i64, _vp, _int, _vp, _int], _int),
     "pm_fir_signs_f64_batch": ([_vp, _int, ctypes.POINTER(_vp), ctypes.POINTER(_i64), _vp, _int, ctypes.POINTER(_vp), _int], _int),
+    "pm_fir_rows_i16": ([_vp, _vp, _i64, _int, _i64, _vp, _int, _vp, _i64, _int], _int),
+    "pm_fir_rows_i16_ptrs": ([_vp, _vp, _i64, _int, _int, _i64, _vp, _int, _vp, _i64, _int], _int),
+    "pm_fir_rows_f64": ([_vp, _vp, _i64, _int, _i64, _vp, _int, _vp, _i64, _int], _int),
+    "pm_fir_rows_signs_f64": ([_vp, _vp, _i64, _int, _i64, _vp, _int, _vp, _i64, _int], _int),
     "pm_afsk_correlate": ([_vp, _vp, _i64, _vp, _vp, _vp, _vp, _int, _vp], _int),
     "pm_afsk_correlate_group": ([_vp, _vp, _i64, _vp, _vp, _vp, _int, _int, _vp, _i64], _int),
     "pm_afsk_sweep_signs": ([_vp, _vp, _i64, _dbl, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(_dbl), _int, _int, _vp, _int, _dbl,
@@ -170,6 +184,13 @@ _SIGS = {
     "pm_afsk_sweep_result": ([_vp, _i64, _vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)], _int),
     "pm_signs_f64": ([_vp, _vp, _i64, _vp], _int),
     "pm_agc_apply": ([_vp, _vp, _i64, ctypes.POINTER(AGCParams), ctypes.POINTER(_dbl)], _int),
+    "pm_agc_rows_apply": ([_vp, _vp, _i64, _vp, _i64, _int, _i64, ctypes.POINTER(AGCParams), ctypes.POINTER(_dbl), ctypes.POINTER(_dbl)], _int),
+    "pm_rows_max_f64": ([_vp, _vp, _i64, _int, _i64, ctypes.POINTER(_dbl)], _int),
+    "pm_lbatch_create": ([_vp, ctypes.POINTER(LBatchDesc), ctypes.POINTER(_vp)], _int),
+    "pm_lbatch_geometry": ([_vp, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64)], _int),
+    "pm_lbatch_run": ([_vp, ctypes.POINTER(_vp), _int, _i64, _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
+    "pm_lbatch_front_ctx": ([_vp], _vp),
+    "pm_lbatch_destroy": ([_vp], _int),
     "pm_costas_bpsk": ([_vp, ctypes.POINTER(Loop), _int, _vp, _vp, _i64, _i64, _vp, _i64], _int),
     "pm_costas_qpsk": ([_vp, ctypes.POINTER(Loop), _int, _vp, _vp, _i64, _i64, _vp, _vp, _i64], _int),
     "pm_pll_afsk": ([_vp, ctypes.POINTER(Loop), _int, _vp, _vp, _i64, _i64, _vp, _i64], _int),

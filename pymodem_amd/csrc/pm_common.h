@@ -76,3 +76,21 @@ struct PmProf {
 int pm_prof_fold(pm_ctx *ctx);      // sync + accumulate pending pairs
 
 static inline int64_t pm_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- launchers shared between translation units (what the batch engine pm_loopbatch.hip strings together) ---------------------
+// `rows` FIRs with the same taps over equal-length streams in one launch (pm_fir.hip).  Input row r: d_x + r * x_stride, or
+// d_x_ptrs[r] + x_off (d_x_ptrs: DEVICE array of row pointers); x_aligned16: every input row starts on a 16-byte boundary.
+// Exactly one of d_y (rows of n - m + 1 doubles, pitch y_stride) and d_bits (sign bitmaps, pitch bits_stride words) is given.
+int pm_fir_rows(pm_ctx *ctx, bool i16, const void *d_x, int64_t x_stride, const void *const *d_x_ptrs, int64_t x_off, bool x_aligned16, int rows,
+                int64_t n, const double *d_taps, int m, double *d_y, int64_t y_stride, uint64_t *d_bits, int64_t bits_stride, int flags);
+// nloops carrier loops resident in device memory; loop l reads input row l / per_row (pm_loops.hip).  modem: PM_MODEM_*.
+int pm_loops_rows(pm_ctx *ctx, int modem, pm_loop *d_loops, int nloops, int per_row, const double *d_table, const int32_t *d_pd,
+                  const double *d_x0, const double *d_x1, int64_t x_stride, int64_t n, double *d_o0, double *d_o1, int64_t out_stride);
+// d_running[r] = max(d_running[r], max of row r) (first != 0: = max of row r).  d_partial: rows * pm_rows_max_parts() doubles of work space.
+int pm_rows_max(pm_ctx *ctx, const double *d_x, int64_t x_stride, int rows, int64_t n, double *d_partial, double *d_running, int first);
+int pm_rows_max_parts(void);
+// d_consts[4r..] = {normal, attack step, decay step, -} from d_running[r] = max(buffer) (agc.py:15-16,67)
+int pm_agc_rows_prepare(pm_ctx *ctx, const double *d_running, int rows, const pm_agc_params *hp, double *d_consts);
+// the envelope follower of every row continued over n more samples: y = target * x / envelope; d_state[2r..] = {envelope, sustain}
+int pm_agc_rows(pm_ctx *ctx, const double *d_x, int64_t x_stride, double *d_y, int64_t y_stride, int rows, int64_t n, const pm_agc_params *hp,
+                const double *d_consts, double *d_state);

@@ -333,6 +333,29 @@ __global__ __launch_bounds__(kThreads) void fir_signs_batch_kernel(FirBatch B, c
     }
 }
 
+// The same FIR over `rows` streams of equal length in ONE launch (blockIdx.y = row): the band-pass, Hilbert and matched filters of
+// a batch of recordings x chains (pm_lbatch, pm_loopbatch.hip).  A row's input is x + row * x_stride, or x_ptrs[row] + x_off when
+// the rows are separate allocations (the recordings of a batch); outputs are rows of one 2-D array.
+struct FirRows {
+    const void *x;
+    int64_t x_stride;
+    const void *const *x_ptrs;
+    int64_t x_off;
+    double *y;
+    int64_t y_stride;
+    uint64_t *bits;
+    int64_t bits_stride;          // 64-bit words
+};
+
+template <typename InT, int R, bool NEG, bool VEC, bool SIGNS>
+__global__ __launch_bounds__(kThreads) void fir_rows_kernel(FirRows A, int64_t n, const double *__restrict__ h, int m, int64_t nout)
+{
+    const int64_t r = blockIdx.y;
+    const InT *x = A.x_ptrs ? reinterpret_cast<const InT *>(A.x_ptrs[r]) + A.x_off : reinterpret_cast<const InT *>(A.x) + r * A.x_stride;
+    fir_tile<InT, R, NEG, VEC, SIGNS>(x, n, h, m, SIGNS ? nullptr : A.y + r * A.y_stride, nout, SIGNS ? A.bits + r * A.bits_stride : nullptr,
+                                      (int64_t)blockIdx.x);
+}
+
 // Four correlators over one staged window; R outputs x 4 filters = 4R accumulators per thread.
 // SPLIT: write the two magnitudes as separate streams (y = mark, y2 = space) instead of their difference (pm_afsk_sweep_signs).
 template <int R, bool VEC, bool SPLIT = false>
@@ -1002,7 +1025,50 @@ int fir_launch(pm_ctx *ctx, const InT *d_x, int64_t n, const double *d_taps, int
                                    : fir_launch2<InT, false>(ctx, d_x, n, d_taps, m, d_y, d_bits);
 }
 
+template <typename InT, bool NEG>
+int fir_rows_launch2(pm_ctx *ctx, const FirRows &A, bool vec, int rows, int64_t n, const double *d_taps, int m)
+{
+    constexpr int R = 8;
+    const int64_t nout = n - m + 1;
+    const int64_t ntiles = pm_cdiv(nout, (int64_t)kThreads * R);
+    PM_ARG(ntiles < (1LL << 31) && rows >= 1 && rows <= 65535);
+    const size_t lds = lds_bytes<R>(m);
+    PmProf prof(ctx, sizeof(InT) == 2 ? PM_K_FIR_I16 : PM_K_FIR_F64);
+    prof.work(rows * ((double)n * sizeof(InT) + (A.bits ? (double)nout / 8 : (double)nout * 8)), 2.0 * m * (double)nout * rows);
+#define PM_ROWS_GO(VECF, SIGNF)                                                                                                   \
+    {                                                                                                                             \
+        if (int rc = allow_lds(fir_rows_kernel<InT, R, NEG, VECF, SIGNF>, lds)) return rc;                                         \
+        hipLaunchKernelGGL((fir_rows_kernel<InT, R, NEG, VECF, SIGNF>), dim3((unsigned)ntiles, (unsigned)rows), dim3(kThreads), lds, \
+                           ctx->stream, A, n, d_taps, m, nout);                                                                   \
+    }
+    if (A.bits) {
+        if (vec) PM_ROWS_GO(true, true) else PM_ROWS_GO(false, true)
+    } else {
+        if (vec) PM_ROWS_GO(true, false) else PM_ROWS_GO(false, false)
+    }
+#undef PM_ROWS_GO
+    PM_HIP(hipGetLastError());
+    return PM_OK;
+}
+
 }  // namespace
+
+// Internal (pm_common.h): what pm_fir_rows_* and the batch engine launch.  `x_aligned16`: every input row starts on a 16-byte boundary.
+int pm_fir_rows(pm_ctx *ctx, bool i16, const void *d_x, int64_t x_stride, const void *const *d_x_ptrs, int64_t x_off, bool x_aligned16, int rows,
+                int64_t n, const double *d_taps, int m, double *d_y, int64_t y_stride, uint64_t *d_bits, int64_t bits_stride, int flags)
+{
+    PM_CTX(ctx);
+    PM_ARG((d_x || d_x_ptrs) && d_taps && ((d_y != nullptr) != (d_bits != nullptr)));
+    PM_ARG(m >= 1 && m <= kMaxTaps && n >= m && rows >= 1);
+    PM_ARG(d_x_ptrs || rows == 1 || x_stride >= n);
+    const int64_t nout = n - m + 1;
+    PM_ARG(rows == 1 || (d_y ? y_stride >= nout : bits_stride >= (nout + 63) / 64));
+    FirRows A{d_x, x_stride, d_x_ptrs, x_off, d_y, y_stride, d_bits, bits_stride};
+    const bool vec = x_aligned16 && (!d_y || ((((uintptr_t)d_y) & 15) == 0 && y_stride % 2 == 0));
+    const bool neg = (flags & PM_FIR_NEGATE) != 0;
+    if (i16) return neg ? fir_rows_launch2<int16_t, true>(ctx, A, vec, rows, n, d_taps, m) : fir_rows_launch2<int16_t, false>(ctx, A, vec, rows, n, d_taps, m);
+    return neg ? fir_rows_launch2<double, true>(ctx, A, vec, rows, n, d_taps, m) : fir_rows_launch2<double, false>(ctx, A, vec, rows, n, d_taps, m);
+}
 
 template <int G>
 static int afsk_group_go(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_w, int m, double *d_y, int64_t y_stride, int64_t nout,
@@ -1093,6 +1159,39 @@ int pm_fir_signs_f64_batch(pm_ctx *ctx, int count, const double *const *h_x, con
 int pm_fir_valid_f64(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_taps, int m, double *d_y, int flags)
 {
     return fir_launch<double>(ctx, d_x, n, d_taps, m, d_y, nullptr, flags);
+}
+
+static bool rows_aligned16(const void *base, int64_t stride_elems, size_t elem, int rows)
+{
+    return (((uintptr_t)base) & 15) == 0 && (rows == 1 || (stride_elems * (int64_t)elem) % 16 == 0);
+}
+
+int pm_fir_rows_i16(pm_ctx *ctx, const int16_t *d_x, int64_t x_stride, int rows, int64_t n, const double *d_taps, int m, double *d_y,
+                    int64_t y_stride, int flags)
+{
+    PM_ARG(d_x != nullptr);
+    return pm_fir_rows(ctx, true, d_x, x_stride, nullptr, 0, rows_aligned16(d_x, x_stride, 2, rows), rows, n, d_taps, m, d_y, y_stride, nullptr, 0, flags);
+}
+
+int pm_fir_rows_i16_ptrs(pm_ctx *ctx, const int16_t *const *d_x_ptrs, int64_t x_off, int x_aligned16, int rows, int64_t n, const double *d_taps,
+                         int m, double *d_y, int64_t y_stride, int flags)
+{
+    PM_ARG(d_x_ptrs != nullptr);
+    return pm_fir_rows(ctx, true, nullptr, 0, (const void *const *)d_x_ptrs, x_off, x_aligned16 != 0, rows, n, d_taps, m, d_y, y_stride, nullptr, 0, flags);
+}
+
+int pm_fir_rows_f64(pm_ctx *ctx, const double *d_x, int64_t x_stride, int rows, int64_t n, const double *d_taps, int m, double *d_y,
+                    int64_t y_stride, int flags)
+{
+    PM_ARG(d_x != nullptr);
+    return pm_fir_rows(ctx, false, d_x, x_stride, nullptr, 0, rows_aligned16(d_x, x_stride, 8, rows), rows, n, d_taps, m, d_y, y_stride, nullptr, 0, flags);
+}
+
+int pm_fir_rows_signs_f64(pm_ctx *ctx, const double *d_x, int64_t x_stride, int rows, int64_t n, const double *d_taps, int m, uint64_t *d_bits,
+                          int64_t bits_stride, int flags)
+{
+    PM_ARG(d_x != nullptr);
+    return pm_fir_rows(ctx, false, d_x, x_stride, nullptr, 0, rows_aligned16(d_x, x_stride, 8, rows), rows, n, d_taps, m, nullptr, 0, d_bits, bits_stride, flags);
 }
 
 int pm_afsk_correlate(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_mark_i, const double *d_mark_q,

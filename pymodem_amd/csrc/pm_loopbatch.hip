@@ -1,0 +1,293 @@
+// Batch engine for the carrier-loop modems: R recordings x C chains through band-pass -> AGC -> (Hilbert pair) -> carrier loop ->
+// matched / output filter -> sign bitmap, in TIME CHUNKS with every sequential state carried on the device.
+//
+// Why: a carrier loop (psk.py:173-189, psk.py:734-747, afsk_pll.py:153-165) is one dependent binary64 chain per sample through
+// quantisers; a GPU lane steps it at 170-300 ns per sample, slower than one host core, and nothing makes one loop faster
+// (DESIGN.md 4.5).  What the GPU has is room: a loop occupies one lane of one wave, so hundreds of loops -- the chains of MANY
+// recordings -- cost what one costs.  This engine is what puts them side by side: one loop launch per chunk steps all R x C loops,
+// each from the state the previous chunk left in device memory.  Chunking keeps the float64 intermediates at
+// R x C x chunk x 16 B instead of R x C x recording x 16 B, so that the number of recordings in flight is bounded by how many the
+// host has, not by HBM.
+//
+// Per chunk t (chunks are cut in the domain of the LAST filter's output, Lc outputs each, so every chunk's sign bits start on a
+// 64-bit word of the bitmaps):
+//   front stream:  band-pass of every recording (rows launch)  ->  AGC rows (envelope follower continued from the carried state)
+//                  ->  MPSK: Hilbert FIR over [carried history | new] + the delayed real part  ->  loop inputs of set t & 1
+//   back stream:   all R x C loops over the chunk (state in d_loops)  ->  matched filter over [carried history | new] writing
+//                  sign bits at word t * Lc / 64 of every stream's bitmap
+// The front stream works one chunk ahead of the back stream (two input sets, events both ways).  AGC.apply normalises by the
+// maximum of the whole band-passed recording (agc.py:67), so a pass of band-pass + row maxima over all chunks precedes chunk 0;
+// the band-pass is computed twice rather than stored (57.6 MB read again against 230 MB written and read per recording).
+// Every kernel is the one the per-recording path uses (or its rows form: same tile code, same arithmetic), every sequential
+// statement executes in the reference's order, chunk boundaries only decide WHEN: results are bit-identical to pm_chain_run and to
+// the stage objects' demod() for every chunk length (tests/test_gpu_loopbatch.py).
+#include "pm_common.h"
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+struct pm_lbatch {
+    pm_ctx *back = nullptr;                  // the caller's context: loops and output filter
+    pm_ctx *front = nullptr;                 // own context: band-pass, AGC, Hilbert pair of the next chunk
+    int modem = 0, R = 0, C = 0;
+    int mb = 0, mh = 0, mo = 0, delay = 0;
+    bool mpsk = false, two_out = false;
+    int64_t Lc = 0, pitch = 0;
+    int Hh = 0, Ho = 0;                      // history slots in front of the windows (mh - 1 and mo - 1 rounded up to even)
+    pm_agc_params agc{};
+    std::vector<double> h_taps;
+    double *d_taps = nullptr;
+    size_t o_in = 0, o_hil = 0, o_out = 0, o_wave = 0;
+    int32_t *d_pd = nullptr;
+    std::vector<pm_loop> h_loops;            // R x C: the C initial loops repeated
+    pm_loop *d_loops = nullptr;
+    double *tmp = nullptr, *awin = nullptr, *in0[2] = {nullptr, nullptr}, *in1[2] = {nullptr, nullptr};
+    double *dwin0 = nullptr, *dwin1 = nullptr;
+    double *d_running = nullptr, *d_partial = nullptr, *d_consts = nullptr, *d_agc_state = nullptr;
+    const int16_t **d_audio = nullptr;
+    std::vector<const int16_t *> h_audio;
+    hipEvent_t front_done[2] = {nullptr, nullptr}, back_done[2] = {nullptr, nullptr}, run_done = nullptr;
+    bool ran = false;
+    int64_t last_chunks = 0;
+};
+
+namespace {
+
+size_t put(std::vector<double> &v, const double *src, int n)
+{
+    const size_t at = v.size();
+    if (src && n > 0) v.insert(v.end(), src, src + n);
+    while (v.size() % 2) v.push_back(0.0);                 // every vector 16-byte aligned on the device
+    return at;
+}
+
+template <typename T>
+int dev_alloc(pm_ctx *ctx, T *&p, size_t count)
+{
+    void *q = nullptr;
+    if (int rc = pm_malloc(ctx, count * sizeof(T), &q)) return rc;
+    p = (T *)q;
+    return PM_OK;
+}
+
+int round_even(int v) { return (v + 1) & ~1; }
+
+}  // namespace
+
+extern "C" {
+
+int pm_lbatch_destroy(pm_lbatch *b)
+{
+    if (!b) return PM_OK;
+    pm_ctx *ctx = b->back;
+    if (b->front) (void)pm_ctx_sync(b->front);
+    if (ctx) (void)pm_ctx_sync(ctx);
+    for (void *p : {(void *)b->d_taps, (void *)b->d_pd, (void *)b->d_loops, (void *)b->tmp, (void *)b->awin, (void *)b->in0[0], (void *)b->in0[1],
+                    (void *)b->in1[0], (void *)b->in1[1], (void *)b->dwin0, (void *)b->dwin1, (void *)b->d_running, (void *)b->d_partial,
+                    (void *)b->d_consts, (void *)b->d_agc_state, (void *)b->d_audio})
+        if (p) (void)pm_free(ctx, p);
+    for (hipEvent_t e : {b->front_done[0], b->front_done[1], b->back_done[0], b->back_done[1], b->run_done})
+        if (e) (void)hipEventDestroy(e);
+    if (b->front) (void)pm_ctx_destroy(b->front);
+    delete b;
+    return PM_OK;
+}
+
+int pm_lbatch_create(pm_ctx *ctx, const pm_lbatch_desc *desc, pm_lbatch **out)
+{
+    PM_CTX(ctx);
+    PM_ARG(desc != nullptr && out != nullptr);
+    const pm_lbatch_desc &d = *desc;
+    PM_ARG(d.modem == PM_MODEM_BPSK || d.modem == PM_MODEM_MPSK || d.modem == PM_MODEM_AFSK_PLL || d.modem == PM_MODEM_QPSK);
+    PM_ARG(d.recordings >= 1 && d.chains >= 1 && (int64_t)d.recordings * d.chains <= (1 << 20));
+    PM_ARG(d.input_fir && d.n_input_fir >= 1 && d.output_fir && d.n_output_fir >= 1 && d.loops && d.wavetable);
+    PM_ARG(d.agc.sample_rate > 0);
+    if (d.modem == PM_MODEM_MPSK) PM_ARG(d.hilbert && d.n_hilbert >= 1 && d.hilbert_delay >= 0 && d.hilbert_delay < d.n_hilbert && d.pd_table);
+    PM_ARG(d.chunk >= 0);
+    pm_lbatch *b = new pm_lbatch();
+    b->back = ctx;
+    b->modem = d.modem;
+    b->R = d.recordings;
+    b->C = d.chains;
+    b->mb = d.n_input_fir;
+    b->mo = d.n_output_fir;
+    b->mpsk = d.modem == PM_MODEM_MPSK;
+    b->mh = b->mpsk ? d.n_hilbert : 1;
+    b->delay = b->mpsk ? d.hilbert_delay : 0;
+    b->two_out = d.modem == PM_MODEM_MPSK || d.modem == PM_MODEM_QPSK;
+    b->agc = d.agc;
+    // a chunk is at least twice the longest filter (the history moves below never overlap) and a whole number of FIR tiles
+    const int64_t longest = std::max(b->mb, std::max(b->mh, b->mo));
+    int64_t lc = d.chunk > 0 ? d.chunk : 262144;
+    lc = std::max<int64_t>(lc, 2 * longest);
+    b->Lc = (lc + 2047) / 2048 * 2048;
+    b->Hh = round_even(b->mh - 1);
+    b->Ho = round_even(b->mo - 1);
+    b->pitch = (b->Lc + 2 * b->mo + 2 * b->mh + 32 + 7) / 8 * 8;
+    int rc = PM_OK;
+    do {
+        if ((rc = pm_ctx_create_prio(ctx->device, 0, &b->front))) break;
+        b->o_in = put(b->h_taps, d.input_fir, d.n_input_fir);
+        if (b->mpsk) b->o_hil = put(b->h_taps, d.hilbert, d.n_hilbert);
+        b->o_out = put(b->h_taps, d.output_fir, d.n_output_fir);
+        b->o_wave = put(b->h_taps, d.wavetable, 256);
+        if ((rc = dev_alloc(ctx, b->d_taps, b->h_taps.size()))) break;
+        if ((rc = pm_h2d(ctx, b->d_taps, b->h_taps.data(), b->h_taps.size() * sizeof(double)))) break;
+        if (b->mpsk) {
+            if ((rc = dev_alloc(ctx, b->d_pd, 4096))) break;
+            if ((rc = pm_h2d(ctx, b->d_pd, d.pd_table, 4096 * sizeof(int32_t)))) break;
+        }
+        const size_t R = (size_t)b->R, RC = R * (size_t)b->C, P = (size_t)b->pitch;
+        b->h_loops.resize(RC);
+        for (size_t r = 0; r < R; ++r)
+            for (int c = 0; c < b->C; ++c) b->h_loops[r * b->C + c] = d.loops[c];
+        if ((rc = dev_alloc(ctx, b->d_loops, RC))) break;
+        if ((rc = dev_alloc(ctx, b->tmp, R * P))) break;
+        if (b->mpsk && (rc = dev_alloc(ctx, b->awin, R * P))) break;
+        for (int s = 0; s < 2 && !rc; ++s) {
+            rc = dev_alloc(ctx, b->in0[s], R * P);
+            if (!rc && b->mpsk) rc = dev_alloc(ctx, b->in1[s], R * P);
+        }
+        if (rc) break;
+        if ((rc = dev_alloc(ctx, b->dwin0, RC * P))) break;
+        if (b->two_out && (rc = dev_alloc(ctx, b->dwin1, RC * P))) break;
+        if ((rc = dev_alloc(ctx, b->d_running, R))) break;
+        if ((rc = dev_alloc(ctx, b->d_partial, R * (size_t)pm_rows_max_parts()))) break;
+        if ((rc = dev_alloc(ctx, b->d_consts, 4 * R))) break;
+        if ((rc = dev_alloc(ctx, b->d_agc_state, 2 * R))) break;
+        if ((rc = dev_alloc(ctx, b->d_audio, R))) break;
+        b->h_audio.resize(R);
+        hipError_t e = hipSuccess;
+        for (hipEvent_t *ev : {&b->front_done[0], &b->front_done[1], &b->back_done[0], &b->back_done[1], &b->run_done})
+            if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+        if (e != hipSuccess) { rc = pm_set_error(PM_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e)); break; }
+        rc = pm_ctx_sync(ctx);                                 // the constants are up before the desc's pointers go away
+    } while (0);
+    if (rc) { pm_lbatch_destroy(b); return rc; }
+    *out = b;
+    return PM_OK;
+}
+
+int pm_lbatch_geometry(pm_lbatch *b, int64_t n, int64_t *h_nout, int64_t *h_chunk, int64_t *h_chunks)
+{
+    PM_ARG(b != nullptr);
+    const int64_t nout = n - (b->mb - 1) - (b->mh - 1) - (b->mo - 1);
+    if (h_nout) *h_nout = nout;
+    if (h_chunk) *h_chunk = b->Lc;
+    if (h_chunks) *h_chunks = nout > 0 ? pm_cdiv(nout, b->Lc) : 0;
+    return PM_OK;
+}
+
+pm_ctx *pm_lbatch_front_ctx(pm_lbatch *b) { return b ? b->front : nullptr; }
+
+int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings, int64_t n, uint64_t *d_bits_i, uint64_t *d_bits_q,
+                  int64_t bits_stride, int64_t *h_nout)
+{
+    PM_ARG(b != nullptr && h_d_audio != nullptr && d_bits_i != nullptr && h_nout != nullptr);
+    pm_ctx *B = b->back, *F = b->front;
+    PM_CTX(B);
+    PM_ARG(recordings >= 1 && recordings <= b->R);
+    PM_ARG(!b->two_out || d_bits_q != nullptr);
+    const int R = recordings, C = b->C, RC = R * C;
+    const int mb = b->mb, mh = b->mh, mo = b->mo;
+    const int64_t P = b->pitch, Lc = b->Lc;
+    const int64_t na = n - (mb - 1), nh = na - (mh - 1), nout = nh - (mo - 1);
+    if (nout < 1)
+        return pm_set_error(PM_ERR_ARG, "pm_lbatch_run: %lld samples are fewer than the filters need for one output (%d + %d + %d taps)",
+                            (long long)n, mb, mh, mo);
+    PM_ARG(bits_stride >= (nout + 63) / 64);
+    *h_nout = nout;
+    const double *T = b->d_taps;
+    bool aligned = true;
+    for (int r = 0; r < R; ++r) {
+        PM_ARG(h_d_audio[r] != nullptr);
+        b->h_audio[r] = h_d_audio[r];
+        aligned = aligned && (((uintptr_t)h_d_audio[r]) & 15) == 0;
+    }
+    // a run starts when the previous one has left both streams (its buffers and states are re-used)
+    if (b->ran) {
+        PM_HIP(hipStreamWaitEvent(F->stream, b->run_done, 0));
+        PM_HIP(hipStreamWaitEvent(B->stream, b->run_done, 0));
+    }
+    // the front stream is ordered behind whatever the caller has enqueued on its context so far (e.g. the recordings' uploads)
+    PM_HIP(hipEventRecord(b->run_done, B->stream));
+    PM_HIP(hipStreamWaitEvent(F->stream, b->run_done, 0));
+    PM_HIP(hipMemcpyAsync(b->d_audio, b->h_audio.data(), sizeof(void *) * (size_t)R, hipMemcpyHostToDevice, F->stream));
+    PM_HIP(hipMemsetAsync(b->d_agc_state, 0, sizeof(double) * 2 * (size_t)R, F->stream));          // fresh AGC objects (agc.py:20-21)
+    PM_HIP(hipMemcpyAsync(b->d_loops, b->h_loops.data(), sizeof(pm_loop) * (size_t)RC, hipMemcpyHostToDevice, B->stream));
+
+    // ---- pass 1: normal = max(band-passed recording) per row (agc.py:67) ------------------------------------------------------
+    for (int64_t at = 0, first = 1; at < na; at += Lc, first = 0) {
+        const int64_t cnt = std::min(Lc, na - at);
+        if (int rc = pm_fir_rows(F, true, nullptr, 0, (const void *const *)b->d_audio, at, aligned, R, cnt + mb - 1, T + b->o_in, mb, b->tmp, P, nullptr,
+                                 0, 0)) return rc;
+        if (int rc = pm_rows_max(F, b->tmp, P, R, cnt, b->d_partial, b->d_running, (int)first)) return rc;
+    }
+    if (int rc = pm_agc_rows_prepare(F, b->d_running, R, &b->agc, b->d_consts)) return rc;
+
+    // ---- pass 2: chunk by chunk ---------------------------------------------------------------------------------------------
+    const int64_t chunks = pm_cdiv(nout, Lc);
+    b->last_chunks = chunks;
+    int64_t s_agc = 0, s_loop = 0;
+    for (int64_t t = 0; t < chunks; ++t) {
+        const int set = (int)(t & 1);
+        const int64_t o0 = t * Lc, o1 = std::min(nout, o0 + Lc);
+        const int64_t e_loop = o1 + mo - 1, e_agc = e_loop + (mh - 1);
+        const int64_t cnt_a = e_agc - s_agc, cnt_l = e_loop - s_loop;
+        const bool more = t + 1 < chunks;
+        // -- front: the loop inputs of chunk t into set t & 1
+        if (t >= 2) PM_HIP(hipStreamWaitEvent(F->stream, b->back_done[set], 0));            // the loops of chunk t - 2 have read the set
+        {
+            // band-pass from the 16-byte boundary at or below the first new sample: `skip` outputs are computed again and not used
+            const int64_t a0 = s_agc & ~(int64_t)7, skip = s_agc - a0;
+            if (int rc = pm_fir_rows(F, true, nullptr, 0, (const void *const *)b->d_audio, a0, aligned, R, cnt_a + skip + mb - 1, T + b->o_in, mb,
+                                     b->tmp, P, nullptr, 0, 0)) return rc;
+            double *agc_out = b->mpsk ? b->awin + b->Hh : b->in0[set];
+            if (int rc = pm_agc_rows(F, b->tmp + skip, P, agc_out, P, R, cnt_a, &b->agc, b->d_consts, b->d_agc_state)) return rc;
+            if (b->mpsk) {
+                // imag = Hilbert FIR over [history | new]; real[k] = a[k + delay] (the delay FIR [1, 0, ..] and [:-delay], psk.py:714-716)
+                const double *hin = t == 0 ? b->awin + b->Hh : b->awin + b->Hh - (mh - 1);
+                const int64_t hn = t == 0 ? cnt_a : cnt_a + mh - 1;
+                if (int rc = pm_fir_rows(F, false, hin, P, nullptr, 0, (((uintptr_t)hin) & 15) == 0, R, hn, T + b->o_hil, mh, b->in1[set], P, nullptr, 0,
+                                         0)) return rc;
+                PM_HIP(hipMemcpy2DAsync(b->in0[set], (size_t)P * 8, hin + b->delay, (size_t)P * 8, (size_t)cnt_l * 8, (size_t)R,
+                                        hipMemcpyDeviceToDevice, F->stream));
+                if (more && mh > 1)         // the last mh - 1 AGC'd samples go in front of the next chunk's (cnt_a >= 2 (mh - 1): no overlap)
+                    PM_HIP(hipMemcpy2DAsync(b->awin + b->Hh - (mh - 1), (size_t)P * 8, b->awin + b->Hh + cnt_a - (mh - 1), (size_t)P * 8,
+                                            (size_t)(mh - 1) * 8, (size_t)R, hipMemcpyDeviceToDevice, F->stream));
+            }
+            PM_HIP(hipEventRecord(b->front_done[set], F->stream));
+        }
+        // -- back: every loop over the chunk, then the output filter's sign bits
+        PM_HIP(hipStreamWaitEvent(B->stream, b->front_done[set], 0));
+        if (int rc = pm_loops_rows(B, b->modem, b->d_loops, RC, C, T + b->o_wave, b->d_pd, b->in0[set], b->in1[set], P, cnt_l, b->dwin0 + b->Ho,
+                                   b->two_out ? b->dwin1 + b->Ho : nullptr, P)) return rc;
+        PM_HIP(hipEventRecord(b->back_done[set], B->stream));
+        {
+            const int64_t back = t == 0 ? 0 : mo - 1, fn = cnt_l + back;
+            const double *f0 = b->dwin0 + b->Ho - back;
+            if (int rc = pm_fir_rows(B, false, f0, P, nullptr, 0, (((uintptr_t)f0) & 15) == 0, RC, fn, T + b->o_out, mo, nullptr, 0, d_bits_i + o0 / 64,
+                                     bits_stride, 0)) return rc;
+            if (b->two_out) {
+                const double *f1 = b->dwin1 + b->Ho - back;
+                if (int rc = pm_fir_rows(B, false, f1, P, nullptr, 0, (((uintptr_t)f1) & 15) == 0, RC, fn, T + b->o_out, mo, nullptr, 0,
+                                         d_bits_q + o0 / 64, bits_stride, 0)) return rc;
+            }
+            if (more && mo > 1) {
+                PM_HIP(hipMemcpy2DAsync(b->dwin0 + b->Ho - (mo - 1), (size_t)P * 8, b->dwin0 + b->Ho + cnt_l - (mo - 1), (size_t)P * 8,
+                                        (size_t)(mo - 1) * 8, (size_t)RC, hipMemcpyDeviceToDevice, B->stream));
+                if (b->two_out)
+                    PM_HIP(hipMemcpy2DAsync(b->dwin1 + b->Ho - (mo - 1), (size_t)P * 8, b->dwin1 + b->Ho + cnt_l - (mo - 1), (size_t)P * 8,
+                                            (size_t)(mo - 1) * 8, (size_t)RC, hipMemcpyDeviceToDevice, B->stream));
+            }
+        }
+        s_agc = e_agc;
+        s_loop = e_loop;
+    }
+    // the run is complete on the caller's context once the back stream gets here; the next run waits for this point on both streams
+    PM_HIP(hipEventRecord(b->run_done, B->stream));
+    b->ran = true;
+    return PM_OK;
+}
+
+}  // extern "C"

@@ -115,8 +115,12 @@ __device__ __forceinline__ int pd_lookup(const int32_t *tbl, double re, double i
 enum { kCostas = 0, kPll = 1, kMpsk = 2, kQpsk = 3 };
 
 // LDS layout (doubles): tab2[257 pairs, 516] | in0[rows_in][kPad] | in1[...] (mpsk) | out0[kG][kPad] | out1[kG][kPad] (mpsk) | pd[4096 int32] (mpsk)
+// Input rows: loop l reads row l / per_row (x0 + row * x_stride): per_row = 1 gives every loop its own input, per_row = nloops (with
+// any stride) one input for all, and a batch of recordings x chains has per_row = chains (the chains of a recording share its
+// front end).  `rows_lds` = the most distinct rows one wave's kG loops can touch (loop_rows_lds), which sizes the LDS image.
 template <int MODE>
-__global__ __launch_bounds__(64) void loop_kernel(pm_loop *__restrict__ loops, int nloops, const double *__restrict__ table,
+__global__ __launch_bounds__(64) void loop_kernel(pm_loop *__restrict__ loops, int nloops, int per_row, int rows_lds,
+                                                  const double *__restrict__ table,
                                                   const int32_t *__restrict__ pd, const double *__restrict__ x0,
                                                   const double *__restrict__ x1, int64_t x_stride, int64_t n,
                                                   double *__restrict__ o0, double *__restrict__ o1, int64_t out_stride)
@@ -125,8 +129,9 @@ __global__ __launch_bounds__(64) void loop_kernel(pm_loop *__restrict__ loops, i
     const int lane = threadIdx.x;
     const int g0 = blockIdx.x * kG;
     const int ng = min(kG, nloops - g0);
-    const bool shared_in = x_stride == 0;
-    const int rows_in = shared_in ? 1 : kG;
+    const int row0 = g0 / per_row;
+    const int rows = (g0 + ng - 1) / per_row - row0 + 1;      // distinct input rows of this wave's loops
+    const int rows_in = rows_lds;
     double2v *tab2 = reinterpret_cast<double2v *>(lds);
     double *in0 = lds + 516;                               // 257 pairs, rounded up to a multiple of 16 bytes
     double *in1 = in0 + rows_in * kPad;
@@ -157,9 +162,8 @@ __global__ __launch_bounds__(64) void loop_kernel(pm_loop *__restrict__ loops, i
     for (int64_t tile0 = 0; tile0 < n; tile0 += kTile) {
         const int len = (int)min((int64_t)kTile, n - tile0);
         // stream the tile in
-        const int rows = shared_in ? 1 : ng;
         for (int r = 0; r < rows; ++r) {
-            const int64_t off = (int64_t)(g0 + r) * x_stride + tile0;
+            const int64_t off = (int64_t)(row0 + r) * x_stride + tile0;
             for (int k = lane; k < len; k += 64) {
                 in0[r * kPad + k] = x0[off + k];
                 if (MODE == kMpsk) in1[r * kPad + k] = x1[off + k];
@@ -167,8 +171,9 @@ __global__ __launch_bounds__(64) void loop_kernel(pm_loop *__restrict__ loops, i
         }
         __syncthreads();
         if (active) {
-            const double *p0 = in0 + (shared_in ? 0 : lane * kPad);
-            const double *p1 = in1 + (shared_in ? 0 : lane * kPad);
+            const int my_row = (g0 + lane) / per_row - row0;
+            const double *p0 = in0 + my_row * kPad;
+            const double *p1 = in1 + my_row * kPad;
             double *q0 = out0 + lane * kPad, *q1 = out1 + lane * kPad;
             for (int k = 0; k < len; ++k) {
                 if (MODE == kCostas) {
@@ -228,11 +233,36 @@ __global__ __launch_bounds__(64) void loop_kernel(pm_loop *__restrict__ loops, i
     }
 }
 
-size_t loop_lds_bytes(int mode, bool shared_in)
+// the most distinct input rows the kG consecutive loops of one wave can touch
+int loop_rows_lds(int per_row, int nloops)
 {
-    const int rows_in = shared_in ? 1 : kG;
+    if (per_row % kG == 0 || per_row >= nloops) return 1;
+    return std::min(kG, (kG - 2) / per_row + 2);
+}
+
+size_t loop_lds_bytes(int mode, int rows_in)
+{
     size_t d = 516 + (size_t)rows_in * kPad * (mode == kMpsk ? 2 : 1) + (size_t)kG * kPad * 2;
     return d * 8 + (mode == kMpsk ? 4096 * 4 : 0);
+}
+
+// The launch itself: d_loops are `nloops` loops in DEVICE memory (parameters and state, read and written); nothing is copied and
+// nothing waits.
+template <int MODE>
+int loop_enqueue(pm_ctx *ctx, pm_loop *d_loops, int nloops, int per_row, const double *d_table, const int32_t *d_pd,
+                 const double *d_x0, const double *d_x1, int64_t x_stride, int64_t n, double *d_o0, double *d_o1, int64_t out_stride)
+{
+    const int rows_lds = loop_rows_lds(per_row, nloops);
+    const size_t lds = loop_lds_bytes(MODE, rows_lds);
+    if (lds > 64 * 1024)
+        PM_HIP(hipFuncSetAttribute((const void *)loop_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        PmProf prof(ctx, PM_K_LOOP);
+        hipLaunchKernelGGL((loop_kernel<MODE>), dim3((unsigned)pm_cdiv(nloops, kG)), dim3(64), lds, ctx->stream,
+                           d_loops, nloops, per_row, rows_lds, d_table, d_pd, d_x0, d_x1, x_stride, n, d_o0, d_o1, out_stride);
+    }
+    PM_HIP(hipGetLastError());
+    return PM_OK;
 }
 
 template <int MODE>
@@ -249,15 +279,8 @@ int loop_launch(pm_ctx *ctx, pm_loop *h_loops, int nloops, const double *d_table
     if (int rc = pm_scratch_reserve(ctx, bytes)) return rc;
     pm_loop *d_loops = (pm_loop *)ctx->d_scratch;
     PM_HIP(hipMemcpyAsync(d_loops, h_loops, bytes, hipMemcpyHostToDevice, ctx->stream));
-    const size_t lds = loop_lds_bytes(MODE, x_stride == 0);
-    if (lds > 64 * 1024)
-        PM_HIP(hipFuncSetAttribute((const void *)loop_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    {
-        PmProf prof(ctx, PM_K_LOOP);
-        hipLaunchKernelGGL((loop_kernel<MODE>), dim3((unsigned)pm_cdiv(nloops, kG)), dim3(64), lds, ctx->stream,
-                           d_loops, nloops, d_table, d_pd, d_x0, d_x1, x_stride, n, d_o0, d_o1, out_stride);
-    }
-    PM_HIP(hipGetLastError());
+    // x_stride == 0: one input for all loops; otherwise loop l reads x + l * x_stride
+    if (int rc = loop_enqueue<MODE>(ctx, d_loops, nloops, x_stride == 0 ? nloops : 1, d_table, d_pd, d_x0, d_x1, x_stride, n, d_o0, d_o1, out_stride)) return rc;
     PM_HIP(hipMemcpyAsync(h_loops, d_loops, bytes, hipMemcpyDeviceToHost, ctx->stream));
     PM_HIP(hipStreamSynchronize(ctx->stream));
     return PM_OK;
@@ -419,7 +442,147 @@ __global__ __launch_bounds__(256) void agc_scale_kernel(double *__restrict__ buf
     }
 }
 
+// ---- AGC over the rows of a batch, chunk by chunk (pm_lbatch) ------------------------------------------------------------------
+// A batch of recordings is processed in time chunks with every sequential state carried on the device, so the envelope follower
+// needs no chunk-parallel fixed point here: row r's follower simply continues from d_state[r] (one wave per row, lane 0 owns the
+// recurrence over an LDS tile, all lanes stream the tile in, divide -- buf[i] = target*s/env is not part of the recurrence,
+// agc.py:75-76 -- and stream it out).  `normal` = max(buffer) (agc.py:67) over the WHOLE band-passed recording is a pass of its own
+// before the first chunk (rows_max_kernel over every chunk, folded into d_running).
+constexpr int kMaxPart = 32;
+
+__global__ __launch_bounds__(256) void rows_max_kernel(const double *__restrict__ x, int64_t x_stride, int64_t n, double *__restrict__ partial)
+{
+    __shared__ double red[256];
+    const double *xr = x + (int64_t)blockIdx.y * x_stride;
+    double m = xr[0];                                  // as max_partial_kernel: seed with a real element, strict >
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double v = xr[i];
+        if (v > m) m = v;
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s && red[threadIdx.x + s] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0];
+}
+
+__global__ void rows_max_fold_kernel(const double *__restrict__ partial, int nparts, double *__restrict__ running, int first, int rows)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    double m = partial[(int64_t)r * nparts];
+    for (int p = 1; p < nparts; ++p)
+        if (partial[(int64_t)r * nparts + p] > m) m = partial[(int64_t)r * nparts + p];
+    running[r] = (first || m > running[r]) ? m : running[r];
+}
+
+// running[r] -> consts[r] = {normal, scaled attack, scaled decay, -} (agc.py:15-16,29,34,67)
+__global__ void agc_rows_prepare_kernel(const double *__restrict__ running, int rows, AgcScale sc, double *__restrict__ consts)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const double m = running[r];
+    consts[4 * r] = m;
+    consts[4 * r + 1] = sc.scaled_attack * m;
+    consts[4 * r + 2] = sc.scaled_decay * m;
+    consts[4 * r + 3] = 0.0;
+}
+
+__global__ __launch_bounds__(64) void agc_rows_kernel(const double *x, int64_t x_stride, double *y, int64_t y_stride,
+                                                      int64_t n, const double *__restrict__ consts, AgcDev P, double2 *__restrict__ state)
+{
+    __shared__ double tile[kTile], envs[kTile];
+    const int lane = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    const double *xr = x + r * x_stride;
+    double *yr = y + r * y_stride;
+    P.att = consts[4 * r + 1];
+    P.dec = consts[4 * r + 2];
+    double env = state[r].x, sustain = state[r].y;
+    for (int64_t tile0 = 0; tile0 < n; tile0 += kTile) {
+        const int len = (int)min((int64_t)kTile, n - tile0);
+        for (int k = lane; k < len; k += 64) tile[k] = xr[tile0 + k];
+        __syncthreads();
+        if (lane == 0) {
+            for (int k = 0; k < len; ++k) {
+                agc_step(tile[k], env, sustain, P);
+                envs[k] = env;
+            }
+        }
+        __syncthreads();
+        for (int k = lane; k < len; k += 64) {
+            const double e = envs[k], s = tile[k];
+            yr[tile0 + k] = e != 0 ? P.target * s / e : s;          // agc.py:75-76
+        }
+        __syncthreads();
+    }
+    if (lane == 0) state[r] = make_double2(env, sustain);
+}
+
 }  // namespace
+
+// ---- internal entry points of the batch engine (pm_common.h) ---------------------------------------------------------------------
+int pm_loops_rows(pm_ctx *ctx, int modem, pm_loop *d_loops, int nloops, int per_row, const double *d_table, const int32_t *d_pd,
+                  const double *d_x0, const double *d_x1, int64_t x_stride, int64_t n, double *d_o0, double *d_o1, int64_t out_stride)
+{
+    PM_CTX(ctx);
+    PM_ARG(d_loops && nloops >= 1 && per_row >= 1 && d_table && d_x0 && d_o0 && n >= 0);
+    if (n == 0) return PM_OK;
+    switch (modem) {
+    case PM_MODEM_BPSK: return loop_enqueue<kCostas>(ctx, d_loops, nloops, per_row, d_table, nullptr, d_x0, nullptr, x_stride, n, d_o0, nullptr, out_stride);
+    case PM_MODEM_AFSK_PLL: return loop_enqueue<kPll>(ctx, d_loops, nloops, per_row, d_table, nullptr, d_x0, nullptr, x_stride, n, d_o0, nullptr, out_stride);
+    case PM_MODEM_QPSK:
+        PM_ARG(d_o1 != nullptr);
+        return loop_enqueue<kQpsk>(ctx, d_loops, nloops, per_row, d_table, nullptr, d_x0, nullptr, x_stride, n, d_o0, d_o1, out_stride);
+    case PM_MODEM_MPSK:
+        PM_ARG(d_x1 && d_o1 && d_pd);
+        return loop_enqueue<kMpsk>(ctx, d_loops, nloops, per_row, d_table, d_pd, d_x0, d_x1, x_stride, n, d_o0, d_o1, out_stride);
+    default: return pm_set_error(PM_ERR_ARG, "pm_loops_rows: modem %d has no carrier loop", modem);
+    }
+}
+
+int pm_rows_max(pm_ctx *ctx, const double *d_x, int64_t x_stride, int rows, int64_t n, double *d_partial, double *d_running, int first)
+{
+    PM_CTX(ctx);
+    PM_ARG(d_x && d_partial && d_running && rows >= 1 && rows <= 65535 && n >= 1);
+    const int parts = (int)std::min<int64_t>(kMaxPart, pm_cdiv(n, 8192));
+    PmProf prof(ctx, PM_K_AGC);
+    hipLaunchKernelGGL(rows_max_kernel, dim3((unsigned)parts, (unsigned)rows), dim3(256), 0, ctx->stream, d_x, x_stride, n, d_partial);
+    hipLaunchKernelGGL(rows_max_fold_kernel, dim3((unsigned)pm_cdiv(rows, 64)), dim3(64), 0, ctx->stream, d_partial, parts, d_running, first, rows);
+    PM_HIP(hipGetLastError());
+    return PM_OK;
+}
+
+int pm_rows_max_parts(void) { return kMaxPart; }
+
+int pm_agc_rows_prepare(pm_ctx *ctx, const double *d_running, int rows, const pm_agc_params *hp, double *d_consts)
+{
+    PM_CTX(ctx);
+    PM_ARG(d_running && d_consts && hp && rows >= 1 && hp->sample_rate > 0);
+    AgcScale sc{hp->attack_rate / hp->sample_rate, hp->decay_rate / hp->sample_rate};      // agc.py:15-16
+    hipLaunchKernelGGL(agc_rows_prepare_kernel, dim3((unsigned)pm_cdiv(rows, 64)), dim3(64), 0, ctx->stream, d_running, rows, sc, d_consts);
+    PM_HIP(hipGetLastError());
+    return PM_OK;
+}
+
+int pm_agc_rows(pm_ctx *ctx, const double *d_x, int64_t x_stride, double *d_y, int64_t y_stride, int rows, int64_t n, const pm_agc_params *hp,
+                const double *d_consts, double *d_state)
+{
+    PM_CTX(ctx);
+    PM_ARG(d_x && d_y && d_consts && d_state && hp && rows >= 1 && n >= 0 && hp->sample_rate > 0);
+    if (n == 0) return PM_OK;
+    AgcDev P;
+    P.sustain_time = hp->sustain_time;
+    P.sustain_inc = 1 / hp->sample_rate;                            // agc.py:17
+    P.target = hp->target_amplitude;
+    P.att = P.dec = 0;
+    PmProf prof(ctx, PM_K_AGC);
+    hipLaunchKernelGGL(agc_rows_kernel, dim3((unsigned)rows), dim3(64), 0, ctx->stream, d_x, x_stride, d_y, y_stride, n, d_consts, P, (double2 *)d_state);
+    PM_HIP(hipGetLastError());
+    return PM_OK;
+}
 
 extern "C" {
 
@@ -446,6 +609,36 @@ int pm_costas_qpsk(pm_ctx *ctx, pm_loop *h_loops, int nloops, const double *d_ta
                    const double *d_x, int64_t x_stride, int64_t n, double *d_i_out, double *d_q_out, int64_t out_stride)
 {
     return loop_launch<kQpsk>(ctx, h_loops, nloops, d_table, nullptr, d_x, nullptr, x_stride, n, d_i_out, d_q_out, out_stride);
+}
+
+int pm_agc_rows_apply(pm_ctx *ctx, const double *d_x, int64_t x_stride, double *d_y, int64_t y_stride, int rows, int64_t n,
+                      const pm_agc_params *hp, const double *h_normal, double *h_state)
+{
+    PM_CTX(ctx);
+    PM_ARG(d_x && d_y && hp && h_normal && h_state && rows >= 1 && n >= 0);
+    // work space: running[rows] | consts[4 rows] | state[2 rows]
+    if (int rc = pm_scratch_reserve(ctx, sizeof(double) * 7 * (size_t)rows)) return rc;
+    double *d_running = (double *)ctx->d_scratch, *d_consts = d_running + rows, *d_state = d_consts + 4 * (size_t)rows;
+    PM_HIP(hipMemcpyAsync(d_running, h_normal, sizeof(double) * (size_t)rows, hipMemcpyHostToDevice, ctx->stream));
+    PM_HIP(hipMemcpyAsync(d_state, h_state, sizeof(double) * 2 * (size_t)rows, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = pm_agc_rows_prepare(ctx, d_running, rows, hp, d_consts)) return rc;
+    if (int rc = pm_agc_rows(ctx, d_x, x_stride, d_y, y_stride, rows, n, hp, d_consts, d_state)) return rc;
+    PM_HIP(hipMemcpyAsync(h_state, d_state, sizeof(double) * 2 * (size_t)rows, hipMemcpyDeviceToHost, ctx->stream));
+    PM_HIP(hipStreamSynchronize(ctx->stream));
+    return PM_OK;
+}
+
+int pm_rows_max_f64(pm_ctx *ctx, const double *d_x, int64_t x_stride, int rows, int64_t n, double *h_max)
+{
+    PM_CTX(ctx);
+    PM_ARG(d_x && h_max && rows >= 1 && n >= 1);
+    const size_t parts = (size_t)pm_rows_max_parts();
+    if (int rc = pm_scratch_reserve(ctx, sizeof(double) * (size_t)rows * (parts + 1))) return rc;
+    double *d_partial = (double *)ctx->d_scratch, *d_running = d_partial + (size_t)rows * parts;
+    if (int rc = pm_rows_max(ctx, d_x, x_stride, rows, n, d_partial, d_running, 1)) return rc;
+    PM_HIP(hipMemcpyAsync(h_max, d_running, sizeof(double) * (size_t)rows, hipMemcpyDeviceToHost, ctx->stream));
+    PM_HIP(hipStreamSynchronize(ctx->stream));
+    return PM_OK;
 }
 
 int pm_agc_apply(pm_ctx *ctx, double *d_buf, int64_t n, const pm_agc_params *hp, double *h_state)

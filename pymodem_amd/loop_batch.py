@@ -1,0 +1,212 @@
+"""Many recordings through carrier-loop chains at once (pm_lbatch, csrc/pm_loopbatch.hip).
+
+A BPSK / MPSK / QPSK / AFSK-PLL chain spends its time in one sequential carrier loop (psk.py:173-189, psk.py:734-747,
+psk.py:434-467, afsk_pll.py:153-165): one GPU lane steps it slower than one host core does, and nothing makes a single loop faster
+(DESIGN.md 4.5).  The GPU's answer is width: a loop needs one lane, so the loops of hundreds of recordings x chains run in the time
+of one.  `LoopBatch` is the object that puts them side by side: R recordings x the C chains of a group that shares its front end
+(band-pass, AGC, Hilbert pair; the chains of configs/qpsk_2400.json differ in carrier_freq only) go through ONE engine run, in time
+chunks, every loop of every recording in one launch per chunk.  `process_recordings_device` is chain_execute.process_chains_device
+for a list of recordings: engine -> all slicers in batches -> LFSR + codec per recording.
+
+Results are those of process_chain on every recording, bit for bit (tests/test_gpu_loopbatch.py).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _native as N
+from ._native import check, lib
+from .data_classes import SignBits
+from .device import Context, DeviceBuffer
+from .modems import AFSKPLLModem, BPSKModem, MPSKModem, QPSKModem
+
+_MODEM_ID = {BPSKModem: N.MODEM_BPSK, MPSKModem: N.MODEM_MPSK, AFSKPLLModem: N.MODEM_AFSK_PLL, QPSKModem: N.MODEM_QPSK}
+
+
+def _output_taps(modem):
+    return modem.output_lpf if isinstance(modem, AFSKPLLModem) else modem.rrc_taps
+
+
+def group_key(modem):
+    """Chains whose modems have equal keys can share one engine run: same kind, same front end, same output filter, same tables;
+    what is left to differ is the loop (carrier_freq, loop filter, PI constants)."""
+    if type(modem) not in _MODEM_ID:
+        return None
+    fe = modem.front_end_key() if hasattr(modem, "front_end_key") else (
+        "qpsk", float(modem.sample_rate), modem.input_bpf.tobytes(),
+        (modem.AGC.attack_rate, modem.AGC.decay_rate, modem.AGC.sustain_time, modem.AGC.target_amplitude))
+    extra = modem.phase_error_table.tobytes() if isinstance(modem, MPSKModem) else b""
+    return (type(modem).__name__, fe, _output_taps(modem).tobytes(), np.asarray(modem.wavetable).tobytes(), extra)
+
+
+class LoopBatch:
+    """One pm_lbatch engine: `recordings` recordings (at most) x the chains of `modems` per run.  `modems`: the modem objects of ONE
+    recording's chains (equal group_key); their loop parameters and initial states are what every recording starts from."""
+
+    def __init__(self, modems, recordings, ctx=None, chunk=0):
+        keys = {group_key(m) for m in modems}
+        if len(keys) != 1 or None in keys:
+            raise ValueError("LoopBatch: the chains of a run must be carrier-loop modems that share front end, output filter and tables")
+        self.ctx = ctx or Context.default()
+        self.recordings, self.chains = int(recordings), len(modems)
+        lead = modems[0]
+        self.kind = type(lead)
+        self.quadrature = isinstance(lead, (MPSKModem, QPSKModem))
+        d = N.LBatchDesc()
+        keep = []
+
+        def vec(x, dtype=np.float64):
+            a = np.ascontiguousarray(x, dtype=dtype)
+            keep.append(a)
+            return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double if dtype == np.float64 else ctypes.c_int32)), len(a)
+        d.modem, d.recordings, d.chains, d.chunk = _MODEM_ID[self.kind], self.recordings, self.chains, int(chunk)
+        d.input_fir, d.n_input_fir = vec(lead.input_bpf)
+        if isinstance(lead, MPSKModem):
+            d.hilbert, d.n_hilbert = vec(lead.hilbert_taps)
+            d.hilbert_delay = lead.hilbert_delay
+            d.pd_table = vec(lead.phase_error_table.reshape(-1), np.int32)[0]
+        d.output_fir, d.n_output_fir = vec(_output_taps(lead))
+        a = lead.AGC
+        d.agc = N.AGCParams(a.attack_rate, a.decay_rate, a.sustain_time, a.sample_rate, a.target_amplitude)
+        loops = (N.Loop * self.chains)()
+        for c, m in enumerate(modems):
+            ctypes.memmove(ctypes.byref(loops[c]), m._loop0, ctypes.sizeof(N.Loop))
+        d.loops = loops
+        d.wavetable = vec(lead.wavetable)[0]
+        self._h = ctypes.c_void_p()
+        check(lib().pm_lbatch_create(self.ctx.handle, ctypes.byref(d), ctypes.byref(self._h)))
+        self._front = None
+
+    def geometry(self, n):
+        """(samples per demodulated stream, final-filter outputs per chunk, chunks) for recordings of n samples."""
+        a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        check(lib().pm_lbatch_geometry(self._h, int(n), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
+
+    @property
+    def front(self):
+        """The engine's own context (band-pass, AGC, Hilbert pair of the next chunk) as a borrowed Context, for profile_read()."""
+        if self._front is None:
+            f = Context.__new__(Context)
+            f._h, f.device = ctypes.c_void_p(lib().pm_lbatch_front_ctx(self._h)), self.ctx.device
+            f.close = lambda: None                          # the engine owns it
+            self._front = f
+        return self._front
+
+    def run(self, audios, slot=0):
+        """audios: DeviceBuffers of int16 recordings of equal length (they may be the same buffer).  Enqueues the whole run and
+        returns [[SignBits of chain 0, chain 1, ...] per recording]; the bitmaps are complete when this context's stream gets there
+        (slice on it, or behind an event recorded on it).  `slot`: which of the caller's bitmap sets to write (a set stays untouched
+        until the same slot is used again)."""
+        r = len(audios)
+        if not 1 <= r <= self.recordings:
+            raise ValueError(f"LoopBatch.run: {r} recordings, the engine was made for {self.recordings}")
+        n = audios[0].n
+        for a in audios:
+            if not isinstance(a, DeviceBuffer) or a.dtype != np.dtype(np.int16) or a.n != n:
+                raise ValueError("LoopBatch.run: recordings must be int16 DeviceBuffers of equal length")
+        nout = self.geometry(n)[0]
+        if nout < 1:
+            raise ValueError(f"input of {n} samples is shorter than the filters of the chain")
+        stride = ((nout + 63) // 64 + 1 + 7) // 8 * 8
+        streams = r * self.chains
+        bits_i = self.ctx.scratch(("lbatch", id(self), slot, "i"), streams * stride, np.uint64)
+        bits_q = self.ctx.scratch(("lbatch", id(self), slot, "q"), streams * stride, np.uint64) if self.quadrature else None
+        ptrs = (ctypes.c_void_p * r)(*[a.ptr.value for a in audios])
+        got = ctypes.c_int64()
+        check(lib().pm_lbatch_run(self._h, ptrs, r, n, bits_i.ptr, bits_q.ptr if bits_q is not None else None, stride, ctypes.byref(got)))
+        out = []
+        for k in range(r):
+            row = []
+            for c in range(self.chains):
+                s = k * self.chains + c
+                row.append(SignBits(bits_i.view(s * stride, stride), bits_q.view(s * stride, stride) if bits_q is not None else None, got.value))
+            out.append(row)
+        return out
+
+    def close(self):
+        if self._h:
+            lib().pm_lbatch_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_ENGINES = {}
+
+
+def engine_for(modems, recordings, ctx=None, chunk=0):
+    """The cached engine for this group of modems on this context (made for at least `recordings` recordings)."""
+    ctx = ctx or Context.default()
+    key = (id(ctx), group_key(modems[0]), tuple(bytes(m._loop0) for m in modems), int(chunk))
+    hit = _ENGINES.get(key)
+    if hit is None or hit.recordings < recordings:
+        if hit is not None:
+            hit.close()
+        hit = _ENGINES[key] = LoopBatch(modems, recordings, ctx, chunk)
+    return hit
+
+
+def close_engines():
+    for e in _ENGINES.values():
+        e.close()
+    _ENGINES.clear()
+
+
+def process_recordings_device(chain_sets, audios, ctx=None, chunk=0, rows=False, chain_ids=None, stages=None, slot=0):
+    """chain_sets[k] = the chains [name, modem, slicer, stream, codec] of recording k (every recording brings the same group of
+    chains, as a service decoding successive recordings with one config does), audios[k] its int16 samples (host array or
+    DeviceBuffer; equal lengths).  -> [[packets of chain 0, ...] per recording], identical to chain_execute.process_chain on each
+    (rows=True: pm_packet rows instead of PacketMeta lists).  All carrier loops of all recordings advance together."""
+    from .chain_execute import _host_rows, _host_stages, _pool
+    from .slicer import slice_batch
+    ctx = ctx or Context.default()
+    r = len(chain_sets)
+    if r == 0:
+        return []
+    dev = []
+    for a in audios:
+        if isinstance(a, DeviceBuffer):
+            dev.append(a)
+        else:
+            a = np.asarray(a)
+            if a.dtype != np.int16:
+                raise ValueError("process_recordings_device takes int16 recordings")
+            dev.append(ctx.upload(a))
+    nchains = len(chain_sets[0])
+    # groups of chains that can share an engine, by position in the chain list (the same for every recording)
+    groups = {}
+    for c, ch in enumerate(chain_sets[0]):
+        k = group_key(ch[1])
+        if k is None:
+            raise ValueError(f"chain {ch[0]!r} is not a carrier-loop chain: use chain_execute.process_chains_device")
+        groups.setdefault(k, []).append(c)
+    for cs in chain_sets:
+        if len(cs) != nchains or any(group_key(cs[c][1]) != k for k, members in groups.items() for c in members):
+            raise ValueError("every recording must bring the same group of chains")
+    bitmaps = [[None] * nchains for _ in range(r)]
+    for gi, (k, members) in enumerate(groups.items()):
+        eng = engine_for([chain_sets[0][c][1] for c in members], r, ctx, chunk)
+        got = eng.run(dev, slot=(slot, gi))
+        for rec in range(r):
+            for j, c in enumerate(members):
+                sl = chain_sets[rec][c][2]
+                sl._ctx = sl._ctx or ctx
+                bitmaps[rec][c] = sl.sign_bitmaps(got[rec][j])
+    flat_slicers = [chain_sets[rec][c][2] for rec in range(r) for c in range(nchains)]
+    flat_bits = [bitmaps[rec][c] for rec in range(r) for c in range(nchains)]
+    sliced = slice_batch(flat_slicers, flat_bits, ctx)
+    if stages is not None:
+        stages["sliced"] = [sliced[rec * nchains:(rec + 1) * nchains] for rec in range(r)]
+    out = []
+    if rows:
+        futs = [_pool().submit(_host_rows, chain_sets[rec], sliced[rec * nchains:(rec + 1) * nchains], chain_ids) for rec in range(r)]
+        return [f.result() for f in futs]
+    futs = [[_pool().submit(_host_stages, ch, sl) for ch, sl in zip(chain_sets[rec], sliced[rec * nchains:(rec + 1) * nchains])] for rec in range(r)]
+    for rec in range(r):
+        out.append([f.result() for f in futs[rec]])
+    return out

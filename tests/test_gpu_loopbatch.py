@@ -1,0 +1,240 @@
+"""The batch engine for the carrier-loop modems (pm_lbatch, pymodem_amd/loop_batch.py) and the rows kernels it is made of, against
+the per-recording path (itself bit-exact against the oracle: tests/test_gpu_chains.py) and against the oracle directly.  The engine
+only changes WHEN a statement runs (time chunks, many recordings per launch), so everything is compared bit for bit."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, noise_i16
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def ctx_lib():
+    import pymodem_amd
+    from pymodem_amd._native import check, lib
+    return pymodem_amd.Context.default(), lib(), check
+
+
+def lines_of(name):
+    with open(os.path.join(GOLDEN, "configs", name)) as f:
+        return [l for l in (json.loads(s) for s in f if s.strip()) if l.get("object_type") == "demod_chain"]
+
+
+def bits_of(buf, n):
+    words = buf.download((n + 63) // 64)
+    return np.unpackbits(words.view(np.uint8), bitorder="little")[:n]
+
+
+# ---- rows kernels -----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m", [1, 8, 130, 163, 241, 961])
+def test_fir_rows_equal_the_single_stream_kernels(m):
+    ctx, L, check = ctx_lib()
+    rng = np.random.default_rng(m)
+    rows, n, stride = 5, 9000 + m, 9000 + m + 24
+    h = rng.standard_normal(m)
+    dh = ctx.upload(h)
+    xi = noise_i16(rows * stride, seed=m).reshape(rows, stride)
+    xf = rng.standard_normal((rows, stride)) * 100
+    nout = n - m + 1
+    ystride = (nout + 9) // 2 * 2
+    d_xi, d_xf = ctx.upload(xi.reshape(-1)), ctx.upload(xf.reshape(-1))
+    d_y = ctx.empty(rows * ystride, np.float64)
+    one = ctx.empty(nout, np.float64)
+    for neg in (0, 1):
+        # int16 rows (strided)
+        check(L.pm_fir_rows_i16(ctx.handle, d_xi.ptr, stride, rows, n, dh.ptr, m, d_y.ptr, ystride, neg))
+        got = d_y.download().reshape(rows, ystride)[:, :nout]
+        for r in range(rows):
+            check(L.pm_fir_valid_i16(ctx.handle, d_xi.view(r * stride, n).ptr, n, dh.ptr, m, one.ptr, neg))
+            assert np.array_equal(got[r], one.download()), (m, r, "i16")
+        want = O.fir_canon(xi[0, :n], h)
+        assert np.array_equal(got[0], -want if neg else want)
+        # float64 rows
+        check(L.pm_fir_rows_f64(ctx.handle, d_xf.ptr, stride, rows, n, dh.ptr, m, d_y.ptr, ystride, neg))
+        got = d_y.download().reshape(rows, ystride)[:, :nout]
+        for r in range(rows):
+            check(L.pm_fir_valid_f64(ctx.handle, d_xf.view(r * stride, n).ptr, n, dh.ptr, m, one.ptr, neg))
+            assert np.array_equal(got[r], one.download()), (m, r, "f64")
+    # sign-only rows, written at a word offset inside a larger bitmap array (what a chunk of the engine does)
+    bstride = (nout + 63) // 64 + 3
+    d_bits = ctx.upload(np.zeros(rows * bstride + 2, np.uint64))
+    check(L.pm_fir_rows_signs_f64(ctx.handle, d_xf.ptr, stride, rows, n, dh.ptr, m, d_bits.view(2, rows * bstride).ptr, bstride, 0))
+    words = d_bits.download()
+    assert not words[:2].any()
+    for r in range(rows):
+        got = np.unpackbits(words[2 + r * bstride:2 + (r + 1) * bstride].view(np.uint8), bitorder="little")[:nout]
+        want = O.fir_canon(xf[r, :n], h) >= 0
+        assert np.array_equal(got.astype(bool), want), (m, r, "signs")
+
+
+def test_fir_rows_from_a_pointer_table_at_any_offset():
+    ctx, L, check = ctx_lib()
+    rng = np.random.default_rng(5)
+    m, n = 130, 20000
+    h = rng.standard_normal(m)
+    dh = ctx.upload(h)
+    recs = [noise_i16(n + 100, seed=k) for k in range(3)]
+    bufs = [ctx.upload(r) for r in recs]
+    table = ctx.upload(np.array([b.ptr.value for b in bufs], dtype=np.uint64))
+    nout = n - m + 1
+    ystride = nout + (nout & 1) + 6
+    d_y = ctx.empty(3 * ystride, np.float64)
+    for off, aligned in [(0, 1), (8, 1), (3, 0), (37, 0)]:
+        check(L.pm_fir_rows_i16_ptrs(ctx.handle, table.ptr, off, aligned, 3, n, dh.ptr, m, d_y.ptr, ystride, 0))
+        got = d_y.download().reshape(3, ystride)[:, :nout]
+        for r in range(3):
+            assert np.array_equal(got[r], O.fir_canon(recs[r][off:off + n], h)), (off, r)
+
+
+def test_agc_rows_in_pieces_equal_agc_apply_on_the_whole():
+    from pymodem_amd._native import AGCParams
+    ctx, L, check = ctx_lib()
+    rows, n = 4, 50000
+    rng = np.random.default_rng(11)
+    t = np.arange(n) / 48000.0
+    x = np.stack([np.sin(2 * np.pi * (1200 + 100 * r) * t) * (200 + 150 * np.sin(2 * np.pi * 0.7 * t + r)) * (1 + (t > 0.5)) + rng.standard_normal(n) * 5
+                  for r in range(rows)])
+    x[2, 30000:] = 0.0                                                   # the envelope decays to zero and the division is skipped
+    p = AGCParams(500.0, 50.0, 0.2, 48000.0, 1.0)
+    want, wstate = [], []
+    for r in range(rows):
+        buf = ctx.upload(x[r])
+        st = (ctypes.c_double * 2)(0.0, 0.0)
+        check(L.pm_agc_apply(ctx.handle, buf.ptr, n, ctypes.byref(p), st))
+        want.append(buf.download())
+        wstate.append((st[0], st[1]))
+        ref, _ = O.agc_apply(x[r].copy(), 48000.0, 500.0, 0.2, 50.0, 1.0)
+        assert np.array_equal(want[-1], ref)
+    stride = n + 8
+    d_x = ctx.upload(np.pad(x, ((0, 0), (0, 8))).reshape(-1))
+    d_y = ctx.empty(rows * stride, np.float64)
+    mx = (ctypes.c_double * rows)()
+    check(L.pm_rows_max_f64(ctx.handle, d_x.ptr, stride, rows, n, mx))
+    assert list(mx) == [x[r].max() for r in range(rows)]
+    state = (ctypes.c_double * (2 * rows))()
+    at = 0
+    for piece in (1, 255, 256, 257, 4096, 20000, n):                       # uneven pieces, the last one takes the rest
+        cnt = min(piece, n - at)
+        check(L.pm_agc_rows_apply(ctx.handle, d_x.view(at, rows * stride - at).ptr, stride, d_y.view(at, rows * stride - at).ptr, stride, rows, cnt,
+                                  ctypes.byref(p), mx, state))
+        at += cnt
+    assert at == n
+    got = d_y.download().reshape(rows, stride)[:, :n]
+    for r in range(rows):
+        assert np.array_equal(got[r], want[r]), r
+        assert (state[2 * r], state[2 * r + 1]) == wstate[r]
+
+
+# ---- the engine against the stage objects -----------------------------------------------------------------------------------------
+def group_modems(cfg, rate, carriers=None, take=None):
+    from pymodem_amd import chain_builder as cb
+    out = []
+    for line in lines_of(cfg)[:take]:
+        if carriers is None:
+            out.append((line, cb.ModemConfigurator(rate, line["modem"])))
+        else:
+            for f in carriers:
+                ln = json.loads(json.dumps(line))
+                ln["modem"]["options"]["carrier_freq"] = str(f)
+                ln["object_name"] += f" {f}"
+                out.append((ln, cb.ModemConfigurator(rate, ln["modem"])))
+            break
+    return out
+
+
+@pytest.mark.parametrize("cfg,rate,carriers,chunk", [
+    ("bpsk_300.json", 48000, [1500.0], 2048),
+    ("bpsk_300.json", 48000, [1490.0, 1500.0, 1512.5], 4096),
+    ("bpsk_1200.json", 8000, [1500.0, 1510.0], 2048),
+    ("qpsk_2400.json", 48000, [1475.0, 1500.0, 1525.0], 2048),
+    ("qpsk_2400.json", 48000, [1500.0 + 3.125 * k for k in range(-4, 4)], 6144),
+    ("qpsk_600.json", 44100, [1500.0], 0),
+    ("afsk_300_pll.json", 8000, None, 2048),
+])
+def test_engine_bitmaps_equal_demod_signs(cfg, rate, carriers, chunk):
+    """Every (recording, chain) bitmap of a run equals modem.demod_signs() on that recording: different audio per recording, chunk
+    lengths from one FIR tile up, chains per recording that do and do not divide the eight loops of a wave."""
+    import pymodem_amd
+    from pymodem_amd.loop_batch import LoopBatch
+    ctx = pymodem_amd.Context.default()
+    group = group_modems(cfg, rate, carriers, take=1 if carriers is None else None)
+    modems = [m for _, m in group]
+    n = 30000 if rate >= 44100 else 12000
+    recs = [noise_i16(n, seed=100 + k, sigma=3000.0 + 2500.0 * k) for k in range(5)]
+    recs[3][n // 2:] //= 16                                             # a level step: the AGC's sustain and decay at work
+    eng = LoopBatch(modems, recordings=6, ctx=ctx, chunk=chunk)
+    try:
+        for take in (5, 2):                                             # a second run on the same engine starts from fresh states
+            dev = [ctx.upload(r) for r in recs[:take]]
+            got = eng.run(dev)
+            ctx.sync()
+            for k in range(take):
+                for c, (line, _) in enumerate(group):
+                    from pymodem_amd import chain_builder as cb
+                    ref = cb.ModemConfigurator(rate, line["modem"]).demod_signs(recs[k])
+                    assert got[k][c].n == ref.n, (cfg, k, c)
+                    assert np.array_equal(bits_of(got[k][c].bits_i, ref.n), bits_of(ref.bits_i, ref.n)), (cfg, k, c, "I")
+                    if ref.bits_q is not None:
+                        assert np.array_equal(bits_of(got[k][c].bits_q, ref.n), bits_of(ref.bits_q, ref.n)), (cfg, k, c, "Q")
+    finally:
+        eng.close()
+
+
+def test_engine_qpsk_modem():
+    """QPSKModem (psk.py:197-476, chain_builder type 'qpsk'): one input, two low-passed arms."""
+    import pymodem_amd
+    from pymodem_amd import chain_builder as cb
+    from pymodem_amd.loop_batch import LoopBatch
+    ctx = pymodem_amd.Context.default()
+    spec = {"type": "qpsk", "config": "2400", "options": {}}
+    modems = [cb.ModemConfigurator(48000, spec)]
+    recs = [noise_i16(20000, seed=7 + k) for k in range(3)]
+    eng = LoopBatch(modems, recordings=3, ctx=ctx, chunk=4096)
+    try:
+        got = eng.run([ctx.upload(r) for r in recs])
+        ctx.sync()
+        for k in range(3):
+            ref = cb.ModemConfigurator(48000, spec).demod_signs(recs[k])
+            assert np.array_equal(bits_of(got[k][0].bits_i, ref.n), bits_of(ref.bits_i, ref.n))
+            assert np.array_equal(bits_of(got[k][0].bits_q, ref.n), bits_of(ref.bits_q, ref.n))
+    finally:
+        eng.close()
+
+
+def pk(pkts):
+    return (np.array([p.streamaddress for p in pkts], dtype=np.int64), np.array([len(p.data) for p in pkts], dtype=np.int64),
+            np.array([p.BytesCorrected for p in pkts], dtype=np.int64), np.array([b for p in pkts for b in p.data], dtype=np.uint8))
+
+
+@pytest.mark.parametrize("mode,cfg", [("qpsk2400_il2p", "qpsk_2400.json"), ("bpsk300_il2p", "bpsk_300.json")])
+def test_recordings_executor_matches_the_oracle_on_packet_bearing_audio(mode, cfg):
+    """process_recordings_device on four different packet-bearing recordings: slicer bytes, addresses and packets of every chain of
+    every recording equal the oracle's (which the reference's goldens pin)."""
+    from pymodem_amd import chain_builder as cb, siggen
+    from pymodem_amd.loop_batch import process_recordings_device
+    rate = 48000
+    lines = lines_of(cfg)
+    recs = []
+    for k in range(4):
+        audio, _ = siggen.recording(mode, rate, packets=2, seed=50 + k, noise_sigma=900.0 + 300.0 * k, payload_len=(20, 40))
+        recs.append(audio)
+    n = min(len(r) for r in recs)
+    recs = [r[:n] for r in recs]
+    chain_sets = [[cb.build_chain(rate, line) for line in lines] for _ in recs]
+    stages = {}
+    got = process_recordings_device(chain_sets, recs, chunk=8192, stages=stages)
+    decoded = 0
+    for k, audio in enumerate(recs):
+        for c, line in enumerate(lines):
+            want = O.run_chain(O.build_chain(rate, line), audio, canon=True)
+            sl = stages["sliced"][k][c]
+            assert np.array_equal(sl.data, want["slice_data"]) and np.array_equal(sl.address, want["slice_addr"]), (cfg, k, c)
+            for a, b in zip(pk(got[k][c]), pk(want["packets"])):
+                assert np.array_equal(a, b), (cfg, k, c)
+            decoded += len(want["packets"])
+    assert decoded > 0
