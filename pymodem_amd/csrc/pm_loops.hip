@@ -114,37 +114,44 @@ __device__ __forceinline__ int pd_lookup(const int32_t *tbl, double re, double i
 
 enum { kCostas = 0, kPll = 1, kMpsk = 2, kQpsk = 3 };
 
-// LDS layout (doubles): tab2[257 pairs, 516] | in0[rows_in][kPad] | in1[...] (mpsk) | out0[kG][kPad] | out1[kG][kPad] (mpsk) | pd[4096 int32] (mpsk)
+// A workgroup is TWO waves.  Wave 0 owns the loops (lane l < ng steps loop g0 + l through one tile of kTile samples, reading and
+// writing LDS only); wave 1 moves the tiles: while wave 0 steps tile s - 1 it loads tile s from memory into the other input buffer
+// and stores tile s - 2 from the other output buffer.  One barrier per tile.  The loop-owning wave therefore never waits for
+// memory: with the tile I/O on the stepping wave itself (round 2) a wave whose eight loops read eight different rows -- eight
+// recordings of a batch -- spent 50 ns per sample of its 228 waiting for its own loads and stores (tools/loop_scaling.py).
+//
+// LDS layout (doubles): tab2[257 pairs, 516] | in[2][rows_in][NIN][kPad] | out[2][NOUT][kG][kPad] | pd[4096 int32] (mpsk)
 // Input rows: loop l reads row l / per_row (x0 + row * x_stride): per_row = 1 gives every loop its own input, per_row = nloops (with
 // any stride) one input for all, and a batch of recordings x chains has per_row = chains (the chains of a recording share its
 // front end).  `rows_lds` = the most distinct rows one wave's kG loops can touch (loop_rows_lds), which sizes the LDS image.
 template <int MODE>
-__global__ __launch_bounds__(64) void loop_kernel(pm_loop *__restrict__ loops, int nloops, int per_row, int rows_lds,
-                                                  const double *__restrict__ table,
-                                                  const int32_t *__restrict__ pd, const double *__restrict__ x0,
-                                                  const double *__restrict__ x1, int64_t x_stride, int64_t n,
-                                                  double *__restrict__ o0, double *__restrict__ o1, int64_t out_stride)
+__global__ __launch_bounds__(128) void loop_kernel(pm_loop *__restrict__ loops, int nloops, int per_row, int rows_lds,
+                                                   const double *__restrict__ table,
+                                                   const int32_t *__restrict__ pd, const double *__restrict__ x0,
+                                                   const double *__restrict__ x1, int64_t x_stride, int64_t n,
+                                                   double *__restrict__ o0, double *__restrict__ o1, int64_t out_stride)
 {
     extern __shared__ double lds[];
-    const int lane = threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g0 = blockIdx.x * kG;
     const int ng = min(kG, nloops - g0);
     const int row0 = g0 / per_row;
-    const int rows = (g0 + ng - 1) / per_row - row0 + 1;      // distinct input rows of this wave's loops
+    const int rows = (g0 + ng - 1) / per_row - row0 + 1;      // distinct input rows of this workgroup's loops
     const int rows_in = rows_lds;
-    double2v *tab2 = reinterpret_cast<double2v *>(lds);
-    double *in0 = lds + 516;                               // 257 pairs, rounded up to a multiple of 16 bytes
-    double *in1 = in0 + rows_in * kPad;
     constexpr bool kTwoOut = MODE == kMpsk || MODE == kQpsk;
-    double *out0 = MODE == kMpsk ? in1 + rows_in * kPad : in1;
-    double *out1 = out0 + kG * kPad;
-    int32_t *pdt = (int32_t *)(out1 + kG * kPad);
+    constexpr int NIN = MODE == kMpsk ? 2 : 1, NOUT = kTwoOut ? 2 : 1;
+    double2v *tab2 = reinterpret_cast<double2v *>(lds);
+    double *in_base = lds + 516;                           // 257 pairs, rounded up to a multiple of 16 bytes
+    const int in_buf = rows_in * NIN * kPad;               // doubles per input buffer: [row][NIN][kPad]
+    double *out_base = in_base + 2 * in_buf;
+    constexpr int out_buf = NOUT * kG * kPad;              // doubles per output buffer: [NOUT][kG][kPad]
+    int32_t *pdt = (int32_t *)(out_base + 2 * out_buf);
 
-    for (int i = lane; i < 257; i += 64) tab2[i] = double2v{table[i & 255], table[(i + 64) & 255]};
+    for (int i = threadIdx.x; i < 257; i += 128) tab2[i] = double2v{table[i & 255], table[(i + 64) & 255]};
     if (MODE == kMpsk)
-        for (int i = lane; i < 4096; i += 64) pdt[i] = pd[i];
+        for (int i = threadIdx.x; i < 4096; i += 128) pdt[i] = pd[i];
 
-    const bool active = lane < ng;
+    const bool active = wave == 0 && lane < ng;
     LoopRegs L;
     if (active) {
         const pm_loop &s = loops[g0 + lane];
@@ -158,29 +165,70 @@ __global__ __launch_bounds__(64) void loop_kernel(pm_loop *__restrict__ loops, i
             L.cx0 = s.cx0; L.cx1 = s.cx1; L.cy0 = s.cy0; L.sx0 = s.sx0; L.sx1 = s.sx1; L.sy0 = s.sy0;
         }
     }
+    const int my_row = active ? (g0 + lane) / per_row - row0 : 0;
 
-    for (int64_t tile0 = 0; tile0 < n; tile0 += kTile) {
-        const int len = (int)min((int64_t)kTile, n - tile0);
-        // stream the tile in
-        for (int r = 0; r < rows; ++r) {
-            const int64_t off = (int64_t)(row0 + r) * x_stride + tile0;
-            for (int k = lane; k < len; k += 64) {
-                in0[r * kPad + k] = x0[off + k];
-                if (MODE == kMpsk) in1[r * kPad + k] = x1[off + k];
+    // step s: wave 1 loads tile s and stores tile s - 2, wave 0 steps tile s - 1; the tables above are complete at the first barrier
+    const int64_t ntiles = (n + kTile - 1) / kTile;
+    for (int64_t s = 0; s < ntiles + 2; ++s) {
+        if (wave == 1) {
+            if (s < ntiles) {
+                const int64_t tile0 = s * kTile;
+                const int len = (int)min((int64_t)kTile, n - tile0);
+                double *ib = in_base + (s & 1) * in_buf;
+                // Two rows at a time, every load of the pair issued before the first LDS write (a load per round trip -- what the
+                // plain loop compiles to -- is 32 dependent memory latencies per tile of eight rows: as long as the tile takes to
+                // step).  Indices are clamped instead of predicated: what lands beyond `len` is never read.
+                constexpr int kPer = kTile / 64;
+                for (int r = 0; r < rows; r += 2) {
+                    const int r1 = min(r + 1, rows - 1);
+                    const int64_t off0 = (int64_t)(row0 + r) * x_stride + tile0, off1 = (int64_t)(row0 + r1) * x_stride + tile0;
+                    double va[2][NIN][kPer];
+#pragma unroll
+                    for (int j = 0; j < kPer; ++j) {
+                        const int k = min(lane + 64 * j, len - 1);
+                        va[0][0][j] = x0[off0 + k];
+                        va[1][0][j] = x0[off1 + k];
+                        if (MODE == kMpsk) {
+                            va[0][NIN - 1][j] = x1[off0 + k];
+                            va[1][NIN - 1][j] = x1[off1 + k];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < kPer; ++j) {
+                        const int k = lane + 64 * j;
+                        ib[(r * NIN) * kPad + k] = va[0][0][j];
+                        ib[(r1 * NIN) * kPad + k] = va[1][0][j];
+                        if (MODE == kMpsk) {
+                            ib[(r * NIN + 1) * kPad + k] = va[0][NIN - 1][j];
+                            ib[(r1 * NIN + 1) * kPad + k] = va[1][NIN - 1][j];
+                        }
+                    }
+                }
             }
-        }
-        __syncthreads();
-        if (active) {
-            const int my_row = (g0 + lane) / per_row - row0;
-            const double *p0 = in0 + my_row * kPad;
-            const double *p1 = in1 + my_row * kPad;
-            double *q0 = out0 + lane * kPad, *q1 = out1 + lane * kPad;
+            if (s >= 2) {
+                const int64_t tile0 = (s - 2) * kTile;
+                const int len = (int)min((int64_t)kTile, n - tile0);
+                const double *ob = out_base + (s & 1) * out_buf;
+                for (int r = 0; r < ng; ++r) {
+                    const int64_t off = (int64_t)(g0 + r) * out_stride + tile0;
+                    for (int k = lane; k < len; k += 64) {
+                        o0[off + k] = ob[r * kPad + k];
+                        if (kTwoOut) o1[off + k] = ob[(kG + r) * kPad + k];
+                    }
+                }
+            }
+        } else if (active && s >= 1 && s <= ntiles) {
+            const int64_t tile0 = (s - 1) * kTile;
+            const int len = (int)min((int64_t)kTile, n - tile0);
+            const double *p0 = in_base + ((s - 1) & 1) * in_buf + (my_row * NIN) * kPad;
+            const double *p1 = p0 + kPad;
+            double *q0 = out_base + ((s - 1) & 1) * out_buf + lane * kPad, *q1 = q0 + kG * kPad;
             for (int k = 0; k < len; ++k) {
                 if (MODE == kCostas) {
-                    const double s = p0[k];
+                    const double sm = p0[k];
                     nco_update(L, tab2);
-                    const double i_mixer = s * L.cosine;              // psk.py:177
-                    const double q_mixer = s * (-L.sine);             // psk.py:182
+                    const double i_mixer = sm * L.cosine;             // psk.py:177
+                    const double q_mixer = sm * (-L.sine);            // psk.py:182
                     const double lp = iir_update(L, i_mixer * q_mixer);
                     L.control = pi_update(L, lp);                     // psk.py:187
                     q0[k] = i_mixer;
@@ -191,10 +239,10 @@ __global__ __launch_bounds__(64) void loop_kernel(pm_loop *__restrict__ loops, i
                     L.control = pi_update(L, lp);                     // afsk_pll.py:160
                     q0[k] = L.proportional;                           // afsk_pll.py:163
                 } else if (MODE == kQpsk) {
-                    const double s = p0[k];
+                    const double sm = p0[k];
                     nco_update(L, tab2);
-                    const double cl = iir1(L.bb0, L.bb1, L.ba1, L.cx0, L.cx1, L.cy0, s * L.cosine);   // psk.py:438-440
-                    const double sl = iir1(L.bb0, L.bb1, L.ba1, L.sx0, L.sx1, L.sy0, s * L.sine);     // psk.py:449-451
+                    const double cl = iir1(L.bb0, L.bb1, L.ba1, L.cx0, L.cx1, L.cy0, sm * L.cosine);   // psk.py:438-440
+                    const double sl = iir1(L.bb0, L.bb1, L.ba1, L.sx0, L.sx1, L.sy0, sm * L.sine);     // psk.py:449-451
                     const double a = sl >= 0 ? cl : -cl;              // cos_lp * sgn(sin_lp)            psk.py:455-459
                     const double b = cl >= 0 ? sl : -sl;              // sin_lp * sgn(cos_lp)            psk.py:444-447
                     const double lp = iir_update(L, a - b);           // psk.py:459-461
@@ -216,14 +264,6 @@ __global__ __launch_bounds__(64) void loop_kernel(pm_loop *__restrict__ loops, i
             }
         }
         __syncthreads();
-        // stream the tile out
-        for (int r = 0; r < ng; ++r) {
-            const int64_t off = (int64_t)(g0 + r) * out_stride + tile0;
-            for (int k = lane; k < len; k += 64) {
-                o0[off + k] = out0[r * kPad + k];
-                if (kTwoOut) o1[off + k] = out1[r * kPad + k];
-            }
-        }
     }
     if (active) {
         pm_loop &s = loops[g0 + lane];
@@ -242,7 +282,8 @@ int loop_rows_lds(int per_row, int nloops)
 
 size_t loop_lds_bytes(int mode, int rows_in)
 {
-    size_t d = 516 + (size_t)rows_in * kPad * (mode == kMpsk ? 2 : 1) + (size_t)kG * kPad * 2;
+    const int nin = mode == kMpsk ? 2 : 1, nout = (mode == kMpsk || mode == kQpsk) ? 2 : 1;
+    size_t d = 516 + 2 * (size_t)rows_in * nin * kPad + 2 * (size_t)nout * kG * kPad;
     return d * 8 + (mode == kMpsk ? 4096 * 4 : 0);
 }
 
@@ -253,12 +294,13 @@ int loop_enqueue(pm_ctx *ctx, pm_loop *d_loops, int nloops, int per_row, const d
                  const double *d_x0, const double *d_x1, int64_t x_stride, int64_t n, double *d_o0, double *d_o1, int64_t out_stride)
 {
     const int rows_lds = loop_rows_lds(per_row, nloops);
-    const size_t lds = loop_lds_bytes(MODE, rows_lds);
+    size_t lds = loop_lds_bytes(MODE, rows_lds);
+    if (const char *e = getenv("PM_LOOP_LDS_MIN")) lds = std::max(lds, (size_t)atol(e));     // experiment: one workgroup per CU
     if (lds > 64 * 1024)
         PM_HIP(hipFuncSetAttribute((const void *)loop_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
         PmProf prof(ctx, PM_K_LOOP);
-        hipLaunchKernelGGL((loop_kernel<MODE>), dim3((unsigned)pm_cdiv(nloops, kG)), dim3(64), lds, ctx->stream,
+        hipLaunchKernelGGL((loop_kernel<MODE>), dim3((unsigned)pm_cdiv(nloops, kG)), dim3(128), lds, ctx->stream,
                            d_loops, nloops, per_row, rows_lds, d_table, d_pd, d_x0, d_x1, x_stride, n, d_o0, d_o1, out_stride);
     }
     PM_HIP(hipGetLastError());
