@@ -153,6 +153,10 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): --chains-per-gpu chains on EVERY rank (beyond the config's own chains the sweep continues in finer "
                          "steps, named in config.workload); strong: the config's own chains (8 for configs[3]) divided over the ranks")
+    ap.add_argument("--loop-batch", type=int, default=128,
+                    help="carrier-loop workloads (bpsk_300, qpsk_2400): recordings per engine run (pymodem_amd.loop_batch) -- the loops of all of "
+                         "them x the rank's chains advance together, one lane each; a step is still one recording")
+    ap.add_argument("--loop-chunk", type=int, default=0, help="carrier-loop workloads: final-filter outputs per time chunk (0 = 262144)")
     ap.add_argument("--also", type=int, default=1, help="1 (default, one GPU only): after the headline workload also measure fsk_9600, "
                     "bpsk_300 and qpsk_2400 (BASELINE configs[2], [1], [4]) briefly and attach them under 'also'")
     args = ap.parse_args()
@@ -227,6 +231,7 @@ def main():
 
 
 ALSO = ("fsk_9600", "bpsk_300", "qpsk_2400")
+LOOP_WORKLOADS = ("bpsk_300", "qpsk_2400")
 ALSO_CPU_SAMPLE = {"fsk_9600": 4_800_000, "bpsk_300": 1_440_000, "qpsk_2400": 1_440_000, "afsk_1200_super_opt": 4_800_000}
 
 
@@ -236,7 +241,7 @@ def also_workloads(args, env, cpu_also=None):
     at full size -- and fsk_9600 is the shortest-tap FIR path.  Never allowed to break the main line."""
     import copy
     out = {}
-    for name, steps, warm in (("fsk_9600", 300, 10), ("bpsk_300", 1, 0), ("qpsk_2400", 1, 0)):
+    for name, steps, warm in (("fsk_9600", 300, 10), ("bpsk_300", 128, 2), ("qpsk_2400", 128, 2)):
         if name == args.workload:
             continue
         a = copy.copy(args)
@@ -250,13 +255,16 @@ def also_workloads(args, env, cpu_also=None):
                          "roofline_fp64_alone_frac": d["roofline_fp64"]["alone_frac"], "dominant_by_time": d["roofline"]["dominant_by_time"]}
             if cpu_also and name in cpu_also:
                 out[name]["cpu_baseline"] = cpu_also[name]
+            if d["config"].get("loop_batch"):
+                out[name]["loop_batch"] = d["config"]["loop_batch"]
             if name == "qpsk_2400":
-                # configs[4] has 64 chains: sharded 8 per GPU each GPU waits for eight sequential carrier loops, which cost what 64 in
-                # ONE launch cost (one lane per loop) -- the whole config on one GPU, one step, for comparison
+                # configs[4] has 64 chains: the whole config on ONE GPU, 16 recordings in flight (the same 1024 loops per launch as 128
+                # recordings x 8 chains), for comparison with the 8-chains-per-GPU sharding
                 a64 = copy.copy(a)
-                a64.chains_per_gpu, a64.steps, a64.warmup = 64, 1, 0
+                a64.chains_per_gpu, a64.steps, a64.warmup, a64.loop_batch = 64, 16, 2, 16
                 d64 = measure(a64, env)
                 out[name]["all_64_chains_on_one_gpu"] = {"value": d64["value"], "unit": d64["unit"], "ms_per_step": d64["ms_per_step"], "chains_per_gpu": 64,
+                                                         "steps": 16, "loop_batch": d64["config"]["loop_batch"],
                                                          "gpu_kernel_ms_per_step": d64["gpu_kernel_ms_per_step"], "packets": d64["packets"]}
         except Exception as e:                                   # noqa: BLE001
             out.setdefault(name, {})["error"] = repr(e)[:300]
@@ -289,12 +297,13 @@ def measure(args, env):
 
     chains_ref = []
 
-    def build_chains():
+    def build_chains(reset=True):
         chains = []
         for c in my:
             line = lines[c]
             modem = modems[c]
-            modem.reset()
+            if reset:
+                modem.reset()
             srate = getattr(modem, "output_sample_rate", args.rate)
             chains.append([line["object_name"], modem, cb.SlicerConfigurator(srate, line["slicer"]),
                            cb.StreamConfigurator(line["stream"]), cb.CodecConfigurator(line["codec"], line["object_name"])])
@@ -316,9 +325,35 @@ def measure(args, env):
 
     stage_ms = {}
     pipes = {}
+    # The carrier-loop workloads (BASELINE configs[1] and [4]): a step is still one recording, but up to --loop-batch recordings go
+    # through ONE engine run -- the sequential carrier loop of every recording x chain on a lane of its own, all of them advancing
+    # together in time chunks (pymodem_amd.loop_batch) -- then all slicers in batches and LFSR + codec per recording.
+    loop_wl = args.workload in LOOP_WORKLOADS
+    loop_info = None
+    if loop_wl:
+        from pymodem_amd import loop_batch as lb
+        batch = max(1, min(args.loop_batch, max(args.steps, 1)))
+        engine = lb.engine_for([modems[c] for c in my], batch, ctx, args.loop_chunk)
+        engine.reserve(batch, args.samples, slot=(0, 0))
+        nout_, chunk_, chunks_ = engine.geometry(args.samples)
+        loop_info = {"recordings_per_run": batch, "loops_in_flight": batch * len(my), "chunk_outputs": chunk_, "chunks_per_recording": chunks_,
+                     "note": "all carrier loops of the run's recordings x this rank's chains advance together, one lane each, state carried "
+                             "in device memory from chunk to chunk; band-pass/AGC/Hilbert of chunk t+1 on a second stream beside the loops of chunk t"}
+
+    def loop_steps(k, audio_dev):
+        res = None
+        for b0 in range(0, k, batch):
+            r = min(batch, k - b0)
+            sets = [build_chains(reset=False) for _ in range(r)]
+            rows = lb.process_recordings_device(sets, [audio_dev] * r, ctx, chunk=args.loop_chunk, rows=True, chain_ids=my)
+            for rr in rows:
+                res = finish(rr)
+        return res
 
     def run_steps(k):
         """k steps; with --overlap the host half of each step runs behind the GPU half of the next one."""
+        if loop_wl:
+            return loop_steps(k, d_audio)
         if not args.overlap:
             res = None
             for _ in range(k):
@@ -395,7 +430,13 @@ def measure(args, env):
         if use_dist:
             torch.distributed.barrier()
 
-    run_steps(args.warmup)
+    if loop_wl:
+        # any run of the engine takes as long as its recordings are (the loops are sequential in time): warm up on the first seconds
+        if args.warmup:
+            loop_steps(min(args.warmup, batch), d_audio.view(0, min(args.samples, 1_500_000)))
+        sides.append(engine.front)
+    else:
+        run_steps(args.warmup)
     fence()
     # The cyclic collector stops every thread (it runs under the interpreter lock): a full collection over the millions of objects
     # torch and numpy bring along took 7-15 ms and landed inside about one 20-step run in three (two slicer batches and the submitting
@@ -463,7 +504,7 @@ def measure(args, env):
     # the same kernels with the GPU to themselves (one more step, strictly sequential, outside the timed region): in the pipelined
     # run two or more streams share the CUs, which stretches every kernel's duration
     alone = {}
-    if args.overlap:
+    if args.overlap and not loop_wl:
         saved, args.overlap = args.overlap, 0
         if args.steps > 1:                                    # (not for the one-step carrier-loop workloads: 5-8 s per step)
             run_steps(1)                                      # the sequential path's own buffers and first launches
@@ -477,6 +518,9 @@ def measure(args, env):
     for p in pipes.values():
         p.close()
     pipes.clear()
+    if loop_wl:
+        sides.remove(engine.front)
+        lb.close_engines()                                    # the engine's work buffers and bitmap sets (gigabytes) go back
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device or "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -484,7 +528,7 @@ def measure(args, env):
 
     # end to end including the recording's way into HBM, overlapped: K more steps with every recording uploaded one step ahead
     h2d_overlapped = None
-    if args.overlap >= 2:
+    if args.overlap >= 2 and not loop_wl:
         run_steps_uploading(args.warmup)
         fence()
         t_u = time.perf_counter()
@@ -533,8 +577,10 @@ def measure(args, env):
                        "parallelism": (f"chains sharded {cpg}/GPU x {world} GPU, packet gather to rank 0" if args.scaling == "weak" else
                                        f"the config's {nchains} chains divided over {world} GPU (contiguous blocks), packet gather to rank 0"),
                        "dist": dist_info(use_dist),
-                       "overlap": {0: "none", 1: "host half of step k behind GPU half of step k+1",
-                                   2: "3-stage pipeline: demod(k+1) | slice(k) on a side stream | host(k-1)"}[min(args.overlap, 2)]},
+                       "overlap": ("carrier-loop batch engine: every recording of a run in flight at once" if loop_wl else
+                                   {0: "none", 1: "host half of step k behind GPU half of step k+1",
+                                    2: "3-stage pipeline: demod(k+1) | slice(k) on a side stream | host(k-1)"}[min(args.overlap, 2)]),
+                       "loop_batch": loop_info},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "avg_kernel_ms": round(avg_ms, 5), "launches": dom_n, "algorithmic_bytes_per_launch": round(per_launch_bytes),

@@ -62,6 +62,7 @@ int pm_event_record(pm_ctx *ctx, void **event);
 int pm_event_wait(pm_ctx *ctx, void *event);
 int pm_event_query(void *event);     /* 1 = everything before the record has finished, 0 = not yet, < 0 = error */
 int pm_event_sync(void *event);      /* host wait for the event */
+int pm_event_sync_relaxed(void *event, int poll_us);   /* the same without spinning: polls every poll_us microseconds (waits of seconds) */
 int pm_event_destroy(void *event);
 int pm_ctx_sync(pm_ctx *ctx);                            /* hipStreamSynchronize on the ctx stream */
 void *pm_ctx_stream(pm_ctx *ctx);                        /* the hipStream_t, for interop */

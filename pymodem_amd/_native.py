@@ -142,6 +142,7 @@ _SIGS = {
     "pm_ctx_scratch": ([_vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)], _int),
     "pm_event_query": ([_vp], _int),
     "pm_event_sync": ([_vp], _int),
+    "pm_event_sync_relaxed": ([_vp, _int], _int),
     "pm_ctx_create_cumask": ([_int, ctypes.POINTER(ctypes.c_uint32), _int, ctypes.POINTER(_vp)], _int),
     "pm_device_cus": ([_int], _int),
     "pm_event_record": ([_vp, ctypes.POINTER(_vp)], _int),

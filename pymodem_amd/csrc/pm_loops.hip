@@ -44,28 +44,34 @@ __device__ __forceinline__ double iir1(double b0, double b1, double a1, double &
 }
 
 // The bodies below are written branch-free: a lone wave pays ~5 cycles per instruction and far more per taken branch, and
-// every statement is on the loop-carried path.  Each select reproduces the reference's `if`/`while` exactly:
-//   while (p >= 2pi) p -= 2pi  ==  one conditional subtract, then (never in practice) the loop for what is left.
+// every statement is on the loop-carried path -- ONE dependent chain of ~25 binary64 operations and two LDS reads per sample, at
+// ~10 cycles per dependent operation: what bounds these kernels is the LENGTH of that chain, not the number of instructions beside it.
 // tab2: 257 (sine, cosine) pairs in LDS, tab2[i] = {table[i], table[(i + 64) & 255]} and tab2[256] = {-, table[64]}: one 16-byte
 // read serves both outputs of the NCO.
+//
+// nco.py:35-40: phase += step; `while p >= 2pi: p -= 2pi`; `while p < 0: p += 2pi`; index = int(p * scale).  For 0 <= p0 < 4pi -- every
+// sample of every real run: the step is positive and far below one turn -- the first loop makes at most one trip (p0 - 2pi is exact
+// there, Sterbenz, and below 2pi) and the second none.  Both candidates' indices are computed side by side and the compare only
+// selects (round 3): the chain no longer runs through compare -> select -> add -> compare -> select before the multiplication,
+// ~45 cycles of ~370.  Anything else (negative, a turn or more per sample, NaN) takes the statements as written.
 __device__ __forceinline__ void nco_update(LoopRegs &L, const double2v *tab2)
 {
     const double ph0 = L.phase + L.phase_scaling * (L.set_frequency + L.control);   // nco.py:35
-    // nco.py:36-39: `while p >= 2pi: p -= 2pi` then `while p < 0: p += 2pi`.  For -2pi <= p < 4pi each loop makes at most one
-    // trip: two selects (2pi <= p < 4pi: p - 2pi is exact and < 2pi; -2pi <= p < 0: p + 2pi may round to exactly 2pi, and stays,
-    // as there).  Anything beyond (|control| above one turn per sample) takes the loops as written.
     const double down = ph0 - kTwoPi;
-    double ph = ph0 >= kTwoPi ? down : ph0;
-    const double up = ph + kTwoPi;
-    ph = ph < 0 ? up : ph;
-    if (__builtin_expect(!(ph0 >= -kTwoPi && ph0 < 2.0 * kTwoPi), 0)) {
+    const bool wrap = ph0 >= kTwoPi;
+    const int i0 = (int)(ph0 * L.index_scaling), i1 = (int)(down * L.index_scaling);  // nco.py:40, int() truncates
+    double ph = wrap ? down : ph0;
+    int idx = wrap ? i1 : i0;                                               // 0..256 on this path: the table read needs no clamp
+    int at = idx;
+    if (__builtin_expect(!(ph0 >= 0.0 && ph0 < 2.0 * kTwoPi), 0)) {
         ph = ph0;
-        while (ph >= kTwoPi) ph = ph - kTwoPi;
-        while (ph < 0) ph = ph + kTwoPi;
+        while (ph >= kTwoPi) ph = ph - kTwoPi;                              // nco.py:36-37
+        while (ph < 0) ph = ph + kTwoPi;                                    // nco.py:38-39 (may round to exactly 2pi, and stays, as there)
+        idx = (int)(ph * L.index_scaling);
+        at = min(max(idx, 0), 256);
     }
     L.phase = ph;
-    const int idx = (int)(ph * L.index_scaling);                            // nco.py:40, int() truncates; 0..256
-    double2v sc = tab2[min(max(idx, 0), 256)];
+    double2v sc = tab2[at];
     asm volatile("" : "+v"(sc));                                            // one unconditional ds_read_b128, no branch around it
     L.sine = idx < 256 ? sc.x : L.sine;                                     // nco.py:41-45: index 256 keeps the old value
     L.cosine = sc.y;                                                        // nco.py:46-51
@@ -98,18 +104,19 @@ __device__ __forceinline__ double pi_update(LoopRegs &L, double sample)
 
 __device__ __forceinline__ int pd_lookup(const int32_t *tbl, double re, double im)
 {
-    // phase_detector.py:124-149, granularity 64: floor(x*64*0.5), clip to +-63, quadrant fold
-    double fr = floor(re * 64 * 0.5), fi = floor(im * 64 * 0.5);
-    fr = fmin(fmax(fr, -1e9), 1e9);
-    fi = fmin(fmax(fi, -1e9), 1e9);
-    int r = (int)fr, i = (int)fi;
-    r = min(max(r, -63), 63);                       // >= 64 -> 63, <= -64 -> -63
-    i = min(max(i, -63), 63);
-    const int ar = abs(r), ai = abs(i);
-    // Q1 T[r][i] | Q4 T[-i][r] | Q2 T[i][-r] | Q3 T[-r][-i]
-    const bool swap = (r >= 0) != (i >= 0);
-    const int row = swap ? ai : ar, col = swap ? ar : ai;
-    return tbl[row * 64 + col];
+    // phase_detector.py:124-149, granularity 64: floor(x * 64 * 0.5), clip to +-63, quadrant fold.  Kept in binary64 up to the one
+    // conversion of the table index (every value below is a small integer, exact in a double), which takes the integer clamps, the
+    // absolute values and the index arithmetic off the dependent chain:
+    //   x * 64 * 0.5 == x * 32 bit for bit (powers of two: both products are exact wherever the reference does not overflow);
+    //   clip(int(f), -63, 63) == int(clip(f, -63.0, 63.0)) for the integer-valued f = floor(..);
+    //   Q1 T[r][i] | Q4 T[-i][r] | Q2 T[i][-r] | Q3 T[-r][-i]: rows and columns swap where the signs differ (0 counts as positive).
+    double fr = floor(re * 32.0), fi = floor(im * 32.0);
+    const bool swap = (fr >= 0) != (fi >= 0);
+    fr = fmin(fmax(fr, -63.0), 63.0);               // >= 64 -> 63, <= -64 -> -63
+    fi = fmin(fmax(fi, -63.0), 63.0);
+    const double ar = fabs(fr), ai = fabs(fi);
+    const double row = swap ? ai : ar, col = swap ? ar : ai;
+    return tbl[(int)__builtin_fma(row, 64.0, col)];
 }
 
 enum { kCostas = 0, kPll = 1, kMpsk = 2, kQpsk = 3 };

@@ -1,6 +1,7 @@
 // Context, memory, error and timer entry points of the C ABI (include/pymodem_amd.h).
 #include "pm_common.h"
 #include <cstring>
+#include <unistd.h>
 
 static thread_local char g_err[512] = "";
 
@@ -143,6 +144,19 @@ int pm_event_sync(void *event)
     PM_ARG(event != nullptr);
     PM_HIP(hipEventSynchronize((hipEvent_t)event));
     return PM_OK;
+}
+
+int pm_event_sync_relaxed(void *event, int poll_us)
+{
+    PM_ARG(event != nullptr && poll_us >= 1);
+    // hipEventSynchronize spins: fine for the sub-millisecond waits of the pipelined executor, a core burnt for seconds behind a run
+    // of the carrier-loop engine
+    for (;;) {
+        hipError_t e = hipEventQuery((hipEvent_t)event);
+        if (e == hipSuccess) return PM_OK;
+        if (e != hipErrorNotReady) return pm_set_error(PM_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(e));
+        usleep((useconds_t)poll_us);
+    }
 }
 
 int pm_event_destroy(void *event)

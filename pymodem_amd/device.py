@@ -102,6 +102,13 @@ class Context:
     def event_sync(event):
         check(lib().pm_event_sync(event))
 
+    def sync_relaxed(self, poll_us=200):
+        """Wait for everything submitted to this context so far without spinning on it (a run of the carrier-loop engine takes
+        seconds)."""
+        ev = self.__dict__.get("_relaxed_event")
+        ev = self.__dict__["_relaxed_event"] = self.record_event(ev)
+        check(lib().pm_event_sync_relaxed(ev, int(poll_us)))
+
     def empty(self, n, dtype):
         return DeviceBuffer(self, int(n), np.dtype(dtype))
 

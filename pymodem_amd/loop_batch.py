@@ -93,6 +93,20 @@ class LoopBatch:
             self._front = f
         return self._front
 
+    def _bits(self, r, nout, slot):
+        stride = ((nout + 63) // 64 + 1 + 7) // 8 * 8
+        streams = r * self.chains
+        bits_i = self.ctx.scratch(("lbatch", id(self), slot, "i"), streams * stride, np.uint64)
+        bits_q = self.ctx.scratch(("lbatch", id(self), slot, "q"), streams * stride, np.uint64) if self.quadrature else None
+        return stride, bits_i, bits_q
+
+    def reserve(self, recordings, n, slot=0):
+        """Allocate the bitmap set of `slot` for `recordings` recordings of n samples now (a warm-up's job: the first run of a size
+        would otherwise do it, with the allocator's wait inside the run)."""
+        nout = self.geometry(n)[0]
+        if nout >= 1:
+            self._bits(int(recordings), nout, slot)
+
     def run(self, audios, slot=0):
         """audios: DeviceBuffers of int16 recordings of equal length (they may be the same buffer).  Enqueues the whole run and
         returns [[SignBits of chain 0, chain 1, ...] per recording]; the bitmaps are complete when this context's stream gets there
@@ -108,10 +122,7 @@ class LoopBatch:
         nout = self.geometry(n)[0]
         if nout < 1:
             raise ValueError(f"input of {n} samples is shorter than the filters of the chain")
-        stride = ((nout + 63) // 64 + 1 + 7) // 8 * 8
-        streams = r * self.chains
-        bits_i = self.ctx.scratch(("lbatch", id(self), slot, "i"), streams * stride, np.uint64)
-        bits_q = self.ctx.scratch(("lbatch", id(self), slot, "q"), streams * stride, np.uint64) if self.quadrature else None
+        stride, bits_i, bits_q = self._bits(r, nout, slot)
         ptrs = (ctypes.c_void_p * r)(*[a.ptr.value for a in audios])
         got = ctypes.c_int64()
         check(lib().pm_lbatch_run(self._h, ptrs, r, n, bits_i.ptr, bits_q.ptr if bits_q is not None else None, stride, ctypes.byref(got)))
@@ -126,8 +137,12 @@ class LoopBatch:
 
     def close(self):
         if self._h:
-            lib().pm_lbatch_destroy(self._h)
+            lib().pm_lbatch_destroy(self._h)                 # waits for both of the engine's streams
             self._h = ctypes.c_void_p()
+            pool = self.ctx.__dict__.get("_pool", {})
+            for tag in [t for t in pool if isinstance(t, tuple) and t[:2] == ("lbatch", id(self))]:
+                pool.pop(tag).free()                         # the bitmap sets
+            self.ctx.__dict__.get("_pool_views", {}).clear()
 
     def __del__(self):
         try:
@@ -197,6 +212,7 @@ def process_recordings_device(chain_sets, audios, ctx=None, chunk=0, rows=False,
                 sl = chain_sets[rec][c][2]
                 sl._ctx = sl._ctx or ctx
                 bitmaps[rec][c] = sl.sign_bitmaps(got[rec][j])
+    ctx.sync_relaxed()                 # seconds: sleep through them instead of spinning in the slicer's first stream wait
     flat_slicers = [chain_sets[rec][c][2] for rec in range(r) for c in range(nchains)]
     flat_bits = [bitmaps[rec][c] for rec in range(r) for c in range(nchains)]
     sliced = slice_batch(flat_slicers, flat_bits, ctx)

@@ -43,3 +43,40 @@ def test_chains_at_full_size_match_the_oracle(workload, chain_ids):
         assert a == b, f"{workload} chain {chain_ids[k]}: packets differ"
         total += len(b)
     assert total > 0            # (the inverted fsk_9600 chain decodes nothing, in the reference too)
+
+
+@pytest.mark.parametrize("workload,check_ids", [("bpsk_300", [0]), ("qpsk_2400", [0, 5])])
+def test_batch_engine_at_full_size(workload, check_ids):
+    """The carrier-loop batch engine (pymodem_amd.loop_batch: every recording x chain of a run in flight, 110 time chunks) at
+    BASELINE size: two different recordings x all the workload's chains per GPU.  Recording 0 = the bench buffer: the checked chains
+    against the oracle (bytes, addresses, packets), every chain against the per-recording group executor; recording 1 = the same
+    buffer rotated by 12 345 samples (another AGC normalisation, other loop trajectories): every chain against the group executor."""
+    from pymodem_amd import chain_builder as cb, chain_execute as ce
+    from pymodem_amd.loop_batch import close_engines, process_recordings_device
+    audio = _buffer(workload)
+    recs = [audio, np.roll(audio, 12345)]
+    factory, cpg, _ = bench.WORKLOADS[workload]
+    lines = [factory(c) for c in range(cpg)]
+    sets = [[cb.build_chain(48000, line) for line in lines] for _ in recs]
+    stages = {}
+    try:
+        packets = process_recordings_device(sets, recs, stages=stages)
+    finally:
+        close_engines()
+    key = lambda pk: [(p.streamaddress, bytes(bytearray(p.data)), p.BytesCorrected) for p in pk]
+    for r, rec in enumerate(recs):
+        ref_stages = {}
+        ref = ce.process_chains_device([cb.build_chain(48000, line) for line in lines], rec, stages=ref_stages)
+        for c in range(cpg):
+            got, want = stages["sliced"][r][c], ref_stages["sliced"][c]
+            assert len(got.data) > 10000
+            assert np.array_equal(got.data, want.data) and np.array_equal(got.address, want.address), (workload, r, c)
+            assert key(packets[r][c]) == key(ref[c]), (workload, r, c)
+    total = 0
+    for c in check_ids:
+        want = O.run_chain(O.build_chain(48000, lines[c]), audio, canon=True)
+        got = stages["sliced"][0][c]
+        assert np.array_equal(got.data, want["slice_data"]) and np.array_equal(got.address, want["slice_addr"]), (workload, c)
+        assert key(packets[0][c]) == key(want["packets"]), (workload, c)
+        total += len(want["packets"])
+    assert total > 0
