@@ -144,7 +144,6 @@ def main():
                          "step k on a high-priority side stream, host half (LFSR, codec, packet gather, de-dup) of step k-1 in threads; "
                          "1: only the host half runs behind the next step's GPU half; 0: strictly one after the other")
     ap.add_argument("--slice-workers", type=int, default=2, help="--overlap 2: recordings whose slicers may be in flight at once")
-    ap.add_argument("--demod-streams", type=int, default=1, help="--overlap 2: streams the demod kernels of successive recordings alternate on")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--buffer", default="signal", choices=["signal", "noise"],
                     help="signal: seeded packet-bearing recording of the workload's mode + AWGN (pymodem_amd.siggen), tiled to --samples; "
@@ -364,7 +363,7 @@ def measure(args, env):
             # the timed region ends when every one of its k recordings has left the last stage (drain)
             pipe = pipes.get("main")
             if pipe is None:
-                pipe = pipes["main"] = ce.RecordingPipeline(slice_workers=args.slice_workers, demod_streams=args.demod_streams)
+                pipe = pipes["main"] = ce.RecordingPipeline(slice_workers=args.slice_workers)
             pipe.reset_stats()
             # the exchange runs one recording behind (dist.Exchanger): the copy back of a gather never waits for the collective
             ex = pdist.Exchanger(nchains, coll_device)
@@ -400,8 +399,6 @@ def measure(args, env):
             return pending.result() if pending is not None else None
 
     sides = [pymodem_amd.Context.side(dev_index, i) for i in range(args.slice_workers)] if args.overlap >= 2 else []
-    if args.overlap >= 2 and args.demod_streams >= 2:
-        sides.append(pymodem_amd.Context.side(dev_index, 100, high_priority=False))       # the second demod stream
     if args.overlap >= 2 and int(os.environ.get("PYMODEM_AMD_CU_SPLIT", "0")) > 0:
         sides.append(pymodem_amd.Context.side(dev_index, 101, high_priority=False))       # the demod stream on the CUs the slicers leave
 
@@ -409,7 +406,7 @@ def measure(args, env):
         """The same pipeline, but every step's recording starts in host memory: its copy to HBM runs one step ahead on a copy stream."""
         pipe = pipes.get("upload")                            # kept across the warm-up and the timed call, like the main one
         if pipe is None:
-            pipe = pipes["upload"] = ce.RecordingPipeline(slice_workers=args.slice_workers, demod_streams=args.demod_streams)
+            pipe = pipes["upload"] = ce.RecordingPipeline(slice_workers=args.slice_workers)
         ex = pdist.Exchanger(nchains, coll_device)
         local_only = not use_dist and not os.environ.get("PYMODEM_AMD_FORCE_GATHER") and not os.environ.get("BENCH_ORDERED_TAIL")
         last, nxt = None, (pipe.prefetch(audio) if k else None)

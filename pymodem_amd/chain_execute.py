@@ -177,16 +177,14 @@ class RecordingPipeline:
     stays usable (bench.py keeps one across warm-up and timed steps); close() ends its threads.  Results are identical to
     process_chains_table on each recording (tests/test_gpu_chains.py)."""
 
-    def __init__(self, slice_workers=2, demod_streams=1, slice_group=4, slots=None):
+    def __init__(self, slice_workers=2, slice_group=4, slots=None):
         from collections import deque
         import os
         import queue
         import threading
         self._workers = max(1, int(slice_workers))
-        # One demod stream.  A second one (round 1: alternate recordings on two streams so that the tail of one recording's FIR
-        # launches overlaps the head of the next) never gained anything measurable, and under this executor's host-side hand-off it
-        # showed an intermittent GPU memory fault that was not root-caused: the argument is accepted and ignored.
-        self._demod_streams = 1
+        # ONE demod stream.  (Rounds 1-2 could alternate recordings on two: it never gained anything measurable, showed an intermittent
+        # GPU memory fault in round 2 that could not be reproduced into a cause, and is gone -- parameter, code path and test case.)
         self._group = max(1, min(int(os.environ.get("PYMODEM_AMD_SLICE_GROUP", slice_group)), 8))
         self._host_blocks_warm = False
         self._collect_lock = None if os.environ.get("PYMODEM_AMD_SLICE_COLLECT") == "free" else threading.Lock()
@@ -205,6 +203,7 @@ class RecordingPipeline:
         self._upload = ThreadPoolExecutor(max_workers=1)      # host -> HBM copies of the NEXT recording, on a stream of their own
         self._uploads = 0
         self._upload_guard = {}                               # upload slot -> event after which its buffer may be overwritten
+        self._upload_user = {}                                # upload slot -> "sliced" future of the recording that read it last
         self._upload_done = {}                                # upload slot -> event marking the end of its copy (re-used)
         # The slicer stage: a batch takes ~3 ms of a few hundred long-lived waves however many streams are in it (pm_slice_batch:
         # one walker per 32 k samples), so a worker takes EVERY recording whose demod has been submitted when it becomes free (up to
@@ -236,18 +235,21 @@ class RecordingPipeline:
         for th in self._slice_threads:
             th.start()
 
-    def _collect_batch(self):
+    def _collect_batch(self, taken=None):
+        """-> the next batch of recordings (None: the pipeline is closing).  `taken` receives every item as soon as it is off the
+        queue, so that a caller can fail them if one of the waits below raises."""
         import queue
         import time
         item = self._pending.get()
         if item is None:
             self._pending.put(None)                            # one marker ends every worker
             return None
+        items = taken if taken is not None else []
+        items.append(item)
         # demod runs in submission order: wait (on the host, holding nothing) for this recording's bitmaps, then take along
         # every later recording whose bitmaps are complete as well
         Context.event_sync(item[2])
         item[6]["ready"] = time.perf_counter()
-        items = [item]
         while len(items) < self._group:
             try:
                 nxt = self._pending.get_nowait()
@@ -256,15 +258,16 @@ class RecordingPipeline:
             if nxt is None:
                 self._pending.put(None)
                 break
+            items.append(nxt)
             if not Context.event_done(nxt[2]):
-                if len(items) < self._min_group:               # its demod is already queued on the GPU (<= 1 ms): a batch of three costs
+                if len(items) <= self._min_group:              # its demod is already queued on the GPU (<= 1 ms): a batch of three costs
                     Context.event_sync(nxt[2])                 # what a batch of one costs, so a short wait here saves whole batches
                 else:
+                    items.pop()
                     with self._pending.mutex:                  # not ready yet: back to the FRONT of the queue
                         self._pending.queue.appendleft(nxt)
                         self._pending.not_empty.notify()
                     break
-            items.append(nxt)
         return items
 
     def _slice_loop(self, side):
@@ -275,20 +278,29 @@ class RecordingPipeline:
             # ONE worker at a time puts a batch together, so that a batch is CONSECUTIVE recordings and starts when its third demod is
             # done; three workers collecting at once took every third recording each, and all three batches started only when the
             # ninth demod was done (seen in the per-recording timeline).  PYMODEM_AMD_SLICE_COLLECT=free: the old behaviour.
-            if self._collect_lock is not None:
-                with self._collect_lock:
-                    items = self._collect_batch()
-            else:
-                items = self._collect_batch()
+            taken = []
+            try:
+                if self._collect_lock is not None:
+                    with self._collect_lock:
+                        items = self._collect_batch(taken)
+                else:
+                    items = self._collect_batch(taken)
+            except BaseException as e:                         # noqa: BLE001
+                # an event wait failed (HIP error, a demod that faulted): the recordings already taken off the queue get the error --
+                # their host stages would wait for ever otherwise -- and the worker lives on
+                for it in taken:
+                    if not it[3].done():
+                        it[3].set_exception(e)
+                continue
             if items is None:
                 return
             t = time.perf_counter()
             try:
                 slicers, bitmaps = [], []
-                for chains, bm, ready, _, sweeps, audio, rec in items:
+                for bi, (chains, bm, ready, _, sweeps, audio, rec) in enumerate(items):
                     rec["slice0"] = t
                     if sweeps:                                 # finished (their event has): overflowed ones are redone exactly, here
-                        resolve_sweeps(chains, bm, sweeps, audio, side)
+                        resolve_sweeps(chains, bm, sweeps, audio, side, tag=bi)
                     slicers += [ch[2] for ch in chains]
                     bitmaps += bm
                 # (copied to the host by this worker before its next batch: ONE output block per worker will do -- keyed by the first
@@ -342,16 +354,27 @@ class RecordingPipeline:
 
     def prefetch(self, host_audio):
         """Start copying a recording (host int16 / float64 array) into HBM on a copy stream; returns a handle for submit().  Call
-        it one recording ahead and the copy runs while the previous recording is demodulated (three rotating device buffers; a
-        buffer is overwritten only after the demod that read it has finished, which the copy stream waits for on the GPU)."""
+        it one recording ahead and the copy runs while the previous recording is demodulated (as many rotating device buffers as
+        bitmap slots; a buffer is overwritten only after the demod that read it has finished, which the copy stream waits for on
+        the GPU, and after its recording has left the slicer stage)."""
         a = np.asarray(host_audio)
         a = np.ascontiguousarray(a if a.dtype == np.int16 else a.astype(np.float64))
-        k = self._uploads % 3
+        k = self._uploads % self._slots
         self._uploads += 1
         guard = self._upload_guard.get(k)
+        user = self._upload_user.pop(k, None)
         cctx = Context.side(index=200, high_priority=False)
 
         def copy():
+            # The buffer's last reader may be the slicer stage: a certified sweep whose list overflowed is demodulated again from the
+            # audio there (resolve_sweeps), long after the demod stream's event.  As many upload buffers as bitmap slots, and the
+            # recording that used this one `slots` uploads ago has left the slicer stage (submit() waits for exactly that before it
+            # hands a slot out again), so this never waits in practice.
+            if user is not None:
+                try:
+                    user.result()
+                except Exception:                              # noqa: BLE001  (its own future reports it)
+                    pass
             if guard is not None:
                 cctx.wait_event(guard)
             buf = cctx.scratch(("upload", k), a.size, a.dtype)
@@ -377,13 +400,11 @@ class RecordingPipeline:
         while len(self._inflight) >= slots - 1:               # the slicer that read this slot `slots` recordings ago is done
             self._inflight.popleft().result()
         t0 = time.perf_counter()
-        # two demod streams, alternating: the tail of one recording's FIR launches (the last, partly filled round of workgroups)
-        # overlaps the head of the next one's instead of leaving CUs idle
         import os
         if int(os.environ.get("PYMODEM_AMD_CU_SPLIT", "0")) > 0:  # demod on the CUs the slicer streams do not use
-            dctx = Context.side(index=101 if (self._demod_streams < 2 or (self._n & 1)) else 100, high_priority=False)
+            dctx = Context.side(index=101, high_priority=False)
         else:
-            dctx = Context.default() if (self._demod_streams < 2 or (self._n & 1)) else Context.side(index=100, high_priority=False)
+            dctx = Context.default()
         upload_slot = None
         if hasattr(input_audio, "result"):                    # a prefetch() handle: the demod stream waits for the copy on the GPU
             input_audio, copied, upload_slot = input_audio.result()
@@ -402,6 +423,8 @@ class RecordingPipeline:
         self.timeline.append(rec)
         if self._watch is not None:
             self._watch.append((rec, ready))
+        if upload_slot is not None:
+            self._upload_user[upload_slot] = f_fetched
         self._pending.put((chains, bitmaps, ready, f_sliced, sweeps, input_audio, rec))
         # the bitmap slot (and the slicers' output block keyed by it) is free again once the slicers' output is on the host
         self._inflight.append(f_fetched)
@@ -568,11 +591,12 @@ def _afsk_group_native(ctx, chains, planned, audio, group_key, front, bitmaps, s
             bitmaps[k] = chains[k][2].sign_bitmaps(SignBits(b, None, nout))
 
 
-def resolve_sweeps(chains, bitmaps, sweeps, audio, ctx):
+def resolve_sweeps(chains, bitmaps, sweeps, audio, ctx, tag=0):
     """The certified gain sweeps of one recording have FINISHED: any whose list of uncertain samples overflowed (digital silence,
     audio far below the stated bound -- never on a signal) did not leave valid bitmaps; its chains are demodulated again with the
     exact kernels on `ctx` (BPF, correlators, low-pass + sign), which is what the in-call fallback of pm_afsk_sweep_signs would have
-    done.  Returns the number of sweeps redone."""
+    done.  `tag`: distinguishes the recordings whose bitmaps must exist side by side (the recordings of one slicer batch).  Returns
+    the number of sweeps redone."""
     redone = 0
     # one copy per producing context for all of the recording's sweeps (pm_afsk_sweep_results)
     over = {}
@@ -590,11 +614,20 @@ def resolve_sweeps(chains, bitmaps, sweeps, audio, ctx):
             continue
         redone += 1
         for k in ks:
-            modem = chains[k][1]
+            # On a PRIVATE copy of the modem: this runs on a slicer worker's thread up to sixteen recordings after the demod, and the
+            # caller may hand the same modem objects to every recording (bench.py does) -- the submitting thread can be inside
+            # process_chains_device with them right now.  The copy shares the taps and the uploaded constants, nothing else;
+            # context, work-buffer keys and FIR history are its own.
+            import copy
+            modem = copy.copy(chains[k][1])
             modem.use_context(ctx)
             modem.scratch_key = ("chain-group", "sweep-fallback")
+            modem.own_key = ("chain-group", "sweep-fallback", "own", tag, k)
+            modem._hist = None
             chains[k][2]._ctx = chains[k][2]._ctx or ctx
-            bitmaps[k] = chains[k][2].sign_bitmaps(modem.demod_signs(audio))
+            sb = modem.demod_signs(audio)
+            # the slicers of this batch read these bitmaps after the call returns: they must not share storage with the next fallback
+            bitmaps[k] = chains[k][2].sign_bitmaps(sb)
     return redone
 
 

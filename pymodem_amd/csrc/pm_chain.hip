@@ -127,9 +127,12 @@ int pm_chain_run(pm_chain *c, const int16_t *audio, int64_t n, int audio_on_devi
     *h_count = 0;
     if (n == 0) return PM_OK;
     PM_ARG(audio != nullptr);
+    c->last_count = -1;                                    // nothing to fetch until this run has produced its output
     const pm_chain_desc &d = c->d;
     const double *T = c->d_taps;
     const int16_t *x = audio;
+    std::vector<int16_t> next_hist;                        // PM_CHAIN_CARRY_HISTORY: committed only when the run has succeeded, so that a
+    bool have_next_hist = false;                           // failed run (allocation, slicer) can be repeated on the same samples
     if (d.flags & PM_CHAIN_CARRY_HISTORY) {
         // seamless pieces: [the previous run's last sum(M - 1) input samples | this run's] goes through the FIR
         // cascade, whose 'valid' output is then exactly the continuation of the previous run's (see _DeviceStage._with_history)
@@ -147,11 +150,13 @@ int pm_chain_run(pm_chain *c, const int16_t *audio, int64_t n, int audio_on_devi
             if (audio_on_device) { if (int rc = pm_d2h(ctx, next.data() + keep, audio + (n - take), (size_t)take * 2)) return rc; }
             else memcpy(next.data() + keep, audio + (n - take), (size_t)take * 2);
         }
-        if (int rc = pm_ctx_sync(ctx)) return rc;          // the tail's upload has left c->hist before it is replaced
-        c->hist.swap(next);
+        if (int rc = pm_ctx_sync(ctx)) return rc;          // the tail's upload has left c->hist (it is replaced at the end of the run)
+        next_hist.swap(next);
+        have_next_hist = true;
         x = (const int16_t *)c->d_audio;
         n += nt;
         if (n <= hlen) {                                   // not one output yet: the samples wait in the tail
+            c->hist.swap(next_hist);
             c->last_count = 0;
             return PM_OK;
         }
@@ -240,6 +245,7 @@ int pm_chain_run(pm_chain *c, const int16_t *audio, int64_t n, int audio_on_devi
     job.cap = need;
     job.h_state = &c->slicer_state;                        // the slicer continues from run to run like the reference's object
     if (int rc = pm_slice_batch(ctx, &job, 1)) return rc;
+    if (have_next_hist) c->hist.swap(next_hist);           // the stream has moved on: only now
     c->last_count = job.count;
     return pm_chain_fetch(c, h_data, h_addr, cap, h_count);
 }

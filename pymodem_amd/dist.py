@@ -259,7 +259,7 @@ def pack_rows(rows_by_chain, nchains, pinned=False):
     if cap is not None:
         # one call: it returns the size it needs and has written the rows if that is within the capacity
         from .device import _host_block
-        block = _pinned_block(head + cap) if pinned else _host_block(head + cap)[:head + cap]
+        block = _pinned_get(head + cap) if (pinned or _FORCE_PINNED_POOL) else _host_block(head + cap)[:head + cap]
         need = check(lib().pm_packets_pack(rows_p, len(mine), block[head:].ctypes.data_as(ctypes.c_void_p), cap)) if len(mine) else 0
         if need <= cap:
             p.block, p.block_cap = block, cap
@@ -267,6 +267,7 @@ def pack_rows(rows_by_chain, nchains, pinned=False):
             hdr[0], hdr[1], hdr[2:] = need, p.nrows, p.counts
             p.payload = block[head:head + need]
             return p
+        _pinned_put(block)                                   # did not fit: nothing refers to it
     need = check(lib().pm_packets_pack(rows_p, len(mine), None, 0)) if len(mine) else 0
     p.payload = np.empty(need, dtype=np.uint8)
     if need:
@@ -304,11 +305,19 @@ def _exchange_issue(packed_list, nchains, device, cap=None):
             side = _SIDE_STREAM[dev] = torch.cuda.Stream(device=dev, priority=-1)
     from .device import _host_block
     one = head + cap
+    # Page-locked blocks and device buffers belong to THIS exchange until _exchange_collect has seen its headers (round 2 handed them
+    # out of rings by counter: a block packed for a recording that was still waiting for the ordered thread came round again after
+    # 8 or 24 allocations and was overwritten with another recording's rows).  `release` = what goes back to the pools then.
+    release = []
     if k_rec == 1 and getattr(packed_list[0], "block", None) is not None and packed_list[0].block_cap == cap:
-        block = packed_list[0].block                      # built by pack_rows on a host-stage thread
+        block = packed_list[0].block                      # built by pack_rows on a host-stage thread (released with the PackedRows)
     else:
         # recycled host memory (page-locked when it goes to a GPU); bytes past a payload are never read by anyone
-        block = _pinned_block(k_rec * one, slots=8) if dev.type == "cuda" else _host_block(k_rec * one)[:k_rec * one]
+        if dev.type == "cuda" or _FORCE_PINNED_POOL:
+            block = _pinned_get(k_rec * one)
+            release.append(block)
+        else:
+            block = _host_block(k_rec * one)[:k_rec * one]
         for k, packed in enumerate(packed_list):
             if getattr(packed, "block", None) is not None and packed.block_cap == cap:
                 block[k * one:(k + 1) * one] = packed.block
@@ -331,17 +340,13 @@ def _exchange_issue(packed_list, nchains, device, cap=None):
             # pipeline the hipMalloc behind it waits for the device.  Sixteen = the executor's depth: a slot comes round again
             # only after its recording has long left the post stage (which reads the payloads out of `out` on rank 0).
             rk = (dev, world, k_rec, one)
-            ring = _DEV_RING.setdefault(rk, [])
-            if len(ring) < 16:
-                ring.append((torch.empty(k_rec * one, dtype=torch.uint8, device=dev), torch.empty((world, k_rec * one), dtype=torch.uint8, device=dev)))
-                t, out = ring[-1]
-            else:
-                t, out = ring[_DEV_SEQ[0] % 16]
-            _DEV_SEQ[0] += 1
+            pair = _dev_get(rk)
+            t, out = pair.t, pair.out
             t.copy_(torch.from_numpy(block), non_blocking=True)
         else:
             t = torch.from_numpy(block)
             out = None
+            pair = None
         if hasattr(dist, "all_gather_into_tensor") and dev.type == "cuda":
             dist.all_gather_into_tensor(out.view(-1), t)
         else:
@@ -359,38 +364,83 @@ def _exchange_issue(packed_list, nchains, device, cap=None):
             heads_host.copy_(out.view(world, k_rec, one)[:, :, :head], non_blocking=True)
             done.record(side)
     return {"rows": packed_list, "nchains": nchains, "device": device, "cap": cap, "head": head, "out": out, "side": side, "key": key,
-            "keep": block, "heads_host": heads_host, "done": done}
+            "keep": block, "heads_host": heads_host, "done": done, "release": release, "pair": pair}
 
 
-_DEV_RING, _DEV_SEQ = {}, [0]
-_PIN_RING, _PIN_LOCK = {}, __import__("threading").Lock()
+_FORCE_PINNED_POOL = False          # tests: use the page-locked pool's bookkeeping without a GPU (plain memory)
+_PIN_FREE, _PIN_OWNED, _PIN_LOCK = {}, {}, __import__("threading").Lock()
 
 
-def _pinned_block(nbytes, slots=24):
-    """A page-locked host block of nbytes from a ring of `slots` per size: whoever got a slot may use it until `slots` more have been
-    handed out -- more than the executor has recordings in flight.  A copy to the device out of pageable memory is staged by the
-    runtime in pieces, each of which the calling thread waits for on a busy GPU; out of page-locked memory it is one asynchronous
-    transfer.  The blocks are ordinary (cached) memory registered with the runtime once (pm_host_pin), not memory the runtime
-    allocated page-locked: the CPU writes and reads the latter at ~1 GB/s here (2.5 ms to put four half-megabyte blocks together),
-    and the packing and the headers are CPU work.  (The general pool of device.py is not used for these: up to sixteen are alive at a
-    time, and pinning and unpinning pool blocks as they come and go costs milliseconds each.)"""
+def _pinned_get(nbytes):
+    """A page-locked host block of nbytes that belongs to the caller until _pinned_put.  A copy to the device out of pageable memory is
+    staged by the runtime in pieces, each of which the calling thread waits for on a busy GPU; out of page-locked memory it is one
+    asynchronous transfer.  The blocks are ordinary (cached) memory registered with the runtime once (pm_host_pin), not memory the
+    runtime allocated page-locked: the CPU writes and reads the latter at ~1 GB/s here (2.5 ms to put four half-megabyte blocks
+    together), and the packing and the headers are CPU work.  Blocks live for the process's life and go round through a free list per
+    size: in steady state nothing is pinned or unpinned (that costs milliseconds each)."""
     import ctypes
     from ._native import lib
     from .device import Context
     with _PIN_LOCK:
-        ring = _PIN_RING.setdefault(nbytes, [[], 0])
-        if len(ring[0]) < slots:
-            blk = np.zeros(nbytes, dtype=np.uint8)
-            try:
-                lib().pm_host_pin(Context.default().handle, blk.ctypes.data_as(ctypes.c_void_p), blk.nbytes)    # for the process's life
-            except Exception:                             # noqa: BLE001  (no GPU: plain memory will do)
-                pass
-            ring[0].append(blk)
-            t = blk
-        else:
-            t = ring[0][ring[1] % slots]
-        ring[1] += 1
-    return t
+        free = _PIN_FREE.setdefault(nbytes, [])
+        if free:
+            return free.pop()
+    blk = np.zeros(nbytes, dtype=np.uint8)
+    if not _FORCE_PINNED_POOL:
+        try:
+            lib().pm_host_pin(Context.default().handle, blk.ctypes.data_as(ctypes.c_void_p), blk.nbytes)    # for the process's life
+        except Exception:                                 # noqa: BLE001  (no GPU: plain memory will do)
+            pass
+    with _PIN_LOCK:
+        _PIN_OWNED[id(blk)] = blk
+    return blk
+
+
+def _pinned_put(blk):
+    """Hand a block back (no-op for memory that is not the pool's)."""
+    if blk is None:
+        return
+    with _PIN_LOCK:
+        if _PIN_OWNED.get(id(blk)) is blk:
+            free = _PIN_FREE.setdefault(blk.nbytes, [])
+            if not any(b is blk for b in free):
+                free.append(blk)
+
+
+class _DevPair:
+    """The device side of one exchange: the rank's block and the gathered blocks of all ranks.  Out of a free list per shape, never
+    from the allocator in steady state (a tensor the collective has used on its own stream goes back to the caching allocator only
+    behind an event, and when the cache runs dry in the middle of the pipeline the hipMalloc behind it waits for the device).  It
+    belongs to its exchange until every reader is done: the ordered thread (headers) and, on rank 0, the post stage of each of its
+    recordings (payloads) -- `users` counts them down."""
+    __slots__ = ("key", "t", "out", "users", "lock")
+
+    def release(self):
+        with self.lock:
+            self.users -= 1
+            last = self.users == 0
+        if last:
+            with _PIN_LOCK:
+                _DEV_FREE.setdefault(self.key, []).append(self)
+
+
+_DEV_FREE = {}
+
+
+def _dev_get(rk):
+    import threading
+    import torch
+    with _PIN_LOCK:
+        free = _DEV_FREE.setdefault(rk, [])
+        pair = free.pop() if free else None
+    if pair is None:
+        dev, world, k_rec, one = rk
+        pair = _DevPair()
+        pair.key, pair.lock = rk, threading.Lock()
+        pair.t = torch.empty(k_rec * one, dtype=torch.uint8, device=dev)
+        pair.out = torch.empty((world, k_rec * one), dtype=torch.uint8, device=dev)
+    pair.users = 1                                        # the exchange itself; _exchange_collect adds rank 0's readers
+    return pair
 
 
 _HEADS_RING, _HEADS_SEQ = {}, [0]       # four page-locked header blocks + events per (device, world, batch): one is in use for a step or two
@@ -414,6 +464,7 @@ def _exchange_collect(state):
     hdrs_all = heads.view(np.int64).reshape(world, k_rec, 2 + nchains)
     most = int(hdrs_all[:, :, 0].max())
     _GATHER_CAP[state["key"]] = max(1 << 16, (most + most // 4 + 4095) // 4096 * 4096)           # same value on every rank
+    pair = state.get("pair")
     results = []
     for k in range(k_rec):
         hdrs = np.ascontiguousarray(hdrs_all[:, k, :])
@@ -425,16 +476,35 @@ def _exchange_collect(state):
             results.append(None)
             continue
         blocks = [out[r, k * one:(k + 1) * one] for r in range(world)]
-        results.append(("blocks", blocks, hdrs, head, side))      # rank 0: the payloads are copied back by table_from_exchange (any thread)
+        if pair is not None:
+            with pair.lock:
+                pair.users += 1                           # released by table_from_exchange once the payloads are on the host
+        results.append(("blocks", blocks, hdrs, head, side, pair))      # rank 0: the payloads are copied back by table_from_exchange (any thread)
+    # The headers have been seen, so the copy up and the collective are complete (the event behind them has fired), and the repeats
+    # above -- the last readers of a PackedRows' payload -- are through: the host blocks go back, and the exchange's own hold on the
+    # device buffers ends (rank 0's post stages still hold theirs).
+    for blk in state.get("release", ()):
+        _pinned_put(blk)
+    for packed in state["rows"]:
+        blk = getattr(packed, "block", None)
+        if blk is not None:
+            packed.block = packed.block_cap = packed.payload = None
+            _pinned_put(blk)
+    if pair is not None:
+        pair.release()
     return results
 
 
-def _streams_from_blocks(blocks, hdrs, head, side):
+def _streams_from_blocks(blocks, hdrs, head, side, pair=None):
     import torch
     world = len(blocks)
     used = int(hdrs[:, 0].max())
-    with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-        got = torch.stack([b[head:head + used] for b in blocks]).cpu().numpy()
+    try:
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            got = torch.stack([b[head:head + used] for b in blocks]).cpu().numpy()
+    finally:
+        if pair is not None:
+            pair.release()                                # the payloads are on the host: this reader is done with the device buffers
     return [got[r, :int(hdrs[r, 0])] for r in range(world)], hdrs[:, 2:].sum(axis=0).tolist()
 
 

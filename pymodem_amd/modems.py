@@ -56,6 +56,10 @@ class _DeviceStage:
         hit = self._dev.get(name)
         if hit is None or hit[0] != key[1]:
             self._dev[name] = (key[1], self._ctx.upload(host))
+            # once per constant: the copy is complete before anybody can use it -- stage objects move between contexts (the pipelined
+            # executor's demod stream, a slicer worker's stream for the deferred sweep fallback), and a kernel on another stream is
+            # not ordered behind a copy on this one
+            self._ctx.sync()
         return self._dev[name][1]
 
     def _input(self, audio):

@@ -18,7 +18,13 @@ import torch.distributed as dist
 from pymodem_amd import dist as pdist
 from pymodem_amd.packet_meta import PacketMeta
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dist.init_process_group("gloo", rank=rank, world_size=world)
+backend, device = os.environ.get("PM_TEST_BACKEND", "gloo"), os.environ.get("PM_TEST_DEVICE") or None
+if backend == "nccl":
+    import torch
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+else:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
 g = np.load(os.path.join(sys.argv[1], "tests", "golden", "wav_chains.npz"))
 names = json.load(open(os.path.join(sys.argv[1], "tests", "golden", "wav_chains_summary.json")))["afsk_300"]["chains"]
 mine = pdist.shard_chains(len(names), rank, world)
@@ -33,7 +39,18 @@ for c in mine:
     pk[c] = lst
 from pymodem_amd._native import packet_dtype
 rows = {}
-for c, lst in pk.items():                # the same packets as pm_packet rows (what the native codecs hand out)
+pk_all = dict(pk)
+for c in range(len(names)):              # (every rank can build every chain's rows: what rank 0 must end up with is known everywhere)
+    if c in pk_all:
+        continue
+    lens, data, addr, corr = g[f"afsk_300__c{c}_pkt_len"], g[f"afsk_300__c{c}_pkt_data"], g[f"afsk_300__c{c}_pkt_addr"], g[f"afsk_300__c{c}_pkt_corrected"]
+    pos, lst = 0, []
+    for k in range(len(lens)):
+        p = PacketMeta(); p.data = data[pos:pos + lens[k]].tolist(); pos += int(lens[k])
+        p.streamaddress, p.BytesCorrected, p.SourceDecoder = int(addr[k]), int(corr[k]), names[c]
+        lst.append(p)
+    pk_all[c] = lst
+for c, lst in pk_all.items():            # the same packets as pm_packet rows (what the native codecs hand out)
     r = np.zeros(len(lst), dtype=packet_dtype())
     for k, p in enumerate(lst):
         p.CalcCRC(); p.Validate()
@@ -41,10 +58,12 @@ for c, lst in pk.items():                # the same packets as pm_packet rows (w
         r[k]["calculated_crc"], r[k]["carried_crc"], r[k]["valid_crc"], r[k]["valid_header"] = p.CalculatedCRC, p.CarriedCRC, p.ValidCRC, p.ValidHeader
         r[k]["data"][:len(p.data)] = p.data
     rows[c] = r
+rows_all = rows
+rows = {c: rows_all[c] for c in mine}
 pdist._GATHER_CAP[(world, len(names))] = 4096      # too small on purpose: the first exchange must notice and repeat itself
-first = pdist.gather_rows({c: r.copy() for c, r in rows.items()}, len(names), names)
+first = pdist.gather_rows({c: r.copy() for c, r in rows.items()}, len(names), names, device)
 assert pdist._GATHER_CAP[(world, len(names))] > 4096
-table = pdist.gather_rows(rows, len(names), names)  # steady state: one collective
+table = pdist.gather_rows(rows, len(names), names, device)  # steady state: one collective
 if rank == 0:
     assert np.array_equal(first.rows, table.rows) and first.counts == table.counts
     assert table.counts == [len(g[f"afsk_300__c{c}_pkt_len"]) for c in range(len(names))]
@@ -58,7 +77,7 @@ else:
 # what the synchronous exchange gave
 for batch in (1, 2):
     pdist._GATHER_CAP[(world, len(names))] = 4096
-    ex = pdist.Exchanger(len(names), batch=batch)
+    ex = pdist.Exchanger(len(names), device, batch=batch)
     futs = [ex.step({c: r.copy() for c, r in rows.items()}) for _ in range(3)]
     if batch == 1:
         assert futs[0].done() and futs[1].done() and not futs[2].done()        # each step resolves the one before it
@@ -72,8 +91,40 @@ for batch in (1, 2):
         else:
             assert t2 is None
     assert pdist._GATHER_CAP[(world, len(names))] > 4096
+# Many recordings packed for the wire BEFORE the ordered thread gets to any of them, across a capacity growth (the first recording
+# does not fit the agreed capacity, the blocks of the others were built for the old one): every recording must come out with its own
+# rows.  Round 2 handed the page-locked blocks out of a ring by counter and a waiting recording's block came round again (ADVICE r2).
+from pymodem_amd.packet_meta import PacketTable
+pdist._FORCE_PINNED_POOL = device is None          # without a GPU: the pool's bookkeeping on plain memory
+def rec_rows(k, chains):
+    out = {}
+    for c in chains:
+        r = rows_all[c]
+        r = r.copy() if k == 0 else r[:(k + c) % 3 + 1].copy()
+        r["streamaddress"] += 100000 * k
+        out[c] = r
+    return out
+for batch in (1, 3):
+    pdist._GATHER_CAP[(world, len(names))] = 4096
+    ex = pdist.Exchanger(len(names), device, batch=batch)
+    NREC = 30
+    packed = [pdist.pack_rows(rec_rows(k, mine), len(names), pinned=device is not None) for k in range(NREC)]
+    assert any(p.block is not None for p in packed[1:])
+    futs = [ex.step(p) for p in packed]
+    ex.flush()
+    for k, f in enumerate(futs):
+        t = pdist.table_from_exchange(f.result(), names)
+        if rank == 0:
+            want = PacketTable(rec_rows(k, range(len(names))), names)
+            assert t.counts == want.counts, (k, t.counts, want.counts)
+            for field in ("streamaddress", "len", "calculated_crc", "source_decoder"):
+                assert np.array_equal(t.heads[field], want.heads[field]), (batch, k, field)
+            assert np.array_equal(t.rows["data"], want.rows["data"]), (batch, k)
+    free = sum(len(v) for v in pdist._PIN_FREE.values())
+    assert free == len(pdist._PIN_OWNED), (free, len(pdist._PIN_OWNED))      # every block went back to the pool
+pdist._FORCE_PINNED_POOL = False
 for _ in range(2):                       # twice: the exchange must be repeatable
-    got = pdist.gather_packets(pk, names)
+    got = pdist.gather_packets(pk, names, device)
 if rank == 0:
     arr = pdist.correlate(got, len(names), 8000 / 40)
     u = arr.unique_packet_array
@@ -117,10 +168,11 @@ def test_record_round_trip(golden):
         assert all(p.SourceDecoder == f"chain{c}" for p in back.get(c, []))
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_multi_rank_gather_and_dedup(tmp_path, golden, world):
-    """world 2: ranks interleave the 5 chains; world 4: one rank owns two chains, one of the others none with packets -- the
-    exchange must cope with empty contributions as well."""
+    """world 2: ranks interleave the 5 chains; world 4: one rank owns two chains, one of the others none with packets; world 8 (the
+    node the scaling bench runs on): three ranks own no chain at all -- the exchange must cope with empty contributions as well.
+    Every world also runs 30 recordings that were packed for the wire before any was exchanged, across a capacity growth."""
     g = golden("wav_chains")
     summ = json.load(open(os.path.join(GOLDEN, "wav_chains_summary.json")))["afsk_300"]
     script = tmp_path / "worker.py"
@@ -142,3 +194,19 @@ def test_multi_rank_gather_and_dedup(tmp_path, golden, world):
     assert res["per_chain"] == {"0": 5, "2": 48, "3": 47}
     tab = json.loads([l for l in outs[0][0].splitlines() if l.startswith("TABLE ")][0][6:])
     assert tab["good"] == 49 and tab["bad"] == 6 and tab["addr"] == res["addr"] and tab["dec"] == res["dec"]
+
+
+@pytest.mark.gpu
+def test_forced_one_rank_rccl_exchange_on_the_gpu(tmp_path, golden):
+    """The same worker with the collectives on the GPU (backend nccl = RCCL, one rank, PYMODEM_AMD_FORCE_GATHER: the exchange runs
+    although nobody else is there): page-locked blocks and device buffers out of their pools, 30 recordings packed before any is
+    exchanged, a capacity growth in between."""
+    summ = json.load(open(os.path.join(GOLDEN, "wav_chains_summary.json")))["afsk_300"]
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29400 + os.getpid() % 500),
+               PM_TEST_BACKEND="nccl", PM_TEST_DEVICE="cuda:0", PYMODEM_AMD_FORCE_GATHER="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    tab = json.loads([l for l in p.stdout.splitlines() if l.startswith("TABLE ")][0][6:])
+    assert tab["good"] == summ["good"] == 49 and tab["bad"] == summ["bad"] == 6

@@ -334,8 +334,7 @@ def test_whole_chain_capacity_error_keeps_the_run():
     nc.close()
 
 
-@pytest.mark.parametrize("demod_streams", [1, 2])
-def test_recording_pipeline_soak(config_lines, demod_streams):
+def test_recording_pipeline_soak(config_lines):
     """Ninety recordings of three different kinds through one pipeline, several in flight on every stage: each result equals the
     one-at-a-time result for its kind (bitmap slots, slicer streams, host and post stages never mix recordings up)."""
     from pymodem_amd import chain_builder as cb, chain_execute as ce, siggen
@@ -344,7 +343,7 @@ def test_recording_pipeline_soak(config_lines, demod_streams):
     kinds[1] = kinds[1][: len(kinds[1]) // 4].copy()          # very different lengths: slicers finish out of submission order,
     kinds[2] = np.tile(kinds[2], 3)                           # so a slicer stream must belong to a task, not to a recording index
     want = [ce.process_chains_table([cb.build_chain(48000, l) for l in lines], a) for a in kinds]
-    pipe = ce.RecordingPipeline(demod_streams=demod_streams)
+    pipe = ce.RecordingPipeline()
     seen = []
     futures = []
     for k in range(90):
@@ -424,7 +423,7 @@ def test_deferred_sweep_fallback_on_degenerate_input(config_lines, kind, monkeyp
     want = [O.run_chain(O.build_chain(48000, l), audio, canon=True) for l in lines]
     redone = []
     real = ce.resolve_sweeps
-    monkeypatch.setattr(ce, "resolve_sweeps", lambda *a: redone.append(real(*a)) or redone[-1])
+    monkeypatch.setattr(ce, "resolve_sweeps", lambda *a, **k: redone.append(real(*a, **k)) or redone[-1])
     st = {}
     ce.process_chains_device([cb.build_chain(48000, l) for l in lines], audio, stages=st)
     if kind == "silence":
@@ -442,6 +441,38 @@ def test_deferred_sweep_fallback_on_degenerate_input(config_lines, kind, monkeyp
     for r in rows:
         for c in range(len(lines)):
             assert np.array_equal(r[c], ref[c])
+    # The way bench.py drives it: ONE set of modem objects for every recording (reset in between), recordings uploaded a step ahead
+    # (prefetch), degenerate and ordinary recordings interleaved, a dozen in flight.  The fallback runs on a slicer worker's thread
+    # many recordings after the demod: it must neither disturb the modems the submitting thread is using nor read an upload buffer
+    # that already holds a later recording.
+    from pymodem_amd import siggen
+    good = siggen.recording("afsk1200_ax25", 48000, packets=3, seed=5, noise_sigma=500.0, payload_len=(20, 60))[0][:n]
+    quiet2 = np.zeros(len(good), np.int16) if kind == "silence" else (np.random.default_rng(4).integers(-1, 2, len(good))).astype(np.int16)
+    kinds = [good, quiet2]
+    refs = [ce.process_chains_table([cb.build_chain(48000, l) for l in lines], a) for a in kinds]
+    modems = [cb.ModemConfigurator(48000, l["modem"]) for l in lines]
+
+    def shared_chains():
+        out = []
+        for l, m in zip(lines, modems):
+            m.reset()
+            out.append([l["object_name"], m, cb.SlicerConfigurator(48000, l["slicer"]), cb.StreamConfigurator(l["stream"]),
+                        cb.CodecConfigurator(l["codec"], l["object_name"])])
+        return out
+    del redone[:]
+    pipe = ce.RecordingPipeline()
+    order = [(k * 3 + k // 4) % 2 for k in range(24)]
+    futs, nxt = [], pipe.prefetch(kinds[order[0]])
+    for i, which in enumerate(order):
+        cur, nxt = nxt, (pipe.prefetch(kinds[order[i + 1]]) if i + 1 < len(order) else None)
+        futs.append((which, pipe.submit(shared_chains(), cur)))
+    for which, f in futs:
+        r = f.result()
+        for c in range(len(lines)):
+            assert np.array_equal(r[c], refs[which][c]), (which, c)
+    pipe.close()
+    if kind == "silence":
+        assert sum(redone) >= order.count(1)
 
 
 def test_bench_line_contract_with_and_without_the_exchange(tmp_path):
