@@ -323,6 +323,7 @@ def measure(args, env):
         return finish(ce.process_chains_split(build_chains(), d_audio)())
 
     stage_ms = {}
+    steady = {}
     pipes = {}
     # The carrier-loop workloads (BASELINE configs[1] and [4]): a step is still one recording, but up to --loop-batch recordings go
     # through ONE engine run -- the sequential carrier loop of every recording x chain on a lane of its own, all of them advancing
@@ -379,6 +380,13 @@ def measure(args, env):
                 pipes.pop("main").close()
             stage_ms.clear()
             stage_ms.update({s: round(v / max(k, 1) * 1e3, 3) for s, v in pipe.stage_seconds.items()})
+            # when each recording left its last stage: the pace between the 6th and the 5th-from-last is the pipeline's steady state,
+            # without the fill (first demods alone on the GPU) and the drain (the last batch, its host stage, de-dup)
+            done = sorted(max(v for kk, v in rec.items() if kk in ("post1", "finish1", "host1")) for rec in pipe.timeline if "host1" in rec)
+            steady.clear()
+            if len(done) >= 16:
+                steady["ms_per_step"] = round((done[-6] - done[5]) / (len(done) - 11) * 1e3, 4)
+                steady["steps"] = len(done) - 11
             if os.environ.get("BENCH_TIMELINE"):              # diagnostic: host clock at every stage boundary of every recording
                 t00 = pipe.timeline[0]["submit0"] if pipe.timeline else 0
                 for i, rec in enumerate(pipe.timeline):
@@ -403,7 +411,9 @@ def measure(args, env):
         sides.append(pymodem_amd.Context.side(dev_index, 101, high_priority=False))       # the demod stream on the CUs the slicers leave
 
     def run_steps_uploading(k):
-        """The same pipeline, but every step's recording starts in host memory: its copy to HBM runs one step ahead on a copy stream."""
+        """The same pipeline, but every step's recording starts in host memory: its copy to HBM runs one step ahead on a copy stream.
+        The source is page-locked (registered once, below): out of pageable memory the runtime stages the copy in pieces at ~45 GB/s,
+        which bounded this figure in round 2."""
         pipe = pipes.get("upload")                            # kept across the warm-up and the timed call, like the main one
         if pipe is None:
             pipe = pipes["upload"] = ce.RecordingPipeline(slice_workers=args.slice_workers)
@@ -518,14 +528,22 @@ def measure(args, env):
     if loop_wl:
         sides.remove(engine.front)
         lb.close_engines()                                    # the engine's work buffers and bitmap sets (gigabytes) go back
+    per_rank_ms = None
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device or "cpu")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        mine_t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device or "cpu")
+        every = [torch.zeros_like(mine_t) for _ in range(world)]
+        torch.distributed.all_gather(every, mine_t)
+        per_rank_ms = [round(float(v.item()) / args.steps * 1e3, 4) for v in every]
+        elapsed = max(float(v.item()) for v in every)           # the slowest rank sets the job's time
 
     # end to end including the recording's way into HBM, overlapped: K more steps with every recording uploaded one step ahead
     h2d_overlapped = None
+    pinned_source = False
     if args.overlap >= 2 and not loop_wl:
+        import ctypes
+        from pymodem_amd._native import lib as _lib
+        pinned_source = os.environ.get("BENCH_PIN_SOURCE", "1") != "0" and \
+            _lib().pm_host_pin(ctx.handle, audio.ctypes.data_as(ctypes.c_void_p), audio.nbytes) == 0
         run_steps_uploading(args.warmup)
         fence()
         t_u = time.perf_counter()
@@ -539,6 +557,8 @@ def measure(args, env):
             tu = torch.tensor([h2d_overlapped], dtype=torch.float64, device=coll_device or "cpu")
             torch.distributed.all_reduce(tu, op=torch.distributed.ReduceOp.MAX)
             h2d_overlapped = float(tu.item())
+    if pinned_source:
+        _lib().pm_host_unpin(audio.ctypes.data_as(ctypes.c_void_p))
     # the recording's way into HBM, outside the timed region (the boundary hands over a host buffer): pageable int16 -> device
     t_up = time.perf_counter()
     d_again = ctx.upload(audio)
@@ -546,6 +566,7 @@ def measure(args, env):
     h2d_ms = (time.perf_counter() - t_up) * 1e3
     del d_again
 
+    dinfo = dist_info(use_dist)                   # (a collective: every rank)
     if rank == 0:
         total_samples = float(args.samples) * nchains * args.steps
         value = total_samples / elapsed / 1e6
@@ -568,18 +589,29 @@ def measure(args, env):
             "metric": "Msamples/s through demod_chain", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "value_with_h2d_overlapped": None if h2d_overlapped is None else round(float(args.samples) * nchains * args.steps / h2d_overlapped / 1e6, 3),
+            "steady_state_ms_per_step": steady.get("ms_per_step"),
+            "steady_state_value": None if not steady else round(float(args.samples) * nchains / (steady["ms_per_step"] * 1e-3) / 1e6, 3),
+            "ms_per_step_by_rank": per_rank_ms,
             "config": {"workload": f"{args.workload}: {desc}" + extra_chains_note(args, nchains), "chains_per_gpu": (cpg if args.scaling == "weak" else round(nchains / world, 3)), "chains_total": nchains,
                        "samples_per_recording": args.samples, "sample_rate": args.rate,
                        "buffer": BUFFER_DESC[args.buffer] + ", resident in HBM",
                        "parallelism": (f"chains sharded {cpg}/GPU x {world} GPU, packet gather to rank 0" if args.scaling == "weak" else
                                        f"the config's {nchains} chains divided over {world} GPU (contiguous blocks), packet gather to rank 0"),
-                       "dist": dist_info(use_dist),
+                       "dist": dinfo,
                        "overlap": ("carrier-loop batch engine: every recording of a run in flight at once" if loop_wl else
                                    {0: "none", 1: "host half of step k behind GPU half of step k+1",
                                     2: "3-stage pipeline: demod(k+1) | slice(k) on a side stream | host(k-1)"}[min(args.overlap, 2)]),
-                       "loop_batch": loop_info},
+                       "loop_batch": loop_info,
+                       "scaling_note": ("carrier-loop workload: a GPU's time per run is one recording's worth of sequential loop steps however "
+                                        "many loops run beside each other, so per-GPU throughput is set by recordings x chains in flight "
+                                        "(--loop-batch x chains per GPU); sharding 8 chains per GPU over N GPUs scales by construction (no "
+                                        "data-path collective; one packet gather per recording)" if loop_wl else None)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_source": None if traffic is None else "committed rocprofv3 PMC passes of this workload (profiles/*_pmc.json: FETCH_SIZE "
+                                           "and WRITE_SIZE in separate runs, x1024, FETCH doubled per the gfx950 note), per launch of this kernel class; "
+                                           "counters cannot be read from inside the process",
                          "avg_kernel_ms": round(avg_ms, 5), "launches": dom_n, "algorithmic_bytes_per_launch": round(per_launch_bytes),
                          "stage": "FIR/correlator", "dominant_by_time": by_time,
                          "alone": None if alone_ms is None else {
@@ -612,10 +644,11 @@ def measure(args, env):
             "h2d": {"ms": round(h2d_ms, 3), "bytes": int(audio.nbytes),
                     "value_with_h2d": round(float(args.samples) * nchains / (elapsed / args.steps + h2d_ms * 1e-3) / 1e6, 3),
                     "value_with_h2d_overlapped": None if h2d_overlapped is None else round(float(args.samples) * nchains * args.steps / h2d_overlapped / 1e6, 3),
+                    "overlapped_source_page_locked": bool(pinned_source),
                     "note": "value_with_h2d: one upload of the recording from pageable host memory, measured after the timed region and added "
-                            "to every step un-overlapped.  value_with_h2d_overlapped: a second timed run of the same K steps in which every "
-                            "step's recording starts in host memory and is copied to HBM one step ahead on a copy stream "
-                            "(RecordingPipeline.prefetch).  `value` itself has the recording resident in HBM"},
+                            "to every step un-overlapped.  value_with_h2d_overlapped (also a top-level field): a second timed run of the same K "
+                            "steps in which every step's recording starts in page-locked host memory and is copied to HBM one step ahead on a "
+                            "copy stream (RecordingPipeline.prefetch).  `value` itself has the recording resident in HBM"},
             "pipeline_stage_ms_per_step": stage_ms or None,
             "host_cpu_ms_per_step": round(host_cpu_ms, 3), "host_cores_visible": len(os.sched_getaffinity(0)),
             "slicer": chains_ref[0][2].last_stats if chains_ref else None,
@@ -642,7 +675,16 @@ def dist_info(use_dist):
     if not use_dist:
         return None
     import torch.distributed as dist
-    return {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rank0_of": dist.get_world_size()}
+    seen = dist.get_world_size()
+    try:                                          # every rank says which GPU it drives: what the collectives really span
+        import torch
+        mine = [torch.cuda.current_device() if torch.cuda.is_available() else -1, int(os.environ.get("LOCAL_RANK", "0"))]
+        every = [None] * seen
+        dist.all_gather_object(every, mine)
+    except Exception:                             # noqa: BLE001
+        every = None
+    return {"world_size": seen, "backend": dist.get_backend(), "rank0_of": seen,
+            "ranks_seen_by_rccl": seen if dist.get_backend() == "nccl" else 0, "device_and_local_rank_by_rank": every}
 
 
 def pmc_traffic(args, kernel_class):
