@@ -9,7 +9,10 @@ import shutil
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-workload, samples = "afsk_1200_super_opt", 28_800_000
+# python tools/summarize_profiles.py <tag>             the headline collection of tools/collect_profiles.sh
+# python tools/summarize_profiles.py <tag> <workload>  one workload of tools/collect_workload_profiles.sh (gpurun_out/wl/<workload>/)
+workload, samples = (sys.argv[2] if len(sys.argv) > 2 else "afsk_1200_super_opt"), 28_800_000
+per_workload = len(sys.argv) > 2
 
 
 def short(n):
@@ -20,11 +23,12 @@ def short(n):
 import os
 
 # gpurun merges every call's files into gpurun_out/: take the newest, not the highest process id
-stats = max(glob.glob("gpurun_out/prof_stats/*/*_kernel_stats.csv"), key=os.path.getmtime)
+base = f"gpurun_out/wl/{workload}" if per_workload else "gpurun_out"
+stats = max(glob.glob(f"{base}/stats/*/*_kernel_stats.csv" if per_workload else "gpurun_out/prof_stats/*/*_kernel_stats.csv"), key=os.path.getmtime)
 shutil.copyfile(stats, f"profiles/{tag}_{workload}_kernel_stats.csv")
 res = {}
 for name, ctr in [("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")]:
-    f = max(glob.glob(f"gpurun_out/{name}/*/*_counter_collection.csv"), key=os.path.getmtime)
+    f = max(glob.glob(f"{base}/{name}/*/*_counter_collection.csv"), key=os.path.getmtime)
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         agg[short(r["Kernel_Name"])][0] += 1
@@ -32,12 +36,16 @@ for name, ctr in [("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")]:
     for k, (n, v) in agg.items():
         res.setdefault(k, {})[ctr + "_KB_avg_per_launch"] = round(v / n, 1)
         res[k][ctr + "_launches"] = n
-CLASSES = {"fir_i16": ["fir_valid_kernel<short", "fir_short_signs_i16_kernel"], "fir_f64": ["fir_valid_kernel<double", "fir_sweep_kernel", "afsk_slide_lpf_kernel"],
+CLASSES = {"fir_i16": ["fir_valid_kernel<short", "fir_short_signs_i16_kernel", "fir_rows_kernel<short"],
+           "fir_f64": ["fir_valid_kernel<double", "fir_sweep_kernel", "afsk_slide_lpf_kernel", "fir_rows_kernel<double"],
+           "loop": ["loop_kernel"], "agc": ["agc_rows_kernel", "rows_max_kernel", "rows_max_fold_kernel", "agc_rows_prepare_kernel", "agc_iter_kernel",
+                                            "max_partial_kernel", "agc_scale_kernel"],
            "afsk_correlate": ["afsk_correlate_kernel", "afsk_slide_kernel"],
            "signs": ["signs_kernel", "sweep_exact_kernel", "afsk_group_kernel", "fir_signs_batch_kernel", "pack_group_taps_kernel"],
            "slice_iter": ["slice_walk_kernel", "slice_iter_kernel"], "slice_emit": ["slice_count_kernel", "slice_scan_kernel", "slice_pack_kernel", "slice_compact_kernel"]}
 out = {"workload": workload, "samples": samples,
-       "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (two separate passes) --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+       "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (two separate passes) --output-format csv -- python3 bench.py "
+                  + (f"--workload {workload} " if per_workload else "") + "--steps 2..4 --warmup 1 --no-cpu-baseline --also 0",
        "corrections": "bytes = counter * 1024; FETCH_SIZE doubled (gfx950 reports half the bytes of a coalesced streaming read, MI355X_MICROARCH.md "
                       "HBM section; calibrated in round 1 on signs_kernel: 230.4 MB read, 115.2 MB reported). Kernels that write only a sign bitmap "
                       "(SIGNS variants) have ~N/8 bytes of writes.  `classes` groups kernel names the way pm_prof_* does (bench.py's "
@@ -55,11 +63,15 @@ for cls, prefixes in CLASSES.items():
         total = sum(out["kernels"][k]["traffic_bytes_per_launch"] * out["kernels"][k].get("FETCH_SIZE_launches", 0) for k in names)
         out["classes"][cls] = {"kernels": names, "launches": n, "traffic_bytes_per_launch": round(total / n)}
 json.dump(out, open(f"profiles/{tag}_{workload}_pmc.json", "w"), indent=1)
-shutil.copyfile("gpurun_out/kernel_bench.jsonl", f"profiles/{tag}_kernel_bench.jsonl")
-shutil.copyfile("gpurun_out/bench_default.json", f"profiles/{tag}_bench_default.json")
-for extra in ("bench_fsk_9600", "bench_overlap0", "bench_driver_cmd"):
-    if os.path.exists(f"gpurun_out/{extra}.json"):
-        shutil.copyfile(f"gpurun_out/{extra}.json", f"profiles/{tag}_{extra}.json")
+if per_workload:
+    if os.path.exists(f"{base}/stats.json") and os.path.getsize(f"{base}/stats.json"):
+        shutil.copyfile(f"{base}/stats.json", f"profiles/{tag}_bench_{workload}_under_rocprof.json")
+else:
+    shutil.copyfile("gpurun_out/kernel_bench.jsonl", f"profiles/{tag}_kernel_bench.jsonl")
+    shutil.copyfile("gpurun_out/bench_default.json", f"profiles/{tag}_bench_default.json")
+    for extra in ("bench_fsk_9600", "bench_overlap0", "bench_driver_cmd"):
+        if os.path.exists(f"gpurun_out/{extra}.json"):
+            shutil.copyfile(f"gpurun_out/{extra}.json", f"profiles/{tag}_{extra}.json")
 for k, v in out["kernels"].items():
     print(f"{k:45s} traffic {v['traffic_bytes_per_launch'] / 1e6:9.1f} MB/launch")
 print(open(f"profiles/{tag}_{workload}_kernel_stats.csv").read()[:1500])
