@@ -405,6 +405,32 @@ class FSKModem:
         return -a if self.invert else a
 
 
+def _carried(obj, key, x, taps):
+    """carry_history (the build's opt-in streaming mode, pymodem_amd.modems._DeviceStage._carry; NOT a behaviour of the reference's
+    demod(), whose every call starts its FIRs afresh): the stage's input with the last len(taps) - 1 samples of the previous calls'
+    input in front.  Off: x as it is."""
+    if not getattr(obj, "carry_history", False):
+        return x
+    h = len(taps) - 1
+    tails = obj.__dict__.setdefault("_tails", {})
+    t = tails.get(key)
+    full = np.asarray(x) if t is None else np.concatenate([t, x])
+    tails[key] = full[max(0, len(full) - h):].copy()
+    return full
+
+
+def _fir_or_empty(fir, x, taps, obj=None):
+    """carry_history: a stage whose [tail | new] is still shorter than its filter gives nothing yet.  Otherwise the FIR as called."""
+    if getattr(obj, "carry_history", False) and len(x) < len(taps):
+        return np.zeros(0)
+    return fir(x, taps)
+
+
+def _agc_piece(a, sample_rate, att, sus, dec, state):
+    if len(a):
+        agc_apply(a, sample_rate, att, sus, dec, 1.0, state=state)          # normal = max of THIS call's samples (agc.py:67)
+
+
 class BPSKModem:
     """psk.py:20-195."""
     PRESETS = {   # psk.py:26-85
@@ -434,11 +460,11 @@ class BPSKModem:
 
     def demod(self, audio, canon=False):          # psk.py:162-195
         fir = fir_canon if canon else fir_ref
-        a = np.ascontiguousarray(fir(audio, self.input_bpf), dtype=np.float64)
+        a = np.ascontiguousarray(_fir_or_empty(fir, _carried(self, "audio", audio, self.input_bpf), self.input_bpf, self), dtype=np.float64)
         att, sus, dec = self.p["agc"]
-        agc_apply(a, self.sample_rate, att, sus, dec, 1.0, state=self._agc_state())
-        d = costas_bpsk(self.loop, a)
-        return fir(d, self.rrc)
+        _agc_piece(a, self.sample_rate, att, sus, dec, self._agc_state())
+        d = costas_bpsk(self.loop, a) if len(a) else np.zeros(0)
+        return _fir_or_empty(fir, _carried(self, "loop", d, self.rrc), self.rrc, self)
 
 
 class QPSKModem:
@@ -473,11 +499,12 @@ class QPSKModem:
 
     def demod(self, audio, canon=False):          # psk.py:426-476
         fir = fir_canon if canon else fir_ref
-        a = np.ascontiguousarray(fir(audio, self.input_bpf), dtype=np.float64)
+        a = np.ascontiguousarray(_fir_or_empty(fir, _carried(self, "audio", audio, self.input_bpf), self.input_bpf, self), dtype=np.float64)
         att, sus, dec = self.p["agc"]
-        agc_apply(a, self.sample_rate, att, sus, dec, 1.0, state=self._agc_state())
-        i_arm, q_arm = costas_qpsk(self.loop, self.branch, a)
-        return fir(i_arm, self.rrc), fir(q_arm, self.rrc)
+        _agc_piece(a, self.sample_rate, att, sus, dec, self._agc_state())
+        i_arm, q_arm = costas_qpsk(self.loop, self.branch, a) if len(a) else (np.zeros(0), np.zeros(0))
+        return (_fir_or_empty(fir, _carried(self, "i_arm", i_arm, self.rrc), self.rrc, self),
+                _fir_or_empty(fir, _carried(self, "q_arm", q_arm, self.rrc), self.rrc, self))
 
 
 class MPSKModem:
@@ -520,18 +547,22 @@ class MPSKModem:
 
     def demod(self, audio, canon=False):          # psk.py:705-773
         fir = fir_canon if canon else fir_ref
-        a = np.ascontiguousarray(fir(audio, self.input_bpf), dtype=np.float64)
+        a = np.ascontiguousarray(_fir_or_empty(fir, _carried(self, "audio", audio, self.input_bpf), self.input_bpf, self), dtype=np.float64)
         att, sus, dec = self.p["agc"]
-        agc_apply(a, self.sample_rate, att, sus, dec, 1.0, state=self._agc_state())
-        imag = fir(a, self.hilbert)                                            # psk.py:714
-        if canon:
+        _agc_piece(a, self.sample_rate, att, sus, dec, self._agc_state())
+        a = np.ascontiguousarray(_carried(self, "agc", a, self.hilbert), dtype=np.float64)
+        imag = _fir_or_empty(fir, a, self.hilbert, self)                           # psk.py:714
+        if len(imag) == 0:
+            real = np.zeros(0)
+        elif canon:
             real = a[self.delay:len(a) - self.delay].copy()                    # delay FIR = pure shift
         else:
             d = np.zeros(self.delay + 1)
             d[0] = 1
             real = fir_ref(a, d)[:-self.delay]                                 # psk.py:715-716
-        i, q = mpsk_loop(self.loop, real, imag)
-        return fir(i, self.rrc), fir(q, self.rrc)
+        i, q = mpsk_loop(self.loop, real, imag) if len(imag) else (np.zeros(0), np.zeros(0))
+        return (_fir_or_empty(fir, _carried(self, "i_mix", i, self.rrc), self.rrc, self),
+                _fir_or_empty(fir, _carried(self, "q_mix", q, self.rrc), self.rrc, self))
 
 
 class AFSKPLLModem:
@@ -552,10 +583,10 @@ class AFSKPLLModem:
 
     def demod(self, audio, canon=False):          # afsk_pll.py:140-170
         fir = fir_canon if canon else fir_ref
-        a = np.ascontiguousarray(fir(audio, self.input_bpf), dtype=np.float64)
-        agc_apply(a, self.sample_rate, 500.0, 1.0, 50.0, 1.0, state=self._agc_state())
-        d = pll_afsk(self.loop, a)
-        return fir(d, self.output_lpf)
+        a = np.ascontiguousarray(_fir_or_empty(fir, _carried(self, "audio", audio, self.input_bpf), self.input_bpf, self), dtype=np.float64)
+        _agc_piece(a, self.sample_rate, 500.0, 1.0, 50.0, self._agc_state())
+        d = pll_afsk(self.loop, a) if len(a) else np.zeros(0)
+        return _fir_or_empty(fir, _carried(self, "loop", d, self.output_lpf), self.output_lpf, self)
 
 
 # =============================================================================================

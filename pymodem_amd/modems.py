@@ -112,6 +112,51 @@ class _DeviceStage:
         self._hist = np.concatenate([tail[nt - min(keep, nt):], fresh]) if (nt and keep) else fresh
         return buf
 
+    # ---- the same for modems with a carrier loop (round 3) --------------------------------------------------------------------------
+    # BPSK / MPSK / QPSK / AFSK-PLL modems are FIR -> AGC -> (FIR) -> loop -> FIR.  With carry_history every FIR of the cascade keeps the
+    # last M - 1 samples of ITS input stream and puts them in front of the next call's: band-pass over [audio tail | audio], Hilbert pair
+    # over [AGC'd tail | new AGC'd samples], matched / output filter over [loop-output tail | new loop outputs].  AGC envelope and loop
+    # registers are carried anyway (reset() clears them).  What stays per call is `normal = max(buffer)` of AGC.apply (agc.py:67): the
+    # reference normalises by the maximum of the band-passed samples of each call, and so do we -- so pieces are NOT the whole here,
+    # they are what the reference's primitives give when they are fed this way (tests/golden/make_goldens.py, psk_history).
+    def _carry(self, name, x, h):
+        """One FIR stage's input with carried history: x = this call's new samples of the stage's input stream (DeviceBuffer) ->
+        [carried tail | x] as a DeviceBuffer, remembering the last h = taps - 1 samples of it."""
+        if not self.carry_history or h <= 0:
+            return x
+        ctx = self._ctx
+        tails = self.__dict__.setdefault("_tails", {})
+        tail = tails.get(name)
+        nt = 0 if tail is None else len(tail)
+        if nt:
+            buf = ctx.scratch((self._own_key(), "carry", name), nt + x.n, x.dtype)
+            check(lib().pm_h2d(ctx.handle, buf.ptr, tail.ctypes.data_as(ctypes.c_void_p), tail.nbytes))
+            if x.n:
+                check(lib().pm_d2d(ctx.handle, buf.ptr.value + tail.nbytes, x.ptr, x.n * x.dtype.itemsize))
+        else:
+            buf = x
+        take = min(h, x.n)
+        fresh = x.view(x.n - take, take).download() if take else np.zeros(0, x.dtype)      # (waits for the stream: the tail is final)
+        keep = h - take
+        tails[name] = np.concatenate([tail[nt - min(keep, nt):], fresh]) if (nt and keep) else fresh
+        return buf
+
+    def _empty(self, tag):
+        return self._ctx.scratch((self._key(), "empty", tag), 1, np.float64).view(0, 0)
+
+    def _fir_carried(self, x, is_i16, taps_name, taps, tag=None, signs=False):
+        """_fir / _fir_signs for a stage whose input may still be shorter than its filter (carry_history: the samples wait in the
+        tail): an empty stream then."""
+        if x.n < len(taps):
+            if not self.carry_history:
+                raise ValueError(f"input of {x.n} samples is shorter than the {len(taps)}-tap filter {taps_name}")
+            if signs:
+                return self._ctx.scratch((self._own_key(), "signs", tag or taps_name), 2, np.uint64), 0
+            return self._empty(tag or taps_name)
+        if signs:
+            return self._fir_signs(x, is_i16, taps_name, taps, tag=tag)
+        return self._fir(x, is_i16, taps_name, taps, tag=tag)
+
     def _starved(self, x, signs, device_out):
         """carry_history: [tail | x] is still shorter than the cascade needs for one output -- nothing comes out of this call (the
         samples wait in the tail).  None when there is enough."""
@@ -145,6 +190,8 @@ class _DeviceStage:
         return bits, nout
 
     def _agc(self, buf):
+        if buf.n == 0:
+            return
         if not hasattr(self, "_agc_state"):
             self._agc_state = (ctypes.c_double * 2)(0.0, 0.0)
         a = self.AGC
@@ -159,6 +206,7 @@ class _DeviceStage:
         if hasattr(self, "_loop0"):
             ctypes.memmove(ctypes.byref(self._loop), self._loop0, ctypes.sizeof(Loop))
         self._hist = None                              # carry_history: the next call starts a new stream
+        self._tails = {}
 
     def _finish(self, y, device_out):
         return y if device_out else y.download()
@@ -604,29 +652,33 @@ class BPSKModem(_DeviceStage):
     def front_end(self, input_audio):
         """Band-pass + AGC (psk.py:165-168): what chains that differ only in carrier_freq share."""
         x, is_i16 = self._input(input_audio)
-        a = self._fir(x, is_i16, "input_bpf", self.input_bpf)
+        x = self._carry("audio", x, len(self.input_bpf) - 1)
+        a = self._fir_carried(x, is_i16, "input_bpf", self.input_bpf)
         self._agc(a)
         return a
 
     def front_end_key(self):
         g = self.AGC
-        return ("bpsk", float(self.sample_rate), self.input_bpf.tobytes(), (g.attack_rate, g.decay_rate, g.sustain_time, g.target_amplitude))
+        return ("bpsk", float(self.sample_rate), self.input_bpf.tobytes(), (g.attack_rate, g.decay_rate, g.sustain_time, g.target_amplitude),
+                id(self) if self.carry_history else 0)
 
     def demod(self, input_audio, device_out=False, signs=False):   # psk.py:162-195
         a = self.front_end(input_audio)
         ctx = self._ctx
         d = ctx.scratch((self._key(), "loop"), a.n, np.float64)
-        check(lib().pm_costas_bpsk(ctx.handle, ctypes.byref(self._loop), 1, self._const("wavetable", self.wavetable).ptr,
-                                   a.ptr, 0, a.n, d.ptr, a.n))
+        if a.n:
+            check(lib().pm_costas_bpsk(ctx.handle, ctypes.byref(self._loop), 1, self._const("wavetable", self.wavetable).ptr,
+                                       a.ptr, 0, a.n, d.ptr, a.n))
         return self.back_end(d, device_out, signs)
 
     def back_end(self, d, device_out=False, signs=False):
         """Matched filter on the loop output (psk.py:193)."""
         self._context()
+        d = self._carry("loop", d, len(self.rrc_taps) - 1)
         if signs:
-            bits, nout = self._fir_signs(d, False, "rrc", self.rrc_taps)
+            bits, nout = self._fir_carried(d, False, "rrc", self.rrc_taps, signs=True)
             return SignBits(bits, None, nout)
-        y = self._fir(d, False, "rrc", self.rrc_taps)
+        y = self._fir_carried(d, False, "rrc", self.rrc_taps)
         return self._finish(y, device_out)
 
     def demod_signs(self, input_audio):
@@ -695,7 +747,8 @@ class QPSKModem(_DeviceStage):
 
     def front_end(self, input_audio):
         x, is_i16 = self._input(input_audio)
-        a = self._fir(x, is_i16, "input_bpf", self.input_bpf)
+        x = self._carry("audio", x, len(self.input_bpf) - 1)
+        a = self._fir_carried(x, is_i16, "input_bpf", self.input_bpf)
         self._agc(a)
         return a
 
@@ -704,14 +757,17 @@ class QPSKModem(_DeviceStage):
         ctx = self._ctx
         i_arm = ctx.scratch((self._key(), "i_arm"), a.n, np.float64)
         q_arm = ctx.scratch((self._key(), "q_arm"), a.n, np.float64)
-        check(lib().pm_costas_qpsk(ctx.handle, ctypes.byref(self._loop), 1, self._const("wavetable", self.wavetable).ptr,
-                                   a.ptr, 0, a.n, i_arm.ptr, q_arm.ptr, a.n))
+        if a.n:
+            check(lib().pm_costas_qpsk(ctx.handle, ctypes.byref(self._loop), 1, self._const("wavetable", self.wavetable).ptr,
+                                       a.ptr, 0, a.n, i_arm.ptr, q_arm.ptr, a.n))
+        i_arm = self._carry("i_arm", i_arm, len(self.rrc_taps) - 1)
+        q_arm = self._carry("q_arm", q_arm, len(self.rrc_taps) - 1)
         if signs:
-            bi, nout = self._fir_signs(i_arm, False, "rrc", self.rrc_taps, tag="i")
-            bq, _ = self._fir_signs(q_arm, False, "rrc", self.rrc_taps, tag="q")
+            bi, nout = self._fir_carried(i_arm, False, "rrc", self.rrc_taps, tag="i", signs=True)
+            bq, _ = self._fir_carried(q_arm, False, "rrc", self.rrc_taps, tag="q", signs=True)
             return SignBits(bi, bq, nout)
-        i_out = self._fir(i_arm, False, "rrc", self.rrc_taps, tag="i_out")
-        q_out = self._fir(q_arm, False, "rrc", self.rrc_taps, tag="q_out")
+        i_out = self._fir_carried(i_arm, False, "rrc", self.rrc_taps, tag="i_out")
+        q_out = self._fir_carried(q_arm, False, "rrc", self.rrc_taps, tag="q_out")
         if device_out:
             return DeviceIQ(i_out, q_out)
         out = IQData()
@@ -783,17 +839,19 @@ class MPSKModem(_DeviceStage):
         """BPF -> AGC -> Hilbert pair (psk.py:710-716): (real, imag) DeviceBuffers of equal length.  Chains that differ
         only in carrier_freq (configs/qpsk_2400.json) share this part; see chain_execute.run_mpsk_group."""
         x, is_i16 = self._input(input_audio)
-        a = self._fir(x, is_i16, "input_bpf", self.input_bpf)
+        x = self._carry("audio", x, len(self.input_bpf) - 1)
+        a = self._fir_carried(x, is_i16, "input_bpf", self.input_bpf)
         self._agc(a)
-        imag = self._fir(a, False, "hilbert", self.hilbert_taps)
+        a = self._carry("agc", a, len(self.hilbert_taps) - 1)
+        imag = self._fir_carried(a, False, "hilbert", self.hilbert_taps)
         # the delay FIR [1,0,...,0] followed by [:-delay] is a pure shift: real[k] = a[k + delay]
-        real = a.view(self.hilbert_delay, imag.n)
+        real = a.view(self.hilbert_delay, imag.n) if imag.n else self._empty("real")
         return real, imag
 
     def front_end_key(self):
         a = self.AGC
         return ("mpsk", float(self.sample_rate), self.input_bpf.tobytes(), self.hilbert_taps.tobytes(),
-                (a.attack_rate, a.decay_rate, a.sustain_time, a.target_amplitude))
+                (a.attack_rate, a.decay_rate, a.sustain_time, a.target_amplitude), id(self) if self.carry_history else 0)
 
     def demod(self, input_audio, device_out=False, signs=False):   # psk.py:705-773
         real, imag = self.front_end(input_audio)
@@ -801,9 +859,10 @@ class MPSKModem(_DeviceStage):
         n = imag.n
         i_mix = ctx.scratch((self._key(), "i_mix"), n, np.float64)
         q_mix = ctx.scratch((self._key(), "q_mix"), n, np.float64)
-        check(lib().pm_mpsk_loop(ctx.handle, ctypes.byref(self._loop), 1, self._const("wavetable", self.wavetable).ptr,
-                                 self._const("pd", self.phase_error_table.reshape(-1), np.int32).ptr,
-                                 real.ptr, imag.ptr, 0, n, i_mix.ptr, q_mix.ptr, n))
+        if n:
+            check(lib().pm_mpsk_loop(ctx.handle, ctypes.byref(self._loop), 1, self._const("wavetable", self.wavetable).ptr,
+                                     self._const("pd", self.phase_error_table.reshape(-1), np.int32).ptr,
+                                     real.ptr, imag.ptr, 0, n, i_mix.ptr, q_mix.ptr, n))
         return self.back_end(i_mix, q_mix, device_out, signs)
 
     def demod_signs(self, input_audio):
@@ -812,12 +871,14 @@ class MPSKModem(_DeviceStage):
     def back_end(self, i_mix, q_mix, device_out=False, signs=False):
         """Matched filter on both arms of the carrier-loop output (psk.py:750-751)."""
         self._context()
+        i_mix = self._carry("i_mix", i_mix, len(self.rrc_taps) - 1)
+        q_mix = self._carry("q_mix", q_mix, len(self.rrc_taps) - 1)
         if signs:
-            bi, nout = self._fir_signs(i_mix, False, "rrc", self.rrc_taps, tag="i")
-            bq, _ = self._fir_signs(q_mix, False, "rrc", self.rrc_taps, tag="q")
+            bi, nout = self._fir_carried(i_mix, False, "rrc", self.rrc_taps, tag="i", signs=True)
+            bq, _ = self._fir_carried(q_mix, False, "rrc", self.rrc_taps, tag="q", signs=True)
             return SignBits(bi, bq, nout)
-        i_out = self._fir(i_mix, False, "rrc", self.rrc_taps, tag="i_out")
-        q_out = self._fir(q_mix, False, "rrc", self.rrc_taps, tag="q_out")
+        i_out = self._fir_carried(i_mix, False, "rrc", self.rrc_taps, tag="i_out")
+        q_out = self._fir_carried(q_mix, False, "rrc", self.rrc_taps, tag="q_out")
         if device_out:
             return DeviceIQ(i_out, q_out)
         out = IQData()
@@ -873,29 +934,33 @@ class AFSKPLLModem(_DeviceStage):
     def front_end(self, input_audio):
         """Band-pass + AGC (afsk_pll.py:143-146)."""
         x, is_i16 = self._input(input_audio)
-        a = self._fir(x, is_i16, "input_bpf", self.input_bpf)
+        x = self._carry("audio", x, len(self.input_bpf) - 1)
+        a = self._fir_carried(x, is_i16, "input_bpf", self.input_bpf)
         self._agc(a)
         return a
 
     def front_end_key(self):
         g = self.AGC
-        return ("pll", float(self.sample_rate), self.input_bpf.tobytes(), (g.attack_rate, g.decay_rate, g.sustain_time, g.target_amplitude))
+        return ("pll", float(self.sample_rate), self.input_bpf.tobytes(), (g.attack_rate, g.decay_rate, g.sustain_time, g.target_amplitude),
+                id(self) if self.carry_history else 0)
 
     def demod(self, input_audio, device_out=False, signs=False):   # afsk_pll.py:140-170
         a = self.front_end(input_audio)
         ctx = self._ctx
         d = ctx.scratch((self._key(), "loop"), a.n, np.float64)
-        check(lib().pm_pll_afsk(ctx.handle, ctypes.byref(self._loop), 1, self._const("wavetable", self.wavetable).ptr,
-                                a.ptr, 0, a.n, d.ptr, a.n))
+        if a.n:
+            check(lib().pm_pll_afsk(ctx.handle, ctypes.byref(self._loop), 1, self._const("wavetable", self.wavetable).ptr,
+                                    a.ptr, 0, a.n, d.ptr, a.n))
         return self.back_end(d, device_out, signs)
 
     def back_end(self, d, device_out=False, signs=False):
         """Output low-pass on the loop's proportional term (afsk_pll.py:168)."""
         self._context()
+        d = self._carry("loop", d, len(self.output_lpf) - 1)
         if signs:
-            bits, nout = self._fir_signs(d, False, "output_lpf", self.output_lpf)
+            bits, nout = self._fir_carried(d, False, "output_lpf", self.output_lpf, signs=True)
             return SignBits(bits, None, nout)
-        y = self._fir(d, False, "output_lpf", self.output_lpf)
+        y = self._fir_carried(d, False, "output_lpf", self.output_lpf)
         return self._finish(y, device_out)
 
     def demod_signs(self, input_audio):

@@ -555,6 +555,92 @@ def gen_segments():
     print("segments.npz:", len(d), "arrays;", json.dumps(summary))
 
 
+PSK_HISTORY_CASES = [("bpsk_300.json", "bpsk300_il2p", 48000), ("qpsk_2400.json", "qpsk2400_il2p", 48000), ("afsk_300_pll.json", "afsk300_il2p", 8000)]
+
+
+class _NoAGC:
+    def apply(self, buf):
+        pass
+
+
+def gen_psk_history():
+    """carry_history for the carrier-loop modems (the build's opt-in streaming mode): what the REFERENCE's primitives give when every FIR
+    of the cascade is fed [last M - 1 samples of its input so far | the new ones] while AGC, NCO, loop filter, PI controller,
+    slicer, LFSR and codec objects simply live on.  Nothing of the reference is restated here: its own demod() does the middle of the
+    cascade (AGC.apply with its per-call max(), the carrier loop; for MPSK the Hilbert pair over the window it is handed) with the
+    outer filters replaced by the identity tap [1.0], and the outer FIRs are numpy.convolve(..., 'valid') with the modem's own taps,
+    as demod() calls it.  A generated recording in three uneven pieces (the first shorter than the filters)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from pymodem_amd import siggen
+    one = np.array([1.0])
+    d, summary = {}, {}
+    for cfgname, mode, rate in PSK_HISTORY_CASES:
+        audio, _ = siggen.recording(mode, rate, packets=3, seed=5, noise_sigma=400.0, payload_len=(20, 40))
+        cuts = [0, 173, len(audio) // 2 + 137, len(audio)]
+        line = [l for l in load_config(cfgname) if l.get("object_type") == "demod_chain"][0]
+        chain = build_chain(rate, line)
+        modem = chain[1]
+        kind = type(modem).__name__
+        bpf = np.array(modem.input_bpf, dtype=np.float64)
+        out_taps = np.array(modem.output_lpf if kind == "AFSKPLLModem" else modem.rrc.taps, dtype=np.float64)
+        modem.input_bpf = one
+        if kind == "AFSKPLLModem":
+            modem.output_lpf = one
+        else:
+            modem.rrc.taps = one
+        tails = {}
+
+        def window(key, new, taps):
+            t = tails.get(key)
+            full = np.asarray(new, dtype=np.float64) if t is None else np.concatenate([t, np.asarray(new, dtype=np.float64)])
+            tails[key] = full[max(0, len(full) - (len(taps) - 1)):].copy()
+            return full
+
+        def valid(x, taps):
+            return np.convolve(x, taps, "valid") if len(x) >= len(taps) else np.zeros(0)
+        tag = cfgname[:-5]
+        d[tag + "__audio"] = audio
+        counts = []
+        for k in range(3):
+            seg = audio[cuts[k]:cuts[k + 1]]
+            a = valid(window("audio", seg, bpf), bpf)
+            with quiet():
+                if kind == "MPSKModem":
+                    if len(a):
+                        modem.AGC.apply(a)                               # per-call max(), envelope carried (agc.py:61-80)
+                    w = window("agc", a, modem.Hilbert.taps)
+                    if len(w) >= len(modem.Hilbert.taps):
+                        agc, modem.AGC = modem.AGC, _NoAGC()
+                        iq = modem.demod(w)                              # Hilbert pair over the window, loop, identity filters
+                        modem.AGC = agc
+                        i_new, q_new = np.asarray(iq.i_data, dtype=np.float64), np.asarray(iq.q_data, dtype=np.float64)
+                    else:
+                        i_new = q_new = np.zeros(0)
+                    demod = IQData()
+                    demod.i_data = valid(window("i", i_new, out_taps), out_taps)
+                    demod.q_data = valid(window("q", q_new, out_taps), out_taps)
+                    n_out = len(demod.i_data)
+                else:
+                    loop_out = np.asarray(modem.demod(a), dtype=np.float64) if len(a) else np.zeros(0)     # AGC.apply + loop, identity filters
+                    demod = valid(window("loop", loop_out, out_taps), out_taps)
+                    n_out = len(demod)
+                sliced = chain[2].slice(demod) if n_out else []
+                stream = chain[3].stream_unscramble_8bit(sliced)
+                pkts = chain[4].decode(stream)
+            prefix = f"{tag}__seg{k}"
+            d[prefix + "_n_demod"] = np.array(n_out, dtype=np.int64)
+            d[prefix + "_slice_data"] = np.array([s.data for s in sliced], dtype=np.uint8)
+            d[prefix + "_slice_addr"] = np.array([s.address for s in sliced], dtype=np.int64)
+            pkts_to_dict(pkts, prefix + "_pkt", d)
+            counts.append(len(pkts))
+        whole = run_chain(build_chain(rate, line), audio, {}, "x", keep_demod=False)
+        summary[tag] = {"rate": rate, "cuts": cuts, "packets_per_segment": counts, "packets_uncut": len(whole)}
+    np.savez_compressed(os.path.join(OUT, "psk_history.npz"), **d)
+    with open(os.path.join(OUT, "psk_history_summary.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+    print("psk_history.npz:", len(d), "arrays;", json.dumps(summary))
+
+
 def gen_reports():
     """Report text of the reference (packet_meta.py:283-370) for the bundled recording and two generated ones, chains added
     in config order (the reference CLI's own order depends on process completion)."""
@@ -591,13 +677,15 @@ def copy_data_files():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["taps", "prims", "synth", "wav", "signal", "reports", "copy", "qpsk", "segments"]
+    which = sys.argv[1:] or ["taps", "prims", "synth", "wav", "signal", "reports", "copy", "qpsk", "segments", "psk_history"]
     if "taps" in which:
         gen_taps()
     if "prims" in which:
         gen_primitives()
     if "segments" in which:
         gen_segments()
+    if "psk_history" in which:
+        gen_psk_history()
     if "qpsk" in which:
         gen_qpsk_modem()
     if "synth" in which:

@@ -105,3 +105,56 @@ def test_carried_fir_history_makes_pieces_equal_the_whole(golden, config_lines, 
     plain = cb.build_chain(48000, line)
     n = sum(len(plain[2].slice(plain[1].demod(audio[a:b]))) for a, b in zip(cuts[1:], cuts[2:]))
     assert n <= len(data)
+
+
+PSK_HISTORY = ["bpsk_300", "qpsk_2400", "afsk_300_pll"]
+
+
+def _history_pieces(golden, tag):
+    g = golden("psk_history")
+    summ = json.load(open(os.path.join(GOLDEN, "psk_history_summary.json")))[tag]
+    audio = g[tag + "__audio"]
+    return g, summ["rate"], [audio[a:b] for a, b in zip(summ["cuts"][:-1], summ["cuts"][1:])]
+
+
+@pytest.mark.parametrize("tag", PSK_HISTORY)
+def test_oracle_carries_fir_history_through_the_carrier_loop_modems(golden, config_lines, tag):
+    """carry_history for BPSK / MPSK / AFSK-PLL: every FIR of the cascade continues from the last M - 1 samples of its input, AGC
+    envelope and loop registers live on, AGC.apply normalises by each call's own maximum (agc.py:67) -- against what the reference's
+    primitives give when fed that way (tests/golden/make_goldens.py psk_history: three uneven pieces, the first shorter than the
+    filters)."""
+    g, rate, pieces = _history_pieces(golden, tag)
+    chain = O.build_chain(rate, config_lines(tag + ".json")[0])
+    chain[0].carry_history = True                  # (the oracle's chain is (modem, slicer, stream, codec))
+    total = 0
+    for k, seg in enumerate(pieces):
+        r = O.run_chain(chain, seg)
+        check_segment(g, f"{tag}__seg{k}", r["slice_data"], r["slice_addr"], r["packets"])
+        total += len(r["slice_data"])
+    assert total > 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", PSK_HISTORY)
+@pytest.mark.parametrize("run", ["stages", "signs", "group"])
+def test_gpu_carries_fir_history_through_the_carrier_loop_modems(golden, config_lines, tag, run):
+    from pymodem_amd import chain_builder as cb, chain_execute as ce
+    g, rate, pieces = _history_pieces(golden, tag)
+    chain = cb.build_chain(rate, config_lines(tag + ".json")[0])
+    chain[1].carry_history = True
+    oracle = O.build_chain(rate, config_lines(tag + ".json")[0])
+    oracle[0].carry_history = True
+    for k, seg in enumerate(pieces):
+        if run == "stages":
+            sliced = chain[2].slice(chain[1].demod(seg))
+            pkts = chain[4].decode(chain[3].stream_unscramble_8bit(sliced))
+        elif run == "signs":
+            sliced = chain[2].slice(chain[1].demod_signs(seg))
+            pkts = chain[4].decode(chain[3].stream_unscramble_8bit(sliced))
+        else:
+            st = {}
+            pkts = ce.process_chains_device([chain], seg, stages=st)[0]
+            sliced = st["sliced"][0]
+        check_segment(g, f"{tag}__seg{k}", sliced.data, sliced.address, pkts)
+        want = O.run_chain(oracle, seg, canon=True)                     # and bit for bit against the oracle in the kernels' FIR order
+        assert np.array_equal(sliced.data, want["slice_data"]) and np.array_equal(sliced.address, want["slice_addr"])
