@@ -337,9 +337,14 @@ int pm_slicer_stats(pm_ctx *ctx, int32_t *iterations, int32_t *chunk_len, int64_
  * with the stream) and its output is kept on the device: call pm_chain_fetch with buffers of that size, do not run again. */
 enum { PM_MODEM_AFSK = 0, PM_MODEM_FSK = 1, PM_MODEM_BPSK = 2, PM_MODEM_MPSK = 3, PM_MODEM_AFSK_PLL = 4, PM_MODEM_QPSK = 5 };
 #define PM_CHAIN_INVERT 1       /* FSK: negate the filter output (fsk.py:153-154) */
-/* AFSK / FSK only, opt-in: keep the last sum(M - 1) input samples of a run and put them in front of the next run's input, so that a
- * recording fed in pieces gives the bytes, addresses and packets of the single call on the whole.  Without it every
- * run starts its FIRs afresh like the reference's per-call numpy.convolve(..., 'valid') (afsk.py:151-166, fsk.py:151). */
+/* Opt-in: every FIR of the chain continues from the tail of its own input stream instead of starting afresh with every run as the
+ * reference's per-call numpy.convolve(..., 'valid') does (afsk.py:151-166, fsk.py:151, psk.py:165,193,710-751, afsk_pll.py:143,168).
+ * AFSK / FSK (FIRs and pointwise operations only): the last sum(M - 1) input samples of a run go in front of the next run's input, and
+ * a recording fed in pieces gives the bytes, addresses and packets of the single call on the whole.  Carrier-loop
+ * modems (BPSK, MPSK, QPSK, AFSK-PLL): band-pass, Hilbert pair and matched / output filter each keep M - 1 samples of their input
+ * (on the device); AGC envelope and loop registers are carried anyway; AGC.apply still normalises by the maximum of each run's
+ * band-passed samples (agc.py:67), so pieces are what the reference's primitives give when fed this way, not the single call.
+ * A run that does not bring a stage up to its filter length produces nothing yet (*h_count = 0). */
 #define PM_CHAIN_CARRY_HISTORY 2
 typedef struct pm_chain_desc {
     int32_t modem;                                   /* PM_MODEM_* */

@@ -833,6 +833,7 @@ class NativeChain:
             d.input_fir, d.n_input_fir = vec(modem.input_lpf)
         else:
             d.modem = {BPSKModem: N.MODEM_BPSK, MPSKModem: N.MODEM_MPSK, AFSKPLLModem: N.MODEM_AFSK_PLL, QPSKModem: N.MODEM_QPSK}[type(modem)]
+            d.flags = N.CHAIN_CARRY_HISTORY if modem.carry_history else 0
             d.input_fir, d.n_input_fir = vec(modem.input_bpf)
             a = modem.AGC
             d.use_agc, d.agc = 1, N.AGCParams(a.attack_rate, a.decay_rate, a.sustain_time, a.sample_rate, a.target_amplitude)

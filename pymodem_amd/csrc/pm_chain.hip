@@ -24,6 +24,12 @@ struct pm_chain {
     uint8_t *d_data = nullptr; int64_t *d_addr = nullptr; size_t data_n = 0, addr_n = 0;
     int64_t last_count = -1;                 // bytes the last pm_chain_run produced (still in d_data / d_addr): pm_chain_fetch
     std::vector<int16_t> hist;               // PM_CHAIN_CARRY_HISTORY: the last sum(M - 1) input samples of the previous run
+    // PM_CHAIN_CARRY_HISTORY for the carrier-loop modems: every later FIR of the cascade keeps the tail of ITS input stream on the device
+    // ([0] AGC'd samples in front of the Hilbert pair, [1] / [2] loop outputs in front of the matched / output filter)
+    double *d_tail[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};      // two each: a run writes the other one, a
+    int tail_sel[3] = {0, 0, 0};                                                                 // successful run makes it current
+    int64_t tail_n[3] = {0, 0, 0};
+    double *d_win[3] = {nullptr, nullptr, nullptr}; size_t win_n[3] = {0, 0, 0};
 };
 
 namespace {
@@ -65,9 +71,8 @@ int pm_chain_create(pm_ctx *ctx, const pm_chain_desc *desc, pm_chain **out)
     if (d.modem == PM_MODEM_BPSK || d.modem == PM_MODEM_MPSK || d.modem == PM_MODEM_AFSK_PLL || d.modem == PM_MODEM_QPSK)
         PM_ARG(d.wavetable != nullptr);
     PM_ARG((d.quadrature != 0) == (d.modem == PM_MODEM_MPSK || d.modem == PM_MODEM_QPSK));
-    // carried FIR history is defined for the modems whose demod() is FIRs and pointwise operations only (the others normalise by the
-    // maximum of each call's buffer, agc.py:67: pieces cannot be the whole there)
-    PM_ARG(!(d.flags & PM_CHAIN_CARRY_HISTORY) || d.modem == PM_MODEM_AFSK || d.modem == PM_MODEM_FSK);
+    // (carried FIR history makes pieces equal the whole for the modems whose demod() is FIRs and pointwise operations only; the
+    // carrier-loop modems normalise by the maximum of each call's buffer, agc.py:67, and keep doing so: see pm_chain_run)
     pm_chain *c = new pm_chain();
     c->ctx = ctx;
     c->d = d;
@@ -104,6 +109,7 @@ int pm_chain_reset(pm_chain *c)
     c->agc_state[0] = c->agc_state[1] = 0.0;
     c->slicer_state = pm_slicer_state{};
     c->hist.clear();
+    c->tail_n[0] = c->tail_n[1] = c->tail_n[2] = 0;
     return PM_OK;
 }
 
@@ -112,7 +118,8 @@ int pm_chain_destroy(pm_chain *c)
     if (!c) return PM_OK;
     pm_ctx *ctx = c->ctx;
     for (void *p : {(void *)c->d_taps, (void *)c->d_pd, (void *)c->d_audio, (void *)c->d_a, (void *)c->d_b, (void *)c->d_bits_i,
-                    (void *)c->d_bits_q, (void *)c->d_data, (void *)c->d_addr})
+                    (void *)c->d_bits_q, (void *)c->d_data, (void *)c->d_addr, (void *)c->d_tail[0][0], (void *)c->d_tail[1][0], (void *)c->d_tail[2][0],
+                    (void *)c->d_tail[0][1], (void *)c->d_tail[1][1], (void *)c->d_tail[2][1], (void *)c->d_win[0], (void *)c->d_win[1], (void *)c->d_win[2]})
         if (p) (void)pm_free(ctx, p);
     delete c;
     return PM_OK;
@@ -167,6 +174,39 @@ int pm_chain_run(pm_chain *c, const int16_t *audio, int64_t n, int audio_on_devi
     }
     const int mi = d.n_input_fir;
     if (n < mi) return pm_set_error(PM_ERR_ARG, "pm_chain_run: %lld samples are fewer than the %d-tap input filter", (long long)n, mi);
+    const bool carry = (d.flags & PM_CHAIN_CARRY_HISTORY) != 0;
+    // One later FIR stage's input with carried history (carrier-loop modems): [tail k | the n_new samples at src] in the chain's window
+    // buffer k, whose last h samples become the new tail -- all on the stream, nothing waits.  *win receives the window (src itself
+    // when there is nothing to carry), *wn its length.
+    int64_t new_tail_n[3] = {c->tail_n[0], c->tail_n[1], c->tail_n[2]};
+    bool used_tail[3] = {false, false, false};
+    auto carried = [&](int k, int h, const double *src, int64_t n_new, const double **win, int64_t *wn) -> int {
+        *win = src;
+        *wn = n_new;
+        if (!carry || h <= 0) return PM_OK;
+        const int64_t nt = c->tail_n[k], total = nt + n_new;
+        for (int b = 0; b < 2; ++b) {
+            if (c->d_tail[k][b]) continue;
+            void *p = nullptr;
+            if (int rc = pm_malloc(ctx, (size_t)h * sizeof(double), &p)) return rc;
+            c->d_tail[k][b] = (double *)p;
+        }
+        const double *cur = c->d_tail[k][c->tail_sel[k]];
+        double *next = c->d_tail[k][c->tail_sel[k] ^ 1];
+        if (nt) {
+            if (int rc = grow(ctx, c->d_win[k], c->win_n[k], (size_t)total)) return rc;
+            if (int rc = pm_d2d(ctx, c->d_win[k], cur, (size_t)nt * sizeof(double))) return rc;
+            if (n_new) { if (int rc = pm_d2d(ctx, c->d_win[k] + nt, src, (size_t)n_new * sizeof(double))) return rc; }
+            *win = c->d_win[k];
+            *wn = total;
+        }
+        // the new tail: the window's last h samples, into the OTHER tail buffer (the current one stays valid until the run succeeds)
+        const int64_t keep = std::min<int64_t>(h, total);
+        if (keep) { if (int rc = pm_d2d(ctx, next, *win + (total - keep), (size_t)keep * sizeof(double))) return rc; }
+        new_tail_n[k] = keep;
+        used_tail[k] = true;
+        return PM_OK;
+    };
     const int64_t n1 = n - mi + 1;                         // after the input filter
     int64_t ns = 0;                                        // samples the slicer sees
     auto bits_for = [&](int64_t count) -> int {
@@ -194,39 +234,55 @@ int pm_chain_run(pm_chain *c, const int16_t *audio, int64_t n, int audio_on_devi
             if (int rc = pm_fir_signs_f64(ctx, c->d_b, n2, T + c->o_out, mo, c->d_bits_i, 0)) return rc;
         } else {
             if (d.use_agc) { if (int rc = pm_agc_apply(ctx, c->d_a, n1, &d.agc, c->agc_state)) return rc; }
+            // With PM_CHAIN_CARRY_HISTORY a stage whose [tail | new] is still shorter than its filter has no output yet (the samples
+            // wait in its tail) and neither has anything behind it; without the flag that is an argument error, as before.
+            const double *w0 = nullptr, *w1 = nullptr;
+            int64_t wn0 = 0, wn1 = 0;
             if (d.modem == PM_MODEM_MPSK) {                                     // psk.py:705-773
-                if (n1 < d.n_hilbert) return pm_set_error(PM_ERR_ARG, "pm_chain_run: input shorter than the Hilbert transformer");
-                const int64_t n2 = n1 - d.n_hilbert + 1;
-                if (n2 < mo) return pm_set_error(PM_ERR_ARG, "pm_chain_run: input shorter than the matched filter");
-                if (int rc = grow(ctx, c->d_b, c->b_n, (size_t)n2 * 3)) return rc;      // imag | i_mix | q_mix
+                if (int rc = carried(0, d.n_hilbert - 1, c->d_a, n1, &w0, &wn0)) return rc;      // the AGC'd stream in front of the Hilbert pair
+                if (wn0 < d.n_hilbert && !carry) return pm_set_error(PM_ERR_ARG, "pm_chain_run: input shorter than the Hilbert transformer");
+                const int64_t n2 = wn0 >= d.n_hilbert ? wn0 - d.n_hilbert + 1 : 0;
+                if (int rc = grow(ctx, c->d_b, c->b_n, (size_t)(n2 + 1) * 3)) return rc;      // imag | i_mix | q_mix
                 double *imag = c->d_b, *i_mix = c->d_b + n2, *q_mix = c->d_b + 2 * n2;
-                if (int rc = pm_fir_valid_f64(ctx, c->d_a, n1, T + c->o_hil, d.n_hilbert, imag, 0)) return rc;
-                // the delay FIR [1,0,...,0] followed by [:-delay] is a pure shift (psk.py:714-716): real[k] = a[k + delay]
-                if (int rc = pm_mpsk_loop(ctx, &c->loop, 1, T + c->o_wave, c->d_pd, c->d_a + d.hilbert_delay, imag, 0, n2, i_mix, q_mix, n2)) return rc;
-                ns = n2 - mo + 1;
+                if (n2) {
+                    if (int rc = pm_fir_valid_f64(ctx, w0, wn0, T + c->o_hil, d.n_hilbert, imag, 0)) return rc;
+                    // the delay FIR [1,0,...,0] followed by [:-delay] is a pure shift (psk.py:714-716): real[k] = a[k + delay]
+                    if (int rc = pm_mpsk_loop(ctx, &c->loop, 1, T + c->o_wave, c->d_pd, w0 + d.hilbert_delay, imag, 0, n2, i_mix, q_mix, n2)) return rc;
+                }
+                if (int rc = carried(1, mo - 1, i_mix, n2, &w0, &wn0)) return rc;
+                if (int rc = carried(2, mo - 1, q_mix, n2, &w1, &wn1)) return rc;
+                if (wn0 < mo && !carry) return pm_set_error(PM_ERR_ARG, "pm_chain_run: input shorter than the matched filter");
+                ns = wn0 >= mo ? wn0 - mo + 1 : 0;
                 if (int rc = bits_for(ns)) return rc;
-                if (int rc = pm_fir_signs_f64(ctx, i_mix, n2, T + c->o_out, mo, c->d_bits_i, 0)) return rc;
-                if (int rc = pm_fir_signs_f64(ctx, q_mix, n2, T + c->o_out, mo, c->d_bits_q, 0)) return rc;
+                if (ns) {
+                    if (int rc = pm_fir_signs_f64(ctx, w0, wn0, T + c->o_out, mo, c->d_bits_i, 0)) return rc;
+                    if (int rc = pm_fir_signs_f64(ctx, w1, wn1, T + c->o_out, mo, c->d_bits_q, 0)) return rc;
+                }
             } else if (d.modem == PM_MODEM_QPSK) {                              // psk.py:426-476
-                if (n1 < mo) return pm_set_error(PM_ERR_ARG, "pm_chain_run: input shorter than the matched filter");
                 if (int rc = grow(ctx, c->d_b, c->b_n, (size_t)n1 * 2)) return rc;      // i (sine branch) | q (cosine branch)
                 double *i_arm = c->d_b, *q_arm = c->d_b + n1;
                 if (int rc = pm_costas_qpsk(ctx, &c->loop, 1, T + c->o_wave, c->d_a, 0, n1, i_arm, q_arm, n1)) return rc;
-                ns = n1 - mo + 1;
+                if (int rc = carried(1, mo - 1, i_arm, n1, &w0, &wn0)) return rc;
+                if (int rc = carried(2, mo - 1, q_arm, n1, &w1, &wn1)) return rc;
+                if (wn0 < mo && !carry) return pm_set_error(PM_ERR_ARG, "pm_chain_run: input shorter than the matched filter");
+                ns = wn0 >= mo ? wn0 - mo + 1 : 0;
                 if (int rc = bits_for(ns)) return rc;
-                if (int rc = pm_fir_signs_f64(ctx, i_arm, n1, T + c->o_out, mo, c->d_bits_i, 0)) return rc;
-                if (int rc = pm_fir_signs_f64(ctx, q_arm, n1, T + c->o_out, mo, c->d_bits_q, 0)) return rc;
+                if (ns) {
+                    if (int rc = pm_fir_signs_f64(ctx, w0, wn0, T + c->o_out, mo, c->d_bits_i, 0)) return rc;
+                    if (int rc = pm_fir_signs_f64(ctx, w1, wn1, T + c->o_out, mo, c->d_bits_q, 0)) return rc;
+                }
             } else {                                                            // psk.py:162-195, afsk_pll.py:140-170
-                if (n1 < mo) return pm_set_error(PM_ERR_ARG, "pm_chain_run: input shorter than the output filter");
                 if (int rc = grow(ctx, c->d_b, c->b_n, (size_t)n1)) return rc;
                 if (d.modem == PM_MODEM_BPSK) {
                     if (int rc = pm_costas_bpsk(ctx, &c->loop, 1, T + c->o_wave, c->d_a, 0, n1, c->d_b, n1)) return rc;
                 } else {
                     if (int rc = pm_pll_afsk(ctx, &c->loop, 1, T + c->o_wave, c->d_a, 0, n1, c->d_b, n1)) return rc;
                 }
-                ns = n1 - mo + 1;
+                if (int rc = carried(1, mo - 1, c->d_b, n1, &w0, &wn0)) return rc;
+                if (wn0 < mo && !carry) return pm_set_error(PM_ERR_ARG, "pm_chain_run: input shorter than the output filter");
+                ns = wn0 >= mo ? wn0 - mo + 1 : 0;
                 if (int rc = bits_for(ns)) return rc;
-                if (int rc = pm_fir_signs_f64(ctx, c->d_b, n1, T + c->o_out, mo, c->d_bits_i, 0)) return rc;
+                if (ns) { if (int rc = pm_fir_signs_f64(ctx, w0, wn0, T + c->o_out, mo, c->d_bits_i, 0)) return rc; }
             }
         }
     }
@@ -244,8 +300,17 @@ int pm_chain_run(pm_chain *c, const int16_t *audio, int64_t n, int audio_on_devi
     job.d_addr = c->d_addr;
     job.cap = need;
     job.h_state = &c->slicer_state;                        // the slicer continues from run to run like the reference's object
-    if (int rc = pm_slice_batch(ctx, &job, 1)) return rc;
+    if (ns > 0) {
+        if (int rc = pm_slice_batch(ctx, &job, 1)) return rc;
+    } else {
+        job.count = 0;                                     // nothing reached the slicer yet (carried history still filling)
+    }
     if (have_next_hist) c->hist.swap(next_hist);           // the stream has moved on: only now
+    for (int k = 0; k < 3; ++k) {
+        if (!used_tail[k]) continue;
+        c->tail_sel[k] ^= 1;
+        c->tail_n[k] = new_tail_n[k];
+    }
     c->last_count = job.count;
     return pm_chain_fetch(c, h_data, h_addr, cap, h_count);
 }

@@ -136,7 +136,7 @@ def test_oracle_carries_fir_history_through_the_carrier_loop_modems(golden, conf
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag", PSK_HISTORY)
-@pytest.mark.parametrize("run", ["stages", "signs", "group"])
+@pytest.mark.parametrize("run", ["stages", "signs", "group", "native"])
 def test_gpu_carries_fir_history_through_the_carrier_loop_modems(golden, config_lines, tag, run):
     from pymodem_amd import chain_builder as cb, chain_execute as ce
     g, rate, pieces = _history_pieces(golden, tag)
@@ -144,8 +144,12 @@ def test_gpu_carries_fir_history_through_the_carrier_loop_modems(golden, config_
     chain[1].carry_history = True
     oracle = O.build_chain(rate, config_lines(tag + ".json")[0])
     oracle[0].carry_history = True
+    nc = ce.NativeChain(chain[1], chain[2]) if run == "native" else None      # pm_chain with PM_CHAIN_CARRY_HISTORY: tails on the device
     for k, seg in enumerate(pieces):
-        if run == "stages":
+        if run == "native":
+            sliced = nc.run(seg)
+            pkts = chain[4].decode(chain[3].stream_unscramble_8bit(sliced))
+        elif run == "stages":
             sliced = chain[2].slice(chain[1].demod(seg))
             pkts = chain[4].decode(chain[3].stream_unscramble_8bit(sliced))
         elif run == "signs":
