@@ -143,6 +143,10 @@ def main():
                          "2: three-stage pipeline (chain_execute.RecordingPipeline): demod of step k+1 on the default stream, slicer of "
                          "step k on a high-priority side stream, host half (LFSR, codec, packet gather, de-dup) of step k-1 in threads; "
                          "1: only the host half runs behind the next step's GPU half; 0: strictly one after the other")
+    ap.add_argument("--executor", default="auto", choices=["auto", "native", "python"],
+                    help="--overlap 2, one rank: native = the library's own pipelined executor (pm_pipe_*: one call per recording, slicer and "
+                         "host stages on the library's threads); python = chain_execute.RecordingPipeline (the stages sequenced by Python "
+                         "threads).  auto: native where it applies (AFSK gain-sweep configs on one rank), python elsewhere")
     ap.add_argument("--slice-workers", type=int, default=2, help="--overlap 2: recordings whose slicers may be in flight at once")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--buffer", default="signal", choices=["signal", "noise"],
@@ -350,10 +354,54 @@ def measure(args, env):
                 res = finish(rr)
         return res
 
+    native_sides = []
+
+    def native_pipe(key):
+        """The library's own executor for this rank's chains (made once, kept across the warm-up and the timed call)."""
+        npipe = pipes.get(key)
+        if npipe is None:
+            npipe = pipes[key] = ce.NativePipeline(build_chains(), args.samples, args.rate / 40, ctx=ctx, names=names, chain_ids=my,
+                                                   slice_workers=args.slice_workers)
+            native_sides[:] = npipe.side_contexts()
+            sides.extend(native_sides)
+        return npipe
+
+    def native_steps(npipe, k, source):
+        """k recordings through the native executor; every recording's result is taken (its de-dup count read, its rows given back),
+        the last one's comes back as the PacketTable the Python executor's `dedupe` returns."""
+        tickets, taken = [], 0
+        nxt = npipe.prefetch(source) if (k and not hasattr(source, "ptr")) else None
+        for i in range(k):
+            if nxt is not None:
+                cur, nxt = nxt, (npipe.prefetch(source) if i + 1 < k else None)
+            else:
+                cur = source
+            tickets.append(npipe.submit(cur))
+            while taken < len(tickets) - 48:                  # results do not pile up: 7 MB of packet rows each
+                npipe.unique(tickets[taken])
+                taken += 1
+        for t in tickets[taken:-1]:
+            npipe.unique(t)
+        res = npipe.table(tickets[-1]) if tickets else None
+        npipe.drain()
+        return res
+
     def run_steps(k):
         """k steps; with --overlap the host half of each step runs behind the GPU half of the next one."""
         if loop_wl:
             return loop_steps(k, d_audio)
+        if native_exec[0] and args.overlap >= 2:
+            npipe = native_pipe("native")
+            before = npipe.stats()
+            res = native_steps(npipe, k, d_audio)
+            after = npipe.stats()
+            stage_ms.clear()
+            if k:
+                stage_ms.update({"executor": "native (pm_pipe_*)", "slice_busy": round((after["slice_busy_ms"] - before["slice_busy_ms"]) / k, 3),
+                                 "host_busy": round((after["host_busy_ms"] - before["host_busy_ms"]) / k, 3),
+                                 "recordings_per_slice_batch": round((after["recordings"] - before["recordings"]) / max(after["slice_batches"] - before["slice_batches"], 1), 2)})
+            steady.clear()
+            return res
         if not args.overlap:
             res = None
             for _ in range(k):
@@ -414,6 +462,8 @@ def measure(args, env):
         """The same pipeline, but every step's recording starts in host memory: its copy to HBM runs one step ahead on a copy stream.
         The source is page-locked (registered once, below): out of pageable memory the runtime stages the copy in pieces at ~45 GB/s,
         which bounded this figure in round 2."""
+        if native_exec[0]:
+            return native_steps(native_pipe("native-upload"), k, audio)
         pipe = pipes.get("upload")                            # kept across the warm-up and the timed call, like the main one
         if pipe is None:
             pipe = pipes["upload"] = ce.RecordingPipeline(slice_workers=args.slice_workers)
@@ -428,6 +478,26 @@ def measure(args, env):
         res = last.result() if last is not None else None
         pipe.drain()
         return res
+
+    native_exec = [False]
+    if args.executor != "python" and args.overlap >= 2 and not loop_wl and not use_dist and not os.environ.get("PYMODEM_AMD_FORCE_GATHER"):
+        try:
+            native_pipe("native")
+            native_exec[0] = True
+        except ValueError:                                    # not a gain-sweep config: the Python-sequenced executor
+            if args.executor == "native":
+                raise
+    elif args.executor == "native":
+        raise SystemExit("--executor native: one rank, --overlap 2, an AFSK gain-sweep workload")
+
+    def close_pipes():
+        for sc in native_sides:                               # the library's own contexts go with their pipeline
+            if sc in sides:
+                sides.remove(sc)
+        del native_sides[:]
+        for p_ in pipes.values():
+            p_.close()
+        pipes.clear()
 
     def fence():
         ctx.sync()
@@ -522,9 +592,7 @@ def measure(args, env):
         alone = ctx.profile_read()
         ctx.profile(False)
         args.overlap = saved
-    for p in pipes.values():
-        p.close()
-    pipes.clear()
+    close_pipes()
     if loop_wl:
         sides.remove(engine.front)
         lb.close_engines()                                    # the engine's work buffers and bitmap sets (gigabytes) go back
@@ -550,9 +618,7 @@ def measure(args, env):
         run_steps_uploading(args.steps)
         fence()
         h2d_overlapped = time.perf_counter() - t_u
-        for p_ in pipes.values():
-            p_.close()
-        pipes.clear()
+        close_pipes()
         if use_dist:
             tu = torch.tensor([h2d_overlapped], dtype=torch.float64, device=coll_device or "cpu")
             torch.distributed.all_reduce(tu, op=torch.distributed.ReduceOp.MAX)
@@ -602,6 +668,9 @@ def measure(args, env):
                        "overlap": ("carrier-loop batch engine: every recording of a run in flight at once" if loop_wl else
                                    {0: "none", 1: "host half of step k behind GPU half of step k+1",
                                     2: "3-stage pipeline: demod(k+1) | slice(k) on a side stream | host(k-1)"}[min(args.overlap, 2)]),
+                       "executor": ("native: pm_pipe_* (one library call per recording; slicer batches, LFSR + codec and de-dup on the library's "
+                                    "own threads)" if native_exec[0] else
+                                    None if loop_wl or args.overlap < 2 else "python: chain_execute.RecordingPipeline sequences the library's stage calls"),
                        "loop_batch": loop_info,
                        "scaling_note": ("carrier-loop workload: a GPU's time per run is one recording's worth of sequential loop steps however "
                                         "many loops run beside each other, so per-GPU throughput is set by recordings x chains in flight "

@@ -489,6 +489,67 @@ int64_t pm_correlate(pm_packet *h_pkts, const int64_t *h_chain_counts, int nchai
 int64_t pm_correlate_strided(void *h_records, int64_t stride, const int64_t *h_chain_counts, int nchains, double address_distance,
                              int64_t *h_unique_idx, int32_t *h_corr_decoders, int64_t corr_cap);
 
+/* ---- pipelined executor for an AFSK chain group: one call per recording -------------------------
+ * What pymodem.py:140-163 does with a process per chain and a queue -- every chain of the config on the same recording, the
+ * packets of all of them de-duplicated -- as a pipeline over RECORDINGS that lives entirely inside the library:
+ *   pm_pipe_submit   launches pm_afsk_group_run for the recording on the context's stream (band-pass + certified sweeps of every
+ *                    chain), records an event, returns; blocks only while all bitmap slots are in use
+ *   slicer threads   (own high-priority streams) wait for the event, take up to `slice_group` consecutive recordings, redo an
+ *                    overflowed sweep with the exact kernels, run pm_slice_batch + pm_slice_compact, copy the output to the host
+ *   host threads     pm_host_decode_batch + pm_codec_fetch_batch (LFSR + AX.25/IL2P per chain, fresh stage objects per recording
+ *                    as chain_builder.py makes them) and pm_correlate over the chains in config order
+ *   pm_pipe_wait     the recording's packet rows, per-chain counts and the de-dup result, in the library's memory until
+ *                    pm_pipe_release
+ * Results equal process_chain on every chain + PacketMetaArray.Correlate, recording by recording.  One submitting thread.  The
+ * device pointers inside the descs (taps) must stay valid for the pipeline's life; host arrays are copied by pm_pipe_create. */
+typedef struct pm_pipe_chain {
+    int32_t sweep, slot;             /* which sweep of pm_pipe_desc.sweeps demodulates this chain, and its place in it (gain index) */
+    pm_slicer_params slicer;         /* binary slicer */
+    uint64_t lfsr_poly;              /* lfsr.py:10-20 */
+    int32_t lfsr_invert;
+    int32_t codec_kind, crc, disable_rs, min_dist, sync_tol;   /* pm_codec_create */
+    int32_t source_decoder;          /* the chain's place in the config */
+} pm_pipe_chain;
+typedef struct pm_pipe_desc {
+    const double *d_bpf; int32_t mb; /* the group's shared input_bpf (device) */
+    int32_t nsweeps;
+    double x_bound;                  /* sum|input_bpf| * 32768 */
+    const pm_afsk_sweep_desc *sweeps;/* h_bits ignored: the pipeline owns the bitmaps */
+    const pm_pipe_chain *chains;     /* config order */
+    int32_t nchains;
+    int32_t slots;                   /* recordings between demod and slicer at most (0 = 16) */
+    int32_t slice_workers;           /* 0 = 2 */
+    int32_t slice_group;             /* most recordings per slicer batch (0 = 4) */
+    int32_t slice_min_group;         /* a batch waits for this many recordings while later ones are queued (0 = slice_group) */
+    int32_t demod_streams;           /* recordings take turns on this many demod streams: the context's own and further ones of the
+                                        pipeline's, each with its own band-passed stream and sweep state (0 = 3) */
+    int32_t host_threads;            /* recordings in the host stage at once (0 = as chain_execute.RecordingPipeline chooses) */
+    int32_t decode_threads;          /* threads inside one recording's host stage (0 = one per chain) */
+    double address_distance;         /* PacketMetaArray.Correlate (packet_meta.py:230) */
+    int64_t max_samples;             /* longest recording */
+} pm_pipe_desc;
+typedef struct pm_pipe_result {
+    int64_t ticket;
+    int32_t status, reserved;        /* PM_OK or the stage error (pm_pipe_wait returns it too, message in pm_last_error) */
+    int64_t rows;                    /* packets of all chains */
+    const pm_packet *h_rows;         /* chain by chain, config order; correlated_count set on the unique ones */
+    const int64_t *h_counts;         /* [nchains] */
+    int64_t unique;
+    const int64_t *h_unique_idx;     /* [unique] row indices by stream address */
+    const int32_t *h_corr_decoders;  /* correlated decoders, consecutive runs of correlated_count per unique packet */
+    double ms_to_demod_done, ms_to_sliced, ms_to_done;   /* from submit, host clock */
+} pm_pipe_result;
+typedef struct pm_pipe pm_pipe;
+int pm_pipe_create(pm_ctx *ctx, const pm_pipe_desc *desc, pm_pipe **out);
+int pm_pipe_submit(pm_pipe *pipe, const int16_t *d_audio, int64_t n, int64_t *h_ticket);     /* d_audio stays untouched until the recording is sliced */
+int pm_pipe_wait(pm_pipe *pipe, int64_t ticket, pm_pipe_result *out);
+int pm_pipe_release(pm_pipe *pipe, int64_t ticket);      /* the result's memory */
+int pm_pipe_drain(pm_pipe *pipe);                        /* every recording submitted so far is through */
+int pm_pipe_stats(pm_pipe *pipe, int64_t *h_batches, int64_t *h_batch_recordings, double *h_slice_busy_ms, double *h_host_busy_ms);
+pm_ctx *pm_pipe_side_ctx(pm_pipe *pipe, int worker);     /* a slicer worker's context (NULL past the last): for pm_prof_* */
+pm_ctx *pm_pipe_demod_ctx(pm_pipe *pipe, int k);         /* demod stream k (0 = the caller's context; NULL past the last) */
+int pm_pipe_destroy(pm_pipe *pipe);                      /* drains first */
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,6 +95,30 @@ class LBatchDesc(ctypes.Structure):
                 ("agc", AGCParams), ("loops", ctypes.POINTER(Loop)), ("wavetable", _dp), ("pd_table", ctypes.POINTER(ctypes.c_int32))]
 
 
+class PipeChain(ctypes.Structure):
+    """pm_pipe_chain"""
+    _i32 = ctypes.c_int32
+    _fields_ = [("sweep", _i32), ("slot", _i32), ("slicer", SlicerParams), ("lfsr_poly", ctypes.c_uint64), ("lfsr_invert", _i32),
+                ("codec_kind", _i32), ("crc", _i32), ("disable_rs", _i32), ("min_dist", _i32), ("sync_tol", _i32), ("source_decoder", _i32)]
+
+
+class PipeDesc(ctypes.Structure):
+    """pm_pipe_desc"""
+    _i32 = ctypes.c_int32
+    _fields_ = [("d_bpf", ctypes.c_void_p), ("mb", _i32), ("nsweeps", _i32), ("x_bound", ctypes.c_double),
+                ("sweeps", ctypes.POINTER(AfskSweepDesc)), ("chains", ctypes.POINTER(PipeChain)), ("nchains", _i32), ("slots", _i32),
+                ("slice_workers", _i32), ("slice_group", _i32), ("slice_min_group", _i32), ("demod_streams", _i32), ("host_threads", _i32), ("decode_threads", _i32),
+                ("address_distance", ctypes.c_double), ("max_samples", ctypes.c_int64)]
+
+
+class PipeResult(ctypes.Structure):
+    """pm_pipe_result"""
+    _fields_ = [("ticket", ctypes.c_int64), ("status", ctypes.c_int32), ("reserved", ctypes.c_int32), ("rows", ctypes.c_int64),
+                ("h_rows", ctypes.c_void_p), ("h_counts", ctypes.POINTER(ctypes.c_int64)), ("unique", ctypes.c_int64),
+                ("h_unique_idx", ctypes.c_void_p), ("h_corr_decoders", ctypes.c_void_p),
+                ("ms_to_demod_done", ctypes.c_double), ("ms_to_sliced", ctypes.c_double), ("ms_to_done", ctypes.c_double)]
+
+
 MODEM_AFSK, MODEM_FSK, MODEM_BPSK, MODEM_MPSK, MODEM_AFSK_PLL, MODEM_QPSK = range(6)
 CHAIN_INVERT = 1
 CHAIN_CARRY_HISTORY = 2
@@ -192,6 +216,15 @@ _SIGS = {
     "pm_lbatch_run": ([_vp, ctypes.POINTER(_vp), _int, _i64, _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
     "pm_lbatch_front_ctx": ([_vp], _vp),
     "pm_lbatch_destroy": ([_vp], _int),
+    "pm_pipe_create": ([_vp, ctypes.POINTER(PipeDesc), ctypes.POINTER(_vp)], _int),
+    "pm_pipe_submit": ([_vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
+    "pm_pipe_wait": ([_vp, _i64, ctypes.POINTER(PipeResult)], _int),
+    "pm_pipe_release": ([_vp, _i64], _int),
+    "pm_pipe_drain": ([_vp], _int),
+    "pm_pipe_stats": ([_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)], _int),
+    "pm_pipe_side_ctx": ([_vp, _int], _vp),
+    "pm_pipe_demod_ctx": ([_vp, _int], _vp),
+    "pm_pipe_destroy": ([_vp], _int),
     "pm_costas_bpsk": ([_vp, ctypes.POINTER(Loop), _int, _vp, _vp, _i64, _i64, _vp, _i64], _int),
     "pm_costas_qpsk": ([_vp, ctypes.POINTER(Loop), _int, _vp, _vp, _i64, _i64, _vp, _vp, _i64], _int),
     "pm_pll_afsk": ([_vp, ctypes.POINTER(Loop), _int, _vp, _vp, _i64, _i64, _vp, _i64], _int),

@@ -631,6 +631,26 @@ def resolve_sweeps(chains, bitmaps, sweeps, audio, ctx, tag=0):
     return redone
 
 
+def _plan_sweeps(chains, afsk_groups):
+    """-> [(chain indices, their modems)] per certified gain sweep: chains of one mark-filter group that differ in space_gain only,
+    eight at most per sweep; a lone chain only if its templates are tones (the sliding sums pay for themselves there)."""
+    planned = []
+    for key, members in afsk_groups.items():
+        sweep_sets = {}
+        for k in members:
+            sk = chains[k][1].sweep_key()
+            if sk is not None:
+                sweep_sets.setdefault(sk, []).append(k)
+        for part_all in sweep_sets.values():
+            for base in range(0, len(part_all), 8):
+                part = part_all[base:base + 8]
+                mods = [chains[k][1] for k in part]
+                if len(part) < 2 and not (AFSKModem.sliding_sums and AFSKModem._sweep_prepare(mods)["tones"] is not None):
+                    continue                 # one chain whose templates are not tones: the exact kernels are cheaper
+                planned.append((part, mods))
+    return planned
+
+
 def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced_only=False, _bitmaps_only=False, _slot=0, _ctx=None):
     """[chain, ...] -> [packets of chain 0, packets of chain 1, ...] (config order), identical to running
     process_chain on each.  See the module docstring for what is shared and batched."""
@@ -717,21 +737,7 @@ def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced
     gi = 0
     # a gain sweep (members differ in space_gain only, int16 audio so that |band-passed| <= sum|bpf| * 32768): certified sign
     # bitmaps from two correlator pairs and two low-passes for the whole sweep (pm_afsk_sweep_signs)
-    planned = []                       # (chain indices, their modems) per certified sweep
-    if int16_audio and _USE_SWEEP:
-        for key, members in afsk_groups.items():
-            sweep_sets = {}
-            for k in members:
-                sk = chains[k][1].sweep_key()
-                if sk is not None:
-                    sweep_sets.setdefault(sk, []).append(k)
-            for part_all in sweep_sets.values():
-                for base in range(0, len(part_all), 8):
-                    part = part_all[base:base + 8]
-                    mods = [chains[k][1] for k in part]
-                    if len(part) < 2 and not (AFSKModem.sliding_sums and AFSKModem._sweep_prepare(mods)["tones"] is not None):
-                        continue                 # one chain whose templates are not tones: the exact kernels are cheaper
-                    planned.append((part, mods))
+    planned = _plan_sweeps(chains, afsk_groups) if int16_audio and _USE_SWEEP else []    # (chain indices, their modems) per certified sweep
     if planned:
         fe = {mods[0].front_end_key() for _, mods in planned}
         if _USE_GROUP_NATIVE and len(fe) == 1 and next(iter(fe)) not in front:
@@ -803,6 +809,219 @@ def process_chains_device(chains, input_audio, stages=None, _rows=False, _sliced
     if stages is not None:
         stages["sliced"] = sliced
     return packets
+
+
+class _PipeRows:
+    """One finished recording's packet rows inside the library (pm_pipe_wait): numpy arrays made from it keep it alive, and the
+    memory goes back (pm_pipe_release) when the last of them is gone."""
+
+    def __init__(self, pipe, ticket, ptr, nbytes):
+        self._pipe, self._ticket = pipe, ticket
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
+        pipe._live += 1
+
+    def __del__(self):
+        pipe = self._pipe
+        if pipe is not None and pipe._h is not None:
+            lib().pm_pipe_release(pipe._h, self._ticket)
+            pipe._live -= 1
+            if pipe._closed and pipe._live == 0:
+                pipe._destroy()
+
+
+class NativePipeline:
+    """RecordingPipeline for an AFSK chain group with every stage inside the library (pm_pipe_*, csrc/pm_pipe.hip): submit() is one
+    native call that launches the recording's demod and returns; slicer batches, LFSR + codec and the cross-chain de-dup run on the
+    library's own threads; table() hands back the finished recording as a PacketTable (correlate() already done).  The chains are
+    the TEMPLATE of every recording: each recording is decoded by fresh slicer / stream / codec states, as chain_builder.py makes
+    them per run of the reference (pymodem.py:140-163).
+
+    Accepts what the certified-sweep path of process_chains_device accepts -- AFSK modems on one shared band-pass whose every chain
+    belongs to a gain sweep (or is a lone tone-template chain), binary slicers, LFSR streams, native codecs, int16 audio -- and
+    raises ValueError for anything else (use RecordingPipeline there)."""
+
+    def __init__(self, chains, max_samples, address_distance, ctx=None, names=None, chain_ids=None, slots=0, slice_workers=0, slice_group=0,
+                 host_threads=0, decode_threads=0, slice_min_group=0, demod_streams=0):
+        import os
+        demod_streams = demod_streams or int(os.environ.get("PYMODEM_AMD_PIPE_DEMOD_STREAMS", 0))
+        slots = slots or int(os.environ.get("PYMODEM_AMD_PIPE_SLOTS", 0))              # tuning knobs (DESIGN.md 4.4b)
+        slice_workers = int(os.environ.get("PYMODEM_AMD_PIPE_WORKERS", 0)) or slice_workers
+        slice_group = slice_group or int(os.environ.get("PYMODEM_AMD_PIPE_GROUP", 0))
+        slice_min_group = slice_min_group or int(os.environ.get("PYMODEM_AMD_PIPE_MIN_GROUP", 0))
+        host_threads = host_threads or int(os.environ.get("PYMODEM_AMD_PIPE_HOST_THREADS", 0))
+        from ._native import AfskSweepDesc, PipeChain, PipeDesc
+        from .codecs import _NativeCodec
+        from .lfsr import LFSR
+        from .slicer import BinarySlicer
+        self._h = None
+        self._closed, self._live = False, 0
+        ctx = self._ctx = ctx or Context.default()
+        n = len(chains)
+        ids = list(range(n)) if chain_ids is None else [int(c) for c in chain_ids]
+        self.names = list(names) if names is not None else [ch[0] for ch in chains]
+        if not n or not all(isinstance(ch[1], AFSKModem) and not ch[1].carry_history and isinstance(ch[2], BinarySlicer) and isinstance(ch[3], LFSR)
+                            and isinstance(ch[4], _NativeCodec) for ch in chains):
+            raise ValueError("NativePipeline: AFSK modem + binary slicer + LFSR + AX25/IL2P codec chains only")
+        groups = {}
+        for k, ch in enumerate(chains):
+            ch[1].use_context(ctx)
+            groups.setdefault(ch[1].mark_key(), []).append(k)
+        planned = _plan_sweeps(chains, groups)
+        covered = sorted(k for part, _ in planned for k in part)
+        if covered != list(range(n)) or len({mods[0].front_end_key() for _, mods in planned}) != 1:
+            raise ValueError("NativePipeline: every chain must belong to a certified sweep on one shared band-pass")
+        lead = planned[0][1][0]
+        taps = lead._const("input_bpf", lead.input_bpf)
+        descs = (AfskSweepDesc * len(planned))()
+        pchains = (PipeChain * n)()
+        self._keep = [taps, chains]
+        for j, (part, mods) in enumerate(planned):
+            prep = AFSKModem._sweep_prepare(mods)
+            k, d = prep["consts"], descs[j]
+            d.d_mark_i, d.d_mark_q, d.d_unit_i, d.d_unit_q, d.d_space = (k[i].ptr.value for i in range(5))
+            d.h_gains, d.groups, d.m = ctypes.addressof(prep["gains"]), len(mods), len(mods[0].mark_correlator_i)
+            d.d_lpf, d.ml, d.lpf_abs_sum = k[5].ptr.value, len(mods[0].output_lpf), prep["lpf_abs"]
+            d.h_bits = None
+            d.h_tones = ctypes.addressof(prep["tones"]) if prep["tones"] is not None else None
+            self._keep.append(prep)
+            for place, c in enumerate(part):
+                ch, pc = chains[c], pchains[c]
+                pc.sweep, pc.slot, pc.slicer = j, place, ch[2]._params()
+                pc.lfsr_poly, pc.lfsr_invert = int(ch[3].polynomial), int(bool(ch[3].invert))
+                pc.codec_kind, pc.crc, pc.disable_rs = int(ch[4]._kind), int(ch[4].collect_trailing_crc), int(ch[4].disable_rs)
+                pc.min_dist, pc.sync_tol, pc.source_decoder = int(ch[4].min_distance), int(ch[4].sync_tolerance), ids[c]
+        ctx.sync()                                          # the constants are in place before another stream reads them
+        desc = PipeDesc()
+        desc.d_bpf, desc.mb, desc.nsweeps = taps.ptr.value, len(lead.input_bpf), len(planned)
+        desc.x_bound = float(np.abs(lead.input_bpf).sum()) * 32768.0
+        desc.sweeps, desc.chains, desc.nchains = descs, pchains, n
+        desc.slots, desc.slice_workers, desc.slice_group, desc.slice_min_group = int(slots), int(slice_workers), int(slice_group), int(slice_min_group)
+        desc.host_threads, desc.decode_threads, desc.demod_streams = int(host_threads), int(decode_threads), int(demod_streams)
+        desc.address_distance, desc.max_samples = float(address_distance), int(max_samples)
+        h = ctypes.c_void_p()
+        check(lib().pm_pipe_create(ctx.handle, ctypes.byref(desc), ctypes.byref(h)))
+        self._h = h
+        self.nchains = n
+        self.slots = max(2, min(int(slots) if slots else 16, 32, 60 // len(planned) * (min(int(demod_streams), 4) if demod_streams else 3)))     # as pm_pipe_create settles it
+
+    def prefetch(self, host_audio):
+        """Start copying a recording (host int16 array) into HBM on a copy stream; returns a handle for submit().  Called one
+        recording ahead, the copy runs while the previous recording is demodulated.  The device buffers rotate: two more than the
+        pipeline has bitmap slots, so a buffer comes round again only after the recording that used it has left the slicer stage
+        (submit() blocks on exactly that before it reuses a slot)."""
+        from concurrent.futures import ThreadPoolExecutor
+        a = np.ascontiguousarray(np.asarray(host_audio))
+        if a.dtype != np.int16:
+            raise ValueError("NativePipeline.prefetch: int16 audio")
+        if getattr(self, "_up_pool", None) is None:
+            self._up_pool, self._up_n, self._up_done = ThreadPoolExecutor(max_workers=1), 0, {}
+        k = self._up_n % (self.slots + 2)
+        self._up_n += 1
+        cctx = Context.side(index=200, high_priority=False)
+
+        def copy():
+            buf = cctx.scratch(("native-pipe-upload", id(self), k), a.size, a.dtype)
+            check(lib().pm_h2d(cctx.handle, buf.ptr, a.ctypes.data_as(ctypes.c_void_p), a.nbytes))
+            self._up_done[k] = done = cctx.record_event(self._up_done.get(k))
+            return buf.view(0, a.size), done
+        return self._up_pool.submit(copy)
+
+    def submit(self, audio):
+        """Start one recording (int16 DeviceBuffer, resident until the recording has been sliced; or a prefetch() handle) -> ticket."""
+        if hasattr(audio, "result"):
+            audio, copied = audio.result()
+            self._ctx.wait_event(copied)
+        if not isinstance(audio, DeviceBuffer) or audio.dtype != np.dtype(np.int16):
+            raise ValueError("NativePipeline.submit: an int16 DeviceBuffer")
+        t = ctypes.c_int64()
+        check(lib().pm_pipe_submit(self._h, audio.ptr, audio.n, ctypes.byref(t)))
+        return t.value
+
+    def _wait(self, ticket):
+        from ._native import PipeResult
+        res = PipeResult()
+        check(lib().pm_pipe_wait(self._h, int(ticket), ctypes.byref(res)))
+        return res
+
+    def unique(self, ticket, release=True):
+        """Waits for the recording -> (unique packets, packets of all chains); by default its rows are given back at once."""
+        res = self._wait(ticket)
+        out = (int(res.unique), int(res.rows))
+        if release:
+            check(lib().pm_pipe_release(self._h, int(ticket)))
+        return out
+
+    def table(self, ticket):
+        """Waits for the recording -> PacketTable over the library's rows (no copy), correlate() done.  The rows go back to the
+        library when the table and every array taken from it are gone."""
+        from ._native import packet_dtype
+        from .packet_meta import PacketTable
+        res = self._wait(ticket)
+        dt = packet_dtype()
+        counts = [res.h_counts[c] for c in range(self.nchains)]
+        k = int(res.unique)
+        uniq = np.ctypeslib.as_array(ctypes.cast(res.h_unique_idx, ctypes.POINTER(ctypes.c_int64)), (max(k, 1),))[:k].copy()
+        corr = np.ctypeslib.as_array(ctypes.cast(res.h_corr_decoders, ctypes.POINTER(ctypes.c_int32)), (max(int(res.rows), 1),)).copy()
+        if res.rows:
+            rows = np.asarray(_PipeRows(self, int(ticket), res.h_rows, res.rows * dt.itemsize)).view(dt)
+        else:
+            rows = np.zeros(0, dtype=dt)
+            check(lib().pm_pipe_release(self._h, int(ticket)))
+        table = PacketTable.from_array(rows, counts, self.names)
+        table.unique_idx, table._corr = uniq, corr
+        table._corr_ends = np.cumsum(rows["correlated_count"][table.unique_idx])
+        table._unique_decoders = None
+        table.latency_ms = {"demod_done": res.ms_to_demod_done, "sliced": res.ms_to_sliced, "done": res.ms_to_done}
+        return table
+
+    def release(self, ticket):
+        check(lib().pm_pipe_release(self._h, int(ticket)))
+
+    def drain(self):
+        check(lib().pm_pipe_drain(self._h))
+
+    def stats(self):
+        b, r = ctypes.c_int64(), ctypes.c_int64()
+        s, h = ctypes.c_double(), ctypes.c_double()
+        check(lib().pm_pipe_stats(self._h, ctypes.byref(b), ctypes.byref(r), ctypes.byref(s), ctypes.byref(h)))
+        return {"slice_batches": b.value, "recordings": r.value, "slice_busy_ms": s.value, "host_busy_ms": h.value}
+
+    def side_contexts(self):
+        """The contexts the library owns -- the slicer workers' and the demod streams beyond the caller's: for Context.profile /
+        profile_read / sync."""
+        out = []
+        for entry, first in ((lib().pm_pipe_side_ctx, 0), (lib().pm_pipe_demod_ctx, 1)):
+            i = first
+            while True:
+                c = entry(self._h, i)
+                if not c:
+                    break
+                out.append(Context.borrowed(c, self._ctx.device))
+                i += 1
+        return out
+
+    def _destroy(self):
+        h, self._h = self._h, None
+        if h is not None:
+            lib().pm_pipe_destroy(h)
+
+    def close(self):
+        """Waits for everything submitted; the library's side goes when the last table made from it has gone."""
+        if self._h is None or self._closed:
+            return
+        if getattr(self, "_up_pool", None) is not None:
+            self._up_pool.shutdown(wait=True)
+            self._up_pool = None
+        check(lib().pm_pipe_drain(self._h))
+        self._closed = True
+        if self._live == 0:
+            self._destroy()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                      # noqa: BLE001
+            pass
 
 
 class NativeChain:

@@ -1,0 +1,739 @@
+// Native pipelined executor for an AFSK chain group (chain_execute.py:30-52 for every chain of a group, recording after recording):
+// the stages of pymodem_amd.chain_execute.RecordingPipeline -- demod on the caller's stream, slicer batches on high-priority side
+// streams, LFSR + codec + cross-chain de-dup on host threads -- with NO interpreter between them.  Round 2 measured what the Python
+// executor costs: one process delivers 235-241 Gsamples/s where two processes sharing the GPU deliver 308 together, and 9-10 ms of host
+// CPU per recording, most of it threads handing the interpreter lock around between 20-microsecond native calls.  Here a recording is
+// ONE call (pm_pipe_submit: launches only) and its packets come back through ONE call (pm_pipe_wait).
+//
+// Nothing new is computed: pm_afsk_group_run (shared band-pass + certified sweeps), pm_afsk_sweep_results (+ the exact kernels for a
+// sweep whose list overflowed), pm_slice_batch + pm_slice_compact, pm_host_decode_batch + pm_codec_fetch_batch, pm_correlate --
+// the entry points the Python executor sequences, in the same order, with the same batching rules (a slicer worker waits on the
+// host for the oldest recording's demod event, takes along up to `slice_group` consecutive recordings, ONE worker collects at a
+// time; bitmaps live in `slots` rotating sets; a slot is free again when its recording's slicer output is on the host).
+#include "pm_common.h"
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+constexpr int kMaxChains = 64;
+constexpr int kCompactHead = PM_COMPACT_HEAD;
+
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct HostBlock {                       // page-locked host memory for one slicer batch's compact output
+    uint8_t *p = nullptr;
+    size_t bytes = 0;
+    ~HostBlock() { if (p) (void)hipHostFree(p); }
+};
+
+struct Rec {                             // one recording on its way through
+    int64_t ticket = 0;
+    int slot = 0;
+    const int16_t *d_audio = nullptr;
+    int64_t n = 0;
+    std::vector<int64_t> nout;                          // per chain: the slicer's input length
+    hipEvent_t demod_done = nullptr;
+    pm_ctx *dctx = nullptr;                             // the context (stream) that demodulates this recording
+    std::vector<int64_t> sweep_tickets;
+    // slicer output (compact form inside `block`)
+    std::shared_ptr<HostBlock> block;
+    std::vector<int64_t> off, count;
+    std::vector<std::vector<int64_t>> full_addr;        // per chain: addresses in full when a step did not fit 16 bits (else empty)
+    // result
+    pm_packet *rows = nullptr;                          // malloc'd: the codecs write every row in full, nothing to clear first
+    int64_t nrows = 0;
+    ~Rec() { free(rows); }
+    std::vector<int64_t> counts, unique_idx;
+    std::vector<int32_t> corr;
+    int64_t unique = 0;
+    int status = PM_OK;
+    std::string error;
+    double t_submit = 0, t_ready = 0, t_sliced = 0, t_done = 0;
+    bool done = false;
+};
+
+}  // namespace
+
+struct pm_pipe {
+    pm_ctx *ctx = nullptr;               // the caller's context: the first demod stream
+    std::vector<pm_ctx *> demod;         // demod streams, recordings take turns (demod[0] == ctx, the others are the pipeline's)
+    std::vector<double *> d_bpf_outs;    // one band-passed stream per demod context
+    std::vector<hipEvent_t> handover;    // per slot: the point of the caller's stream a recording submitted to another demod stream starts behind
+    std::vector<pm_ctx *> side;          // slicer streams, one per worker
+    int nchains = 0, nsweeps = 0, slots = 16, group = 4, min_group = 4, host_threads = 3, decode_threads = 8;
+    double address_distance = 0, x_bound = 0;
+    int64_t max_samples = 0;
+    int mb = 0;
+    const double *d_bpf = nullptr;
+    std::vector<pm_pipe_chain> chains;
+    std::vector<pm_afsk_sweep_desc> sweeps;              // as given (device pointers stay the caller's; h_gains / h_tones copied below)
+    std::vector<std::vector<double>> gains;
+    std::vector<pm_afsk_tones> tones;
+    std::vector<char> has_tones;
+    std::vector<int> ml_of_chain, mc_of_chain;
+    // device memory owned by the pipeline
+    std::vector<uint64_t *> d_bits;                      // [slot * nchains + chain]
+    size_t bits_words = 0;
+    std::vector<std::vector<uint64_t *>> sweep_bits;     // [slot][sweep] -> host array of device pointers (what h_bits wants), flattened below
+    std::vector<std::vector<std::vector<uint64_t *>>> sweep_bits_store;
+    std::vector<hipEvent_t> slot_event;
+    // per worker: slicer output blocks on the device
+    struct Work {
+        uint8_t *d_out = nullptr, *d_dense = nullptr;
+        size_t out_bytes = 0, dense_bytes = 0, tmp_n = 0;
+        double *d_tmp = nullptr;
+        bool reserved = false;
+    };
+    // page-locked host blocks for the compact output: a block is in use until the host stages of all its recordings are through;
+    // one made in front of a copy costs 8-20 ms there (touch + pin), so they are made once and go round
+    std::mutex pool_mu;
+    std::vector<HostBlock *> pool;
+    std::vector<Work> work;
+    // queues
+    std::mutex mu;
+    std::condition_variable cv_slot, cv_slice, cv_host, cv_done;
+    std::mutex collect_mu;
+    std::deque<std::shared_ptr<Rec>> slice_q, host_q;
+    std::map<int64_t, std::shared_ptr<Rec>> results;
+    std::vector<char> slot_busy;
+    int64_t next_ticket = 0, submitted = 0, finished = 0;
+    bool closing = false;
+    std::vector<std::thread> threads;
+    // statistics
+    std::atomic<int64_t> batches{0}, batch_recordings{0};
+    double busy_slice_ms = 0, busy_host_ms = 0, t_origin = now_ms();
+};
+
+namespace {
+
+int fail(Rec &r, int rc)
+{
+    char buf[512];
+    pm_last_error(buf, sizeof(buf));
+    r.status = rc;
+    r.error = buf;
+    return rc;
+}
+
+std::shared_ptr<HostBlock> block_get(pm_pipe *p, size_t need, size_t room)
+{
+    HostBlock *b = nullptr;
+    {
+        std::unique_lock<std::mutex> lk(p->pool_mu);
+        for (size_t i = 0; i < p->pool.size(); ++i)
+            if (p->pool[i]->bytes >= need) {
+                b = p->pool[i];
+                p->pool.erase(p->pool.begin() + i);
+                break;
+            }
+    }
+    if (!b) {
+        b = new HostBlock();
+        b->bytes = std::max<size_t>(std::max(need, room), 64);
+        if (hipHostMalloc((void **)&b->p, b->bytes, hipHostMallocDefault) != hipSuccess) {
+            b->p = nullptr;
+            delete b;
+            return nullptr;
+        }
+    }
+    return std::shared_ptr<HostBlock>(b, [p](HostBlock *q) {
+        std::unique_lock<std::mutex> lk(p->pool_mu);
+        p->pool.push_back(q);
+    });
+}
+
+// The exact chain of one modem on `side` (a sweep whose list of uncertain samples overflowed: digital silence, audio far below the
+// stated bound): band-pass, this modem's own four correlators, low-pass + sign -- what resolve_sweeps does in the Python executor.
+int exact_chain(pm_pipe *p, pm_ctx *side, pm_pipe::Work &w, const Rec &r, int chain)
+{
+    const pm_pipe_chain &c = p->chains[chain];
+    const pm_afsk_sweep_desc &s = p->sweeps[c.sweep];
+    const int64_t nb = r.n - p->mb + 1, nc = nb - s.m + 1;
+    const size_t need = (size_t)nb + (size_t)nc + 16;
+    if (w.tmp_n < need) {
+        if (w.d_tmp) { if (int rc = pm_free(side, w.d_tmp)) return rc; w.d_tmp = nullptr; w.tmp_n = 0; }
+        void *q = nullptr;
+        if (int rc = pm_malloc(side, need * sizeof(double), &q)) return rc;
+        w.d_tmp = (double *)q;
+        w.tmp_n = need;
+    }
+    double *bpf = w.d_tmp, *corr = w.d_tmp + ((nb + 1) & ~(int64_t)1);
+    if (int rc = pm_fir_valid_i16(side, r.d_audio, r.n, p->d_bpf, p->mb, bpf, 0)) return rc;
+    const double *space = s.d_space + (size_t)c.slot * 2 * s.m;
+    if (int rc = pm_afsk_correlate(side, bpf, nb, s.d_mark_i, s.d_mark_q, space, space + s.m, s.m, corr)) return rc;
+    return pm_fir_signs_f64(side, corr, nc, s.d_lpf, s.ml, p->d_bits[(size_t)r.slot * p->nchains + chain], 0);
+}
+
+void slice_worker(pm_pipe *p, int wi)
+{
+    pm_ctx *side = p->side[wi];
+    pm_pipe::Work &w = p->work[wi];
+    (void)hipSetDevice(side->device);
+    for (;;) {
+        std::vector<std::shared_ptr<Rec>> batch;
+        {
+            // ONE worker at a time puts a batch together: consecutive recordings, started when its last demod is done
+            std::unique_lock<std::mutex> collect(p->collect_mu);
+            {
+                std::unique_lock<std::mutex> lk(p->mu);
+                p->cv_slice.wait(lk, [&] { return p->closing || !p->slice_q.empty(); });
+                if (p->slice_q.empty()) return;
+                batch.push_back(p->slice_q.front());
+                p->slice_q.pop_front();
+            }
+            (void)hipEventSynchronize(batch[0]->demod_done);
+            batch[0]->t_ready = now_ms();
+            while ((int)batch.size() < p->group) {
+                std::shared_ptr<Rec> nxt;
+                {
+                    std::unique_lock<std::mutex> lk(p->mu);
+                    if (p->slice_q.empty()) break;
+                    nxt = p->slice_q.front();
+                    const bool ready = hipEventQuery(nxt->demod_done) == hipSuccess;
+                    if (!ready && (int)batch.size() >= p->min_group) break;
+                    p->slice_q.pop_front();
+                }
+                (void)hipEventSynchronize(nxt->demod_done);          // already queued on the GPU: a batch of four costs what one costs
+                nxt->t_ready = now_ms();
+                batch.push_back(nxt);
+            }
+        }
+        const double t0 = now_ms();
+        const int nch = p->nchains, nb = (int)batch.size();
+        int rc = PM_OK;
+        // certified sweeps that overflowed are redone with the exact kernels, here
+        for (auto &r : batch) {
+            std::vector<int64_t> unc(p->nsweeps);
+            int64_t cap = 0;
+            if ((rc = pm_afsk_sweep_results(r->dctx, r->sweep_tickets.data(), p->nsweeps, side, unc.data(), &cap))) { fail(*r, rc); continue; }
+            for (int s = 0; s < p->nsweeps && !r->status; ++s) {
+                if (unc[s] <= cap) continue;
+                for (int c = 0; c < nch && !r->status; ++c)
+                    if (p->chains[c].sweep == s && (rc = exact_chain(p, side, w, *r, c))) fail(*r, rc);
+            }
+        }
+        // all slicers of the batch in one pm_slice_batch (groups of <= 64 jobs), compact form, one copy to the host
+        std::vector<pm_slice_job> jobs((size_t)nb * nch);
+        std::vector<pm_slicer_state> states((size_t)nb * nch);
+        std::vector<int64_t> caps(jobs.size());
+        auto lay_out = [&](bool tight) -> size_t {
+            size_t at = 0;
+            for (int b = 0; b < nb; ++b)
+                for (int c = 0; c < nch; ++c) {
+                    const pm_slicer_params &sp = p->chains[c].slicer;
+                    const int64_t no = batch[b]->nout[c];
+                    int64_t cap = no * sp.bits_per_symbol / 8 + 5;
+                    if (tight) cap = std::min<int64_t>(cap, (int64_t)(no * sp.bits_per_symbol / (8.0 * sp.samples_per_symbol) * 1.5) + 64);
+                    caps[(size_t)b * nch + c] = cap;
+                    at += (size_t)cap * 8;
+                }
+            for (size_t j = 0; j < caps.size(); ++j) at += ((size_t)caps[j] + 4 + 7) / 8 * 8;
+            return at;
+        };
+        auto run = [&](bool tight) -> int {
+            const size_t bytes = lay_out(tight);
+            const size_t reserve = bytes * (size_t)p->group / (size_t)nb;       // sized for a full batch at first use: no free in mid-stream
+            if (w.out_bytes < bytes) {
+                if (w.d_out) { if (int rc2 = pm_free(side, w.d_out)) return rc2; w.d_out = nullptr; w.out_bytes = 0; }
+                void *q = nullptr;
+                if (int rc2 = pm_malloc(side, std::max(bytes, reserve), &q)) return rc2;
+                w.d_out = (uint8_t *)q;
+                w.out_bytes = std::max(bytes, reserve);
+            }
+            size_t a_at = 0, d_at = 0;
+            for (size_t j = 0; j < caps.size(); ++j) d_at += (size_t)caps[j] * 8;
+            for (int b = 0; b < nb; ++b)
+                for (int c = 0; c < nch; ++c) {
+                    const size_t j = (size_t)b * nch + c;
+                    pm_slice_job &q = jobs[j];
+                    memset(&q, 0, sizeof(q));
+                    memset(&states[j], 0, sizeof(pm_slicer_state));
+                    q.d_bits_i = p->d_bits[(size_t)batch[b]->slot * nch + c];
+                    q.d_bits_q = nullptr;
+                    q.n = batch[b]->nout[c];
+                    q.params = p->chains[c].slicer;
+                    q.d_addr = (int64_t *)(w.d_out + a_at);
+                    q.d_data = w.d_out + d_at;
+                    q.cap = caps[j];
+                    q.h_state = &states[j];
+                    a_at += (size_t)caps[j] * 8;
+                    d_at += ((size_t)caps[j] + 4 + 7) / 8 * 8;
+                }
+            for (size_t j0 = 0; j0 < jobs.size(); j0 += 64) {
+                const int nj = (int)std::min<size_t>(64, jobs.size() - j0);
+                if (int rc2 = pm_slice_batch(side, jobs.data() + j0, nj)) return rc2;
+            }
+            return PM_OK;
+        };
+        const double t_a = now_ms();
+        rc = run(true);
+        if (rc == PM_ERR_CAPACITY) rc = run(false);
+        const double t_b = now_ms();          // a stream with more than 1.5x its nominal symbol count: the full bound
+        std::shared_ptr<HostBlock> hb;
+        std::vector<int64_t> offs(jobs.size());
+        if (!rc) {
+            size_t dense_cap = 0;
+            for (size_t j = 0; j < caps.size(); ++j)
+                dense_cap += kCompactHead + ((size_t)2 * jobs[j].count + 7) / 8 * 8 + ((size_t)jobs[j].count + 7) / 8 * 8;
+            if (w.dense_bytes < dense_cap) {
+                if (w.d_dense) { (void)pm_free(side, w.d_dense); w.d_dense = nullptr; w.dense_bytes = 0; }
+                void *q = nullptr;
+                const size_t want = dense_cap * 3 / 2 * (size_t)p->group / (size_t)nb + 4096;
+                if (!(rc = pm_malloc(side, want, &q))) { w.d_dense = (uint8_t *)q; w.dense_bytes = want; }
+            }
+            size_t used = 0, at = 0;
+            for (size_t j0 = 0; j0 < jobs.size() && !rc; j0 += 64) {
+                const int nj = (int)std::min<size_t>(64, jobs.size() - j0);
+                size_t u = 0;
+                rc = pm_slice_compact(side, jobs.data() + j0, nj, w.d_dense + at, w.dense_bytes - at, offs.data() + j0, &u);
+                for (int k = 0; k < nj; ++k) offs[j0 + k] += (int64_t)at;
+                at += (u + 255) & ~(size_t)255;
+                used = at;
+            }
+            if (!rc && !w.reserved) {
+                // first batch of this worker: the stream's work block (checkpoints, symbol bitmaps, lists: ~150 MB per recording) sized
+                // for a full batch now -- growing it later is a free + malloc in the middle of the pipeline -- and the host blocks made
+                w.reserved = true;
+                size_t have = 0;
+                if (!(rc = pm_ctx_scratch(side, 0, &have))) rc = pm_ctx_scratch(side, have * (size_t)p->group / (size_t)nb, nullptr);
+                std::vector<std::shared_ptr<HostBlock>> warm;
+                for (int k = 0; k < 4 && !rc; ++k) {
+                    warm.push_back(block_get(p, w.dense_bytes, w.dense_bytes));
+                    if (!warm.back()) rc = pm_set_error(PM_ERR_HIP, "hipHostMalloc of %zu bytes failed", w.dense_bytes);
+                }
+            }
+            if (!rc) {
+                hb = block_get(p, used, w.dense_bytes);
+                if (!hb) rc = pm_set_error(PM_ERR_HIP, "hipHostMalloc of %zu bytes failed", w.dense_bytes);
+                if (!rc && hipMemcpyAsync(hb->p, w.d_dense, used, hipMemcpyDeviceToHost, side->stream) != hipSuccess) rc = pm_set_error(PM_ERR_HIP, "copy of the slicer output failed");
+                if (!rc && hipStreamSynchronize(side->stream) != hipSuccess) rc = pm_set_error(PM_ERR_HIP, "slicer stream failed");
+            }
+        }
+        const double t1 = now_ms();
+        static const bool trace = getenv("PM_PIPE_TRACE") != nullptr;
+        if (trace)
+            fprintf(stderr, "[pm_pipe] worker %d batch of %d (first %lld): demod done at %.2f, collected %.2f, sweeps checked +%.2f, sliced +%.2f, on the host +%.2f ms\n", wi, nb,
+                    (long long)batch[0]->ticket, batch[0]->t_ready - p->t_origin, t0 - p->t_origin, t_a - t0, t_b - t_a, t1 - t_b);
+        for (int b = 0; b < nb; ++b) {
+            Rec &r = *batch[b];
+            if (rc && !r.status) fail(r, rc);
+            if (!r.status) {
+                r.block = hb;
+                r.off.assign(nch, 0);
+                r.count.assign(nch, 0);
+                r.full_addr.assign(nch, {});
+                for (int c = 0; c < nch && !r.status; ++c) {
+                    const size_t j = (size_t)b * nch + c;
+                    r.off[c] = offs[j];
+                    r.count[c] = jobs[j].count;
+                    const uint8_t *flags = hb->p + offs[j] + 16;
+                    bool wide = false;
+                    for (int f = 0; f < 64 && jobs[j].count; ++f) wide = wide || flags[f] != 0;
+                    if (wide) {                                  // a step beyond 16 bits: this stream's addresses in full
+                        r.full_addr[c].resize((size_t)jobs[j].count);
+                        if (hipMemcpy(r.full_addr[c].data(), jobs[j].d_addr, (size_t)jobs[j].count * 8, hipMemcpyDeviceToHost) != hipSuccess)
+                            fail(r, pm_set_error(PM_ERR_HIP, "copy of the slicer addresses failed"));
+                    }
+                }
+            }
+            r.t_sliced = t1;
+        }
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            for (auto &r : batch) {
+                p->slot_busy[r->slot] = 0;                       // the bitmaps are consumed and the output is on the host
+                p->host_q.push_back(r);
+            }
+            p->busy_slice_ms += t1 - t0;
+        }
+        p->batches++;
+        p->batch_recordings += nb;
+        p->cv_slot.notify_all();
+        p->cv_host.notify_all();
+    }
+}
+
+void host_worker(pm_pipe *p)
+{
+    for (;;) {
+        std::shared_ptr<Rec> rp;
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->cv_host.wait(lk, [&] { return p->closing || !p->host_q.empty(); });
+            if (p->host_q.empty()) {
+                if (p->closing) return;
+                continue;
+            }
+            rp = p->host_q.front();
+            p->host_q.pop_front();
+        }
+        Rec &r = *rp;
+        const double t0 = now_ms();
+        const int nch = p->nchains;
+        std::vector<pm_codec *> codecs(nch, nullptr);
+        if (!r.status) {
+            std::vector<pm_host_job> jobs(nch);
+            int rc = PM_OK;
+            for (int c = 0; c < nch && !rc; ++c) {
+                const pm_pipe_chain &ch = p->chains[c];
+                rc = pm_codec_create(ch.codec_kind, ch.crc, ch.disable_rs, ch.min_dist, ch.sync_tol, ch.source_decoder, &codecs[c]);
+                pm_host_job &j = jobs[c];
+                memset(&j, 0, sizeof(j));
+                j.codec = codecs[c];
+                const int64_t cnt = r.count[c];
+                const uint8_t *base = r.block->p + r.off[c];
+                j.n = cnt;
+                j.h_data = base + kCompactHead + ((size_t)2 * cnt + 7) / 8 * 8;
+                if (!r.full_addr[c].empty()) {
+                    j.h_addr = r.full_addr[c].data();
+                } else {
+                    j.h_addr = nullptr;
+                    j.h_addr_delta = (const uint16_t *)(base + kCompactHead);
+                    memcpy(&j.addr_first, base, 8);
+                }
+                j.lfsr_poly = ch.lfsr_poly;
+                j.lfsr_state = 0;
+                j.lfsr_invert = ch.lfsr_invert;
+            }
+            if (!rc) rc = pm_host_decode_batch(jobs.data(), nch, p->decode_threads);
+            static const bool trace = getenv("PM_PIPE_TRACE") != nullptr;
+            if (trace) {
+                std::string line = "[pm_pipe] recording " + std::to_string(r.ticket) + " rc " + std::to_string(rc) + ": slicer bytes / packets per chain";
+                for (int c = 0; c < nch; ++c) line += " " + std::to_string(r.count[c]) + "/" + std::to_string(jobs[c].pending);
+                line += "; host stage began " + std::to_string(t0 - p->t_origin) + ", decode done " + std::to_string(now_ms() - p->t_origin);
+                fprintf(stderr, "%s\n", line.c_str());
+            }
+            if (!rc) {
+                r.counts.resize(nch);
+                int64_t total = 0;
+                for (int c = 0; c < nch; ++c) total += (r.counts[c] = jobs[c].pending);
+                r.rows = (pm_packet *)malloc((size_t)std::max<int64_t>(total, 1) * sizeof(pm_packet));
+                r.nrows = total;
+                if (!r.rows) rc = pm_set_error(PM_ERR_ARG, "out of host memory for %lld packet rows", (long long)total);
+                if (!rc) rc = pm_codec_fetch_batch(codecs.data(), r.counts.data(), nch, r.rows, p->decode_threads);
+                if (!rc) {
+                    // PacketMetaArray.Correlate over the chains in config order (packet_meta.py:230-271)
+                    r.unique_idx.resize((size_t)std::max<int64_t>(total, 1));
+                    r.corr.resize((size_t)std::max<int64_t>(total, 1));
+                    const int64_t k = total ? pm_correlate(r.rows, r.counts.data(), nch, p->address_distance, r.unique_idx.data(), r.corr.data(),
+                                                           (int64_t)r.corr.size())
+                                            : 0;
+                    if (k < 0) rc = (int)k;
+                    else r.unique = k;
+                }
+            }
+            if (rc) fail(r, rc);
+        }
+        for (pm_codec *c : codecs)
+            if (c) (void)pm_codec_destroy(c);
+        r.block.reset();
+        r.t_done = now_ms();
+        static const bool trace_done = getenv("PM_PIPE_TRACE") != nullptr;
+        if (trace_done) fprintf(stderr, "[pm_pipe] recording %lld done at %.2f\n", (long long)r.ticket, r.t_done - p->t_origin);
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            r.done = true;
+            p->finished++;
+            p->busy_host_ms += r.t_done - t0;
+        }
+        p->cv_done.notify_all();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pm_pipe_destroy(pm_pipe *p)
+{
+    if (!p) return PM_OK;
+    {
+        std::unique_lock<std::mutex> lk(p->mu);
+        // everything submitted goes through first
+        p->cv_done.wait(lk, [&] { return p->finished == p->submitted; });
+        p->closing = true;
+    }
+    p->cv_slice.notify_all();
+    p->cv_host.notify_all();
+    for (auto &t : p->threads) t.join();
+    pm_ctx *ctx = p->ctx;
+    (void)pm_ctx_sync(ctx);
+    for (uint64_t *b : p->d_bits)
+        if (b) (void)pm_free(ctx, b);
+    for (size_t i = 1; i < p->demod.size(); ++i) (void)pm_ctx_sync(p->demod[i]);
+    for (double *b : p->d_bpf_outs)
+        if (b) (void)pm_free(ctx, b);
+    for (size_t i = 1; i < p->demod.size(); ++i) (void)pm_ctx_destroy(p->demod[i]);
+    for (hipEvent_t e : p->handover)
+        if (e) (void)hipEventDestroy(e);
+    for (size_t i = 0; i < p->work.size(); ++i) {
+        pm_ctx *s = p->side[i];
+        for (void *q : {(void *)p->work[i].d_out, (void *)p->work[i].d_dense, (void *)p->work[i].d_tmp})
+            if (q) (void)pm_free(s, q);
+    }
+    for (hipEvent_t e : p->slot_event)
+        if (e) (void)hipEventDestroy(e);
+    for (pm_ctx *s : p->side) (void)pm_ctx_destroy(s);
+    p->results.clear();
+    for (HostBlock *b : p->pool) delete b;
+    delete p;
+    return PM_OK;
+}
+
+int pm_pipe_create(pm_ctx *ctx, const pm_pipe_desc *desc, pm_pipe **out)
+{
+    PM_CTX(ctx);
+    PM_ARG(desc != nullptr && out != nullptr);
+    const pm_pipe_desc &d = *desc;
+    PM_ARG(d.d_bpf && d.mb >= 1 && d.x_bound > 0 && d.sweeps && d.nsweeps >= 1 && d.nsweeps <= 16 && d.chains && d.nchains >= 1 && d.nchains <= kMaxChains);
+    PM_ARG(d.max_samples >= d.mb && d.address_distance >= 0);
+    pm_pipe *p = new pm_pipe();
+    p->ctx = ctx;
+    p->nchains = d.nchains;
+    p->nsweeps = d.nsweeps;
+    p->slots = d.slots > 0 ? std::min(d.slots, 32) : 16;
+    const int nd = d.demod_streams > 0 ? std::min(d.demod_streams, 4) : 3;
+    p->slots = std::max(2, std::min(p->slots, 60 / d.nsweeps * nd));  // a sweep's counter stays readable for 63 further sweeps of its context
+    p->group = d.slice_group > 0 ? std::min(d.slice_group, 16) : 4;
+    p->min_group = d.slice_min_group > 0 ? std::min(d.slice_min_group, p->group) : p->group;
+    p->host_threads = d.host_threads > 0 ? d.host_threads : std::max(2, std::min(8, 24 / d.nchains)) + 1;
+    p->decode_threads = d.decode_threads > 0 ? d.decode_threads : d.nchains;
+    p->address_distance = d.address_distance;
+    p->x_bound = d.x_bound;
+    p->max_samples = d.max_samples;
+    p->mb = d.mb;
+    p->d_bpf = d.d_bpf;
+    p->chains.assign(d.chains, d.chains + d.nchains);
+    p->sweeps.assign(d.sweeps, d.sweeps + d.nsweeps);
+    p->gains.resize(d.nsweeps);
+    p->tones.resize(d.nsweeps);
+    p->has_tones.assign(d.nsweeps, 0);
+    int rc = PM_OK;
+    do {
+        for (int s = 0; s < d.nsweeps; ++s) {
+            pm_afsk_sweep_desc &w = p->sweeps[s];
+            if (!(w.groups >= 1 && w.groups <= PM_AFSK_GROUP_MAX && w.h_gains && w.m >= 1 && w.ml >= 1)) { rc = pm_set_error(PM_ERR_ARG, "pm_pipe_create: sweep %d is malformed", s); break; }
+            p->gains[s].assign(w.h_gains, w.h_gains + w.groups);
+            w.h_gains = p->gains[s].data();
+            if (w.h_tones) {
+                p->tones[s] = *w.h_tones;
+                p->has_tones[s] = 1;
+            }
+            w.h_tones = p->has_tones[s] ? &p->tones[s] : nullptr;
+            w.h_bits = nullptr;
+        }
+        if (rc) break;
+        // every chain names its sweep and its place in it exactly once
+        std::vector<std::vector<int>> seen(d.nsweeps);
+        for (int s = 0; s < d.nsweeps; ++s) seen[s].assign(p->sweeps[s].groups, -1);
+        for (int c = 0; c < d.nchains && !rc; ++c) {
+            const pm_pipe_chain &ch = p->chains[c];
+            if (ch.sweep < 0 || ch.sweep >= d.nsweeps || ch.slot < 0 || ch.slot >= p->sweeps[ch.sweep].groups || seen[ch.sweep][ch.slot] >= 0 ||
+                ch.slicer.bits_per_symbol != 1)
+                rc = pm_set_error(PM_ERR_ARG, "pm_pipe_create: chain %d does not name a free place of a sweep (or is not a binary-slicer chain)", c);
+            else
+                seen[ch.sweep][ch.slot] = c;
+        }
+        for (int s = 0; s < d.nsweeps && !rc; ++s)
+            for (int g = 0; g < p->sweeps[s].groups; ++g)
+                if (seen[s][g] < 0) rc = pm_set_error(PM_ERR_ARG, "pm_pipe_create: place %d of sweep %d has no chain", g, s);
+        if (rc) break;
+        const int64_t nb = d.max_samples - d.mb + 1;
+        void *q = nullptr;
+        p->demod.push_back(ctx);
+        for (int k = 1; k < nd && !rc; ++k) {
+            pm_ctx *c = nullptr;
+            if (!(rc = pm_ctx_create_prio(ctx->device, 0, &c))) p->demod.push_back(c);
+        }
+        for (int k = 0; k < nd && !rc; ++k)
+            if (!(rc = pm_malloc(ctx, (size_t)nb * sizeof(double), &q))) p->d_bpf_outs.push_back((double *)q);
+        if (rc) break;
+        p->bits_words = (size_t)(d.max_samples + 63) / 64 + 2;
+        p->d_bits.assign((size_t)p->slots * d.nchains, nullptr);
+        for (size_t i = 0; i < p->d_bits.size() && !rc; ++i) {
+            if (!(rc = pm_malloc(ctx, p->bits_words * 8, &q))) p->d_bits[i] = (uint64_t *)q;
+        }
+        if (rc) break;
+        p->sweep_bits_store.resize(p->slots);
+        for (int sl = 0; sl < p->slots; ++sl) {
+            p->sweep_bits_store[sl].resize(d.nsweeps);
+            for (int s = 0; s < d.nsweeps; ++s) {
+                p->sweep_bits_store[sl][s].resize(p->sweeps[s].groups);
+                for (int g = 0; g < p->sweeps[s].groups; ++g) p->sweep_bits_store[sl][s][g] = p->d_bits[(size_t)sl * d.nchains + seen[s][g]];
+            }
+        }
+        p->slot_busy.assign(p->slots, 0);
+        p->slot_event.assign(p->slots, nullptr);
+        p->handover.assign(p->slots, nullptr);
+        for (int sl = 0; sl < p->slots && !rc; ++sl)
+            if (hipEventCreateWithFlags(&p->slot_event[sl], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&p->handover[sl], hipEventDisableTiming) != hipSuccess)
+                rc = pm_set_error(PM_ERR_HIP, "hipEventCreate failed");
+        if (rc) break;
+        const int workers = d.slice_workers > 0 ? std::min(d.slice_workers, 4) : 2;
+        p->work.resize(workers);
+        for (int wk = 0; wk < workers && !rc; ++wk) {
+            pm_ctx *s = nullptr;
+            if (!(rc = pm_ctx_create_prio(ctx->device, 1, &s))) {
+                p->side.push_back(s);
+                rc = pm_slicer_tune(s, 16384);
+            }
+        }
+        if (rc) break;
+        for (int wk = 0; wk < workers; ++wk) p->threads.emplace_back(slice_worker, p, wk);
+        for (int h = 0; h < p->host_threads; ++h) p->threads.emplace_back(host_worker, p);
+    } while (0);
+    if (rc) {
+        char keep[512];
+        pm_last_error(keep, sizeof(keep));
+        pm_pipe_destroy(p);
+        return pm_set_error(rc, "%s", keep);
+    }
+    *out = p;
+    return PM_OK;
+}
+
+int pm_pipe_submit(pm_pipe *p, const int16_t *d_audio, int64_t n, int64_t *h_ticket)
+{
+    PM_ARG(p != nullptr && d_audio != nullptr && h_ticket != nullptr);
+    PM_CTX(p->ctx);
+    PM_ARG(n >= p->mb && n <= p->max_samples);
+    auto r = std::make_shared<Rec>();
+    r->d_audio = d_audio;
+    r->n = n;
+    const int64_t nb = n - p->mb + 1;
+    {
+        std::unique_lock<std::mutex> lk(p->mu);
+        r->ticket = p->next_ticket++;
+        r->slot = (int)(r->ticket % p->slots);
+        const double tw = now_ms();
+        p->cv_slot.wait(lk, [&] { return !p->slot_busy[r->slot]; });      // the recording that used this slot `slots` submissions ago is sliced
+        p->slot_busy[r->slot] = 1;
+        static const bool trace = getenv("PM_PIPE_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "[pm_pipe] submit %lld at %.2f (waited %.2f ms for its slot)\n", (long long)r->ticket, now_ms() - p->t_origin, now_ms() - tw);
+    }
+    r->nout.resize(p->nchains);
+    for (int c = 0; c < p->nchains; ++c) {
+        const pm_afsk_sweep_desc &w = p->sweeps[p->chains[c].sweep];
+        r->nout[c] = nb - w.m - w.ml + 2;
+        if (r->nout[c] < 1) {
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->slot_busy[r->slot] = 0;
+            p->cv_slot.notify_all();
+            return pm_set_error(PM_ERR_ARG, "pm_pipe_submit: %lld samples are fewer than the filters of chain %d need", (long long)n, c);
+        }
+    }
+    r->t_submit = now_ms();
+    std::vector<pm_afsk_sweep_desc> sw(p->sweeps);
+    for (int s = 0; s < p->nsweeps; ++s) sw[s].h_bits = p->sweep_bits_store[r->slot][s].data();
+    r->sweep_tickets.assign(p->nsweeps, 0);
+    const size_t di = (size_t)(r->ticket % (int64_t)p->demod.size());
+    r->dctx = p->demod[di];
+    int rc = PM_OK;
+    if (r->dctx != p->ctx) {
+        // the recording is in place at this point of the CALLER's stream (an upload enqueued there, an event it waits for): the other
+        // demod stream starts behind that point
+        if (hipEventRecord(p->handover[r->slot], p->ctx->stream) != hipSuccess || hipStreamWaitEvent(r->dctx->stream, p->handover[r->slot], 0) != hipSuccess)
+            rc = pm_set_error(PM_ERR_HIP, "handing the recording to demod stream %zu failed", di);
+    }
+    if (!rc) rc = pm_afsk_group_run(r->dctx, d_audio, n, p->d_bpf, p->mb, p->d_bpf_outs[di], p->x_bound, sw.data(), p->nsweeps, r->sweep_tickets.data());
+    if (!rc && hipEventRecord(p->slot_event[r->slot], r->dctx->stream) != hipSuccess) rc = pm_set_error(PM_ERR_HIP, "hipEventRecord failed");
+    r->demod_done = p->slot_event[r->slot];
+    if (rc) {
+        std::unique_lock<std::mutex> lk(p->mu);
+        p->slot_busy[r->slot] = 0;
+        p->cv_slot.notify_all();
+        return rc;
+    }
+    {
+        std::unique_lock<std::mutex> lk(p->mu);
+        p->results[r->ticket] = r;
+        p->slice_q.push_back(r);
+        p->submitted++;
+    }
+    p->cv_slice.notify_one();
+    *h_ticket = r->ticket;
+    return PM_OK;
+}
+
+int pm_pipe_wait(pm_pipe *p, int64_t ticket, pm_pipe_result *out)
+{
+    PM_ARG(p != nullptr && out != nullptr);
+    std::shared_ptr<Rec> r;
+    {
+        std::unique_lock<std::mutex> lk(p->mu);
+        auto it = p->results.find(ticket);
+        if (it == p->results.end()) return pm_set_error(PM_ERR_ARG, "pm_pipe_wait: ticket %lld is unknown (or released)", (long long)ticket);
+        r = it->second;
+        p->cv_done.wait(lk, [&] { return r->done; });
+    }
+    memset(out, 0, sizeof(*out));
+    out->ticket = ticket;
+    out->status = r->status;
+    out->rows = r->nrows;
+    out->h_rows = r->rows;
+    out->h_counts = r->counts.data();
+    out->unique = r->unique;
+    out->h_unique_idx = r->unique_idx.data();
+    out->h_corr_decoders = r->corr.data();
+    out->ms_to_demod_done = r->t_ready - r->t_submit;
+    out->ms_to_sliced = r->t_sliced - r->t_submit;
+    out->ms_to_done = r->t_done - r->t_submit;
+    if (r->status) return pm_set_error(r->status, "%s", r->error.c_str());
+    return PM_OK;
+}
+
+int pm_pipe_release(pm_pipe *p, int64_t ticket)
+{
+    PM_ARG(p != nullptr);
+    std::unique_lock<std::mutex> lk(p->mu);
+    auto it = p->results.find(ticket);
+    if (it == p->results.end()) return PM_OK;
+    if (!it->second->done) return pm_set_error(PM_ERR_ARG, "pm_pipe_release: recording %lld is still in flight", (long long)ticket);
+    p->results.erase(it);
+    return PM_OK;
+}
+
+int pm_pipe_drain(pm_pipe *p)
+{
+    PM_ARG(p != nullptr);
+    std::unique_lock<std::mutex> lk(p->mu);
+    p->cv_done.wait(lk, [&] { return p->finished == p->submitted; });
+    return PM_OK;
+}
+
+int pm_pipe_stats(pm_pipe *p, int64_t *h_batches, int64_t *h_batch_recordings, double *h_slice_busy_ms, double *h_host_busy_ms)
+{
+    PM_ARG(p != nullptr);
+    std::unique_lock<std::mutex> lk(p->mu);
+    if (h_batches) *h_batches = p->batches.load();
+    if (h_batch_recordings) *h_batch_recordings = p->batch_recordings.load();
+    if (h_slice_busy_ms) *h_slice_busy_ms = p->busy_slice_ms;
+    if (h_host_busy_ms) *h_host_busy_ms = p->busy_host_ms;
+    return PM_OK;
+}
+
+pm_ctx *pm_pipe_side_ctx(pm_pipe *p, int worker)
+{
+    return (p && worker >= 0 && worker < (int)p->side.size()) ? p->side[worker] : nullptr;
+}
+
+pm_ctx *pm_pipe_demod_ctx(pm_pipe *p, int k)
+{
+    return (p && k >= 0 && k < (int)p->demod.size()) ? p->demod[k] : nullptr;
+}
+
+}  // extern "C"

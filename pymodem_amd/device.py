@@ -24,6 +24,13 @@ class Context:
         else:
             check(lib().pm_ctx_create_prio(device, int(bool(high_priority)), ctypes.byref(self._h)))
 
+    @classmethod
+    def borrowed(cls, handle, device=0):
+        """A view of a context the library owns (a pipeline's slicer stream): for profile()/sync(), never destroyed from here."""
+        self = cls.__new__(cls)
+        self._h, self.device, self._borrowed = ctypes.c_void_p(handle), device, True
+        return self
+
     @staticmethod
     def cu_split(device, per_xcd):
         """(slicer mask, demod mask): the first `per_xcd` CUs of each of the 8 XCDs for the slicers' streams, the rest for the FIR
@@ -221,6 +228,9 @@ class Context:
         return ms.value
 
     def close(self):
+        if getattr(self, "_borrowed", False):
+            self._h = ctypes.c_void_p()
+            return
         if self._h:
             for chunk in self.__dict__.pop("_arena_chunks", []):
                 chunk[0].free()

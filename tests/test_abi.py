@@ -53,11 +53,14 @@ def test_header_is_plain_c_and_ctypes_mirrors_match(tmp_path):
         pytest.skip("no C compiler")
     structs = {"pm_packet": N.Packet, "pm_loop": N.Loop, "pm_agc_params": N.AGCParams, "pm_slicer_params": N.SlicerParams,
                "pm_slicer_state": N.SlicerState, "pm_slice_job": N.SliceJob, "pm_chain_desc": N.ChainDesc, "pm_host_job": N.HostJob, "pm_afsk_tones": N.AfskTones,
-               "pm_afsk_sweep_desc": N.AfskSweepDesc, "pm_lbatch_desc": N.LBatchDesc}
+               "pm_afsk_sweep_desc": N.AfskSweepDesc, "pm_lbatch_desc": N.LBatchDesc,
+               "pm_pipe_chain": N.PipeChain, "pm_pipe_desc": N.PipeDesc, "pm_pipe_result": N.PipeResult}
     fields = [("pm_packet", "data"), ("pm_packet", "correlated_count"), ("pm_loop", "bb0"), ("pm_loop", "sy0"), ("pm_slice_job", "h_state"),
               ("pm_slice_job", "count"), ("pm_slicer_state", "streamaddress"), ("pm_chain_desc", "slicer"), ("pm_chain_desc", "loop"),
               ("pm_chain_desc", "pd_table"), ("pm_chain_desc", "agc"), ("pm_slicer_params", "demap"), ("pm_afsk_sweep_desc", "h_tones"),
-              ("pm_afsk_sweep_desc", "lpf_abs_sum"), ("pm_lbatch_desc", "agc"), ("pm_lbatch_desc", "pd_table"), ("pm_lbatch_desc", "output_fir")]
+              ("pm_afsk_sweep_desc", "lpf_abs_sum"), ("pm_lbatch_desc", "agc"), ("pm_lbatch_desc", "pd_table"), ("pm_lbatch_desc", "output_fir"),
+              ("pm_pipe_chain", "lfsr_poly"), ("pm_pipe_chain", "source_decoder"), ("pm_pipe_desc", "x_bound"), ("pm_pipe_desc", "max_samples"),
+              ("pm_pipe_desc", "address_distance"), ("pm_pipe_result", "h_corr_decoders"), ("pm_pipe_result", "ms_to_done")]
     src = ['#include "pymodem_amd.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void) {",
            '    printf("version %d\\n", pm_version());']
     for name in structs:

@@ -1,0 +1,119 @@
+"""The native pipelined executor (pm_pipe_*, pymodem_amd.chain_execute.NativePipeline) against the one-recording-at-a-time group
+executor and the oracle: same packet rows per chain, same de-dup, for recordings of different lengths and kinds in flight together
+(including the degenerate ones whose certified sweeps overflow and are redone with the exact kernels on the slicer worker)."""
+import numpy as np
+import pytest
+
+from conftest import noise_i16
+import oracle.oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CFG = "afsk_1200_ax25_super_opt.json"
+
+
+def _recordings():
+    from pymodem_amd import siggen
+    a = siggen.recording("afsk1200_ax25", 48000, packets=6, seed=11, noise_sigma=800.0, payload_len=(20, 80))[0]
+    b = siggen.recording("afsk1200_ax25", 48000, packets=3, seed=12, noise_sigma=2500.0, payload_len=(10, 40))[0]
+    return {"a": a, "b": b, "half": a[: len(a) // 2].copy(), "noise": noise_i16(300000), "silence": np.zeros(250000, np.int16),
+            "whisper": np.random.default_rng(3).integers(-1, 2, 200000).astype(np.int16), "short": a[:20000].copy()}
+
+
+def _want(lines, audio, rate=48000):
+    from pymodem_amd import chain_builder as cb, chain_execute as ce
+    from pymodem_amd.packet_meta import PacketTable
+    rows = ce.process_chains_table([cb.build_chain(rate, l) for l in lines], audio)
+    table = PacketTable(dict(rows), [l["object_name"] for l in lines]).correlate(rate / 40)
+    return rows, table
+
+
+@pytest.mark.parametrize("demod_streams", [1, 3])
+def test_native_pipeline_matches_the_group_executor(config_lines, demod_streams):
+    import pymodem_amd
+    from pymodem_amd import chain_builder as cb, chain_execute as ce
+    lines = config_lines(CFG)
+    recs = _recordings()
+    want = {k: _want(lines, v) for k, v in recs.items()}
+    ctx = pymodem_amd.Context.default()
+    dev = {k: ctx.upload(v) for k, v in recs.items()}
+    ctx.sync()
+    pipe = ce.NativePipeline([cb.build_chain(48000, l) for l in lines], max(len(v) for v in recs.values()), 48000 / 40, ctx=ctx,
+                              demod_streams=demod_streams)
+    order = ["a", "silence", "b", "half", "a", "noise", "whisper", "short", "b", "a", "silence", "half"] * 3
+    tickets = [(k, pipe.submit(dev[k])) for k in order]
+    tables = []
+    for k, t in tickets:
+        table = pipe.table(t)
+        rows_w, table_w = want[k]
+        at = 0
+        for c in range(len(lines)):
+            got = table.rows[at:at + table.counts[c]]
+            at += table.counts[c]
+            assert np.array_equal(got, rows_w[c]) or (
+                len(got) == len(rows_w[c]) and all(np.array_equal(got[f], rows_w[c][f]) for f in got.dtype.names if f != "correlated_count")), (k, c)
+        assert np.array_equal(table.unique_idx, table_w.unique_idx), k
+        assert table.unique_decoders == table_w.unique_decoders, k
+        assert table.CountGood() == table_w.CountGood() and table.CountBad() == table_w.CountBad()
+        tables.append(table)
+    assert want["a"][1].CountGood() >= 5
+    st = pipe.stats()
+    assert st["recordings"] == len(order) and st["slice_batches"] <= len(order)
+    # a table outlives close(): its rows stay in the library until it is gone
+    keep = tables[0].rows
+    del tables, table
+    pipe.close()
+    assert np.array_equal(keep[: want["a"][1].counts[0]]["data"], want["a"][0][0]["data"])
+    del keep
+
+
+def test_native_pipeline_rows_equal_the_oracle(config_lines):
+    """Straight against the CPU restatement for one recording: slicer-to-packet results per chain."""
+    import pymodem_amd
+    from pymodem_amd import chain_builder as cb, chain_execute as ce, siggen
+    lines = config_lines(CFG)
+    audio = siggen.recording("afsk1200_ax25", 48000, packets=4, seed=31, noise_sigma=1200.0, payload_len=(20, 60))[0]
+    ctx = pymodem_amd.Context.default()
+    d = ctx.upload(audio)
+    ctx.sync()
+    pipe = ce.NativePipeline([cb.build_chain(48000, l) for l in lines], len(audio), 48000 / 40, ctx=ctx, chain_ids=[7 + c for c in range(len(lines))])
+    tk = [pipe.submit(d) for _ in range(5)]
+    for t in tk[:-1]:
+        u, n = pipe.unique(t)
+    table = pipe.table(tk[-1])
+    assert (u, n) == (table.CountGood(), len(table.rows))
+    at = 0
+    for c, l in enumerate(lines):
+        w = O.run_chain(O.build_chain(48000, l), audio, canon=True)
+        got = table.rows[at:at + table.counts[c]]
+        at += table.counts[c]
+        assert [int(a) for a in got["streamaddress"]] == [int(p.streamaddress) for p in w["packets"]], c
+        assert [bytes(r["data"][: r["len"]]) for r in got] == [bytes(bytearray(p.data)) for p in w["packets"]], c
+        assert [int(b) for b in got["bytes_corrected"]] == [int(p.BytesCorrected) for p in w["packets"]], c
+        assert (got["source_decoder"] == 7 + c).all()
+    del table, got
+    pipe.close()
+
+
+def test_native_pipeline_refuses_what_it_does_not_cover(config_lines):
+    import pymodem_amd
+    from pymodem_amd import chain_builder as cb, chain_execute as ce
+    ctx = pymodem_amd.Context.default()
+    with pytest.raises(ValueError):
+        ce.NativePipeline([cb.build_chain(48000, l) for l in config_lines("fsk_9600.json")], 100000, 1200.0, ctx=ctx)
+    lines = config_lines(CFG)
+    pipe = ce.NativePipeline([cb.build_chain(48000, l) for l in lines], 100000, 1200.0, ctx=ctx)
+    with pytest.raises(ValueError):
+        pipe.submit(np.zeros(1000, np.int16))
+    too_long = ctx.upload(np.zeros(100001, np.int16))
+    with pytest.raises(pymodem_amd.NativeError):
+        pipe.submit(too_long)
+    tiny = ctx.upload(np.zeros(64, np.int16))
+    with pytest.raises(pymodem_amd.NativeError):
+        pipe.submit(tiny)
+    with pytest.raises(pymodem_amd.NativeError):
+        pipe.table(12345)
+    ok = ctx.upload(noise_i16(100000))
+    t = pipe.submit(ok)
+    assert pipe.unique(t)[0] == 0
+    pipe.close()
