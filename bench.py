@@ -144,9 +144,9 @@ def main():
                          "step k on a high-priority side stream, host half (LFSR, codec, packet gather, de-dup) of step k-1 in threads; "
                          "1: only the host half runs behind the next step's GPU half; 0: strictly one after the other")
     ap.add_argument("--executor", default="auto", choices=["auto", "native", "python"],
-                    help="--overlap 2, one rank: native = the library's own pipelined executor (pm_pipe_*: one call per recording, slicer and "
-                         "host stages on the library's threads); python = chain_execute.RecordingPipeline (the stages sequenced by Python "
-                         "threads).  auto: native where it applies (AFSK gain-sweep configs on one rank), python elsewhere")
+                    help="--overlap 2: native = the library's own pipelined executor (pm_pipe_*: one call per recording, slicer and host "
+                         "stages on the library's threads); python = chain_execute.RecordingPipeline (the stages sequenced by Python "
+                         "threads).  auto: native where it applies (AFSK gain-sweep configs), python elsewhere")
     ap.add_argument("--slice-workers", type=int, default=2, help="--overlap 2: recordings whose slicers may be in flight at once")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--buffer", default="signal", choices=["signal", "noise"],
@@ -355,13 +355,15 @@ def measure(args, env):
         return res
 
     native_sides = []
+    exchanging = use_dist or bool(os.environ.get("PYMODEM_AMD_FORCE_GATHER"))
 
     def native_pipe(key):
         """The library's own executor for this rank's chains (made once, kept across the warm-up and the timed call)."""
         npipe = pipes.get(key)
         if npipe is None:
-            npipe = pipes[key] = ce.NativePipeline(build_chains(), args.samples, args.rate / 40, ctx=ctx, names=names, chain_ids=my,
-                                                   slice_workers=args.slice_workers)
+            # (with an exchange behind it the de-dup is rank 0's, over every rank's rows: none inside the executor)
+            npipe = pipes[key] = ce.NativePipeline(build_chains(), args.samples, -1.0 if exchanging else args.rate / 40, ctx=ctx,
+                                                   names=[names[c] for c in my], chain_ids=my, slice_workers=args.slice_workers)
             native_sides[:] = npipe.side_contexts()
             sides.extend(native_sides)
         return npipe
@@ -369,6 +371,8 @@ def measure(args, env):
     def native_steps(npipe, k, source):
         """k recordings through the native executor; every recording's result is taken (its de-dup count read, its rows given back),
         the last one's comes back as the PacketTable the Python executor's `dedupe` returns."""
+        if exchanging:
+            return native_steps_exchange(npipe, k, source)
         tickets, taken = [], 0
         nxt = npipe.prefetch(source) if (k and not hasattr(source, "ptr")) else None
         for i in range(k):
@@ -385,6 +389,59 @@ def measure(args, env):
         res = npipe.table(tickets[-1]) if tickets else None
         npipe.drain()
         return res
+
+    def native_steps_exchange(npipe, k, source):
+        """The same with the one exchange step behind the executor (N > 1, or the forced one-rank exchange): every recording's rows are
+        packed for the wire (two threads), handed to dist.Exchanger.step by ONE thread in submission order -- the collectives must come in
+        the same order on every rank -- and de-duplicated on rank 0 by a third."""
+        import queue
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        ex = pdist.Exchanger(nchains, coll_device)
+        packed, gathered, out, errors = queue.Queue(), queue.Queue(), {}, []
+
+        def pack(t):
+            return ex.prepare(dict(zip(my, npipe.rows(t))))
+
+        def ordered():
+            try:
+                while True:
+                    f = packed.get()
+                    if f is None:
+                        break
+                    gathered.put(ex.step(f.result()))
+                ex.flush()
+            except BaseException as e:                        # noqa: BLE001
+                errors.append(e)
+            gathered.put(None)
+
+        def post():
+            try:
+                while True:
+                    f = gathered.get()
+                    if f is None:
+                        break
+                    out["last"] = dedupe(f.result())
+            except BaseException as e:                        # noqa: BLE001
+                errors.append(e)
+        threads = [threading.Thread(target=ordered), threading.Thread(target=post)]
+        for th in threads:
+            th.start()
+        with ThreadPoolExecutor(max_workers=2) as packers:
+            nxt = npipe.prefetch(source) if (k and not hasattr(source, "ptr")) else None
+            for i in range(k):
+                if nxt is not None:
+                    cur, nxt = nxt, (npipe.prefetch(source) if i + 1 < k else None)
+                else:
+                    cur = source
+                packed.put(packers.submit(pack, npipe.submit(cur)))
+            packed.put(None)
+            for th in threads:
+                th.join()
+        npipe.drain()
+        if errors:
+            raise errors[0]
+        return out.get("last")
 
     def run_steps(k):
         """k steps; with --overlap the host half of each step runs behind the GPU half of the next one."""
@@ -480,7 +537,7 @@ def measure(args, env):
         return res
 
     native_exec = [False]
-    if args.executor != "python" and args.overlap >= 2 and not loop_wl and not use_dist and not os.environ.get("PYMODEM_AMD_FORCE_GATHER"):
+    if args.executor != "python" and args.overlap >= 2 and not loop_wl:
         try:
             native_pipe("native")
             native_exec[0] = True
@@ -488,7 +545,7 @@ def measure(args, env):
             if args.executor == "native":
                 raise
     elif args.executor == "native":
-        raise SystemExit("--executor native: one rank, --overlap 2, an AFSK gain-sweep workload")
+        raise SystemExit("--executor native: --overlap 2 and an AFSK gain-sweep workload")
 
     def close_pipes():
         for sc in native_sides:                               # the library's own contexts go with their pipeline
@@ -668,7 +725,9 @@ def measure(args, env):
                        "overlap": ("carrier-loop batch engine: every recording of a run in flight at once" if loop_wl else
                                    {0: "none", 1: "host half of step k behind GPU half of step k+1",
                                     2: "3-stage pipeline: demod(k+1) | slice(k) on a side stream | host(k-1)"}[min(args.overlap, 2)]),
-                       "executor": ("native: pm_pipe_* (one library call per recording; slicer batches, LFSR + codec and de-dup on the library's "
+                       "executor": ("native: pm_pipe_* per rank (one library call per recording; slicer batches and LFSR + codec on the library's own "
+                                    "threads), the rows to dist.Exchanger, de-dup on rank 0" if native_exec[0] and exchanging else
+                                    "native: pm_pipe_* (one library call per recording; slicer batches, LFSR + codec and de-dup on the library's "
                                     "own threads)" if native_exec[0] else
                                     None if loop_wl or args.overlap < 2 else "python: chain_execute.RecordingPipeline sequences the library's stage calls"),
                        "loop_batch": loop_info,

@@ -525,7 +525,8 @@ typedef struct pm_pipe_desc {
                                         pipeline's, each with its own band-passed stream and sweep state (0 = 3) */
     int32_t host_threads;            /* recordings in the host stage at once (0 = as chain_execute.RecordingPipeline chooses) */
     int32_t decode_threads;          /* threads inside one recording's host stage (0 = one per chain) */
-    double address_distance;         /* PacketMetaArray.Correlate (packet_meta.py:230) */
+    double address_distance;         /* PacketMetaArray.Correlate (packet_meta.py:230); < 0: no de-dup here (the chains are a part of
+                                        the config: the rows go to the exchange, rank 0 de-duplicates), unique = 0 */
     int64_t max_samples;             /* longest recording */
 } pm_pipe_desc;
 typedef struct pm_pipe_result {

@@ -951,6 +951,25 @@ class NativePipeline:
             check(lib().pm_pipe_release(self._h, int(ticket)))
         return out
 
+    def rows(self, ticket):
+        """Waits for the recording -> [pm_packet rows of chain 0, chain 1, ...]: views of the library's memory (no copy), which goes
+        back when the last of them is gone.  For pipelines that de-duplicate elsewhere (address_distance < 0: this rank holds a part
+        of the config and its rows go to dist.Exchanger)."""
+        from ._native import packet_dtype
+        res = self._wait(ticket)
+        dt = packet_dtype()
+        counts = [res.h_counts[c] for c in range(self.nchains)]
+        if res.rows:
+            block = np.asarray(_PipeRows(self, int(ticket), res.h_rows, res.rows * dt.itemsize)).view(dt)
+        else:
+            block = np.zeros(0, dtype=dt)
+            check(lib().pm_pipe_release(self._h, int(ticket)))
+        out, at = [], 0
+        for c in counts:
+            out.append(block[at:at + c])
+            at += c
+        return out
+
     def table(self, ticket):
         """Waits for the recording -> PacketTable over the library's rows (no copy), correlate() done.  The rows go back to the
         library when the table and every array taken from it are gone."""

@@ -428,7 +428,7 @@ void host_worker(pm_pipe *p)
                     // PacketMetaArray.Correlate over the chains in config order (packet_meta.py:230-271)
                     r.unique_idx.resize((size_t)std::max<int64_t>(total, 1));
                     r.corr.resize((size_t)std::max<int64_t>(total, 1));
-                    const int64_t k = total ? pm_correlate(r.rows, r.counts.data(), nch, p->address_distance, r.unique_idx.data(), r.corr.data(),
+                    const int64_t k = total && p->address_distance >= 0 ? pm_correlate(r.rows, r.counts.data(), nch, p->address_distance, r.unique_idx.data(), r.corr.data(),
                                                            (int64_t)r.corr.size())
                                             : 0;
                     if (k < 0) rc = (int)k;
@@ -499,7 +499,7 @@ int pm_pipe_create(pm_ctx *ctx, const pm_pipe_desc *desc, pm_pipe **out)
     PM_ARG(desc != nullptr && out != nullptr);
     const pm_pipe_desc &d = *desc;
     PM_ARG(d.d_bpf && d.mb >= 1 && d.x_bound > 0 && d.sweeps && d.nsweeps >= 1 && d.nsweeps <= 16 && d.chains && d.nchains >= 1 && d.nchains <= kMaxChains);
-    PM_ARG(d.max_samples >= d.mb && d.address_distance >= 0);
+    PM_ARG(d.max_samples >= d.mb);
     pm_pipe *p = new pm_pipe();
     p->ctx = ctx;
     p->nchains = d.nchains;
