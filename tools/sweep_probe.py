@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The certified AFSK sweep (pm_afsk_sweep_signs_tones, 7 gains and 1 gain) alone on the bench recording's band-passed stream, a few
-launches: the target of counter passes (tools/_scratch / collect scripts).  PM_AFSK_NO_DECIMATE=1 selects the full-rate kernel."""
+launches: the target of counter passes (tools/_scratch / collect scripts).  PM_AFSK_LPF64=1 selects the kernel with binary64 low-passes."""
 import ctypes
 import json
 import os
@@ -38,4 +38,10 @@ for name, mods in (("g=7", modems[1:]), ("g=1", modems[:1])):
         ctx.timer_start()
         AFSKModem.sweep_signs(mods, bpf, bound)
         times.append(ctx.timer_stop())
-    print(json.dumps({"sweep": name, "ms": [round(t, 4) for t in times], "uncertain": AFSKModem.sweep_uncertain(ctx)}))
+    ctx.profile(True)                                        # the library's own per-class HIP-event timing: fused kernel / exact kernel apart
+    for _ in range(5):
+        AFSKModem.sweep_signs(mods, bpf, bound)
+    ctx.sync()
+    prof = {k: round(v[0] / max(v[1], 1), 4) for k, v in ctx.profile_read().items() if v[1]}
+    ctx.profile(False)
+    print(json.dumps({"sweep": name, "ms": [round(t, 4) for t in times], "uncertain": AFSKModem.sweep_uncertain(ctx), "avg_ms_by_class": prof}))
