@@ -408,7 +408,10 @@ int pm_lbatch_destroy(pm_lbatch *batch);
 /* LFSR.stream_unscramble_8bit (lfsr.py:22-52).  *h_shift_register is read and written.  h_out must not alias h_in. */
 int pm_lfsr_unscramble(const uint8_t *h_in, int64_t n, uint64_t poly, int invert, uint64_t *h_shift_register, uint8_t *h_out);
 
-/* Packet record shared by the codecs and the de-dup (PacketMeta, packet_meta.py:178-195). */
+/* Packet record shared by the codecs and the de-dup (PacketMeta, packet_meta.py:178-195).  IL2P packets are at most 1023 + 2 bytes
+ * and AX.25 frames between flags likewise on any signal; the reference's AX.25 decoder can however close a frame of any length after
+ * a long stretch without a flag (its byte counter wraps at 1023, the collected bytes stay: ax25.py:41-47).  Such a frame's row holds
+ * its first PM_PKT_MAX bytes (len = PM_PKT_MAX); its CRC fields and valid_crc are those of the whole frame. */
 #define PM_PKT_MAX 1280
 typedef struct pm_packet {
     int64_t streamaddress;

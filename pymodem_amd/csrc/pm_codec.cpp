@@ -938,6 +938,15 @@ int pm_codec_fetch(pm_codec *c, pm_packet *h_out, int64_t cap, int64_t *h_count)
         memcpy(p.data, src.data.data(), (size_t)p.len);
         memset(p.data + p.len, 0, sizeof(p.data) - (size_t)p.len);
         finalize(p);
+        if (src.data.size() > PM_PKT_MAX) {
+            // A frame longer than a row: the reference's AX.25 decoder never drops collected bytes when its byte counter wraps at 1023
+            // (ax25.py:41-47), so a flag after a long stretch without one can close a frame of any length.  The row keeps its first
+            // PM_PKT_MAX bytes; CRC and validity are those of the WHOLE frame, as PacketMeta.CalcCRC would find them.
+            const size_t L = src.data.size();
+            p.carried_crc = src.data[L - 1] * 256 + src.data[L - 2];
+            p.calculated_crc = crc16(src.data.data(), (int)(L - 2));
+            p.valid_crc = p.carried_crc == p.calculated_crc;
+        }
     }
     c->sink.q.erase(c->sink.q.begin(), c->sink.q.begin() + take);
     *h_count = take;

@@ -58,6 +58,39 @@ def test_ax25_matches_oracle_on_random_streams(p_one):
     assert p_one != 0.5 or len(want) > 0
 
 
+def test_ax25_frames_longer_than_a_row():
+    """A flag after a long stretch without one closes a frame of any length in the reference (the byte counter wraps at 1023, the bytes
+    stay: ax25.py:41-47).  The native row keeps the first PM_PKT_MAX bytes; address, count, CRC fields and validity are the whole
+    frame's."""
+    import ctypes
+    from pymodem_amd._native import PKT_MAX, Packet, check, lib
+    rng = np.random.default_rng(5)
+    long_frames = 0
+    for trial in range(12):
+        n = 20000
+        bits = (rng.random(n * 8) < rng.choice([0.3, 0.2, 0.1])).astype(np.uint8)
+        for pos in rng.integers(0, n * 8 - 8, 60):
+            bits[pos:pos + 8] = [0, 1, 1, 1, 1, 1, 1, 0]
+        data = np.packbits(bits)
+        addr = (np.arange(n, dtype=np.int64) + 1) * 40
+        want = O.AX25Codec(ident="x").decode(data, addr)
+        h = ctypes.c_void_p()
+        check(lib().pm_codec_create(0, 1, 0, 0, 2, 0, ctypes.byref(h)))
+        pend, cnt = ctypes.c_int64(), ctypes.c_int64()
+        check(lib().pm_codec_decode(h, data.ctypes.data_as(ctypes.c_void_p), addr.ctypes.data_as(ctypes.c_void_p), n, ctypes.byref(pend)))
+        rows = (Packet * max(pend.value, 1))()
+        check(lib().pm_codec_fetch(h, rows, pend.value, ctypes.byref(cnt)))
+        lib().pm_codec_destroy(h)
+        assert cnt.value == len(want)
+        for r, w in zip(rows, want):
+            full = bytes(bytearray(w.data))
+            long_frames += len(full) > PKT_MAX
+            w.check()
+            assert r.streamaddress == w.streamaddress and r.len == min(len(full), PKT_MAX) and bytes(r.data[:r.len]) == full[:PKT_MAX]
+            assert (r.calculated_crc, r.carried_crc, bool(r.valid_crc)) == (w.CalculatedCRC, w.CarriedCRC, bool(w.ValidCRC))
+    assert long_frames >= 3
+
+
 def il2p_stream(rng, n, sync_every):
     """Random bytes with the IL2P sync word 0xF15E48 planted (sometimes with bit errors) so headers get attempted."""
     data = rng.integers(0, 256, n, dtype=np.uint8)
