@@ -66,6 +66,11 @@ class PacketMeta:
 
     def CalcCRC(self):                        # packet_meta.py:197-203, crc_functions.py:9-61
         raw = self.raw()
+        whole = getattr(self, "_frame_crc", None)
+        if whole is not None:
+            self.CalculatedCRC, self.CarriedCRC = whole
+            self.ValidCRC = self.CarriedCRC == self.CalculatedCRC
+            return self.ValidCRC
         self.CarriedCRC = int((raw[-1] * 256) + raw[-2])
         self.CalculatedCRC = lib().pm_crc16_ccitt(raw, len(raw) - 2)
         self.ValidCRC = self.CarriedCRC == self.CalculatedCRC
@@ -86,7 +91,12 @@ def rows_to_packets(rows, decoder_name):
     """pm_packet rows -> list[PacketMeta] (CRC fields are left for CalcCRC, like the reference's codecs leave them)."""
     lens, addrs, corr = rows["len"].tolist(), rows["streamaddress"].tolist(), rows["bytes_corrected"].tolist()
     data = rows["data"]
-    return [PacketMeta.from_bytes(data[k, :lens[k]].tobytes(), addrs[k], decoder_name, corr[k]) for k in range(len(rows))]
+    out = [PacketMeta.from_bytes(data[k, :lens[k]].tobytes(), addrs[k], decoder_name, corr[k]) for k in range(len(rows))]
+    from ._native import PKT_MAX
+    for k, n in enumerate(lens):
+        if n >= PKT_MAX:        # possibly the head of a longer AX.25 frame (pymodem_amd.h, PM_PKT_MAX): the codec's CRC is the whole frame's
+            out[k]._frame_crc = (int(rows["calculated_crc"][k]), int(rows["carried_crc"][k]))
+    return out
 
 
 def _stamp(rows, c):
