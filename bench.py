@@ -368,7 +368,7 @@ def measure(args, env):
             sides.extend(native_sides)
         return npipe
 
-    def native_steps(npipe, k, source):
+    def native_steps(npipe, k, source, pace=True):
         """k recordings through the native executor; every recording's result is taken (its de-dup count read, its rows given back),
         the last one's comes back as the PacketTable the Python executor's `dedupe` returns."""
         if exchanging:
@@ -388,6 +388,13 @@ def measure(args, env):
             npipe.unique(t)
         res = npipe.table(tickets[-1]) if tickets else None
         npipe.drain()
+        # the pace between the 6th recording done and the 5th-from-last: the steady state, without fill and drain (as for the Python executor)
+        done = sorted(npipe.done_at_ms.pop(t) for t in tickets if t in npipe.done_at_ms)
+        if pace:
+            steady.clear()
+            if len(done) >= 16:
+                steady["ms_per_step"] = round((done[-6] - done[5]) / (len(done) - 11), 4)
+                steady["steps"] = len(done) - 11
         return res
 
     def native_steps_exchange(npipe, k, source):
@@ -457,7 +464,6 @@ def measure(args, env):
                 stage_ms.update({"executor": "native (pm_pipe_*)", "slice_busy": round((after["slice_busy_ms"] - before["slice_busy_ms"]) / k, 3),
                                  "host_busy": round((after["host_busy_ms"] - before["host_busy_ms"]) / k, 3),
                                  "recordings_per_slice_batch": round((after["recordings"] - before["recordings"]) / max(after["slice_batches"] - before["slice_batches"], 1), 2)})
-            steady.clear()
             return res
         if not args.overlap:
             res = None
@@ -520,7 +526,7 @@ def measure(args, env):
         The source is page-locked (registered once, below): out of pageable memory the runtime stages the copy in pieces at ~45 GB/s,
         which bounded this figure in round 2."""
         if native_exec[0]:
-            return native_steps(native_pipe("native-upload"), k, audio)
+            return native_steps(native_pipe("native-upload"), k, audio, pace=False)
         pipe = pipes.get("upload")                            # kept across the warm-up and the timed call, like the main one
         if pipe is None:
             pipe = pipes["upload"] = ce.RecordingPipeline(slice_workers=args.slice_workers)
@@ -628,6 +634,17 @@ def measure(args, env):
         sys.exit(0)
     prof = ctx.profile_read()
     work = ctx.profile_work()
+    # when every launch of the FIR/correlator classes began and ended, over all streams (the native executor demodulates on three):
+    # how many launches of a class were in flight together, and for how long the class kept the GPU busy at all
+    spans = {}
+    for name in ("fir_i16", "fir_f64", "afsk_correlate"):
+        iv = [c.profile_intervals(name) for c in [ctx] + sides]
+        iv = np.concatenate([v for v in iv if len(v)]) if any(len(v) for v in iv) else np.zeros((0, 2))
+        if len(iv):
+            iv = iv[np.argsort(iv[:, 0])]
+            ends = np.maximum.accumulate(iv[:, 1])
+            busy = float(np.sum(ends - np.maximum(iv[:, 0], np.concatenate(([iv[0, 0]], ends[:-1])))))      # length of the union
+            spans[name] = {"busy_ms": busy, "sum_ms": float(np.sum(iv[:, 1] - iv[:, 0])), "launches": int(len(iv))}
     ctx.profile(False)
     for sc in sides:
         for name, (ms, cnt) in sc.profile_read().items():
@@ -741,6 +758,17 @@ def measure(args, env):
                                            "and WRITE_SIZE in separate runs, x1024, FETCH doubled per the gfx950 note), per launch of this kernel class; "
                                            "counters cannot be read from inside the process",
                          "avg_kernel_ms": round(avg_ms, 5), "launches": dom_n, "algorithmic_bytes_per_launch": round(per_launch_bytes),
+                         "in_flight": None if dom not in spans else {
+                             "launches_in_flight_on_average": round(spans[dom]["sum_ms"] / max(spans[dom]["busy_ms"], 1e-9), 3),
+                             "class_busy_ms_per_step": round(spans[dom]["busy_ms"] / args.steps, 5),
+                             "achieved_over_busy_time": round(dom_bytes / (spans[dom]["busy_ms"] * 1e-3) / 1e9, 2),
+                             "frac_over_busy_time": round(dom_bytes / (spans[dom]["busy_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                             "tflops_f64_over_busy_time": round(dom_flops / (spans[dom]["busy_ms"] * 1e-3) / 1e12, 3),
+                             "note": "the executor runs this class on several streams at once (recordings take turns on three demod streams): "
+                                     "a launch that shares the GPU with two others of its kind takes longer, so `achieved` (bytes of a launch / "
+                                     "its own duration, what a kernel trace shows) falls as throughput rises.  Over-busy-time figures divide the "
+                                     "class's bytes and flops by the time during which at least one of its launches was running (union of the "
+                                     "HIP-event intervals of all streams)"},
                          "stage": "FIR/correlator", "dominant_by_time": by_time,
                          "alone": None if alone_ms is None else {
                              "avg_kernel_ms": round(alone_ms, 5), "achieved": round(per_launch_bytes / (alone_ms * 1e-3) / 1e9, 2),

@@ -96,6 +96,11 @@ int pm_prof_read(pm_ctx *ctx, int kernel_class, double *total_ms, int64_t *launc
  * written once, at their stored width) and f64 flops (2 per fused multiply-add of the FIR sums; epilogues not counted).
  * Zero for the classes that are neither (slicer iterations, carrier loops, AGC). */
 int pm_prof_work(pm_ctx *ctx, int kernel_class, double *bytes, double *flops);
+/* When each tracked launch of the class began and ended, in milliseconds since one reference event per device (recorded when
+ * profiling is first enabled there): launches of several contexts of a device can be laid over each other -- a host that runs
+ * the same kernel class on several streams at once learns how many were in flight together and for how long the class kept
+ * the GPU busy at all.  *h_n = intervals held (the first min(*h_n, cap) are written). */
+int pm_prof_intervals(pm_ctx *ctx, int kernel_class, double *h_start_ms, double *h_end_ms, int64_t cap, int64_t *h_n);
 
 /* ---- FIR stages -------------------------------------------------------------------------------
  * numpy.convolve(x, h, 'valid'): y[k] = sum_j h[j] * x[k+m-1-j], k = 0 .. n-m.  Replaces the 19
@@ -542,6 +547,7 @@ typedef struct pm_pipe_result {
     const int64_t *h_unique_idx;     /* [unique] row indices by stream address */
     const int32_t *h_corr_decoders;  /* correlated decoders, consecutive runs of correlated_count per unique packet */
     double ms_to_demod_done, ms_to_sliced, ms_to_done;   /* from submit, host clock */
+    double done_at_ms;               /* when the recording left the last stage, host clock since pm_pipe_create */
 } pm_pipe_result;
 typedef struct pm_pipe pm_pipe;
 int pm_pipe_create(pm_ctx *ctx, const pm_pipe_desc *desc, pm_pipe **out);

@@ -116,7 +116,8 @@ class PipeResult(ctypes.Structure):
     _fields_ = [("ticket", ctypes.c_int64), ("status", ctypes.c_int32), ("reserved", ctypes.c_int32), ("rows", ctypes.c_int64),
                 ("h_rows", ctypes.c_void_p), ("h_counts", ctypes.POINTER(ctypes.c_int64)), ("unique", ctypes.c_int64),
                 ("h_unique_idx", ctypes.c_void_p), ("h_corr_decoders", ctypes.c_void_p),
-                ("ms_to_demod_done", ctypes.c_double), ("ms_to_sliced", ctypes.c_double), ("ms_to_done", ctypes.c_double)]
+                ("ms_to_demod_done", ctypes.c_double), ("ms_to_sliced", ctypes.c_double), ("ms_to_done", ctypes.c_double),
+                ("done_at_ms", ctypes.c_double)]
 
 
 MODEM_AFSK, MODEM_FSK, MODEM_BPSK, MODEM_MPSK, MODEM_AFSK_PLL, MODEM_QPSK = range(6)
@@ -216,6 +217,7 @@ _SIGS = {
     "pm_lbatch_run": ([_vp, ctypes.POINTER(_vp), _int, _i64, _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
     "pm_lbatch_front_ctx": ([_vp], _vp),
     "pm_lbatch_destroy": ([_vp], _int),
+    "pm_prof_intervals": ([_vp, _int, _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
     "pm_pipe_create": ([_vp, ctypes.POINTER(PipeDesc), ctypes.POINTER(_vp)], _int),
     "pm_pipe_submit": ([_vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
     "pm_pipe_wait": ([_vp, _i64, ctypes.POINTER(PipeResult)], _int),

@@ -902,6 +902,7 @@ class NativePipeline:
         check(lib().pm_pipe_create(ctx.handle, ctypes.byref(desc), ctypes.byref(h)))
         self._h = h
         self.nchains = n
+        self.done_at_ms = {}                                # ticket -> when it left the last stage (host clock since the pipeline was made)
         self.slots = max(2, min(int(slots) if slots else 16, 32, 60 // len(planned) * (min(int(demod_streams), 4) if demod_streams else 3)))     # as pm_pipe_create settles it
 
     def prefetch(self, host_audio):
@@ -947,6 +948,7 @@ class NativePipeline:
         """Waits for the recording -> (unique packets, packets of all chains); by default its rows are given back at once."""
         res = self._wait(ticket)
         out = (int(res.unique), int(res.rows))
+        self.done_at_ms[int(ticket)] = res.done_at_ms
         if release:
             check(lib().pm_pipe_release(self._h, int(ticket)))
         return out
@@ -991,6 +993,7 @@ class NativePipeline:
         table._corr_ends = np.cumsum(rows["correlated_count"][table.unique_idx])
         table._unique_decoders = None
         table.latency_ms = {"demod_done": res.ms_to_demod_done, "sliced": res.ms_to_sliced, "done": res.ms_to_done}
+        self.done_at_ms[int(ticket)] = res.done_at_ms
         return table
 
     def release(self, ticket):

@@ -26,6 +26,7 @@ struct pm_ctx {
     double prof_ms[PM_K_COUNT] = {0};
     int64_t prof_n[PM_K_COUNT] = {0};
     double prof_bytes[PM_K_COUNT] = {0}, prof_flops[PM_K_COUNT] = {0};   // algorithmic work of the tracked launches
+    std::vector<float> prof_iv[PM_K_COUNT];   // (start, end) of every tracked launch in ms since the device's reference event (pm_prof_intervals)
     // slicer diagnostics
     int32_t sl_iterations = 0, sl_chunk_len = 0;
     int64_t sl_chunks = 0;

@@ -692,6 +692,7 @@ int pm_pipe_wait(pm_pipe *p, int64_t ticket, pm_pipe_result *out)
     out->ms_to_demod_done = r->t_ready - r->t_submit;
     out->ms_to_sliced = r->t_sliced - r->t_submit;
     out->ms_to_done = r->t_done - r->t_submit;
+    out->done_at_ms = r->t_done - p->t_origin;
     if (r->status) return pm_set_error(r->status, "%s", r->error.c_str());
     return PM_OK;
 }

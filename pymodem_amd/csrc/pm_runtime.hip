@@ -2,6 +2,7 @@
 #include "pm_common.h"
 #include <cstring>
 #include <unistd.h>
+#include <mutex>
 
 static thread_local char g_err[512] = "";
 
@@ -288,15 +289,37 @@ PmProf::~PmProf()
     if (c->prof_pending.size() >= 2048) pm_prof_fold(c);
 }
 
+// One reference event per device, recorded (and finished) when profiling is first switched on there: launch intervals of every context
+// of the device are measured from it, so that launches on different streams can be laid over each other (pm_prof_intervals).
+static hipEvent_t g_prof_ref[64];
+static std::mutex g_prof_ref_mu;
+
+static hipEvent_t prof_ref(pm_ctx *c, bool make)
+{
+    std::lock_guard<std::mutex> lk(g_prof_ref_mu);
+    if (c->device < 0 || c->device >= 64) return nullptr;
+    if (!g_prof_ref[c->device] && make) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) == hipSuccess && hipEventRecord(e, c->stream) == hipSuccess && hipEventSynchronize(e) == hipSuccess) g_prof_ref[c->device] = e;
+    }
+    return g_prof_ref[c->device];
+}
+
 int pm_prof_fold(pm_ctx *c)
 {
     if (c->prof_pending.empty()) return PM_OK;
     PM_HIP(hipStreamSynchronize(c->stream));
+    hipEvent_t ref = prof_ref(c, false);
     for (auto &p : c->prof_pending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             c->prof_ms[p.cls] += ms;
             c->prof_n[p.cls] += 1;
+            float at = 0;
+            if (ref && c->prof_iv[p.cls].size() < (size_t)1 << 22 && hipEventElapsedTime(&at, ref, p.a) == hipSuccess) {
+                c->prof_iv[p.cls].push_back(at);
+                c->prof_iv[p.cls].push_back(at + ms);
+            }
         }
         c->prof_free.push_back(p.a);
         c->prof_free.push_back(p.b);
@@ -309,8 +332,25 @@ extern "C" int pm_prof_enable(pm_ctx *c, int on)
 {
     PM_ARG(c != nullptr);
     if (int rc = pm_prof_fold(c)) return rc;
-    for (int k = 0; k < PM_K_COUNT; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; c->prof_bytes[k] = 0; c->prof_flops[k] = 0; }
+    for (int k = 0; k < PM_K_COUNT; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; c->prof_bytes[k] = 0; c->prof_flops[k] = 0; c->prof_iv[k].clear(); }
+    if (on) {
+        PM_HIP(hipSetDevice(c->device));
+        (void)prof_ref(c, true);
+    }
     c->prof_on = on != 0;
+    return PM_OK;
+}
+
+extern "C" int pm_prof_intervals(pm_ctx *c, int cls, double *h_start_ms, double *h_end_ms, int64_t cap, int64_t *h_n)
+{
+    PM_ARG(c != nullptr && cls >= 0 && cls < PM_K_COUNT && h_n != nullptr && cap >= 0 && (cap == 0 || (h_start_ms && h_end_ms)));
+    if (int rc = pm_prof_fold(c)) return rc;
+    const int64_t n = (int64_t)c->prof_iv[cls].size() / 2;
+    for (int64_t k = 0; k < std::min(n, cap); ++k) {
+        h_start_ms[k] = c->prof_iv[cls][2 * k];
+        h_end_ms[k] = c->prof_iv[cls][2 * k + 1];
+    }
+    *h_n = n;
     return PM_OK;
 }
 

@@ -209,6 +209,17 @@ class Context:
             out[name] = (ms.value, n.value)
         return out
 
+    def profile_intervals(self, name):
+        """(start, end) in ms of every tracked launch of one kernel class since the device's reference event -> float64 array [n, 2].
+        Intervals of several contexts of the device share the time base."""
+        from ._native import KERNEL_CLASSES
+        k = KERNEL_CLASSES.index(name)
+        n = ctypes.c_int64()
+        check(lib().pm_prof_intervals(self._h, k, None, None, 0, ctypes.byref(n)))
+        out = np.empty((2, max(n.value, 1)), dtype=np.float64)
+        check(lib().pm_prof_intervals(self._h, k, out[0].ctypes.data_as(ctypes.c_void_p), out[1].ctypes.data_as(ctypes.c_void_p), n.value, ctypes.byref(n)))
+        return out[:, :n.value].T.copy()
+
     def profile_work(self):
         """{kernel class: (algorithmic HBM bytes, f64 flops)} of the launches profile_read() timed."""
         from ._native import KERNEL_CLASSES
