@@ -156,10 +156,12 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): --chains-per-gpu chains on EVERY rank (beyond the config's own chains the sweep continues in finer "
                          "steps, named in config.workload); strong: the config's own chains (8 for configs[3]) divided over the ranks")
-    ap.add_argument("--loop-batch", type=int, default=128,
+    ap.add_argument("--loop-batch", type=int, default=0,
                     help="carrier-loop workloads (bpsk_300, qpsk_2400): recordings per engine run (pymodem_amd.loop_batch) -- the loops of all of "
-                         "them x the rank's chains advance together, one lane each; a step is still one recording")
-    ap.add_argument("--loop-chunk", type=int, default=0, help="carrier-loop workloads: final-filter outputs per time chunk (0 = 262144)")
+                         "them x the rank's chains advance together, one lane each; a step is still one recording.  0 (default): as many as "
+                         "give 16384 loops in flight (every lane of one stepping wave per CU), 4096 recordings at most, never more than --steps")
+    ap.add_argument("--loop-chunk", type=int, default=0, help="carrier-loop workloads: final-filter outputs per time chunk (0 = 131072 for runs "
+                    "of more than 8192 loops, whose work buffers are sized by it, else 262144)")
     ap.add_argument("--also", type=int, default=1, help="1 (default, one GPU only): after the headline workload also measure fsk_9600, "
                     "bpsk_300 and qpsk_2400 (BASELINE configs[2], [1], [4]) briefly and attach them under 'also'")
     args = ap.parse_args()
@@ -238,17 +240,23 @@ LOOP_WORKLOADS = ("bpsk_300", "qpsk_2400")
 ALSO_CPU_SAMPLE = {"fsk_9600": 4_800_000, "bpsk_300": 1_440_000, "qpsk_2400": 1_440_000, "afsk_1200_super_opt": 4_800_000}
 
 
+LOOPS_IN_FLIGHT = 16384        # carrier loops per engine run: 64 per stepping wave, one stepping wave per CU
+
+
 def also_workloads(args, env, cpu_also=None):
     """BASELINE configs[1], [2] and [4] measured after the headline workload in the same process (one GPU only): the single-chain
     BPSK-300 Costas path and the 8-chain QPSK-2400 path are bound by their sequential carrier loops -- one step each
     at full size -- and fsk_9600 is the shortest-tap FIR path.  Never allowed to break the main line."""
     import copy
     out = {}
-    for name, steps, warm in (("fsk_9600", 300, 10), ("bpsk_300", 128, 2), ("qpsk_2400", 128, 2)):
+    # (the carrier-loop workloads: one full engine run each -- 4096 recordings x 1 chain, 2048 x 8 chains; a run takes as long as
+    # its recordings are, however many there are)
+    for name, steps, warm in (("fsk_9600", 300, 10), ("bpsk_300", 4096, 1), ("qpsk_2400", 2048, 1)):
         if name == args.workload:
             continue
         a = copy.copy(args)
         a.workload, a.steps, a.warmup, a.no_cpu_baseline, a.chains_per_gpu = name, steps, warm, True, 0
+        a.loop_batch, a.loop_chunk = 0, 0
         try:
             d = measure(a, env)
             out[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": steps, "config": d["config"]["workload"],
@@ -261,13 +269,13 @@ def also_workloads(args, env, cpu_also=None):
             if d["config"].get("loop_batch"):
                 out[name]["loop_batch"] = d["config"]["loop_batch"]
             if name == "qpsk_2400":
-                # configs[4] has 64 chains: the whole config on ONE GPU, 16 recordings in flight (the same 1024 loops per launch as 128
+                # configs[4] has 64 chains: the whole config on ONE GPU, 256 recordings in flight (the same 16384 loops per launch as 2048
                 # recordings x 8 chains), for comparison with the 8-chains-per-GPU sharding
                 a64 = copy.copy(a)
-                a64.chains_per_gpu, a64.steps, a64.warmup, a64.loop_batch = 64, 16, 2, 16
+                a64.chains_per_gpu, a64.steps, a64.warmup, a64.loop_batch, a64.loop_chunk = 64, 256, 1, 0, 0
                 d64 = measure(a64, env)
                 out[name]["all_64_chains_on_one_gpu"] = {"value": d64["value"], "unit": d64["unit"], "ms_per_step": d64["ms_per_step"], "chains_per_gpu": 64,
-                                                         "steps": 16, "loop_batch": d64["config"]["loop_batch"],
+                                                         "steps": 256, "loop_batch": d64["config"]["loop_batch"],
                                                          "gpu_kernel_ms_per_step": d64["gpu_kernel_ms_per_step"], "packets": d64["packets"]}
         except Exception as e:                                   # noqa: BLE001
             out.setdefault(name, {})["error"] = repr(e)[:300]
@@ -336,7 +344,9 @@ def measure(args, env):
     loop_info = None
     if loop_wl:
         from pymodem_amd import loop_batch as lb
-        batch = max(1, min(args.loop_batch, max(args.steps, 1)))
+        batch = max(1, min(args.loop_batch or min(4096, LOOPS_IN_FLIGHT // max(len(my), 1)), max(args.steps, 1)))
+        if not args.loop_chunk:
+            args.loop_chunk = 131072 if batch * len(my) > 8192 else 262144
         engine = lb.engine_for([modems[c] for c in my], batch, ctx, args.loop_chunk)
         engine.reserve(batch, args.samples, slot=(0, 0))
         nout_, chunk_, chunks_ = engine.geometry(args.samples)

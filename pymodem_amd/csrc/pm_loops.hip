@@ -18,9 +18,7 @@
 
 namespace {
 
-constexpr int kG = 8;            // loops per wave
-constexpr int kTile = 256;       // samples per LDS tile
-constexpr int kPad = kTile + 1;  // row pitch (doubles): rows of different lanes start on different banks
+constexpr int kTile = 256;       // samples per LDS tile (AGC kernels; the loop kernels have their own shapes)
 constexpr double kTwoPi = 2.0 * 3.141592653589793;
 
 typedef double double2v __attribute__((ext_vector_type(2)));
@@ -131,7 +129,13 @@ enum { kCostas = 0, kPll = 1, kMpsk = 2, kQpsk = 3 };
 // Input rows: loop l reads row l / per_row (x0 + row * x_stride): per_row = 1 gives every loop its own input, per_row = nloops (with
 // any stride) one input for all, and a batch of recordings x chains has per_row = chains (the chains of a recording share its
 // front end).  `rows_lds` = the most distinct rows one wave's kG loops can touch (loop_rows_lds), which sizes the LDS image.
-template <int MODE>
+//
+// Two shapes.  <8, 256>: eight loops per workgroup and tiles of 256 samples -- a launch of up to ~2000 loops spreads over all 256 CUs
+// (the stepping wave is bound by instruction issue whatever the number of active lanes, so the fewer loops a wave holds the more
+// waves step at once).  <64, 32>: every lane of the stepping wave holds a loop -- for launches with more loops than that, where
+// eight-lane waves would queue up behind each other for the CUs (measured, tools/loop_scaling.py: 4096 MPSK loops in eight-lane
+// waves take twice as long as 2048; 8192 four times) -- with tiles of 32 samples so that 2 x 128 output rows still fit the LDS.
+template <int MODE, int G, int TILE>
 __global__ __launch_bounds__(128) void loop_kernel(pm_loop *__restrict__ loops, int nloops, int per_row, int rows_lds,
                                                    const double *__restrict__ table,
                                                    const int32_t *__restrict__ pd, const double *__restrict__ x0,
@@ -139,6 +143,7 @@ __global__ __launch_bounds__(128) void loop_kernel(pm_loop *__restrict__ loops, 
                                                    double *__restrict__ o0, double *__restrict__ o1, int64_t out_stride)
 {
     extern __shared__ double lds[];
+    constexpr int kG = G, kTile = TILE, kPad = TILE + 1;   // (row pitch kPad: rows of different lanes start on different banks)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g0 = blockIdx.x * kG;
     const int ng = min(kG, nloops - g0);
@@ -182,32 +187,54 @@ __global__ __launch_bounds__(128) void loop_kernel(pm_loop *__restrict__ loops, 
                 const int64_t tile0 = s * kTile;
                 const int len = (int)min((int64_t)kTile, n - tile0);
                 double *ib = in_base + (s & 1) * in_buf;
-                // Two rows at a time, every load of the pair issued before the first LDS write (a load per round trip -- what the
-                // plain loop compiles to -- is 32 dependent memory latencies per tile of eight rows: as long as the tile takes to
-                // step).  Indices are clamped instead of predicated: what lands beyond `len` is never read.
-                constexpr int kPer = kTile / 64;
-                for (int r = 0; r < rows; r += 2) {
-                    const int r1 = min(r + 1, rows - 1);
-                    const int64_t off0 = (int64_t)(row0 + r) * x_stride + tile0, off1 = (int64_t)(row0 + r1) * x_stride + tile0;
-                    double va[2][NIN][kPer];
+                if (kTile >= 64) {
+                    // Two rows at a time, every load of the pair issued before the first LDS write (a load per round trip -- what the
+                    // plain loop compiles to -- is 32 dependent memory latencies per tile of eight rows: as long as the tile takes to
+                    // step).  Indices are clamped instead of predicated: what lands beyond `len` is never read.
+                    constexpr int kPer = kTile >= 64 ? kTile / 64 : 1;
+                    for (int r = 0; r < rows; r += 2) {
+                        const int r1 = min(r + 1, rows - 1);
+                        const int64_t off0 = (int64_t)(row0 + r) * x_stride + tile0, off1 = (int64_t)(row0 + r1) * x_stride + tile0;
+                        double va[2][NIN][kPer];
 #pragma unroll
-                    for (int j = 0; j < kPer; ++j) {
-                        const int k = min(lane + 64 * j, len - 1);
-                        va[0][0][j] = x0[off0 + k];
-                        va[1][0][j] = x0[off1 + k];
-                        if (MODE == kMpsk) {
-                            va[0][NIN - 1][j] = x1[off0 + k];
-                            va[1][NIN - 1][j] = x1[off1 + k];
+                        for (int j = 0; j < kPer; ++j) {
+                            const int k = min(lane + 64 * j, len - 1);
+                            va[0][0][j] = x0[off0 + k];
+                            va[1][0][j] = x0[off1 + k];
+                            if (MODE == kMpsk) {
+                                va[0][NIN - 1][j] = x1[off0 + k];
+                                va[1][NIN - 1][j] = x1[off1 + k];
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < kPer; ++j) {
+                            const int k = lane + 64 * j;
+                            ib[(r * NIN) * kPad + k] = va[0][0][j];
+                            ib[(r1 * NIN) * kPad + k] = va[1][0][j];
+                            if (MODE == kMpsk) {
+                                ib[(r * NIN + 1) * kPad + k] = va[0][NIN - 1][j];
+                                ib[(r1 * NIN + 1) * kPad + k] = va[1][NIN - 1][j];
+                            }
                         }
                     }
+                } else {
+                    // short tiles: 64 / kTile rows per pass (a part of the wave each), four passes in flight before the first LDS write
+                    constexpr int kRows = 64 / kTile, kFly = 4;
+                    const int sub = lane / kTile, k = lane % kTile, kc = min(k, len - 1);
+                    for (int r = 0; r < rows; r += kRows * kFly) {
+                        double va[kFly][NIN];
 #pragma unroll
-                    for (int j = 0; j < kPer; ++j) {
-                        const int k = lane + 64 * j;
-                        ib[(r * NIN) * kPad + k] = va[0][0][j];
-                        ib[(r1 * NIN) * kPad + k] = va[1][0][j];
-                        if (MODE == kMpsk) {
-                            ib[(r * NIN + 1) * kPad + k] = va[0][NIN - 1][j];
-                            ib[(r1 * NIN + 1) * kPad + k] = va[1][NIN - 1][j];
+                        for (int j = 0; j < kFly; ++j) {
+                            const int rr = min(r + j * kRows + sub, rows - 1);
+                            const int64_t off = (int64_t)(row0 + rr) * x_stride + tile0 + kc;
+                            va[j][0] = x0[off];
+                            if (MODE == kMpsk) va[j][NIN - 1] = x1[off];
+                        }
+#pragma unroll
+                        for (int j = 0; j < kFly; ++j) {
+                            const int rr = min(r + j * kRows + sub, rows - 1);      // (rows past the last repeat it: the same value again)
+                            ib[(rr * NIN) * kPad + k] = va[j][0];
+                            if (MODE == kMpsk) ib[(rr * NIN + 1) * kPad + k] = va[j][NIN - 1];
                         }
                     }
                 }
@@ -216,11 +243,36 @@ __global__ __launch_bounds__(128) void loop_kernel(pm_loop *__restrict__ loops, 
                 const int64_t tile0 = (s - 2) * kTile;
                 const int len = (int)min((int64_t)kTile, n - tile0);
                 const double *ob = out_base + (s & 1) * out_buf;
-                for (int r = 0; r < ng; ++r) {
-                    const int64_t off = (int64_t)(g0 + r) * out_stride + tile0;
-                    for (int k = lane; k < len; k += 64) {
-                        o0[off + k] = ob[r * kPad + k];
-                        if (kTwoOut) o1[off + k] = ob[(kG + r) * kPad + k];
+                if (kTile >= 64) {
+                    for (int r = 0; r < ng; ++r) {
+                        const int64_t off = (int64_t)(g0 + r) * out_stride + tile0;
+                        for (int k = lane; k < len; k += 64) {
+                            o0[off + k] = ob[r * kPad + k];
+                            if (kTwoOut) o1[off + k] = ob[(kG + r) * kPad + k];
+                        }
+                    }
+                } else {
+                    // 64 / kTile loops per pass, each part of the wave writing one loop's run of kTile samples (256 contiguous bytes);
+                    // four passes' LDS reads before their stores
+                    constexpr int kRows = 64 / kTile, kFly = 4;
+                    const int sub = lane / kTile, k = lane % kTile;
+                    for (int r = 0; r < ng; r += kRows * kFly) {
+                        double va[kFly][NOUT];
+#pragma unroll
+                        for (int j = 0; j < kFly; ++j) {
+                            const int rr = min(r + j * kRows + sub, kG - 1);
+                            va[j][0] = ob[rr * kPad + k];
+                            if (kTwoOut) va[j][NOUT - 1] = ob[(kG + rr) * kPad + k];
+                        }
+#pragma unroll
+                        for (int j = 0; j < kFly; ++j) {
+                            const int rr = r + j * kRows + sub;
+                            if (rr < ng && k < len) {
+                                const int64_t off = (int64_t)(g0 + rr) * out_stride + tile0 + k;
+                                o0[off] = va[j][0];
+                                if (kTwoOut) o1[off] = va[j][NOUT - 1];
+                            }
+                        }
                     }
                 }
             }
@@ -280,17 +332,18 @@ __global__ __launch_bounds__(128) void loop_kernel(pm_loop *__restrict__ loops, 
     }
 }
 
-// the most distinct input rows the kG consecutive loops of one wave can touch
-int loop_rows_lds(int per_row, int nloops)
+// the most distinct input rows the g consecutive loops of one workgroup can touch
+int loop_rows_lds(int per_row, int nloops, int g)
 {
-    if (per_row % kG == 0 || per_row >= nloops) return 1;
-    return std::min(kG, (kG - 2) / per_row + 2);
+    if (per_row >= nloops) return 1;
+    if (per_row % g == 0) return 1;
+    return std::min(g, (g - 2) / per_row + 2);
 }
 
-size_t loop_lds_bytes(int mode, int rows_in)
+size_t loop_lds_bytes(int mode, int rows_in, int g, int tile)
 {
     const int nin = mode == kMpsk ? 2 : 1, nout = (mode == kMpsk || mode == kQpsk) ? 2 : 1;
-    size_t d = 516 + 2 * (size_t)rows_in * nin * kPad + 2 * (size_t)nout * kG * kPad;
+    size_t d = 516 + 2 * (size_t)rows_in * nin * (tile + 1) + 2 * (size_t)nout * g * (tile + 1);
     return d * 8 + (mode == kMpsk ? 4096 * 4 : 0);
 }
 
@@ -300,16 +353,21 @@ template <int MODE>
 int loop_enqueue(pm_ctx *ctx, pm_loop *d_loops, int nloops, int per_row, const double *d_table, const int32_t *d_pd,
                  const double *d_x0, const double *d_x1, int64_t x_stride, int64_t n, double *d_o0, double *d_o1, int64_t out_stride)
 {
-    const int rows_lds = loop_rows_lds(per_row, nloops);
-    size_t lds = loop_lds_bytes(MODE, rows_lds);
+    // every lane a loop once eight-lane waves would outnumber the CUs (PM_LOOP_WIDE=0 / 1 forces the shape: tests, measurements)
+    bool wide = nloops > 8 * 256;
+    if (const char *e = getenv("PM_LOOP_WIDE")) wide = atoi(e) != 0;
+    const int g = wide ? 64 : 8, tile = wide ? 32 : 256;
+    const int rows_lds = loop_rows_lds(per_row, nloops, g);
+    size_t lds = loop_lds_bytes(MODE, rows_lds, g, tile);
     if (const char *e = getenv("PM_LOOP_LDS_MIN")) lds = std::max(lds, (size_t)atol(e));     // experiment: one workgroup per CU
-    if (lds > 64 * 1024)
-        PM_HIP(hipFuncSetAttribute((const void *)loop_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    {
+    auto go = [&](auto kernel) -> int {
+        if (lds > 64 * 1024) PM_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         PmProf prof(ctx, PM_K_LOOP);
-        hipLaunchKernelGGL((loop_kernel<MODE>), dim3((unsigned)pm_cdiv(nloops, kG)), dim3(128), lds, ctx->stream,
-                           d_loops, nloops, per_row, rows_lds, d_table, d_pd, d_x0, d_x1, x_stride, n, d_o0, d_o1, out_stride);
-    }
+        hipLaunchKernelGGL(kernel, dim3((unsigned)pm_cdiv(nloops, g)), dim3(128), lds, ctx->stream, d_loops, nloops, per_row, rows_lds, d_table,
+                           d_pd, d_x0, d_x1, x_stride, n, d_o0, d_o1, out_stride);
+        return PM_OK;
+    };
+    if (int rc = wide ? go(loop_kernel<MODE, 64, 32>) : go(loop_kernel<MODE, 8, 256>)) return rc;
     PM_HIP(hipGetLastError());
     return PM_OK;
 }

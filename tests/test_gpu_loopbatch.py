@@ -156,9 +156,12 @@ def group_modems(cfg, rate, carriers=None, take=None):
     ("qpsk_600.json", 44100, [1500.0], 0),
     ("afsk_300_pll.json", 8000, None, 2048),
 ])
-def test_engine_bitmaps_equal_demod_signs(cfg, rate, carriers, chunk):
+@pytest.mark.parametrize("wide", [0, 1])
+def test_engine_bitmaps_equal_demod_signs(cfg, rate, carriers, chunk, wide, monkeypatch):
     """Every (recording, chain) bitmap of a run equals modem.demod_signs() on that recording: different audio per recording, chunk
-    lengths from one FIR tile up, chains per recording that do and do not divide the eight loops of a wave."""
+    lengths from one FIR tile up, chains per recording that do and do not divide the loops of a wave.  wide: the engine's loop
+    launches in the shape for runs of thousands of loops (every lane of the stepping wave a loop, 32-sample tiles: PM_LOOP_WIDE),
+    the per-recording reference in the eight-loop shape."""
     import pymodem_amd
     from pymodem_amd.loop_batch import LoopBatch
     ctx = pymodem_amd.Context.default()
@@ -171,8 +174,10 @@ def test_engine_bitmaps_equal_demod_signs(cfg, rate, carriers, chunk):
     try:
         for take in (5, 2):                                             # a second run on the same engine starts from fresh states
             dev = [ctx.upload(r) for r in recs[:take]]
+            monkeypatch.setenv("PM_LOOP_WIDE", str(wide))
             got = eng.run(dev)
             ctx.sync()
+            monkeypatch.setenv("PM_LOOP_WIDE", "0")
             for k in range(take):
                 for c, (line, _) in enumerate(group):
                     from pymodem_amd import chain_builder as cb
@@ -183,6 +188,56 @@ def test_engine_bitmaps_equal_demod_signs(cfg, rate, carriers, chunk):
                         assert np.array_equal(bits_of(got[k][c].bits_q, ref.n), bits_of(ref.bits_q, ref.n)), (cfg, k, c, "Q")
     finally:
         eng.close()
+
+
+def test_loop_kernel_shapes_agree(monkeypatch):
+    """150 loops in one launch (three workgroups of the 64-loop shape, the last one part full), a length that is no multiple of either
+    tile: outputs and end states of the four loop kernels bit for bit the same in both shapes, own input rows and one shared row."""
+    import ctypes
+    import math
+    import pymodem_amd
+    from pymodem_amd import taps as T
+    from pymodem_amd._native import Loop, check, lib
+    ctx = pymodem_amd.Context.default()
+    n, nl = 5003, 150
+    tab = ctx.upload(np.array([math.sin(i * 2.0 * math.pi / 256) for i in range(256)]))
+    pd = ctx.upload(np.ascontiguousarray(T.qpsk_error_table().reshape(-1), dtype=np.int32))
+    b0, b1, a1 = T.one_pole_lowpass(48000.0, 250.0, 1.0)
+    rng = np.random.default_rng(9)
+    x_own = ctx.upload(rng.standard_normal(n * nl) * 0.6)
+    x_im = ctx.upload(rng.standard_normal(n * nl) * 0.6)
+
+    def fresh():
+        loops = (Loop * nl)()
+        for k in range(nl):
+            lp = loops[k]
+            lp.phase_scaling, lp.index_scaling, lp.set_frequency = 2.0 * math.pi / 48000.0, 256 / (2.0 * math.pi), 1400.0 + 1.7 * k
+            lp.b0, lp.b1, lp.a1 = b0, b1, a1
+            lp.bb0, lp.bb1, lp.ba1 = b0, b1, a1
+            lp.p_rate, lp.i_rate, lp.i_limit, lp.gain = 0.3, 0.3 / 2000, 31.25, 14400 / 65536
+        return loops
+    L = lib()
+    o1, o2 = ctx.empty(n * nl, np.float64), ctx.empty(n * nl, np.float64)
+    calls = {
+        "costas own rows": lambda lp: check(L.pm_costas_bpsk(ctx.handle, lp, nl, tab.ptr, x_own.ptr, n, n, o1.ptr, n)),
+        "costas shared": lambda lp: check(L.pm_costas_bpsk(ctx.handle, lp, nl, tab.ptr, x_own.ptr, 0, n, o1.ptr, n)),
+        "pll own rows": lambda lp: check(L.pm_pll_afsk(ctx.handle, lp, nl, tab.ptr, x_own.ptr, n, n, o1.ptr, n)),
+        "qpsk costas own rows": lambda lp: check(L.pm_costas_qpsk(ctx.handle, lp, nl, tab.ptr, x_own.ptr, n, n, o1.ptr, o2.ptr, n)),
+        "mpsk own rows": lambda lp: check(L.pm_mpsk_loop(ctx.handle, lp, nl, tab.ptr, pd.ptr, x_own.ptr, x_im.ptr, n, n, o1.ptr, o2.ptr, n)),
+        "mpsk shared": lambda lp: check(L.pm_mpsk_loop(ctx.handle, lp, nl, tab.ptr, pd.ptr, x_own.ptr, x_im.ptr, 0, n, o1.ptr, o2.ptr, n)),
+    }
+    for name, call in calls.items():
+        got = {}
+        for wide in (0, 1):
+            monkeypatch.setenv("PM_LOOP_WIDE", str(wide))
+            check(lib().pm_memset(ctx.handle, o1.ptr, 0, n * nl * 8))
+            check(lib().pm_memset(ctx.handle, o2.ptr, 0, n * nl * 8))
+            lp = fresh()
+            call(lp)
+            got[wide] = (o1.download(), o2.download(), bytes(lp))
+        assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1]), name
+        assert got[0][2] == got[1][2], name
+        assert np.any(got[0][0] != 0), name
 
 
 def test_engine_qpsk_modem():
