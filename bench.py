@@ -354,14 +354,21 @@ def measure(args, env):
                      "note": "all carrier loops of the run's recordings x this rank's chains advance together, one lane each, state carried "
                              "in device memory from chunk to chunk; band-pass/AGC/Hilbert of chunk t+1 on a second stream beside the loops of chunk t"}
 
+    loop_phase_s = {}
+
     def loop_steps(k, audio_dev):
         res = None
+        loop_phase_s.clear()
         for b0 in range(0, k, batch):
             r = min(batch, k - b0)
             sets = [build_chains(reset=False) for _ in range(r)]
-            rows = lb.process_recordings_device(sets, [audio_dev] * r, ctx, chunk=args.loop_chunk, rows=True, chain_ids=my)
+            st = {}
+            rows = lb.process_recordings_device(sets, [audio_dev] * r, ctx, chunk=args.loop_chunk, rows=True, chain_ids=my, stages=st)
+            t_f = time.perf_counter()
             for rr in rows:
                 res = finish(rr)
+            for k2, v in dict(st.get("seconds", {}), finish=time.perf_counter() - t_f).items():
+                loop_phase_s[k2] = loop_phase_s.get(k2, 0.0) + v
         return res
 
     native_sides = []
@@ -757,7 +764,7 @@ def measure(args, env):
                                     "native: pm_pipe_* (one library call per recording; slicer batches, LFSR + codec and de-dup on the library's "
                                     "own threads)" if native_exec[0] else
                                     None if loop_wl or args.overlap < 2 else "python: chain_execute.RecordingPipeline sequences the library's stage calls"),
-                       "loop_batch": loop_info,
+                       "loop_batch": None if loop_info is None else dict(loop_info, phase_ms_per_step={k2: round(v / args.steps * 1e3, 3) for k2, v in loop_phase_s.items()}),
                        "scaling_note": ("carrier-loop workload: a GPU's time per run is one recording's worth of sequential loop steps however "
                                         "many loops run beside each other, so per-GPU throughput is set by recordings x chains in flight "
                                         "(--loop-batch x chains per GPU); sharding 8 chains per GPU over N GPUs scales by construction (no "

@@ -203,6 +203,8 @@ def process_recordings_device(chain_sets, audios, ctx=None, chunk=0, rows=False,
     for cs in chain_sets:
         if len(cs) != nchains or any(group_key(cs[c][1]) != k for k, members in groups.items() for c in members):
             raise ValueError("every recording must bring the same group of chains")
+    import time
+    t0 = time.perf_counter()
     bitmaps = [[None] * nchains for _ in range(r)]
     for gi, (k, members) in enumerate(groups.items()):
         eng = engine_for([chain_sets[0][c][1] for c in members], r, ctx, chunk)
@@ -213,15 +215,29 @@ def process_recordings_device(chain_sets, audios, ctx=None, chunk=0, rows=False,
                 sl._ctx = sl._ctx or ctx
                 bitmaps[rec][c] = sl.sign_bitmaps(got[rec][j])
     ctx.sync_relaxed()                 # seconds: sleep through them instead of spinning in the slicer's first stream wait
+    t1 = time.perf_counter()
     flat_slicers = [chain_sets[rec][c][2] for rec in range(r) for c in range(nchains)]
     flat_bits = [bitmaps[rec][c] for rec in range(r) for c in range(nchains)]
-    sliced = slice_batch(flat_slicers, flat_bits, ctx)
+    if len(flat_slicers) >= 256:
+        # thousands of streams go through pm_slice_batch 64 at a time, each call a sequence of short lockstep launches that ends in a
+        # wait: two halves on two streams (two threads) overlap their waits, as the two slicer workers of the AFSK pipeline do
+        half = (r // 2) * nchains
+        sides = [ctx, Context.side(ctx.device, 1)]
+        futs = [_pool().submit(slice_batch, flat_slicers[lo:hi], flat_bits[lo:hi], c) for (lo, hi), c in zip(((0, half), (half, len(flat_slicers))), sides)]
+        sliced = futs[0].result() + futs[1].result()
+    else:
+        sliced = slice_batch(flat_slicers, flat_bits, ctx)
+    t2 = time.perf_counter()
     if stages is not None:
         stages["sliced"] = [sliced[rec * nchains:(rec + 1) * nchains] for rec in range(r)]
+        stages["seconds"] = {"engine": t1 - t0, "slicers": t2 - t1}
     out = []
     if rows:
         futs = [_pool().submit(_host_rows, chain_sets[rec], sliced[rec * nchains:(rec + 1) * nchains], chain_ids) for rec in range(r)]
-        return [f.result() for f in futs]
+        out = [f.result() for f in futs]
+        if stages is not None:
+            stages["seconds"]["host"] = time.perf_counter() - t2
+        return out
     futs = [[_pool().submit(_host_stages, ch, sl) for ch, sl in zip(chain_sets[rec], sliced[rec * nchains:(rec + 1) * nchains])] for rec in range(r)]
     for rec in range(r):
         out.append([f.result() for f in futs[rec]])
