@@ -159,9 +159,9 @@ def main():
     ap.add_argument("--loop-batch", type=int, default=0,
                     help="carrier-loop workloads (bpsk_300, qpsk_2400): recordings per engine run (pymodem_amd.loop_batch) -- the loops of all of "
                          "them x the rank's chains advance together, one lane each; a step is still one recording.  0 (default): as many as "
-                         "give 16384 loops in flight (every lane of one stepping wave per CU), 4096 recordings at most, never more than --steps")
+                         "give 16384 loops in flight (every lane of one stepping wave per CU), 8192 recordings at most, never more than --steps")
     ap.add_argument("--loop-chunk", type=int, default=0, help="carrier-loop workloads: final-filter outputs per time chunk (0 = 131072 for runs "
-                    "of more than 8192 loops, whose work buffers are sized by it, else 262144)")
+                    "of 2048 recordings or 8192 loops and more, whose work buffers are sized by it, else 262144)")
     ap.add_argument("--also", type=int, default=1, help="1 (default, one GPU only): after the headline workload also measure fsk_9600, "
                     "bpsk_300 and qpsk_2400 (BASELINE configs[2], [1], [4]) briefly and attach them under 'also'")
     args = ap.parse_args()
@@ -249,9 +249,9 @@ def also_workloads(args, env, cpu_also=None):
     at full size -- and fsk_9600 is the shortest-tap FIR path.  Never allowed to break the main line."""
     import copy
     out = {}
-    # (the carrier-loop workloads: one full engine run each -- 4096 recordings x 1 chain, 2048 x 8 chains; a run takes as long as
+    # (the carrier-loop workloads: one full engine run each -- 8192 recordings x 1 chain, 2048 x 8 chains; a run takes as long as
     # its recordings are, however many there are)
-    for name, steps, warm in (("fsk_9600", 300, 10), ("bpsk_300", 4096, 1), ("qpsk_2400", 2048, 1)):
+    for name, steps, warm in (("fsk_9600", 300, 10), ("bpsk_300", 8192, 1), ("qpsk_2400", 2048, 1)):
         if name == args.workload:
             continue
         a = copy.copy(args)
@@ -344,9 +344,9 @@ def measure(args, env):
     loop_info = None
     if loop_wl:
         from pymodem_amd import loop_batch as lb
-        batch = max(1, min(args.loop_batch or min(4096, LOOPS_IN_FLIGHT // max(len(my), 1)), max(args.steps, 1)))
+        batch = max(1, min(args.loop_batch or min(8192, LOOPS_IN_FLIGHT // max(len(my), 1)), max(args.steps, 1)))
         if not args.loop_chunk:
-            args.loop_chunk = 131072 if batch * len(my) > 8192 else 262144
+            args.loop_chunk = 131072 if batch >= 2048 or batch * len(my) > 8192 else 262144
         engine = lb.engine_for([modems[c] for c in my], batch, ctx, args.loop_chunk)
         engine.reserve(batch, args.samples, slot=(0, 0))
         nout_, chunk_, chunks_ = engine.geometry(args.samples)

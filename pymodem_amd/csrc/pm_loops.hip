@@ -597,35 +597,67 @@ __global__ void agc_rows_prepare_kernel(const double *__restrict__ running, int 
     consts[4 * r + 3] = 0.0;
 }
 
-__global__ __launch_bounds__(64) void agc_rows_kernel(const double *x, int64_t x_stride, double *y, int64_t y_stride,
+// One wave steps kAgcRows rows: lane l < rows carries row l's envelope recurrence through the tile (the step is branch-free, so the
+// lanes do not diverge), then all 64 lanes divide.  With one row per wave (the first version) the recurrence's ten f64 instructions per
+// sample were issued for ONE useful lane: for thousands of rows that was as much vector issue as the matched filters of the whole
+// chain (qpsk_2400 / bpsk_300 engine runs: AGC rows 15 % / 29 % of the GPU time, profiles/r03_*_kernel_stats.csv), taken from the
+// FIR kernels running beside it.  Eight tile values are read ahead of the steps that use them: the chain is the recurrence, not LDS.
+constexpr int kAgcRows = 16;
+__global__ __launch_bounds__(64) void agc_rows_kernel(const double *x, int64_t x_stride, double *y, int64_t y_stride, int rows,
                                                       int64_t n, const double *__restrict__ consts, AgcDev P, double2 *__restrict__ state)
 {
-    __shared__ double tile[kTile], envs[kTile];
+    extern __shared__ double agc_lds[];
+    constexpr int kP = kTile + 1;
+    double *tile = agc_lds, *envs = agc_lds + kAgcRows * kP;
     const int lane = threadIdx.x;
-    const int64_t r = blockIdx.x;
-    const double *xr = x + r * x_stride;
-    double *yr = y + r * y_stride;
+    const int64_t r0 = (int64_t)blockIdx.x * kAgcRows;
+    const int nr = (int)min((int64_t)kAgcRows, rows - r0);
+    const bool stepping = lane < nr;
+    const int64_t r = r0 + (stepping ? lane : 0);
     P.att = consts[4 * r + 1];
     P.dec = consts[4 * r + 2];
     double env = state[r].x, sustain = state[r].y;
+    const double *tl = tile + lane * kP;
+    double *el = envs + lane * kP;
     for (int64_t tile0 = 0; tile0 < n; tile0 += kTile) {
         const int len = (int)min((int64_t)kTile, n - tile0);
-        for (int k = lane; k < len; k += 64) tile[k] = xr[tile0 + k];
-        __syncthreads();
-        if (lane == 0) {
-            for (int k = 0; k < len; ++k) {
-                agc_step(tile[k], env, sustain, P);
-                envs[k] = env;
+        for (int rr = 0; rr < nr; ++rr) {
+            const double *xr = x + (r0 + rr) * x_stride + tile0;
+#pragma unroll
+            for (int j = 0; j < kTile / 64; ++j) {
+                const int k = lane + 64 * j;
+                tile[rr * kP + k] = xr[min(k, len - 1)];
             }
         }
         __syncthreads();
-        for (int k = lane; k < len; k += 64) {
-            const double e = envs[k], s = tile[k];
-            yr[tile0 + k] = e != 0 ? P.target * s / e : s;          // agc.py:75-76
+        if (stepping) {
+            int k = 0;
+            for (; k + 8 <= len; k += 8) {
+                double v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = tl[k + j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    agc_step(v[j], env, sustain, P);
+                    el[k + j] = env;
+                }
+            }
+            for (; k < len; ++k) {
+                agc_step(tl[k], env, sustain, P);
+                el[k] = env;
+            }
+        }
+        __syncthreads();
+        for (int rr = 0; rr < nr; ++rr) {
+            double *yr = y + (r0 + rr) * y_stride + tile0;
+            for (int k = lane; k < len; k += 64) {
+                const double e = envs[rr * kP + k], sv = tile[rr * kP + k];
+                yr[k] = e != 0 ? P.target * sv / e : sv;          // agc.py:75-76
+            }
         }
         __syncthreads();
     }
-    if (lane == 0) state[r] = make_double2(env, sustain);
+    if (stepping) state[r] = make_double2(env, sustain);
 }
 
 }  // namespace
@@ -686,7 +718,14 @@ int pm_agc_rows(pm_ctx *ctx, const double *d_x, int64_t x_stride, double *d_y, i
     P.target = hp->target_amplitude;
     P.att = P.dec = 0;
     PmProf prof(ctx, PM_K_AGC);
-    hipLaunchKernelGGL(agc_rows_kernel, dim3((unsigned)rows), dim3(64), 0, ctx->stream, d_x, x_stride, d_y, y_stride, n, d_consts, P, (double2 *)d_state);
+    const size_t lds = (size_t)2 * kAgcRows * (kTile + 1) * sizeof(double);
+    static bool allowed = false;
+    if (!allowed) {
+        PM_HIP(hipFuncSetAttribute((const void *)agc_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        allowed = true;
+    }
+    hipLaunchKernelGGL(agc_rows_kernel, dim3((unsigned)pm_cdiv(rows, kAgcRows)), dim3(64), lds, ctx->stream, d_x, x_stride, d_y, y_stride, rows, n,
+                       d_consts, P, (double2 *)d_state);
     PM_HIP(hipGetLastError());
     return PM_OK;
 }
