@@ -160,8 +160,8 @@ def main():
                     help="carrier-loop workloads (bpsk_300, qpsk_2400): recordings per engine run (pymodem_amd.loop_batch) -- the loops of all of "
                          "them x the rank's chains advance together, one lane each; a step is still one recording.  0 (default): as many as "
                          "give 16384 loops in flight (every lane of one stepping wave per CU), 8192 recordings at most, never more than --steps")
-    ap.add_argument("--loop-chunk", type=int, default=0, help="carrier-loop workloads: final-filter outputs per time chunk (0 = 131072 for runs "
-                    "of 2048 recordings or 8192 loops and more, whose work buffers are sized by it, else 262144)")
+    ap.add_argument("--loop-chunk", type=int, default=0, help="carrier-loop workloads: final-filter outputs per time chunk (0: 65536 for runs of "
+                    "more than 8192 loops, 131072 from 2048 recordings, else 262144 -- the work buffers are sized by it)")
     ap.add_argument("--also", type=int, default=1, help="1 (default, one GPU only): after the headline workload also measure fsk_9600, "
                     "bpsk_300 and qpsk_2400 (BASELINE configs[2], [1], [4]) briefly and attach them under 'also'")
     args = ap.parse_args()
@@ -346,7 +346,7 @@ def measure(args, env):
         from pymodem_amd import loop_batch as lb
         batch = max(1, min(args.loop_batch or min(8192, LOOPS_IN_FLIGHT // max(len(my), 1)), max(args.steps, 1)))
         if not args.loop_chunk:
-            args.loop_chunk = 131072 if batch >= 2048 or batch * len(my) > 8192 else 262144
+            args.loop_chunk = 65536 if batch * len(my) > 8192 else 131072 if batch >= 2048 else 262144
         engine = lb.engine_for([modems[c] for c in my], batch, ctx, args.loop_chunk)
         engine.reserve(batch, args.samples, slot=(0, 0))
         nout_, chunk_, chunks_ = engine.geometry(args.samples)
@@ -591,7 +591,7 @@ def measure(args, env):
         # any run of the engine takes as long as its recordings are (the loops are sequential in time): warm up on the first seconds
         if args.warmup:
             loop_steps(min(args.warmup, batch), d_audio.view(0, min(args.samples, 1_500_000)))
-        sides.append(engine.front)
+        sides.extend([engine.front, engine.tail])
     else:
         run_steps(args.warmup)
     fence()
@@ -686,6 +686,7 @@ def measure(args, env):
     close_pipes()
     if loop_wl:
         sides.remove(engine.front)
+        sides.remove(engine.tail)
         lb.close_engines()                                    # the engine's work buffers and bitmap sets (gigabytes) go back
     per_rank_ms = None
     if use_dist:

@@ -400,12 +400,13 @@ int pm_lbatch_create(pm_ctx *ctx, const pm_lbatch_desc *desc, pm_lbatch **out); 
 /* samples per demodulated stream, outputs per chunk and chunks for recordings of n samples */
 int pm_lbatch_geometry(pm_lbatch *batch, int64_t n, int64_t *h_nout, int64_t *h_chunk, int64_t *h_chunks);
 /* h_d_audio: HOST array of `recordings` device pointers to int16 recordings of n samples each (they may be the same buffer).
- * Everything is enqueued (two streams: the context's and one of the engine's own); nothing waits for the GPU: the bitmaps are
+ * Everything is enqueued (three streams: the context's and two of the engine's own); nothing waits for the GPU: the bitmaps are
  * complete when the context's stream has reached the end of the call.  Every run starts from fresh AGC and loop states.
  * bits_stride >= (nout + 63) / 64 + 1 words. */
 int pm_lbatch_run(pm_lbatch *batch, const int16_t *const *h_d_audio, int recordings, int64_t n, uint64_t *d_bits_i, uint64_t *d_bits_q,
                   int64_t bits_stride, int64_t *h_nout);
-pm_ctx *pm_lbatch_front_ctx(pm_lbatch *batch);       /* the engine's own context (band-pass, AGC, Hilbert): for pm_prof_* */
+pm_ctx *pm_lbatch_front_ctx(pm_lbatch *batch);       /* the engine's own contexts, for pm_prof_*: band-pass, AGC, Hilbert of chunk t + 1 ... */
+pm_ctx *pm_lbatch_tail_ctx(pm_lbatch *batch);        /* ... and the matched filters of chunk t - 1, beside the loops of chunk t on the caller's */
 int pm_lbatch_destroy(pm_lbatch *batch);
 
 /* ---- host-integer stages (native C++, no GPU) --------------------------------------------------

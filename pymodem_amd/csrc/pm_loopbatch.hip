@@ -23,12 +23,14 @@
 // the stage objects' demod() for every chunk length (tests/test_gpu_loopbatch.py).
 #include "pm_common.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 struct pm_lbatch {
     pm_ctx *back = nullptr;                  // the caller's context: loops and output filter
     pm_ctx *front = nullptr;                 // own context: band-pass, AGC, Hilbert pair of the next chunk
+    pm_ctx *tail = nullptr;                  // own context: the matched filter(s) of chunk t beside the loops of chunk t + 1
     int modem = 0, R = 0, C = 0;
     int mb = 0, mh = 0, mo = 0, delay = 0;
     bool mpsk = false, two_out = false;
@@ -42,11 +44,11 @@ struct pm_lbatch {
     std::vector<pm_loop> h_loops;            // R x C: the C initial loops repeated
     pm_loop *d_loops = nullptr;
     double *tmp = nullptr, *awin = nullptr, *in0[2] = {nullptr, nullptr}, *in1[2] = {nullptr, nullptr};
-    double *dwin0 = nullptr, *dwin1 = nullptr;
+    double *dwin0[2] = {nullptr, nullptr}, *dwin1[2] = {nullptr, nullptr};    // the loops' outputs, two sets taking turns
     double *d_running = nullptr, *d_partial = nullptr, *d_consts = nullptr, *d_agc_state = nullptr;
     const int16_t **d_audio = nullptr;
     std::vector<const int16_t *> h_audio;
-    hipEvent_t front_done[2] = {nullptr, nullptr}, back_done[2] = {nullptr, nullptr}, run_done = nullptr;
+    hipEvent_t front_done[2] = {nullptr, nullptr}, back_done[2] = {nullptr, nullptr}, hist_done[2] = {nullptr, nullptr}, run_done = nullptr;
     bool ran = false;
     int64_t last_chunks = 0;
 };
@@ -106,14 +108,16 @@ int pm_lbatch_destroy(pm_lbatch *b)
     if (!b) return PM_OK;
     pm_ctx *ctx = b->back;
     if (b->front) (void)pm_ctx_sync(b->front);
+    if (b->tail) (void)pm_ctx_sync(b->tail);
     if (ctx) (void)pm_ctx_sync(ctx);
     for (void *p : {(void *)b->d_taps, (void *)b->d_pd, (void *)b->d_loops, (void *)b->tmp, (void *)b->awin, (void *)b->in0[0], (void *)b->in0[1],
-                    (void *)b->in1[0], (void *)b->in1[1], (void *)b->dwin0, (void *)b->dwin1, (void *)b->d_running, (void *)b->d_partial,
+                    (void *)b->in1[0], (void *)b->in1[1], (void *)b->dwin0[0], (void *)b->dwin0[1], (void *)b->dwin1[0], (void *)b->dwin1[1], (void *)b->d_running, (void *)b->d_partial,
                     (void *)b->d_consts, (void *)b->d_agc_state, (void *)b->d_audio})
         if (p) (void)pm_free(ctx, p);
-    for (hipEvent_t e : {b->front_done[0], b->front_done[1], b->back_done[0], b->back_done[1], b->run_done})
+    for (hipEvent_t e : {b->front_done[0], b->front_done[1], b->back_done[0], b->back_done[1], b->hist_done[0], b->hist_done[1], b->run_done})
         if (e) (void)hipEventDestroy(e);
     if (b->front) (void)pm_ctx_destroy(b->front);
+    if (b->tail) (void)pm_ctx_destroy(b->tail);
     delete b;
     return PM_OK;
 }
@@ -152,6 +156,7 @@ int pm_lbatch_create(pm_ctx *ctx, const pm_lbatch_desc *desc, pm_lbatch **out)
     int rc = PM_OK;
     do {
         if ((rc = pm_ctx_create_prio(ctx->device, 0, &b->front))) break;
+        if ((rc = pm_ctx_create_prio(ctx->device, 0, &b->tail))) break;
         b->o_in = put(b->h_taps, d.input_fir, d.n_input_fir);
         if (b->mpsk) b->o_hil = put(b->h_taps, d.hilbert, d.n_hilbert);
         b->o_out = put(b->h_taps, d.output_fir, d.n_output_fir);
@@ -174,8 +179,11 @@ int pm_lbatch_create(pm_ctx *ctx, const pm_lbatch_desc *desc, pm_lbatch **out)
             if (!rc && b->mpsk) rc = dev_alloc(ctx, b->in1[s], R * P);
         }
         if (rc) break;
-        if ((rc = dev_alloc(ctx, b->dwin0, RC * P))) break;
-        if (b->two_out && (rc = dev_alloc(ctx, b->dwin1, RC * P))) break;
+        for (int k = 0; k < 2 && !rc; ++k) {
+            rc = dev_alloc(ctx, b->dwin0[k], RC * P);
+            if (!rc && b->two_out) rc = dev_alloc(ctx, b->dwin1[k], RC * P);
+        }
+        if (rc) break;
         if ((rc = dev_alloc(ctx, b->d_running, R))) break;
         if ((rc = dev_alloc(ctx, b->d_partial, R * (size_t)pm_rows_max_parts()))) break;
         if ((rc = dev_alloc(ctx, b->d_consts, 4 * R))) break;
@@ -183,7 +191,7 @@ int pm_lbatch_create(pm_ctx *ctx, const pm_lbatch_desc *desc, pm_lbatch **out)
         if ((rc = dev_alloc(ctx, b->d_audio, R))) break;
         b->h_audio.resize(R);
         hipError_t e = hipSuccess;
-        for (hipEvent_t *ev : {&b->front_done[0], &b->front_done[1], &b->back_done[0], &b->back_done[1], &b->run_done})
+        for (hipEvent_t *ev : {&b->front_done[0], &b->front_done[1], &b->back_done[0], &b->back_done[1], &b->hist_done[0], &b->hist_done[1], &b->run_done})
             if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
         if (e != hipSuccess) { rc = pm_set_error(PM_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e)); break; }
         rc = pm_ctx_sync(ctx);                                 // the constants are up before the desc's pointers go away
@@ -204,12 +212,20 @@ int pm_lbatch_geometry(pm_lbatch *b, int64_t n, int64_t *h_nout, int64_t *h_chun
 }
 
 pm_ctx *pm_lbatch_front_ctx(pm_lbatch *b) { return b ? b->front : nullptr; }
+pm_ctx *pm_lbatch_tail_ctx(pm_lbatch *b) { return b ? b->tail : nullptr; }
 
 int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings, int64_t n, uint64_t *d_bits_i, uint64_t *d_bits_q,
                   int64_t bits_stride, int64_t *h_nout)
 {
     PM_ARG(b != nullptr && h_d_audio != nullptr && d_bits_i != nullptr && h_nout != nullptr);
-    pm_ctx *B = b->back, *F = b->front;
+    static const int tail_mode = getenv("PM_LBATCH_TAIL") ? atoi(getenv("PM_LBATCH_TAIL")) : -1;
+    // The matched filters of chunk t beside the loops of chunk t + 1 (third stream), or behind them on the caller's stream.  Beside
+    // them the loops run 1.8-2.8x slower (their table look-ups queue behind the filters' LDS traffic; wave priority changes nothing), so
+    // it pays only where the filters are the longer half and the front end is light: measured on one box, same minute -- bpsk_300
+    // (8192 x 1) 11 255 against 10 169 Msamples/s, qpsk_2400 256 x 64 chains 21 783 against 19 446, but 2048 x 8 chains 16 354 against
+    // 17 687 (AGC, Hilbert pair and band-pass of 2048 recordings run beside them as well).  PM_LBATCH_TAIL=0 / 1 forces it.
+    const bool use_tail = tail_mode >= 0 ? tail_mode != 0 : (!b->two_out || b->C >= 16);
+    pm_ctx *B = b->back, *F = b->front, *Tl = use_tail ? b->tail : b->back;
     PM_CTX(B);
     PM_ARG(recordings >= 1 && recordings <= b->R);
     PM_ARG(!b->two_out || d_bits_q != nullptr);
@@ -233,6 +249,7 @@ int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings,
     if (b->ran) {
         PM_HIP(hipStreamWaitEvent(F->stream, b->run_done, 0));
         PM_HIP(hipStreamWaitEvent(B->stream, b->run_done, 0));
+        PM_HIP(hipStreamWaitEvent(Tl->stream, b->run_done, 0));
     }
     // the front stream is ordered behind whatever the caller has enqueued on its context so far (e.g. the recordings' uploads)
     PM_HIP(hipEventRecord(b->run_done, B->stream));
@@ -253,7 +270,7 @@ int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings,
     // ---- pass 2: chunk by chunk ---------------------------------------------------------------------------------------------
     const int64_t chunks = pm_cdiv(nout, Lc);
     b->last_chunks = chunks;
-    int64_t s_agc = 0, s_loop = 0;
+    int64_t s_agc = 0, s_loop = 0, prev_cnt_l = 0;
     for (int64_t t = 0; t < chunks; ++t) {
         const int set = (int)(t & 1);
         const int64_t o0 = t * Lc, o1 = std::min(nout, o0 + Lc);
@@ -281,30 +298,41 @@ int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings,
             }
             PM_HIP(hipEventRecord(b->front_done[set], F->stream));
         }
-        // -- back: every loop over the chunk, then the output filter's sign bits
+        // -- back: every loop over the chunk into output set t & 1.  The set is free once the matched filters of chunk t - 2 have read it
+        // and chunk t - 1's history has been taken out of... the OTHER set; both lie behind hist_done of chunk t - 1 on the tail stream.
         PM_HIP(hipStreamWaitEvent(B->stream, b->front_done[set], 0));
-        if (int rc = pm_loops_rows(B, b->modem, b->d_loops, RC, C, T + b->o_wave, b->d_pd, b->in0[set], b->in1[set], P, cnt_l, b->dwin0 + b->Ho,
-                                   b->two_out ? b->dwin1 + b->Ho : nullptr, P)) return rc;
+        if (t >= 1) PM_HIP(hipStreamWaitEvent(B->stream, b->hist_done[(t - 1) & 1], 0));
+        if (int rc = pm_loops_rows(B, b->modem, b->d_loops, RC, C, T + b->o_wave, b->d_pd, b->in0[set], b->in1[set], P, cnt_l, b->dwin0[set] + b->Ho,
+                                   b->two_out ? b->dwin1[set] + b->Ho : nullptr, P)) return rc;
         PM_HIP(hipEventRecord(b->back_done[set], B->stream));
+        // -- tail: the output filter's sign bits for chunk t, beside the loops of chunk t + 1.  Its window is [history | new]: the last
+        // mo - 1 loop outputs of chunk t - 1 come over from the other set first (the loops of chunk t + 1, which overwrite them, wait
+        // for that copy: hist_done).
+        PM_HIP(hipStreamWaitEvent(Tl->stream, b->back_done[set], 0));
         {
             const int64_t back = t == 0 ? 0 : mo - 1, fn = cnt_l + back;
-            const double *f0 = b->dwin0 + b->Ho - back;
-            if (int rc = pm_fir_rows(B, false, f0, P, nullptr, 0, (((uintptr_t)f0) & 15) == 0, RC, fn, T + b->o_out, mo, nullptr, 0, d_bits_i + o0 / 64,
+            if (t >= 1 && mo > 1) {
+                if (int rc = rows_copy(Tl, b->dwin0[set] + b->Ho - (mo - 1), P, b->dwin0[set ^ 1] + b->Ho + prev_cnt_l - (mo - 1), P, mo - 1, RC)) return rc;
+                if (b->two_out)
+                    if (int rc = rows_copy(Tl, b->dwin1[set] + b->Ho - (mo - 1), P, b->dwin1[set ^ 1] + b->Ho + prev_cnt_l - (mo - 1), P, mo - 1, RC)) return rc;
+            }
+            PM_HIP(hipEventRecord(b->hist_done[set], Tl->stream));
+            const double *f0 = b->dwin0[set] + b->Ho - back;
+            if (int rc = pm_fir_rows(Tl, false, f0, P, nullptr, 0, (((uintptr_t)f0) & 15) == 0, RC, fn, T + b->o_out, mo, nullptr, 0, d_bits_i + o0 / 64,
                                      bits_stride, 0)) return rc;
             if (b->two_out) {
-                const double *f1 = b->dwin1 + b->Ho - back;
-                if (int rc = pm_fir_rows(B, false, f1, P, nullptr, 0, (((uintptr_t)f1) & 15) == 0, RC, fn, T + b->o_out, mo, nullptr, 0,
+                const double *f1 = b->dwin1[set] + b->Ho - back;
+                if (int rc = pm_fir_rows(Tl, false, f1, P, nullptr, 0, (((uintptr_t)f1) & 15) == 0, RC, fn, T + b->o_out, mo, nullptr, 0,
                                          d_bits_q + o0 / 64, bits_stride, 0)) return rc;
             }
-            if (more && mo > 1) {
-                if (int rc = rows_copy(B, b->dwin0 + b->Ho - (mo - 1), P, b->dwin0 + b->Ho + cnt_l - (mo - 1), P, mo - 1, RC)) return rc;
-                if (b->two_out)
-                    if (int rc = rows_copy(B, b->dwin1 + b->Ho - (mo - 1), P, b->dwin1 + b->Ho + cnt_l - (mo - 1), P, mo - 1, RC)) return rc;
-            }
         }
+        prev_cnt_l = cnt_l;
         s_agc = e_agc;
         s_loop = e_loop;
     }
+    // the tail stream's last filter ends the run: the caller's context waits for it
+    PM_HIP(hipEventRecord(b->hist_done[0], Tl->stream));
+    PM_HIP(hipStreamWaitEvent(B->stream, b->hist_done[0], 0));
     // the run is complete on the caller's context once the back stream gets here; the next run waits for this point on both streams
     PM_HIP(hipEventRecord(b->run_done, B->stream));
     b->ran = true;

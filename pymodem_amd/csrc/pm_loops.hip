@@ -164,6 +164,9 @@ __global__ __launch_bounds__(128) void loop_kernel(pm_loop *__restrict__ loops, 
         for (int i = threadIdx.x; i < 4096; i += 128) pdt[i] = pd[i];
 
     const bool active = wave == 0 && lane < ng;
+    // the stepping wave is one dependent chain: every issue slot it loses to the FIR waves that share its SIMD (the engine's matched
+    // filters run beside the loops) is time added to the run, while the FIR waves lose nothing they cannot make up
+    if (wave == 0) __builtin_amdgcn_s_setprio(3);
     LoopRegs L;
     if (active) {
         const pm_loop &s = loops[g0 + lane];

@@ -93,6 +93,13 @@ class LoopBatch:
             self._front = f
         return self._front
 
+    @property
+    def tail(self):
+        """The engine's third context (the matched filters of chunk t - 1 beside the loops of chunk t), borrowed, for profile_read()."""
+        if getattr(self, "_tail", None) is None:
+            self._tail = Context.borrowed(lib().pm_lbatch_tail_ctx(self._h), self.ctx.device)
+        return self._tail
+
     def _bits(self, r, nout, slot):
         stride = ((nout + 63) // 64 + 1 + 7) // 8 * 8
         streams = r * self.chains
