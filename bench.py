@@ -688,6 +688,11 @@ def measure(args, env):
         sides.remove(engine.front)
         sides.remove(engine.tail)
         lb.close_engines()                                    # the engine's work buffers and bitmap sets (gigabytes) go back
+        chains_ref[:] = []
+        import gc
+        gc.collect()
+        for c_ in [ctx] + [pymodem_amd.Context.side(dev_index, i) for i in range(2)]:
+            c_.drop_scratch()                                 # ... and the slicers' output blocks of thousands of streams
     per_rank_ms = None
     if use_dist:
         mine_t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device or "cpu")

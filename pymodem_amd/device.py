@@ -192,6 +192,8 @@ class Context:
             return _ArenaBuffer(self, nb, ptr)
 
     def _arena_release(self, buf):
+        if getattr(buf, "_gen", 0) != self.__dict__.get("_arena_gen", 0):
+            return                                         # its block went back to the device meanwhile (drop_scratch)
         self.sync()                                        # like pm_free: what this stream still does with it finishes first
         with self.__dict__.setdefault("_arena_lock", threading.Lock()):
             self.__dict__.setdefault("_arena_free", {}).setdefault(buf.n, []).append(buf.ptr.value)
@@ -237,6 +239,23 @@ class Context:
         ms = ctypes.c_float()
         check(lib().pm_timer_stop(self._h, ctypes.byref(ms)))
         return ms.value
+
+    def drop_scratch(self):
+        """Give every work buffer of this context (scratch() pool and the arena blocks behind it) back to the device.  For a process
+        that moves on to a workload of a different shape: a run over thousands of streams leaves tens of gigabytes of slicer output
+        blocks in the pool.  Nothing obtained from scratch() may be in use or be used afterwards."""
+        self.sync()
+        self.__dict__.get("_pool_views", {}).clear()
+        pool = self.__dict__.get("_pool", {})
+        for tag in list(pool):
+            buf = pool.pop(tag)
+            if not isinstance(buf, _ArenaBuffer):
+                buf.free()
+        with self.__dict__.setdefault("_arena_lock", threading.Lock()):
+            for chunk in self.__dict__.pop("_arena_chunks", []):
+                chunk[0].free()
+            self.__dict__.pop("_arena_free", None)
+            self._arena_gen = self.__dict__.get("_arena_gen", 0) + 1      # ranges handed out before this are nobody's any more
 
     def close(self):
         if getattr(self, "_borrowed", False):
@@ -342,6 +361,7 @@ class _ArenaBuffer(DeviceBuffer):
 
     def __init__(self, ctx, nbytes, ptr):
         super().__init__(ctx, nbytes, np.uint8, ptr=ptr)
+        self._gen = ctx.__dict__.get("_arena_gen", 0)
 
     def free(self):
         if self.ptr:
