@@ -421,11 +421,29 @@ def measure(args, env):
         import queue
         import threading
         from concurrent.futures import ThreadPoolExecutor
-        ex = pdist.Exchanger(nchains, coll_device)
+        # four recordings per collective: the ordered thread's half-dozen torch calls cost about the same per CALL whatever they carry
+        # (forced one-rank RCCL exchange, 400 steps: 1.31 ms per step with one recording per collective, 1.06-1.08 with four or eight,
+        # 0.93 without the exchange)
+        ex = pdist.Exchanger(nchains, coll_device, batch=int(os.environ.get("PYMODEM_AMD_EXCHANGE_BATCH", "4")))
         packed, gathered, out, errors = queue.Queue(), queue.Queue(), {}, []
 
+        acc = {"pack": 0.0, "step": 0.0, "dedupe": 0.0, "wait_rows": 0.0}
+
         def pack(t):
-            return ex.prepare(dict(zip(my, npipe.rows(t))))
+            t0_ = time.perf_counter()
+            rows_ = npipe.rows(t)
+            t1_ = time.perf_counter()
+            out_ = ex.prepare(dict(zip(my, rows_)))
+            acc["wait_rows"] += t1_ - t0_
+            acc["pack"] += time.perf_counter() - t1_
+            return out_
+
+        def timed_dedupe(g):
+            x_ = g.result()
+            t0_ = time.perf_counter()
+            r_ = dedupe(x_)
+            acc["dedupe"] += time.perf_counter() - t0_
+            return r_
 
         def ordered():
             try:
@@ -433,19 +451,32 @@ def measure(args, env):
                     f = packed.get()
                     if f is None:
                         break
-                    gathered.put(ex.step(f.result()))
+                    x_ = f.result()
+                    t0_ = time.perf_counter()
+                    gathered.put(ex.step(x_))
+                    acc["step"] += time.perf_counter() - t0_
                 ex.flush()
             except BaseException as e:                        # noqa: BLE001
                 errors.append(e)
             gathered.put(None)
 
         def post():
+            # rank 0 indexes and de-duplicates every rank's rows: 2 ms per recording at 64 chains, more than a step -- several at a time
+            # (the recordings' results do not depend on each other; the last one's is what the caller gets)
             try:
-                while True:
-                    f = gathered.get()
-                    if f is None:
-                        break
-                    out["last"] = dedupe(f.result())
+                with ThreadPoolExecutor(max_workers=4) as dedupers:
+                    pending = []
+                    while True:
+                        f = gathered.get()
+                        if f is None:
+                            break
+                        pending.append(dedupers.submit(timed_dedupe, f))
+                        while len(pending) > 8:
+                            pending.pop(0).result()
+                    for p_ in pending[:-1]:
+                        p_.result()
+                    if pending:
+                        out["last"] = pending[-1].result()
             except BaseException as e:                        # noqa: BLE001
                 errors.append(e)
         threads = [threading.Thread(target=ordered), threading.Thread(target=post)]
@@ -465,6 +496,9 @@ def measure(args, env):
         npipe.drain()
         if errors:
             raise errors[0]
+        if k:
+            stage_ms.update({"exchange_pack": round(acc["pack"] / k * 1e3, 3), "exchange_ordered_step": round(acc["step"] / k * 1e3, 3),
+                             "exchange_dedupe_rank0": round(acc["dedupe"] / k * 1e3, 3)})
         return out.get("last")
 
     def run_steps(k):
@@ -474,9 +508,9 @@ def measure(args, env):
         if native_exec[0] and args.overlap >= 2:
             npipe = native_pipe("native")
             before = npipe.stats()
+            stage_ms.clear()
             res = native_steps(npipe, k, d_audio)
             after = npipe.stats()
-            stage_ms.clear()
             if k:
                 stage_ms.update({"executor": "native (pm_pipe_*)", "slice_busy": round((after["slice_busy_ms"] - before["slice_busy_ms"]) / k, 3),
                                  "host_busy": round((after["host_busy_ms"] - before["host_busy_ms"]) / k, 3),

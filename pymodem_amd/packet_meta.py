@@ -203,15 +203,19 @@ class PacketTable:
         if len(parts) == 1:
             return parts[0]
         base = parts[0].base
-        if isinstance(base, np.ndarray) and base.dtype == parts[0].dtype and all(p.base is base for p in parts):
+        if isinstance(base, np.ndarray) and base.flags.c_contiguous and all(p.base is base for p in parts):
             addr = parts[0].ctypes.data
             for p in parts:
                 if p.ctypes.data != addr or not p.flags.c_contiguous:
                     break
                 addr += p.nbytes
             else:
-                start = (parts[0].ctypes.data - base.ctypes.data) // base.dtype.itemsize
-                return base[start:start + sum(len(p) for p in parts)]
+                total = sum(len(p) for p in parts)
+                if base.dtype == parts[0].dtype:
+                    start = (parts[0].ctypes.data - base.ctypes.data) // base.dtype.itemsize
+                    return base[start:start + total]
+                # (the executor inside the library hands its rows out as views of a byte array over its own memory)
+                return np.ndarray((total,), dtype=parts[0].dtype, buffer=base, offset=parts[0].ctypes.data - base.ctypes.data)
         return np.concatenate(parts)
 
     def correlate(self, address_distance):
