@@ -653,9 +653,7 @@ def measure(args, env):
             profs.append(pr)
             sys.setprofile(None)
             pr.enable()
-        for p_ in list(pipes.values()):                       # threads are made when the executor is: start a fresh one under the hook
-            p_.close()
-        pipes.clear()
+        close_pipes()                                         # threads are made when the executor is: start a fresh one under the hook
         threading.setprofile(boot)
         pr0 = cProfile.Profile()
         result = pr0.runcall(run_steps, args.steps)

@@ -264,6 +264,33 @@ def test_work_buffers_come_from_arenas_and_are_reused():
         ctx.close()
 
 
+def test_drop_scratch_gives_the_blocks_back_and_forgets_old_ranges():
+    """Context.drop_scratch: pool and arena blocks go back to the device; a range handed out before the drop that is released
+    afterwards (its owner collected late) is not put on the new free list, and later requests get fresh, working memory."""
+    import gc
+    import pymodem_amd
+    ctx = pymodem_amd.Context.side(index=77, high_priority=False)
+
+    class Owner:
+        pass
+    o = Owner()
+    a = ctx.scratch((ctx.owner_key(o), "x"), 1000, np.float64)
+    big = ctx.scratch(("big",), 80_000_000, np.float64)              # past the arena: a block of its own
+    old_ptr = a.ptr.value
+    assert ctx.__dict__.get("_arena_chunks")
+    ctx.drop_scratch()
+    assert not ctx.__dict__.get("_arena_chunks") and not ctx.__dict__.get("_pool")
+    del o, a, big
+    gc.collect()                                                     # the owner's finaliser runs now, with a range of the old block
+    assert not ctx.__dict__.get("_arena_free")
+    b = ctx.scratch(("y",), 1000, np.float64)
+    x = np.arange(1000, dtype=np.float64)
+    from pymodem_amd._native import check, lib
+    import ctypes
+    check(lib().pm_h2d(ctx.handle, b.ptr, x.ctypes.data_as(ctypes.c_void_p), x.nbytes))
+    assert np.array_equal(b.download(), x) and old_ptr is not None
+
+
 @pytest.mark.parametrize("cfg,rate", [("afsk_1200.json", 48000), ("fsk_9600.json", 48000), ("bpsk_300.json", 48000), ("qpsk_2400.json", 48000),
                                       ("afsk_300_pll.json", 8000), ("afsk_300.json", 8000)])
 def test_whole_chain_entry_point_matches_the_stage_path(config_lines, cfg, rate):

@@ -325,3 +325,21 @@ def test_codec_set_source_stamps_the_rows(golden, config_lines):
         lf = stream.stream_unscramble_8bit(AddressedArray(g["afsk_300__c0_slice_data"], g["afsk_300__c0_slice_addr"]))
         rows = codec.decode_rows(lf)
         assert len(rows) == len(g["afsk_300__c0_pkt_addr"]) > 3 and (rows["source_decoder"] == src).all()
+
+
+def test_packet_rows_that_are_views_of_a_byte_block_are_stacked_without_a_copy():
+    """The executor inside the library hands a recording's rows out as views of ONE byte array over its own memory: per-chain slices of
+    it go back together as one array over the same memory (PacketTable._stack), not through a 7 MB concatenate per recording."""
+    from pymodem_amd._native import packet_dtype
+    from pymodem_amd.packet_meta import PacketTable
+    dt = packet_dtype()
+    raw = np.zeros(10 * dt.itemsize + 64, dtype=np.uint8)
+    block = raw[64:].view(dt)
+    block["streamaddress"] = np.arange(10)
+    parts = [block[0:3], block[3:7], block[7:10]]
+    whole = PacketTable._stack(parts)
+    assert np.shares_memory(whole, raw) and whole["streamaddress"].tolist() == list(range(10))
+    whole["len"][4] = 77
+    assert block["len"][4] == 77
+    gap = PacketTable._stack([block[0:3], block[4:7]])              # not consecutive: a copy
+    assert not np.shares_memory(gap, raw) and gap["streamaddress"].tolist() == [0, 1, 2, 4, 5, 6]
