@@ -227,7 +227,7 @@ int pm_agc_apply(pm_ctx *ctx, double *d_buf, int64_t n, const pm_agc_params *h_p
  * {envelope, sustain_count} over n more samples, out of place (y may be x): what a recording processed in time chunks needs, where
  * `normal` = max(buffer) over the WHOLE buffer (agc.py:67) is known before the first chunk (h_normal[r]; pm_rows_max_f64 gives the
  * maxima of the rows of a chunk).  Pieces of a buffer run through this one after the other give the bits of pm_agc_apply on the
- * whole.  One wave per row steps the recurrence; the division is done by all lanes. */
+ * whole.  One lane per row (64 rows per wave) steps the recurrence and divides. */
 int pm_agc_rows_apply(pm_ctx *ctx, const double *d_x, int64_t x_stride, double *d_y, int64_t y_stride, int rows, int64_t n,
                       const pm_agc_params *h_params, const double *h_normal, double *h_state);
 int pm_rows_max_f64(pm_ctx *ctx, const double *d_x, int64_t x_stride, int rows, int64_t n, double *h_max);

@@ -600,67 +600,50 @@ __global__ void agc_rows_prepare_kernel(const double *__restrict__ running, int 
     consts[4 * r + 3] = 0.0;
 }
 
-// One wave steps kAgcRows rows: lane l < rows carries row l's envelope recurrence through the tile (the step is branch-free, so the
-// lanes do not diverge), then all 64 lanes divide.  With one row per wave (the first version) the recurrence's ten f64 instructions per
-// sample were issued for ONE useful lane: for thousands of rows that was as much vector issue as the matched filters of the whole
-// chain (qpsk_2400 / bpsk_300 engine runs: AGC rows 15 % / 29 % of the GPU time, profiles/r03_*_kernel_stats.csv), taken from the
-// FIR kernels running beside it.  Eight tile values are read ahead of the steps that use them: the chain is the recurrence, not LDS.
-constexpr int kAgcRows = 16;
+// One LANE per row, 64 rows per wave, nothing through LDS: lane l loads eight samples of its row (the next eight already in flight),
+// steps the envelope recurrence through them (branch-free, so the lanes do not diverge), divides, stores.  History of this kernel:
+// one row per wave with lane 0 stepping and all lanes dividing issued the recurrence's instructions for ONE useful lane -- for
+// thousands of rows as much vector issue as the chain's matched filters (15 % / 29 % of the GPU time of a qpsk / bpsk engine run);
+// sixteen rows per wave with the tiles in LDS fixed that (bpsk_300 +27 %) but ran five times slower beside the engine's FIR
+// kernels than alone (61 against 12.7 ms per 131 072-sample chunk of 8192 rows, tools/agc_rows_probe.py): its LDS traffic queued
+// behind theirs.  The rows of a wave are a pitch apart, so a load or store touches 64 cache lines -- at eight bytes per 100 ns and
+// lane that is nothing.
 __global__ __launch_bounds__(64) void agc_rows_kernel(const double *x, int64_t x_stride, double *y, int64_t y_stride, int rows,
                                                       int64_t n, const double *__restrict__ consts, AgcDev P, double2 *__restrict__ state)
 {
-    extern __shared__ double agc_lds[];
-    constexpr int kP = kTile + 1;
-    double *tile = agc_lds, *envs = agc_lds + kAgcRows * kP;
-    const int lane = threadIdx.x;
-    const int64_t r0 = (int64_t)blockIdx.x * kAgcRows;
-    const int nr = (int)min((int64_t)kAgcRows, rows - r0);
-    const bool stepping = lane < nr;
-    const int64_t r = r0 + (stepping ? lane : 0);
+    const int64_t r = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (r >= rows) return;
+    const double *xr = x + r * x_stride;
+    double *yr = y + r * y_stride;
     P.att = consts[4 * r + 1];
     P.dec = consts[4 * r + 2];
     double env = state[r].x, sustain = state[r].y;
-    const double *tl = tile + lane * kP;
-    double *el = envs + lane * kP;
-    for (int64_t tile0 = 0; tile0 < n; tile0 += kTile) {
-        const int len = (int)min((int64_t)kTile, n - tile0);
-        for (int rr = 0; rr < nr; ++rr) {
-            const double *xr = x + (r0 + rr) * x_stride + tile0;
+    __builtin_amdgcn_s_setprio(3);             // one dependent chain per lane: issue slots lost to the FIR waves of the other streams are time
+    constexpr int B = 8;
+    double cur[B], nxt[B];
+    const int64_t full = n / B * B;
 #pragma unroll
-            for (int j = 0; j < kTile / 64; ++j) {
-                const int k = lane + 64 * j;
-                tile[rr * kP + k] = xr[min(k, len - 1)];
-            }
-        }
-        __syncthreads();
-        if (stepping) {
-            int k = 0;
-            for (; k + 8 <= len; k += 8) {
-                double v[8];
+    for (int j = 0; j < B; ++j) cur[j] = xr[min((int64_t)j, n - 1)];
+    for (int64_t k0 = 0; k0 < full; k0 += B) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = tl[k + j];
+        for (int j = 0; j < B; ++j) nxt[j] = xr[min(k0 + B + j, n - 1)];
+        double out[B];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    agc_step(v[j], env, sustain, P);
-                    el[k + j] = env;
-                }
-            }
-            for (; k < len; ++k) {
-                agc_step(tl[k], env, sustain, P);
-                el[k] = env;
-            }
+        for (int j = 0; j < B; ++j) {
+            agc_step(cur[j], env, sustain, P);
+            out[j] = env != 0 ? P.target * cur[j] / env : cur[j];          // agc.py:75-76
         }
-        __syncthreads();
-        for (int rr = 0; rr < nr; ++rr) {
-            double *yr = y + (r0 + rr) * y_stride + tile0;
-            for (int k = lane; k < len; k += 64) {
-                const double e = envs[rr * kP + k], sv = tile[rr * kP + k];
-                yr[k] = e != 0 ? P.target * sv / e : sv;          // agc.py:75-76
-            }
-        }
-        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < B; ++j) yr[k0 + j] = out[j];
+#pragma unroll
+        for (int j = 0; j < B; ++j) cur[j] = nxt[j];
     }
-    if (stepping) state[r] = make_double2(env, sustain);
+    for (int64_t k = full; k < n; ++k) {
+        const double sv = xr[k];
+        agc_step(sv, env, sustain, P);
+        yr[k] = env != 0 ? P.target * sv / env : sv;
+    }
+    state[r] = make_double2(env, sustain);
 }
 
 }  // namespace
@@ -721,14 +704,8 @@ int pm_agc_rows(pm_ctx *ctx, const double *d_x, int64_t x_stride, double *d_y, i
     P.target = hp->target_amplitude;
     P.att = P.dec = 0;
     PmProf prof(ctx, PM_K_AGC);
-    const size_t lds = (size_t)2 * kAgcRows * (kTile + 1) * sizeof(double);
-    static bool allowed = false;
-    if (!allowed) {
-        PM_HIP(hipFuncSetAttribute((const void *)agc_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        allowed = true;
-    }
-    hipLaunchKernelGGL(agc_rows_kernel, dim3((unsigned)pm_cdiv(rows, kAgcRows)), dim3(64), lds, ctx->stream, d_x, x_stride, d_y, y_stride, rows, n,
-                       d_consts, P, (double2 *)d_state);
+    hipLaunchKernelGGL(agc_rows_kernel, dim3((unsigned)pm_cdiv(rows, 64)), dim3(64), 0, ctx->stream, d_x, x_stride, d_y, y_stride, rows, n, d_consts, P,
+                       (double2 *)d_state);
     PM_HIP(hipGetLastError());
     return PM_OK;
 }
