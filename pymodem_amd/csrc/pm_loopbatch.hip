@@ -219,12 +219,11 @@ int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings,
 {
     PM_ARG(b != nullptr && h_d_audio != nullptr && d_bits_i != nullptr && h_nout != nullptr);
     static const int tail_mode = getenv("PM_LBATCH_TAIL") ? atoi(getenv("PM_LBATCH_TAIL")) : -1;
-    // The matched filters of chunk t beside the loops of chunk t + 1 (third stream), or behind them on the caller's stream.  Beside
-    // them the loops run 1.8-2.8x slower (their table look-ups queue behind the filters' LDS traffic; wave priority changes nothing), so
-    // it pays only where the filters are the longer half and the front end is light: measured on one box, same minute -- bpsk_300
-    // (8192 x 1) 11 255 against 10 169 Msamples/s, qpsk_2400 256 x 64 chains 21 783 against 19 446, but 2048 x 8 chains 16 354 against
-    // 17 687 (AGC, Hilbert pair and band-pass of 2048 recordings run beside them as well).  PM_LBATCH_TAIL=0 / 1 forces it.
-    const bool use_tail = tail_mode >= 0 ? tail_mode != 0 : (!b->two_out || b->C >= 16);
+    // The matched filters of chunk t beside the loops of chunk t + 1 (third stream; PM_LBATCH_TAIL=0: behind them on the caller's stream).
+    // With the tiled loop shapes this paid only sometimes -- beside a filter those loops ran 1.8-2.8x slower, their LDS traffic queuing
+    // behind the filter's -- with the direct shape (no tiles in LDS) it pays everywhere: same box, same minute, third stream on / off:
+    // bpsk_300 (8192 x 1) 14 744 / 12 035 Msamples/s, qpsk_2400 2048 x 8 chains 18 616 / 17 438, 256 x 64 chains 22 062 / 18 865.
+    const bool use_tail = tail_mode != 0;
     pm_ctx *B = b->back, *F = b->front, *Tl = use_tail ? b->tail : b->back;
     PM_CTX(B);
     PM_ARG(recordings >= 1 && recordings <= b->R);

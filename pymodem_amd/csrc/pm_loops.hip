@@ -119,6 +119,50 @@ __device__ __forceinline__ int pd_lookup(const int32_t *tbl, double re, double i
 
 enum { kCostas = 0, kPll = 1, kMpsk = 2, kQpsk = 3 };
 
+// One sample of one loop: the reference's statements in the reference's order (psk.py:173-189 Costas, afsk_pll.py:153-165 PLL,
+// psk.py:434-467 QPSK Costas, psk.py:734-747 MPSK).  s0 (and s1: the Hilbert arm, MPSK) in; o0 (and o1 for the two-output loops) out.
+template <int MODE>
+__device__ __forceinline__ void loop_step(LoopRegs &L, const double2v *tab2, const int32_t *pdt, double s0, double s1, double &o0, double &o1)
+{
+    if (MODE == kCostas) {
+        const double sm = s0;
+        nco_update(L, tab2);
+        const double i_mixer = sm * L.cosine;             // psk.py:177
+        const double q_mixer = sm * (-L.sine);            // psk.py:182
+        const double lp = iir_update(L, i_mixer * q_mixer);
+        L.control = pi_update(L, lp);                     // psk.py:187
+        o0 = i_mixer;
+    } else if (MODE == kPll) {
+        nco_update(L, tab2);
+        const double mixer = s0 * L.sine;                 // afsk_pll.py:156
+        const double lp = iir_update(L, mixer);
+        L.control = pi_update(L, lp);                     // afsk_pll.py:160
+        o0 = L.proportional;                              // afsk_pll.py:163
+    } else if (MODE == kQpsk) {
+        const double sm = s0;
+        nco_update(L, tab2);
+        const double cl = iir1(L.bb0, L.bb1, L.ba1, L.cx0, L.cx1, L.cy0, sm * L.cosine);   // psk.py:438-440
+        const double sl = iir1(L.bb0, L.bb1, L.ba1, L.sx0, L.sx1, L.sy0, sm * L.sine);     // psk.py:449-451
+        const double a = sl >= 0 ? cl : -cl;              // cos_lp * sgn(sin_lp)            psk.py:455-459
+        const double b = cl >= 0 ? sl : -sl;              // sin_lp * sgn(cos_lp)            psk.py:444-447
+        const double lp = iir_update(L, a - b);           // psk.py:459-461
+        L.control = pi_update(L, lp);                     // psk.py:463
+        o0 = sl;                                          // i_data <- Sine_LPF              psk.py:452
+        o1 = cl;                                          // q_data <- Cosine_LPF            psk.py:453
+    } else {
+        const double sr = s0, si = s1;
+        nco_update(L, tab2);
+        const double ar = L.cosine, ai = -L.sine;         // nco.py:52-53
+        const double re = (sr * ar) - (si * ai);          // complexmath.py:16
+        const double im = (ar * si) + (sr * ai);          // complexmath.py:17
+        const int e = pd_lookup(pdt, re, im);             // psk.py:739
+        const double lp = iir_update(L, (double)e);
+        L.control = rint(pi_update(L, lp));               // psk.py:740, round() is half-to-even
+        o0 = re;
+        o1 = im;
+    }
+}
+
 // A workgroup is TWO waves.  Wave 0 owns the loops (lane l < ng steps loop g0 + l through one tile of kTile samples, reading and
 // writing LDS only); wave 1 moves the tiles: while wave 0 steps tile s - 1 it loads tile s from memory into the other input buffer
 // and stores tile s - 2 from the other output buffer.  One barrier per tile.  The loop-owning wave therefore never waits for
@@ -285,45 +329,7 @@ __global__ __launch_bounds__(128) void loop_kernel(pm_loop *__restrict__ loops, 
             const double *p0 = in_base + ((s - 1) & 1) * in_buf + (my_row * NIN) * kPad;
             const double *p1 = p0 + kPad;
             double *q0 = out_base + ((s - 1) & 1) * out_buf + lane * kPad, *q1 = q0 + kG * kPad;
-            for (int k = 0; k < len; ++k) {
-                if (MODE == kCostas) {
-                    const double sm = p0[k];
-                    nco_update(L, tab2);
-                    const double i_mixer = sm * L.cosine;             // psk.py:177
-                    const double q_mixer = sm * (-L.sine);            // psk.py:182
-                    const double lp = iir_update(L, i_mixer * q_mixer);
-                    L.control = pi_update(L, lp);                     // psk.py:187
-                    q0[k] = i_mixer;
-                } else if (MODE == kPll) {
-                    nco_update(L, tab2);
-                    const double mixer = p0[k] * L.sine;              // afsk_pll.py:156
-                    const double lp = iir_update(L, mixer);
-                    L.control = pi_update(L, lp);                     // afsk_pll.py:160
-                    q0[k] = L.proportional;                           // afsk_pll.py:163
-                } else if (MODE == kQpsk) {
-                    const double sm = p0[k];
-                    nco_update(L, tab2);
-                    const double cl = iir1(L.bb0, L.bb1, L.ba1, L.cx0, L.cx1, L.cy0, sm * L.cosine);   // psk.py:438-440
-                    const double sl = iir1(L.bb0, L.bb1, L.ba1, L.sx0, L.sx1, L.sy0, sm * L.sine);     // psk.py:449-451
-                    const double a = sl >= 0 ? cl : -cl;              // cos_lp * sgn(sin_lp)            psk.py:455-459
-                    const double b = cl >= 0 ? sl : -sl;              // sin_lp * sgn(cos_lp)            psk.py:444-447
-                    const double lp = iir_update(L, a - b);           // psk.py:459-461
-                    L.control = pi_update(L, lp);                     // psk.py:463
-                    q0[k] = sl;                                       // i_data <- Sine_LPF              psk.py:452
-                    q1[k] = cl;                                       // q_data <- Cosine_LPF            psk.py:453
-                } else {
-                    const double sr = p0[k], si = p1[k];
-                    nco_update(L, tab2);
-                    const double ar = L.cosine, ai = -L.sine;         // nco.py:52-53
-                    const double re = (sr * ar) - (si * ai);          // complexmath.py:16
-                    const double im = (ar * si) + (sr * ai);          // complexmath.py:17
-                    const int e = pd_lookup(pdt, re, im);             // psk.py:739
-                    const double lp = iir_update(L, (double)e);
-                    L.control = rint(pi_update(L, lp));               // psk.py:740, round() is half-to-even
-                    q0[k] = re;
-                    q1[k] = im;
-                }
-            }
+            for (int k = 0; k < len; ++k) loop_step<MODE>(L, tab2, pdt, p0[k], MODE == kMpsk ? p1[k] : 0.0, q0[k], q1[k]);
         }
         __syncthreads();
     }
@@ -333,6 +339,89 @@ __global__ __launch_bounds__(128) void loop_kernel(pm_loop *__restrict__ loops, 
         s.x0 = L.x0; s.x1 = L.x1; s.y0 = L.y0; s.integral = L.integral; s.proportional = L.proportional;
         if (MODE == kQpsk) { s.cx0 = L.cx0; s.cx1 = L.cx1; s.cy0 = L.cy0; s.sx0 = L.sx0; s.sx1 = L.sx1; s.sy0 = L.sy0; }
     }
+}
+
+// The third shape: one wave per workgroup, a loop on every lane, NOTHING but the tables in LDS.  A lane loads eight samples of its input
+// row (the next eight already in flight), steps them, stores its eight outputs: no tiles, no second wave, no barrier after the tables.
+// Why: beside the engine's FIR kernels the tiled shapes run 1.8-2.8x slower than alone -- their LDS traffic (tile reads and writes of
+// the stepping wave, the I/O wave's copies) queues behind the filters' -- as the LDS form of the AGC rows kernel did (five times).
+// What stays in LDS is what the recurrence looks up by a computed index: the NCO pair table and the phase-detector table.
+template <int MODE>
+__global__ __launch_bounds__(64) void loop_direct_kernel(pm_loop *__restrict__ loops, int nloops, int per_row, const double *__restrict__ table,
+                                                         const int32_t *__restrict__ pd, const double *__restrict__ x0,
+                                                         const double *__restrict__ x1, int64_t x_stride, int64_t n, double *__restrict__ o0,
+                                                         double *__restrict__ o1, int64_t out_stride)
+{
+    extern __shared__ double lds[];
+    constexpr bool kTwoOut = MODE == kMpsk || MODE == kQpsk;
+    double2v *tab2 = reinterpret_cast<double2v *>(lds);
+    int32_t *pdt = (int32_t *)(lds + 516);
+    for (int i = threadIdx.x; i < 257; i += 64) tab2[i] = double2v{table[i & 255], table[(i + 64) & 255]};
+    if (MODE == kMpsk)
+        for (int i = threadIdx.x; i < 4096; i += 64) pdt[i] = pd[i];
+    __syncthreads();
+    const int l = blockIdx.x * 64 + threadIdx.x;
+    if (l >= nloops) return;
+    LoopRegs L;
+    {
+        const pm_loop &s = loops[l];
+        L.phase_scaling = s.phase_scaling; L.index_scaling = s.index_scaling; L.set_frequency = s.set_frequency;
+        L.b0 = s.b0; L.b1 = s.b1; L.a1 = s.a1;
+        L.p_rate = s.p_rate; L.i_rate = s.i_rate; L.i_limit = s.i_limit; L.gain = s.gain;
+        L.phase = s.phase; L.control = s.control; L.sine = s.sine; L.cosine = s.cosine;
+        L.x0 = s.x0; L.x1 = s.x1; L.y0 = s.y0; L.integral = s.integral; L.proportional = s.proportional;
+        if (MODE == kQpsk) {
+            L.bb0 = s.bb0; L.bb1 = s.bb1; L.ba1 = s.ba1;
+            L.cx0 = s.cx0; L.cx1 = s.cx1; L.cy0 = s.cy0; L.sx0 = s.sx0; L.sx1 = s.sx1; L.sy0 = s.sy0;
+        }
+    }
+    const int64_t row = l / per_row;
+    const double *p0 = x0 + row * x_stride, *p1 = MODE == kMpsk ? x1 + row * x_stride : nullptr;
+    double *q0 = o0 + (int64_t)l * out_stride, *q1 = kTwoOut ? o1 + (int64_t)l * out_stride : nullptr;
+    __builtin_amdgcn_s_setprio(3);
+    constexpr int B = 8;
+    double c0[B], c1[B], n0[B], n1[B];
+    const int64_t full = n / B * B;
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+        const int64_t k = min((int64_t)j, n - 1);
+        c0[j] = p0[k];
+        c1[j] = MODE == kMpsk ? p1[k] : 0.0;
+    }
+    for (int64_t k0 = 0; k0 < full; k0 += B) {
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            const int64_t k = min(k0 + B + j, n - 1);
+            n0[j] = p0[k];
+            n1[j] = MODE == kMpsk ? p1[k] : 0.0;
+        }
+        double r0[B], r1[B];
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            r1[j] = 0.0;
+            loop_step<MODE>(L, tab2, pdt, c0[j], c1[j], r0[j], r1[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            q0[k0 + j] = r0[j];
+            if (kTwoOut) q1[k0 + j] = r1[j];
+        }
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            c0[j] = n0[j];
+            c1[j] = n1[j];
+        }
+    }
+    for (int64_t k = full; k < n; ++k) {
+        double a = 0.0, b = 0.0;
+        loop_step<MODE>(L, tab2, pdt, p0[k], MODE == kMpsk ? p1[k] : 0.0, a, b);
+        q0[k] = a;
+        if (kTwoOut) q1[k] = b;
+    }
+    pm_loop &s = loops[l];
+    s.phase = L.phase; s.control = L.control; s.sine = L.sine; s.cosine = L.cosine;
+    s.x0 = L.x0; s.x1 = L.x1; s.y0 = L.y0; s.integral = L.integral; s.proportional = L.proportional;
+    if (MODE == kQpsk) { s.cx0 = L.cx0; s.cx1 = L.cx1; s.cy0 = L.cy0; s.sx0 = L.sx0; s.sx1 = L.sx1; s.sy0 = L.sy0; }
 }
 
 // the most distinct input rows the g consecutive loops of one workgroup can touch
@@ -356,9 +445,19 @@ template <int MODE>
 int loop_enqueue(pm_ctx *ctx, pm_loop *d_loops, int nloops, int per_row, const double *d_table, const int32_t *d_pd,
                  const double *d_x0, const double *d_x1, int64_t x_stride, int64_t n, double *d_o0, double *d_o1, int64_t out_stride)
 {
-    // every lane a loop once eight-lane waves would outnumber the CUs (PM_LOOP_WIDE=0 / 1 forces the shape: tests, measurements)
-    bool wide = nloops > 8 * 256;
-    if (const char *e = getenv("PM_LOOP_WIDE")) wide = atoi(e) != 0;
+    // every lane a loop once eight-lane waves would outnumber the CUs (PM_LOOP_WIDE=0 / 1 / 2 forces the shape: tests, measurements;
+    // 1 = the tiled 64-loop shape, 2 = the direct one)
+    int shape = nloops > 8 * 256 ? 2 : 0;
+    if (const char *e = getenv("PM_LOOP_WIDE")) shape = atoi(e);
+    if (shape == 2) {
+        const size_t lds2 = 516 * 8 + (MODE == kMpsk ? 4096 * 4 : 0);
+        PmProf prof(ctx, PM_K_LOOP);
+        hipLaunchKernelGGL((loop_direct_kernel<MODE>), dim3((unsigned)pm_cdiv(nloops, 64)), dim3(64), lds2, ctx->stream, d_loops, nloops, per_row, d_table,
+                           d_pd, d_x0, d_x1, x_stride, n, d_o0, d_o1, out_stride);
+        PM_HIP(hipGetLastError());
+        return PM_OK;
+    }
+    const bool wide = shape == 1;
     const int g = wide ? 64 : 8, tile = wide ? 32 : 256;
     const int rows_lds = loop_rows_lds(per_row, nloops, g);
     size_t lds = loop_lds_bytes(MODE, rows_lds, g, tile);

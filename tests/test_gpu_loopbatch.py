@@ -156,7 +156,7 @@ def group_modems(cfg, rate, carriers=None, take=None):
     ("qpsk_600.json", 44100, [1500.0], 0),
     ("afsk_300_pll.json", 8000, None, 2048),
 ])
-@pytest.mark.parametrize("wide", [0, 1])
+@pytest.mark.parametrize("wide", [0, 1, 2])
 def test_engine_bitmaps_equal_demod_signs(cfg, rate, carriers, chunk, wide, monkeypatch):
     """Every (recording, chain) bitmap of a run equals modem.demod_signs() on that recording: different audio per recording, chunk
     lengths from one FIR tile up, chains per recording that do and do not divide the loops of a wave.  wide: the engine's loop
@@ -228,7 +228,7 @@ def test_loop_kernel_shapes_agree(monkeypatch):
     }
     for name, call in calls.items():
         got = {}
-        for wide in (0, 1):
+        for wide in (0, 1, 2):
             monkeypatch.setenv("PM_LOOP_WIDE", str(wide))
             check(lib().pm_memset(ctx.handle, o1.ptr, 0, n * nl * 8))
             check(lib().pm_memset(ctx.handle, o2.ptr, 0, n * nl * 8))
@@ -236,6 +236,7 @@ def test_loop_kernel_shapes_agree(monkeypatch):
             call(lp)
             got[wide] = (o1.download(), o2.download(), bytes(lp))
         assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1]), name
+        assert np.array_equal(got[0][0], got[2][0]) and np.array_equal(got[0][1], got[2][1]) and got[0][2] == got[2][2], (name, "direct")
         assert got[0][2] == got[1][2], name
         assert np.any(got[0][0] != 0), name
 
