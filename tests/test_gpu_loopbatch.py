@@ -190,7 +190,8 @@ def test_engine_bitmaps_equal_demod_signs(cfg, rate, carriers, chunk, wide, monk
         eng.close()
 
 
-def test_loop_kernel_shapes_agree(monkeypatch):
+@pytest.mark.parametrize("n", [5, 5003])
+def test_loop_kernel_shapes_agree(monkeypatch, n):
     """150 loops in one launch (three workgroups of the 64-loop shape, the last one part full), a length that is no multiple of either
     tile: outputs and end states of the four loop kernels bit for bit the same in both shapes, own input rows and one shared row."""
     import ctypes
@@ -199,7 +200,7 @@ def test_loop_kernel_shapes_agree(monkeypatch):
     from pymodem_amd import taps as T
     from pymodem_amd._native import Loop, check, lib
     ctx = pymodem_amd.Context.default()
-    n, nl = 5003, 150
+    nl = 150
     tab = ctx.upload(np.array([math.sin(i * 2.0 * math.pi / 256) for i in range(256)]))
     pd = ctx.upload(np.ascontiguousarray(T.qpsk_error_table().reshape(-1), dtype=np.int32))
     b0, b1, a1 = T.one_pole_lowpass(48000.0, 250.0, 1.0)
