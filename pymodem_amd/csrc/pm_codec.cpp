@@ -879,7 +879,21 @@ int pm_lfsr_unscramble(const uint8_t *h_in, int64_t n, uint64_t poly, int invert
     int taps[64], ntaps = 0;
     for (uint64_t p = poly; p; p &= p - 1) taps[ntaps++] = __builtin_ctzll(p);
     uint64_t prev = 0, cur = load(0);
-    for (int64_t w = 0; w < nwords; ++w) {
+    int64_t w0 = 0;
+    if (poly == 1 && n >= 16) {
+        // the identity polynomial (configs/fsk_9600.json: "poly": "0x1", with and without inversion): out = in past the first word, which
+        // alone sees the incoming register -- a byte loop the compiler vectorises instead of a word at a time through the tap loop
+        uint64_t r = reg0, rev = 0;
+        for (int i = 0; i < 64; ++i, r >>= 1) rev = (rev << 1) | (r & 1);
+        uint64_t o = cur ^ rev;
+        if (invert) o = ~o;
+        const uint64_t be = __builtin_bswap64(o);
+        memcpy(h_out, &be, 8);
+        const uint8_t flip = invert ? 0xFF : 0x00;
+        for (int64_t i = 8; i < n; ++i) h_out[i] = h_in[i] ^ flip;
+        w0 = nwords;
+    }
+    for (int64_t w = w0; w < nwords; ++w) {
         uint64_t o = 0;
         for (int q = 0; q < ntaps; ++q) {
             const int j = taps[q];
