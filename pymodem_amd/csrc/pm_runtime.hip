@@ -1,5 +1,6 @@
 // Context, memory, error and timer entry points of the C ABI (include/pymodem_amd.h).
 #include "pm_common.h"
+#include <algorithm>
 #include <cstring>
 #include <unistd.h>
 #include <mutex>

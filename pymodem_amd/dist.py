@@ -123,7 +123,7 @@ def exchange_rows(rows_by_chain, nchains, device=None):
     if dev.type == "cuda":                                   # copies and the collective on a high-priority stream of their own
         side = _SIDE_STREAM.get(dev)
         if side is None:
-            side = _SIDE_STREAM[dev] = torch.cuda.Stream(device=dev, priority=-1)
+            side = _SIDE_STREAM[dev] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("PYMODEM_AMD_EXCHANGE_PRIO", "0")))
     ctxmgr = torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
     with ctxmgr:
         while True:
@@ -161,7 +161,7 @@ def exchange_rows(rows_by_chain, nchains, device=None):
 
 class Exchanger:
     """exchange_rows for a stream of recordings, behind: `step(rows)` first collects the gathered blocks of the exchange enqueued
-    before -- a step or more ago, so the copy back does not wait for the collective to find room on a busy GPU -- then, once
+    `depth` (2) collectives before -- steps ago, so the copy back does not wait for the collective to find room on a busy GPU -- then, once
     `batch` recordings have come in, enqueues ONE all_gather for them, and returns a Future of what exchange_rows would have
     returned.  `flush()` resolves what is left.  Call both from ONE thread, in the same order on every rank: every collective,
     including the repeat after a capacity miss (decided from headers all ranks see), is issued there.  `batch` (default 1,
@@ -174,7 +174,11 @@ class Exchanger:
         import os
         self.nchains, self.device = nchains, device
         self.batch = max(1, int(batch or os.environ.get("PYMODEM_AMD_EXCHANGE_BATCH", 1)))
-        self._pending = None                   # (futures, state of the enqueued collective)
+        # how many enqueued collectives may be outstanding before the oldest is collected: with one, step() k waited for the
+        # collective of step k - 1 -- a tiny kernel that has to find room on a GPU kept full by 14 000-workgroup FIR launches -- for
+        # 2 ms per call (Event.synchronize in an all-thread profile); with two it has had a whole further step to finish
+        self.depth = max(1, int(os.environ.get("PYMODEM_AMD_EXCHANGE_DEPTH", 2)))
+        self._pending = []                     # [(futures, state of an enqueued collective)], oldest first
         self._waiting = []                     # (future, rows) not yet enqueued
 
     def prepare(self, rows_by_chain):
@@ -202,8 +206,9 @@ class Exchanger:
     def _issue(self):
         waiting, self._waiting = self._waiting, []
         try:
-            self._collect()
-            self._pending = ([f for f, _ in waiting], _exchange_issue([r for _, r in waiting], self.nchains, self.device))
+            while len(self._pending) >= self.depth:
+                self._collect()
+            self._pending.append(([f for f, _ in waiting], _exchange_issue([r for _, r in waiting], self.nchains, self.device)))
         except BaseException as e:
             for f, _ in waiting:
                 if not f.done():
@@ -212,13 +217,15 @@ class Exchanger:
     def flush(self):
         if self._waiting:
             self._issue()
-        self._collect()
+        while self._pending:
+            self._collect()
 
     def _collect(self):
-        if self._pending is None:
+        """The oldest outstanding collective's results to their futures (every rank collects in the same order: a repeat after a
+        capacity miss, decided from headers all ranks see, is a collective of its own)."""
+        if not self._pending:
             return
-        futs, state = self._pending
-        self._pending = None
+        futs, state = self._pending.pop(0)
         try:
             for f, res in zip(futs, _exchange_collect(state)):
                 f.set_result(res)
@@ -286,6 +293,7 @@ def _wire_cap(nchains):
 def _exchange_issue(packed_list, nchains, device, cap=None):
     """Enqueue ONE all_gather carrying this rank's fixed-capacity blocks (header + packed rows) of len(packed_list) recordings;
     nothing waits for the GPU."""
+    import os
     import torch
     import torch.distributed as dist
     if not isinstance(packed_list, (list, tuple)):
@@ -300,9 +308,14 @@ def _exchange_issue(packed_list, nchains, device, cap=None):
         cap = max(_GATHER_CAP.get(key, 1 << 16), 1 << 12)
     side = None
     if dev.type == "cuda":
+        # A stream of the exchange's own, at NORMAL priority (PYMODEM_AMD_EXCHANGE_PRIO=-1: highest).  Round 2 ran it at the highest so
+        # that the tiny collective got onto a full GPU sooner; with the executor's slicer streams at that priority too the exchange's
+        # first call of every step -- whatever it was: torch's copy_, a stream query, a plain kernel launch -- blocked the ordered thread
+        # for 1.7-1.9 ms (tools/exchange_probe.py: 1.69 ms against 0.02 at normal priority; the interpreter lock was not it: giving it
+        # away and taking it back took 5 us there): high-priority streams share a hardware queue.
         side = _SIDE_STREAM.get(dev)
         if side is None:
-            side = _SIDE_STREAM[dev] = torch.cuda.Stream(device=dev, priority=-1)
+            side = _SIDE_STREAM[dev] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("PYMODEM_AMD_EXCHANGE_PRIO", "0")))
     from .device import _host_block
     one = head + cap
     # Page-locked blocks and device buffers belong to THIS exchange until _exchange_collect has seen its headers (round 2 handed them
@@ -340,15 +353,20 @@ def _exchange_issue(packed_list, nchains, device, cap=None):
             # pipeline the hipMalloc behind it waits for the device.  Sixteen = the executor's depth: a slot comes round again
             # only after its recording has long left the post stage (which reads the payloads out of `out` on rank 0).
             rk = (dev, world, k_rec, one)
+            _tt = _trace_t()
             pair = _dev_get(rk)
             t, out = pair.t, pair.out
+            _tt("dev_get")
             t.copy_(torch.from_numpy(block), non_blocking=True)
+            _tt("copy_up")
         else:
+            _tt = _trace_t()
             t = torch.from_numpy(block)
             out = None
             pair = None
         if hasattr(dist, "all_gather_into_tensor") and dev.type == "cuda":
             dist.all_gather_into_tensor(out.view(-1), t)
+            _tt("all_gather")
         else:
             parts = [torch.empty_like(t) for _ in range(world)]
             dist.all_gather(parts, t)
@@ -362,9 +380,31 @@ def _exchange_issue(packed_list, nchains, device, cap=None):
                 heads_host, done = ring[_HEADS_SEQ[0] % 4]
             _HEADS_SEQ[0] += 1
             heads_host.copy_(out.view(world, k_rec, one)[:, :, :head], non_blocking=True)
+            _tt("heads_down")
             done.record(side)
+            _tt("event")
     return {"rows": packed_list, "nchains": nchains, "device": device, "cap": cap, "head": head, "out": out, "side": side, "key": key,
             "keep": block, "heads_host": heads_host, "done": done, "release": release, "pair": pair}
+
+
+_ISSUE_TRACE = {}
+
+
+def _trace_t():
+    """PYMODEM_AMD_GATHER_TRACE=2: wall time of each call inside _exchange_issue, summed per name (printed by whoever asks)."""
+    import os
+    import time
+    if os.environ.get("PYMODEM_AMD_GATHER_TRACE") != "2":
+        return lambda name: None
+    last = [time.perf_counter()]
+
+    def mark(name):
+        now = time.perf_counter()
+        e = _ISSUE_TRACE.setdefault(name, [0, 0.0])
+        e[0] += 1
+        e[1] += now - last[0]
+        last[0] = now
+    return mark
 
 
 _FORCE_PINNED_POOL = False          # tests: use the page-locked pool's bookkeeping without a GPU (plain memory)

@@ -75,12 +75,15 @@ else:
     assert table is None
 # the deferred form: three recordings through an Exchanger, the first against a capacity that is too small; every future must give
 # what the synchronous exchange gave
-for batch in (1, 2):
+for batch, depth in ((1, 1), (2, 1), (1, 2), (2, 2)):
     pdist._GATHER_CAP[(world, len(names))] = 4096
     ex = pdist.Exchanger(len(names), device, batch=batch)
+    ex.depth = depth                                                           # collectives outstanding before the oldest is collected
     futs = [ex.step({c: r.copy() for c, r in rows.items()}) for _ in range(3)]
-    if batch == 1:
+    if batch == 1 and depth == 1:
         assert futs[0].done() and futs[1].done() and not futs[2].done()        # each step resolves the one before it
+    elif batch == 1:
+        assert futs[0].done() and not futs[1].done() and not futs[2].done()    # ... the one two before it
     else:
         assert not any(f.done() for f in futs)                                 # two recordings per collective: enqueued at the second step
     ex.flush()
