@@ -505,20 +505,19 @@ __host__ __device__ __forceinline__ int slide_slot(int p) { return p + p / L; }
 template <int L>
 size_t slide_lds_bytes(int m) { return (size_t)(slide_slot<L>(kSlideThreads * L + m - 1) + 2 + 4 * m) * sizeof(double); }
 
-// sqrt for the sliding sums: reciprocal-square-root seed and two coupled Newton steps, within 2 units in the last place of the
-// root for every v that is not so small that v itself underflows in the seed's square (those come out as 0: an absolute error
-// below 1e-150, nothing against the bound of the certified decision).  The IEEE sqrt costs twice the instructions (scaling of
-// subnormal and huge arguments, class checks), which matters here: two roots are half of a sliding step.
+// sqrt for the sliding sums: reciprocal-square-root seed and ONE coupled Newton step.  With the seed y = (1 + d) / sqrt(v), g = v y and
+// h = y / 2 give r = 1/2 - h g = -d - d^2/2 and g (1 + r) = sqrt(v) (1 - 3/2 d^2 + O(d^3)): a seed good to 2^-20 (the ISA manuals give
+// V_RSQ_F64 2^29 units in the last place, 2^-23) leaves a relative error below 1.5e-12, which slide_bound() adds to the bound of the
+// certified decision (0.1 % of its thousandfold slack) -- the decision needs a value and a bound, not the last bit.  Round 2 took a
+// second step (2 units in the last place): three more dependent fma per root, two roots per output, 2 % of the fused kernel.  A v so
+// small that v itself underflows in the seed's square comes out as 0: an absolute error below 1e-150.  The IEEE sqrt costs twice the
+// instructions again (scaling of subnormal and huge arguments, class checks).
 __device__ __forceinline__ double slide_sqrt(double v)
 {
     const double y = __builtin_amdgcn_rsq(v);
-    double g = v * y, h = 0.5 * y;
+    const double g = v * y, h = 0.5 * y;
     const double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    const double e = __builtin_fma(-g, g, v);
-    g = __builtin_fma(e, h, g);
-    return v > 1e-300 ? g : 0.0;
+    return v > 1e-300 ? __builtin_fma(g, r, g) : 0.0;
 }
 
 // One run: the direct sums of output k0 of the staged tile with the real taps, ascending input index (afsk.py:153-160; every lane
@@ -1269,7 +1268,8 @@ static int afsk_group_dispatch(pm_ctx *ctx, int groups, const double *d_x, int64
 static double slide_bound(const pm_afsk_tones *tones, int m, double x_bound, int steps = 16)
 {
     const double u = 1.1102230246251565e-16;
-    return (16.0 * steps * u * (m + 1) + 3.0 * m * tones->tap_dev + 3.0 * u * m * m + 6.0 * u * m) * x_bound;
+    // (last term: slide_sqrt's one Newton step, relative 1.5e-12 of a magnitude that is at most sqrt2 m x_bound)
+    return (16.0 * steps * u * (m + 1) + 3.0 * m * tones->tap_dev + 3.0 * u * m * m + 6.0 * u * m + 1.5e-12 * 1.4143 * m) * x_bound;
 }
 
 // M = |mark correlators|, S = |unit-gain space correlators| over x, one stream each (nc = n - m + 1 values): by the sliding sum when
