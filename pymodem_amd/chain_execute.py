@@ -821,12 +821,15 @@ class _PipeRows:
         pipe._live += 1
 
     def __del__(self):
-        pipe = self._pipe
-        if pipe is not None and pipe._h is not None:
-            lib().pm_pipe_release(pipe._h, self._ticket)
-            pipe._live -= 1
-            if pipe._closed and pipe._live == 0:
-                pipe._destroy()
+        try:
+            pipe = self._pipe
+            if pipe is not None and pipe._h is not None:
+                lib().pm_pipe_release(pipe._h, self._ticket)
+                pipe._live -= 1
+                if pipe._closed and pipe._live == 0:
+                    pipe._destroy()
+        except Exception:                                      # noqa: BLE001  (interpreter shutdown: the library may be gone)
+            pass
 
 
 class NativePipeline:
