@@ -501,6 +501,19 @@ struct Il2p : pm_codec {
                 feed(d[k], a[k], sink);
                 continue;
             }
+            // Between packets nearly every byte fails the feasibility test below, which reads nothing but the two input bytes in front
+            // of it: skip ahead on the input itself -- no shift register carried from byte to byte -- and rebuild the register (the last
+            // 32 bits seen) where the run of infeasible bytes ends.
+            if (feasible && k >= 4 && k + 1 < n) {
+                int64_t j = k;
+                while (j < n && !feasible[((unsigned)d[j - 2] << 8) | d[j - 1]]) ++j;
+                if (j > k) {
+                    nbits += 8 * (int)(j - k);
+                    word = ((uint32_t)d[j - 4] << 24) | ((uint32_t)d[j - 3] << 16) | ((uint32_t)d[j - 2] << 8) | d[j - 1];
+                    k = j;
+                    if (k >= n) break;
+                }
+            }
             // sync search (il2p.py:367-376): the last 32 bits before each of the byte's 8 bit positions, tested without a
             // per-bit loop; a hit (rare) hands the rest of the byte to the state machine
             const uint64_t win = ((uint64_t)word << 8) | d[k];
