@@ -83,12 +83,10 @@ struct pm_pipe {
     std::vector<std::vector<double>> gains;
     std::vector<pm_afsk_tones> tones;
     std::vector<char> has_tones;
-    std::vector<int> ml_of_chain, mc_of_chain;
     // device memory owned by the pipeline
     std::vector<uint64_t *> d_bits;                      // [slot * nchains + chain]
     size_t bits_words = 0;
-    std::vector<std::vector<uint64_t *>> sweep_bits;     // [slot][sweep] -> host array of device pointers (what h_bits wants), flattened below
-    std::vector<std::vector<std::vector<uint64_t *>>> sweep_bits_store;
+    std::vector<std::vector<std::vector<uint64_t *>>> sweep_bits_store;      // [slot][sweep] -> the device pointers of the sweep's bitmaps (what h_bits wants)
     std::vector<hipEvent_t> slot_event;
     // per worker: slicer output blocks on the device
     struct Work {
