@@ -18,7 +18,6 @@
 
 namespace {
 
-constexpr int kTile = 256;       // samples per LDS tile (AGC kernels; the loop kernels have their own shapes)
 constexpr double kTwoPi = 2.0 * 3.141592653589793;
 
 typedef double double2v __attribute__((ext_vector_type(2)));
