@@ -819,3 +819,32 @@ def test_afsk_group_run_equals_the_separate_calls(ctx, config_lines):
     for c in range(len(lines)):
         assert len(res[True][c][0]) > 100
         assert np.array_equal(res[True][c][0], res[False][c][0]) and np.array_equal(res[True][c][1], res[False][c][1]), c
+
+
+def test_profiler_intervals_share_a_time_base_across_contexts(ctx):
+    """pm_prof_intervals: every tracked launch's (start, end) on the device's common time base -- launches of one context are
+    disjoint and in order, launches on a second context fall in the same time span, and the sums equal pm_prof_read's."""
+    import pymodem_amd
+    side = pymodem_amd.Context.side(index=78, high_priority=False)
+    n, m = 2_000_000, 100
+    taps = ctx.upload(np.linspace(-1.0, 1.0, m))
+    x = ctx.upload(np.random.default_rng(2).standard_normal(n))
+    y1, y2 = ctx.empty(n - m + 1, np.float64), side.empty(n - m + 1, np.float64)
+    ctx.sync()
+    for c in (ctx, side):
+        c.profile(True)
+    for _ in range(5):
+        chk(L().pm_fir_valid_f64(ctx.handle, x.ptr, n, taps.ptr, m, y1.ptr, 0))
+        chk(L().pm_fir_valid_f64(side.handle, x.ptr, n, taps.ptr, m, y2.ptr, 0))
+    ctx.sync()
+    side.sync()
+    iv = {name: c.profile_intervals("fir_f64") for name, c in (("ctx", ctx), ("side", side))}
+    read = {name: c.profile_read()["fir_f64"] for name, c in (("ctx", ctx), ("side", side))}
+    for c in (ctx, side):
+        c.profile(False)
+    for name, v in iv.items():
+        assert v.shape == (5, 2) and np.all(v[:, 1] > v[:, 0]) and np.all(v[1:, 0] >= v[:-1, 1] - 1e-3), name      # disjoint, in order
+        assert abs(float(np.sum(v[:, 1] - v[:, 0])) - read[name][0]) < 1e-2 and read[name][1] == 5
+    lo, hi = min(v[:, 0].min() for v in iv.values()), max(v[:, 1].max() for v in iv.values())
+    assert hi - lo < 1000.0 and iv["side"][:, 0].min() < iv["ctx"][:, 1].max()        # one time base: the two streams' launches interleave
+    assert ctx.profile_intervals("fir_f64").shape == (0, 2)                            # switching off clears
