@@ -728,7 +728,7 @@ def measure(args, env):
         chains_ref[:] = []
         import gc
         gc.collect()
-        for c_ in [ctx] + [pymodem_amd.Context.side(dev_index, i) for i in range(2)]:
+        for c_ in [ctx] + [pymodem_amd.Context.side(dev_index, 400 + i) for i in range(8)]:
             c_.drop_scratch()                                 # ... and the slicers' output blocks of thousands of streams
     per_rank_ms = None
     if use_dist:

@@ -328,6 +328,11 @@ int pm_slice_compact(pm_ctx *ctx, const pm_slice_job *h_jobs, int njobs, void *d
  * Lane-steps are N (1 + m/L) for merge length m (10-20 k samples) and chunk length L, the depth is (L + longest merge) x the
  * step time: long chunks are cheap, short ones are quick.  Results do not depend on it. */
 int pm_slicer_tune(pm_ctx *ctx, int64_t target_lanes);
+/* The longest chunk, in 64-sample words (0 restores the default 384 = 24.6 k samples: the optimum when a batch is a few dozen streams
+ * and its depth matters, as in the pipelined executor).  A host that slices thousands of streams after a run of the batch engine has
+ * its parallelism in the streams and several calls in flight: long chunks (thousands of words) do N (1 + m/L) lane-steps with m/L
+ * close to nothing instead of 0.6.  Results do not depend on it. */
+int pm_slicer_limits(pm_ctx *ctx, int64_t max_chunk_words);
 /* Diagnostics of the last slicer call on this ctx: lockstep launches until no walker was left, chunk length, chunks. */
 int pm_slicer_stats(pm_ctx *ctx, int32_t *iterations, int32_t *chunk_len, int64_t *chunks);
 

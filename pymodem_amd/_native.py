@@ -236,6 +236,7 @@ _SIGS = {
     "pm_slice_quadrature": ([_vp, _vp, _vp, _i64, ctypes.POINTER(SlicerParams), _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
     "pm_slice_batch": ([_vp, ctypes.POINTER(SliceJob), _int], _int),
     "pm_slicer_tune": ([_vp, _i64], _int),
+    "pm_slicer_limits": ([_vp, _i64], _int),
     "pm_slice_compact": ([_vp, _vp, _int, _vp, ctypes.c_size_t, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_size_t)], _int),
     "pm_slicer_stats": ([_vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_i64)], _int),
     "pm_chain_create": ([_vp, ctypes.POINTER(ChainDesc), ctypes.POINTER(_vp)], _int),

@@ -31,6 +31,7 @@ struct pm_ctx {
     int32_t sl_iterations = 0, sl_chunk_len = 0;
     int64_t sl_chunks = 0;
     int64_t sl_target_lanes = 16384;   // walkers (= chunks) a slicer batch is cut into (pm_slicer_tune)
+    int64_t sl_max_chunk_words = 384;  // longest chunk in 64-sample words (pm_slicer_limits)
     int64_t sl_hint_shape = 0;         // chunk/launch geometry sl_launch_hint was learnt on
     int32_t sl_launch_hint = 0;        // lockstep launches to enqueue before the emit kernels without asking the device
     int *sweep_count = nullptr;        // device counter of the last pm_afsk_sweep_signs on this ctx (a slot of d_sweep)

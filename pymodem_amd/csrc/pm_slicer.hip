@@ -643,7 +643,7 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
     // (N (1 + m/L)), i.e. less of the vector ALU taken from the demod kernels beside them, shorter ones a shallower first launch;
     // measured in the pipelined executor (medians of interleaved runs, 20 / 400 steps): 256 words 1.52 / 1.17 ms per step, 384 words
     // 1.45 / 1.16, 512 words 1.48 / 1.25
-    const int64_t lc_max = getenv("PM_SLICER_MAX_CHUNK_WORDS") ? std::max(16, atoi(getenv("PM_SLICER_MAX_CHUNK_WORDS"))) : 384;
+    const int64_t lc_max = getenv("PM_SLICER_MAX_CHUNK_WORDS") ? std::max(16, atoi(getenv("PM_SLICER_MAX_CHUNK_WORDS"))) : ctx->sl_max_chunk_words;
     int64_t lc_words = std::max<int64_t>(16, std::min<int64_t>(pm_cdiv(all_words, ctx->sl_target_lanes), lc_max));
     if (const char *e = getenv("PM_SLICER_CHUNK_WORDS")) { if (atoi(e) > 0) lc_words = atoi(e); }
     // Words per lockstep launch once the walkers are beyond their own chunks (never more than a chunk: see slice_walk_kernel).
@@ -975,6 +975,13 @@ int pm_slicer_tune(pm_ctx *ctx, int64_t target_lanes)
 {
     PM_ARG(ctx != nullptr && target_lanes >= 0);
     ctx->sl_target_lanes = target_lanes ? std::max<int64_t>(64, target_lanes) : 16384;
+    return PM_OK;
+}
+
+int pm_slicer_limits(pm_ctx *ctx, int64_t max_chunk_words)
+{
+    PM_ARG(ctx != nullptr && max_chunk_words >= 0);
+    ctx->sl_max_chunk_words = max_chunk_words ? std::max<int64_t>(16, max_chunk_words) : 384;
     return PM_OK;
 }
 

@@ -226,12 +226,31 @@ def process_recordings_device(chain_sets, audios, ctx=None, chunk=0, rows=False,
     flat_slicers = [chain_sets[rec][c][2] for rec in range(r) for c in range(nchains)]
     flat_bits = [bitmaps[rec][c] for rec in range(r) for c in range(nchains)]
     if len(flat_slicers) >= 256:
-        # thousands of streams go through pm_slice_batch 64 at a time, each call a sequence of short lockstep launches that ends in a
-        # wait: two halves on two streams (two threads) overlap their waits, as the two slicer workers of the AFSK pipeline do
-        half = (r // 2) * nchains
-        sides = [ctx, Context.side(ctx.device, 1)]
-        futs = [_pool().submit(slice_batch, flat_slicers[lo:hi], flat_bits[lo:hi], c) for (lo, hi), c in zip(((0, half), (half, len(flat_slicers))), sides)]
-        sliced = futs[0].result() + futs[1].result()
+        # Thousands of streams go through pm_slice_batch 64 at a time, each call a sequence of lockstep launches that ends in a wait.
+        # Here the parallelism is in the streams, not inside one: long chunks (1024 words instead of 384: N (1 + m/L) lane-steps with m/L
+        # a few percent instead of 0.6) and eight calls in flight on eight streams of their own (eight threads) -- qpsk_2400, 2048 x 8
+        # quadrature streams: 2.4 ms per recording with two calls of short chunks in flight
+        import os
+        parts = max(1, min(int(os.environ.get("PYMODEM_AMD_LOOP_SLICE_STREAMS", "8")), r))
+        words = int(os.environ.get("PYMODEM_AMD_LOOP_SLICE_CHUNK_WORDS", "1024"))
+        cuts = [(r * p // parts) * nchains for p in range(parts + 1)]
+        sides = [Context.side(ctx.device, 400 + p) for p in range(parts)]
+        for sc in sides:
+            if getattr(sc, "_loop_slice_words", None) != words:
+                check(lib().pm_slicer_limits(sc.handle, words))
+                sc._loop_slice_words = words
+        # ... and the output crosses to the host in pm_slice_compact's form (exact counts, 16-bit address steps: 3 bytes per data byte
+        # instead of 9 x the 1.5x capacity -- 18 GB instead of 80 for that run)
+        # -- one group of 64 streams at a time, fetched before the next: the device blocks of a stream's context are the same for
+        # every group (a key per group kept 80 GB of them alive beside the bitmaps)
+        def part(p):
+            out = []
+            for lo in range(cuts[p], cuts[p + 1], 64):
+                hi = min(lo + 64, cuts[p + 1])
+                out += slice_batch(flat_slicers[lo:hi], flat_bits[lo:hi], sides[p], defer=True, compact=True, out_tag=("loop-slice", p))(sides[p])
+            return out
+        futs = [_pool().submit(part, p) for p in range(parts)]
+        sliced = [x for f in futs for x in f.result()]
     else:
         sliced = slice_batch(flat_slicers, flat_bits, ctx)
     t2 = time.perf_counter()
