@@ -365,8 +365,15 @@ def measure(args, env):
             st = {}
             rows = lb.process_recordings_device(sets, [audio_dev] * r, ctx, chunk=args.loop_chunk, rows=True, chain_ids=my, stages=st)
             t_f = time.perf_counter()
-            for rr in rows:
-                res = finish(rr)
+            if use_dist or len(my) < 4:
+                for rr in rows:                                   # (collectives: in order, on this thread; one chain: nothing to share out)
+                    res = finish(rr)
+            else:
+                # the recordings' de-dups do not depend on each other (PacketTable + pm_correlate, mostly native): four at a time
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=4) as fin:
+                    for res in fin.map(finish, rows):
+                        pass
             for k2, v in dict(st.get("seconds", {}), finish=time.perf_counter() - t_f).items():
                 loop_phase_s[k2] = loop_phase_s.get(k2, 0.0) + v
         return res
