@@ -509,15 +509,16 @@ size_t slide_lds_bytes(int m) { return (size_t)(slide_slot<L>(kSlideThreads * L 
 // h = y / 2 give r = 1/2 - h g = -d - d^2/2 and g (1 + r) = sqrt(v) (1 - 3/2 d^2 + O(d^3)): a seed good to 2^-20 (the ISA manuals give
 // V_RSQ_F64 2^29 units in the last place, 2^-23) leaves a relative error below 1.5e-12, which slide_bound() adds to the bound of the
 // certified decision (0.1 % of its thousandfold slack) -- the decision needs a value and a bound, not the last bit.  Round 2 took a
-// second step (2 units in the last place): three more dependent fma per root, two roots per output, 2 % of the fused kernel.  A v so
-// small that v itself underflows in the seed's square comes out as 0: an absolute error below 1e-150.  The IEEE sqrt costs twice the
+// second step (2 units in the last place): three more dependent fma per root, two roots per output, 2 % of the fused kernel.  A v
+// below 1e-300 (0 on digital silence, where the seed would be infinite) is raised to that: a root of 1e-150 at most instead of 0.  The IEEE sqrt costs twice the
 // instructions again (scaling of subnormal and huge arguments, class checks).
 __device__ __forceinline__ double slide_sqrt(double v)
 {
+    v = __builtin_fmax(v, 1e-300);                            // one instruction where a compare and two selects stood
     const double y = __builtin_amdgcn_rsq(v);
     const double g = v * y, h = 0.5 * y;
     const double r = __builtin_fma(-h, g, 0.5);
-    return v > 1e-300 ? __builtin_fma(g, r, g) : 0.0;
+    return __builtin_fma(g, r, g);
 }
 
 // One run: the direct sums of output k0 of the staged tile with the real taps, ascending input index (afsk.py:153-160; every lane
@@ -760,6 +761,53 @@ struct SweepArgs {
     uint64_t *bits[kSweepMax];
 };
 
+// The combine step of a thread's R = 8 consecutive outputs: y_g = A - g B (ONE: y = A as it stands), one bitmap byte per modem, and
+// the (sample, modem) pairs that cannot be certified (|y| <= E, NaN too) to the list, whose bits sweep_exact_kernel decides afterwards.
+// A wave whose outputs all lie inside the stream and are all certified -- all but one in ~1e5 -- spends three vector instructions per
+// output and modem: the fma, the sign bit shifted into the byte from the high word (v_alignbit; y != 0 there, so the sign bit is
+// `y >= 0` negated) and one compare whose lane mask is folded into a scalar; otherwise the wave goes through its modems once more, lane
+// by lane (same bytes for the certified outputs).
+template <int R, bool ONE>
+__device__ __forceinline__ void sweep_combine(const double (&a)[R], const double (&b)[R], int64_t go, int64_t nout, int G, const SweepArgs &P,
+                                              double E, unsigned long long *__restrict__ list, int *__restrict__ count, int cap)
+{
+    static_assert(R == 8, "one bitmap byte per thread");
+    const bool whole = __all(go + R <= nout);
+    unsigned long long unsure_any = 0;
+    if (whole) {
+        for (int g = 0; g < G; ++g) {
+            const double mg = -P.gain[g];
+            unsigned neg = 0;
+#pragma unroll
+            for (int r = R - 1; r >= 0; --r) {
+                const double y = ONE ? a[r] : __builtin_fma(mg, b[r], a[r]);
+                neg = __builtin_amdgcn_alignbit(neg, (unsigned)__double2hiint(y), 31);      // (neg << 1) | sign bit
+                unsure_any |= __ballot(!(fabs(y) > E));
+            }
+            reinterpret_cast<uint8_t *>(P.bits[g])[go >> 3] = (uint8_t)~neg;
+        }
+        if (unsure_any == 0) return;
+    }
+    for (int g = 0; g < G; ++g) {                            // the stream's last outputs, or something in this wave is uncertain
+        const double mg = -P.gain[g];
+        unsigned byte = 0, unsure = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double y = ONE ? a[r] : __builtin_fma(mg, b[r], a[r]);
+            const bool in = go + r < nout;
+            byte |= (unsigned)(in && y >= 0.0) << r;
+            unsure |= (unsigned)(in && !(fabs(y) > E)) << r;                 // cannot be certified (NaN lands here too)
+        }
+        reinterpret_cast<uint8_t *>(P.bits[g])[go >> 3] = (uint8_t)byte;     // bits past nout: 0 up to the end of the last word
+        while (unsure) {
+            const int r = __ffs((int)unsure) - 1;
+            unsure &= unsure - 1;
+            const int idx = atomicAdd(count, 1);
+            if (idx < cap) list[idx] = ((unsigned long long)g << 48) | (unsigned long long)(go + r);
+        }
+    }
+}
+
 // The second low-pass of the sweep with the combine step as its epilogue: B = LPF(S) stays in registers, A = LPF(M) is read back
 // (the thread's eight consecutive values), and what leaves the kernel is one bitmap byte per modem and thread plus the list of
 // samples that could not be certified.
@@ -776,24 +824,8 @@ __global__ __launch_bounds__(kThreads) void fir_sweep_kernel(const double *__res
     double a[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) a[r] = A && go + r < nout ? A[go + r] : 0.0;
-    for (int g = 0; g < G; ++g) {
-        const double mg = -P.gain[g];
-        unsigned byte = 0, unsure = 0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const double y = A ? __builtin_fma(mg, b[r], a[r]) : b[r];       // no A: the input already is mark - gain * space (one chain)
-            const bool in = go + r < nout;
-            byte |= (unsigned)(in && y >= 0.0) << r;
-            unsure |= (unsigned)(in && !(fabs(y) > E)) << r;                 // cannot be certified (NaN lands here too)
-        }
-        reinterpret_cast<uint8_t *>(P.bits[g])[go >> 3] = (uint8_t)byte;     // bits past nout: 0 up to the end of the last word
-        while (unsure) {
-            const int r = __ffs((int)unsure) - 1;
-            unsure &= unsure - 1;
-            const int idx = atomicAdd(count, 1);
-            if (idx < cap) list[idx] = ((unsigned long long)g << 48) | (unsigned long long)(go + r);
-        }
-    }
+    if (A) sweep_combine<R, false>(a, b, go, nout, G, P, E, list, count, cap);
+    else sweep_combine<R, true>(b, b, go, nout, G, P, E, list, count, cap);      // no A: the input already is mark - gain * space (one chain)
 }
 
 // Sliding sums, low-pass(es) and the certified combine in ONE kernel: the magnitude streams never reach memory.  A workgroup owns
@@ -878,24 +910,7 @@ __global__ __launch_bounds__(kThreads) void afsk_slide_lpf_kernel(const double *
     if (!ONE) fir_acc_image<R>(xs, h, ml, b);
     const int64_t go = tile0 + (int64_t)t * R;
     if (go >= ((nout + 63) >> 6) * 64) return;
-    for (int g = 0; g < G; ++g) {
-        const double mg = -P.gain[g];
-        unsigned byte = 0, unsure = 0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const double y = ONE ? a[r] : __builtin_fma(mg, b[r], a[r]);
-            const bool in = go + r < nout;
-            byte |= (unsigned)(in && y >= 0.0) << r;
-            unsure |= (unsigned)(in && !(fabs(y) > E)) << r;                 // cannot be certified (NaN lands here too)
-        }
-        reinterpret_cast<uint8_t *>(P.bits[g])[go >> 3] = (uint8_t)byte;     // bits past nout: 0 up to the end of the last word
-        while (unsure) {
-            const int r = __ffs((int)unsure) - 1;
-            unsure &= unsure - 1;
-            const int idx = atomicAdd(count, 1);
-            if (idx < cap) list[idx] = ((unsigned long long)g << 48) | (unsigned long long)(go + r);
-        }
-    }
+    sweep_combine<R, ONE>(a, b, go, nout, G, P, E, list, count, cap);
 }
 
 // The exact chain for single samples: correlator bank of modem g at the ml positions the low-pass needs, then the low-pass, every
