@@ -524,9 +524,12 @@ __device__ __forceinline__ double slide_sqrt(double v)
 // One run: the direct sums of output k0 of the staged tile with the real taps, ascending input index (afsk.py:153-160; every lane
 // reads the same four taps per step, an LDS broadcast), then L - 1 sliding steps; the 2 x L magnitudes stay in registers.
 template <int L>
-__device__ __forceinline__ void slide_run(const double *__restrict__ xs, const double *__restrict__ tp, int k0, int m, const SlideTones &T,
+__device__ __forceinline__ void slide_run(const double *__restrict__ xs, const double *__restrict__ tp, int run, int m, const SlideTones &T,
                                           double (&mv)[L], double (&sv)[L])
 {
+    // run starts at input run * L = slot run * (L + 1); input run * L + j sits j + j / L slots further, and j is the same in every lane:
+    // the division stays on the scalar unit (as slide_slot(run * L + j) it was a dozen vector instructions per read)
+    const double *xr = xs + run * (L + 1);
     double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
     {
         const double2v *tq = reinterpret_cast<const double2v *>(tp);
@@ -534,7 +537,7 @@ __device__ __forceinline__ void slide_run(const double *__restrict__ xs, const d
         for (; i + 4 <= m; i += 4) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const double v = xs[slide_slot<L>(k0 + i + q)];
+                const double v = xr[slide_slot<L>(i + q)];
                 const double2v h01 = tq[2 * (i + q)], h23 = tq[2 * (i + q) + 1];
                 a = __builtin_fma(h01.x, v, a);
                 b = __builtin_fma(h01.y, v, b);
@@ -543,7 +546,7 @@ __device__ __forceinline__ void slide_run(const double *__restrict__ xs, const d
             }
         }
         for (; i < m; ++i) {
-            const double v = xs[slide_slot<L>(k0 + i)];
+            const double v = xr[slide_slot<L>(i)];
             const double2v h01 = tq[2 * i], h23 = tq[2 * i + 1];
             a = __builtin_fma(h01.x, v, a);
             b = __builtin_fma(h01.y, v, b);
@@ -556,7 +559,7 @@ __device__ __forceinline__ void slide_run(const double *__restrict__ xs, const d
         mv[i] = slide_sqrt(a * a + b * b);                   // afsk.py:157
         sv[i] = slide_sqrt(c * c + d * d);
         if (i + 1 < L) {
-            const double xk = xs[slide_slot<L>(k0 + i)], xn = xs[slide_slot<L>(k0 + i + m)];
+            const double xk = xr[i], xn = xr[slide_slot<L>(i + m)];
             const double a2 = __builtin_fma(T.mr, a, __builtin_fma(-T.ms, b, __builtin_fma(-T.mer, xk, xn)));
             const double b2 = __builtin_fma(T.ms, a, __builtin_fma(T.mr, b, -T.mes * xk));
             const double c2 = __builtin_fma(T.sr, c, __builtin_fma(-T.ss, d, __builtin_fma(-T.ser, xk, xn)));
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(kSlideThreads) void afsk_slide_kernel(const double 
     // "L consecutive outputs per lane" into coalesced stores, one stream after the other.
     const int k0 = t * L;
     double mv[L], sv[L];
-    slide_run<L>(xs, tp, k0, m, T, mv, sv);
+    slide_run<L>(xs, tp, t, m, T, mv, sv);
     if (!S) {                                                // one chain: its mark - space difference (afsk.py:162) in ONE stream
 #pragma unroll
         for (int i = 0; i < L; ++i) mv[i] = __builtin_fma(-gain, sv[i], mv[i]);
@@ -887,7 +890,7 @@ __global__ __launch_bounds__(kThreads) void afsk_slide_lpf_kernel(const double *
     }
     lds_barrier();
     double mv[L], sv[L];
-    if (t < nruns) slide_run<L>(xs, tp, t * L, m, T, mv, sv);
+    if (t < nruns) slide_run<L>(xs, tp, t, m, T, mv, sv);
     lds_barrier();                                           // every lane is done with the window of x
     if (t < nruns) {
         const double g0 = P.gain[0];
