@@ -108,6 +108,11 @@ int pm_prof_intervals(pm_ctx *ctx, int kernel_class, double *h_start_ms, double 
  * d_taps holds h in the reference's order.  flags: PM_FIR_NEGATE writes -y (fsk.py:153-154). */
 #define PM_FIR_NEGATE 1
 int pm_fir_valid_i16(pm_ctx *ctx, const int16_t *d_x, int64_t n, const double *d_taps, int m, double *d_y, int flags);
+/* The same sum for callers that need a value with a bound, not the reference's rounding (the certified AFSK sweeps inside pm_pipe_*):
+ * taps quantised to 48-bit integers, samples and taps as signed base-256 digits, exact int32 products on the int8 matrix pipe
+ * (v_mfma_i32_16x16x64_i8), recombined in binary64.  |d_y[k] - reference sum| <= *h_bound (~1e-13 of sum|taps| * 32768).  m <= 177,
+ * d_x 16-byte aligned, h_taps on the HOST; synchronous (plans its tables per call: the pipeline keeps them).  Test and measurement entry. */
+int pm_fir_valid_i16_limbs(pm_ctx *ctx, const int16_t *d_x, int64_t n, const double *h_taps, int m, double *d_y, double *h_bound);
 int pm_fir_valid_f64(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_taps, int m, double *d_y, int flags);
 
 /* The same FIRs fused with the slicer's sign test: only the (y >= 0) bitmap of the n-m+1 outputs is written (bit k of the

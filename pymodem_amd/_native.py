@@ -187,6 +187,7 @@ _SIGS = {
     "pm_prof_read": ([_vp, _int, ctypes.POINTER(_dbl), ctypes.POINTER(_i64)], _int),
     "pm_prof_work": ([_vp, _int, ctypes.POINTER(_dbl), ctypes.POINTER(_dbl)], _int),
     "pm_fir_valid_i16": ([_vp, _vp, _i64, _vp, _int, _vp, _int], _int),
+    "pm_fir_valid_i16_limbs": ([_vp, _vp, _i64, _vp, _int, _vp, _vp], _int),
     "pm_fir_valid_f64": ([_vp, _vp, _i64, _vp, _int, _vp, _int], _int),
     "pm_fir_signs_i16": ([_vp, _vp, _i64, _vp, _int, _vp, _int], _int),
     "pm_fir_signs_f64": ([_vp, _vp, _i64, _vp, _int, _vp, _int], _int),

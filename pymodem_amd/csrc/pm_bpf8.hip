@@ -1,0 +1,215 @@
+// The shared band-pass of an AFSK chain group (afsk.py:151: int16 audio, ~150 real taps) on the int8 matrix pipe, for consumers that
+// need a VALUE WITH A BOUND and not the reference's rounding: the certified gain sweeps (pm_fir.hip).  Every other
+// caller keeps fir_valid_kernel<short>, the reference's sum in its canonical order.
+//
+// Why: in binary64 the band-pass is 148 vector fma per sample, 0.165 ms per recording alone and 29 % of the demod stage's fma issue
+// slots; f64 and f32 MFMA were measured earlier and do not run beside vector f64 work.  The int8 MFMA does (tools/ubench/mfma_i8.hip:
+// 1.4 P mac/s alone, 0.9 P beside 28 T vector fma/s from the same waves), and integer products need no rounding analysis:
+//
+//   taps      h[t] ~ q[t] 2^-S,  q[t] a 48-bit integer written in six balanced base-256 digits  q = sum_b d_b 256^b,  d_b in [-128, 127]
+//   samples   x = 256 s1 + s0 + 128  with  s1 = x >> 8  and  s0 = (x & 255) - 128,  both in [-128, 127]
+//   y[k] = sum_t h[K-1-t] x[k+t]  ~  2^-S ( sum_w 256^w W_w[k] )  +  128 2^-S sum_t q[t],     W_w = sum_t ( d_w s0 + d_(w-1) s1 )[k+t]
+//
+// The seven W_w are exact int32 sums (|W_w| < 148 * 2 * 2^14): 12 int8 products per tap and sample instead of one f64 fma, 36
+// v_mfma_i32_16x16x64_i8 per 256 outputs (576 matrix cycles against 2368 vector cycles).  As a matrix product: the tile's outputs
+// y[T + 16 i + j] = sum_c A[i][c] B[c][j] with A[i][c] = s[T + 16 i + c] (16 consecutive bytes of a digit plane per lane: one
+// ds_read_b128) and the Toeplitz band B[c][j] = d[c - j], c < 192, prepared once per tap set by the host and held in registers.
+// What separates the result from the reference's sum:  sum_t |h[t] - q[t] 2^-S| * 32768  (quantisation, ~148 * 2^-49 * 32768)  +  the
+// seven roundings of the recombination  +  the reference's own (K + 1) u sum|h| 32768: pm_bpf8_error() returns the sum, the sweep adds
+// sqrt2 m times that to the bound of its sliding magnitudes -- 0.1 % of the certified decision's slack, no sample more goes to the
+// exact recomputation, which now starts from the audio (sweep_exact_kernel<true>).
+#include "pm_common.h"
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+typedef int i4 __attribute__((ext_vector_type(4)));
+
+constexpr int kDigits = 6, kBlocks = 3, kWeights = kDigits + 1;
+constexpr int kTilesPerWave = 4, kWaves = 4, kWgOut = 256 * kTilesPerWave * kWaves;      // 4096 outputs per workgroup
+constexpr int kSpan = kWgOut + 64 * kBlocks + 240 - 256 + 16;                            // bytes of a digit plane a workgroup reads
+constexpr int kPlane = (kSpan + 15) / 16 * 16;
+
+struct Scales { double s[kWeights]; double c0; };
+
+__global__ __launch_bounds__(256) void bpf8_kernel(const int16_t *__restrict__ x, int64_t n, const i4 *__restrict__ btab, Scales sc,
+                                                   double *__restrict__ y, int64_t nout)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char plane[2][kPlane];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t wg0 = (int64_t)blockIdx.x * kWgOut;
+    // stage: 8 samples per thread and step -> 8 bytes of each digit plane
+    for (int p = t * 8; p < kPlane; p += 256 * 8) {
+        const int64_t gi = wg0 + p;
+        uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+        if (gi + 8 <= n) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(x + gi);
+            d0 = v.x; d1 = v.y; d2 = v.z; d3 = v.w;
+        } else {
+            uint16_t s[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s[q] = gi + q < n ? (uint16_t)x[gi + q] : (uint16_t)0;
+            d0 = s[0] | (uint32_t)s[1] << 16; d1 = s[2] | (uint32_t)s[3] << 16; d2 = s[4] | (uint32_t)s[5] << 16; d3 = s[6] | (uint32_t)s[7] << 16;
+        }
+        const uint32_t lo0 = __builtin_amdgcn_perm(d1, d0, 0x06040200u) ^ 0x80808080u, lo1 = __builtin_amdgcn_perm(d3, d2, 0x06040200u) ^ 0x80808080u;
+        const uint32_t hi0 = __builtin_amdgcn_perm(d1, d0, 0x07050301u), hi1 = __builtin_amdgcn_perm(d3, d2, 0x07050301u);
+        *reinterpret_cast<uint2 *>(&plane[0][p]) = make_uint2(lo0, lo1);
+        *reinterpret_cast<uint2 *>(&plane[1][p]) = make_uint2(hi0, hi1);
+    }
+    // the band, digit by digit and block by block: 18 operands of four registers, the same for every tile
+    i4 B[kDigits][kBlocks];
+#pragma unroll
+    for (int b = 0; b < kDigits; ++b)
+#pragma unroll
+        for (int kb = 0; kb < kBlocks; ++kb) B[b][kb] = btab[(b * kBlocks + kb) * 64 + lane];
+    __syncthreads();
+    const int r = lane & 15, g = lane >> 4;
+#pragma unroll 1
+    for (int q = 0; q < kTilesPerWave; ++q) {
+        const int tl = (wave * kTilesPerWave + q) * 256;               // the tile's first output, within the workgroup
+        if (wg0 + tl >= nout) break;
+        i4 acc[kWeights];
+#pragma unroll
+        for (int w = 0; w < kWeights; ++w) acc[w] = i4{0, 0, 0, 0};
+#pragma unroll
+        for (int kb = 0; kb < kBlocks; ++kb) {
+            const int at = tl + 16 * r + 64 * kb + 16 * g;
+            const i4 a0 = *reinterpret_cast<const i4 *>(&plane[0][at]), a1 = *reinterpret_cast<const i4 *>(&plane[1][at]);
+#pragma unroll
+            for (int b = 0; b < kDigits; ++b) {
+                acc[b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, B[b][kb], acc[b], 0, 0, 0);
+                acc[b + 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, B[b][kb], acc[b + 1], 0, 0, 0);
+            }
+        }
+        // lane (r, g) holds outputs 16 (4 g + v) + r, v = 0..3
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            double val = sc.c0;
+#pragma unroll
+            for (int w = 0; w < kWeights; ++w) val = __builtin_fma((double)acc[w][v], sc.s[w], val);
+            const int64_t k = wg0 + tl + 16 * (4 * g + v) + r;
+            if (k < nout) y[k] = val;
+        }
+    }
+}
+
+}  // namespace
+
+struct pm_bpf8_plan {
+    int m = 0;
+    double err = 0;
+    Scales sc;
+    i4 *d_btab = nullptr;
+    int device = 0;
+};
+
+int pm_bpf8_plan_create(pm_ctx *ctx, const double *h_taps, int m, pm_bpf8_plan **out)
+{
+    PM_CTX(ctx);
+    PM_ARG(h_taps != nullptr && out != nullptr && m >= 1);
+    *out = nullptr;
+    if (m + 15 > 64 * kBlocks) return pm_set_error(PM_ERR_ARG, "int8 band-pass: %d taps do not fit the %d-column band", m, 64 * kBlocks);
+    double hmax = 0.0, habs = 0.0;
+    for (int t = 0; t < m; ++t) {
+        if (!std::isfinite(h_taps[t])) return pm_set_error(PM_ERR_ARG, "int8 band-pass: tap %d is not finite", t);
+        hmax = std::max(hmax, std::fabs(h_taps[t]));
+        habs += std::fabs(h_taps[t]);
+    }
+    if (hmax == 0.0) return pm_set_error(PM_ERR_ARG, "int8 band-pass: all taps are zero");
+    int e = 0;
+    (void)std::frexp(hmax, &e);                              // hmax = f 2^e, f in [0.5, 1)
+    const int S = 46 - e;                                    // |q| <= 2^46 (+ 1/2): six balanced digits reach +-2^47
+    std::vector<int64_t> q(m);
+    double quant = 0.0;
+    int64_t qsum = 0;
+    std::vector<int8_t> dig((size_t)kDigits * m);
+    double part = 0.0;                                       // bound on the sum of the magnitudes of the recombination's terms
+    for (int t = 0; t < m; ++t) {
+        const double scaled = std::ldexp(h_taps[t], S);      // exact
+        q[t] = (int64_t)std::llrint(scaled);
+        quant += std::fabs(scaled - (double)q[t]);           // both below 2^53: the difference is exact
+        qsum += q[t];
+        int64_t v = q[t];
+        for (int b = 0; b < kDigits; ++b) {
+            const int64_t d = ((v + 128) & 255) - 128;
+            dig[(size_t)b * m + t] = (int8_t)d;
+            v = (v - d) / 256;
+        }
+        if (v != 0) return pm_set_error(PM_ERR_ARG, "int8 band-pass: tap %d does not fit six digits", t);
+    }
+    pm_bpf8_plan *p = new pm_bpf8_plan();
+    p->m = m;
+    p->device = ctx->device;
+    for (int w = 0; w < kWeights; ++w) {
+        p->sc.s[w] = std::ldexp(1.0, 8 * w - S);
+        double mag = 0.0;
+        for (int t = 0; t < m; ++t) {
+            if (w < kDigits) mag += std::fabs((double)dig[(size_t)w * m + t]);
+            if (w >= 1) mag += std::fabs((double)dig[(size_t)(w - 1) * m + t]);
+        }
+        part += mag * 128.0 * p->sc.s[w];
+    }
+    p->sc.c0 = std::ldexp((double)(128 * qsum), -S);             // |128 sum q| < 2^62; its conversion is one of the nine roundings below
+    part += std::fabs(p->sc.c0);
+    const double u = 1.1102230246251565e-16;
+    // quantisation (|x| <= 32768) + the constant's and the seven fma's roundings + the reference's own sum (K + 1) u sum|h| 32768
+    p->err = (std::ldexp(quant, -S) * 32768.0 + 9.0 * u * part + (m + 1) * u * habs * 32768.0) * 1.000001;      // (the bound's own roundings)
+    // B[c][j] = hr[c - j], hr[t] = h[m - 1 - t] (the reference's sum ascends through the input): lane (j, g), bytes c = 64 kb + 16 g + 0..15
+    std::vector<int8_t> tab((size_t)kDigits * kBlocks * 64 * 16, 0);
+    for (int b = 0; b < kDigits; ++b)
+        for (int kb = 0; kb < kBlocks; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 16; ++i) {
+                    const int c = 64 * kb + 16 * (lane >> 4) + i, idx = c - (lane & 15);
+                    if (idx >= 0 && idx < m) tab[(((size_t)b * kBlocks + kb) * 64 + lane) * 16 + i] = dig[(size_t)b * m + (m - 1 - idx)];
+                }
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void **)&p->d_btab, tab.size()) != hipSuccess) {
+        delete p;
+        return pm_set_error(PM_ERR_HIP, "int8 band-pass: no device memory for the band table");
+    }
+    if (hipMemcpy(p->d_btab, tab.data(), tab.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(p->d_btab);
+        delete p;
+        return pm_set_error(PM_ERR_HIP, "int8 band-pass: copying the band table failed");
+    }
+    *out = p;
+    return PM_OK;
+}
+
+void pm_bpf8_plan_destroy(pm_bpf8_plan *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->d_btab) (void)hipFree(p->d_btab);
+    delete p;
+}
+
+double pm_bpf8_error(const pm_bpf8_plan *p) { return p ? p->err : 0.0; }
+int pm_bpf8_taps(const pm_bpf8_plan *p) { return p ? p->m : 0; }
+
+int pm_bpf8_run(pm_ctx *ctx, const pm_bpf8_plan *p, const int16_t *d_audio, int64_t n, double *d_y)
+{
+    PM_CTX(ctx);
+    PM_ARG(p != nullptr && d_audio != nullptr && d_y != nullptr && n >= p->m && p->device == ctx->device);
+    PM_ARG(((uintptr_t)d_audio & 15) == 0);
+    const int64_t nout = n - p->m + 1, wgs = pm_cdiv(nout, (int64_t)kWgOut);
+    PM_ARG(wgs < (1LL << 31));
+    PmProf prof(ctx, PM_K_FIR_I16);
+    prof.work((double)n * 2 + (double)nout * 8, 2.0 * p->m * (double)nout);       // the flops of the sum it stands for
+    hipLaunchKernelGGL(bpf8_kernel, dim3((unsigned)wgs), dim3(256), 0, ctx->stream, d_audio, n, p->d_btab, p->sc, d_y, nout);
+    PM_HIP(hipGetLastError());
+    return PM_OK;
+}
+
+extern "C" int pm_fir_valid_i16_limbs(pm_ctx *ctx, const int16_t *d_x, int64_t n, const double *h_taps, int m, double *d_y, double *h_bound)
+{
+    pm_bpf8_plan *p = nullptr;
+    if (int rc = pm_bpf8_plan_create(ctx, h_taps, m, &p)) return rc;
+    if (h_bound) *h_bound = p->err;
+    int rc = pm_bpf8_run(ctx, p, d_x, n, d_y);
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = pm_set_error(PM_ERR_HIP, "int8 band-pass: the launch failed");
+    pm_bpf8_plan_destroy(p);
+    return rc;
+}

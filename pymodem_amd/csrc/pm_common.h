@@ -79,6 +79,18 @@ int pm_prof_fold(pm_ctx *ctx);      // sync + accumulate pending pairs
 
 static inline int64_t pm_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ---- the group band-pass on the int8 matrix pipe (pm_bpf8.hip): a value within pm_bpf8_error() of the reference's sum, for the
+// certified sweeps only.  A plan belongs to one tap set (host copy given once) and one device.
+struct pm_bpf8_plan;
+int pm_bpf8_plan_create(pm_ctx *ctx, const double *h_taps, int m, pm_bpf8_plan **out);      // PM_ERR_ARG: more than 177 taps
+void pm_bpf8_plan_destroy(pm_bpf8_plan *p);
+double pm_bpf8_error(const pm_bpf8_plan *p);
+int pm_bpf8_taps(const pm_bpf8_plan *p);
+int pm_bpf8_run(pm_ctx *ctx, const pm_bpf8_plan *p, const int16_t *d_audio, int64_t n, double *d_y);      // d_audio 16-byte aligned
+// pm_afsk_group_run with the band-pass from a plan (nullptr: the reference's sum); every sweep must then carry tones
+int pm_afsk_group_run_plan(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const double *d_bpf, int mb, double *d_bpf_out, double x_bound,
+                           const pm_afsk_sweep_desc *h_sweeps, int nsweeps, int64_t *h_tickets, const pm_bpf8_plan *plan);
+
 // ---- launchers shared between translation units (what the batch engine pm_loopbatch.hip strings together) ---------------------
 // `rows` FIRs with the same taps over equal-length streams in one launch (pm_fir.hip).  Input row r: d_x + r * x_stride, or
 // d_x_ptrs[r] + x_off (d_x_ptrs: DEVICE array of row pointers); x_aligned16: every input row starts on a 16-byte boundary.

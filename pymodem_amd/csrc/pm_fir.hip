@@ -611,7 +611,6 @@ __global__ __launch_bounds__(kSlideThreads) void afsk_slide_kernel(const double 
     lds_barrier();
     // The run's 2 x L results stay in registers; once every lane is done with the staged inputs, the LDS image is reused to turn
     // "L consecutive outputs per lane" into coalesced stores, one stream after the other.
-    const int k0 = t * L;
     double mv[L], sv[L];
     slide_run<L>(xs, tp, t, m, T, mv, sv);
     if (!S) {                                                // one chain: its mark - space difference (afsk.py:162) in ONE stream
@@ -918,10 +917,19 @@ __global__ __launch_bounds__(kThreads) void afsk_slide_lpf_kernel(const double *
 
 // The exact chain for single samples: correlator bank of modem g at the ml positions the low-pass needs, then the low-pass, every
 // sum in the canonical order of afsk_correlate_kernel / fir_valid_kernel.  Runs after fir_sweep_kernel (its bitmap bytes are final).
+// AUDIO: the band-passed stream the sweep saw was itself a value with a bound (pm_bpf8.hip), so the recomputation starts one stage
+// earlier -- the mc + ml - 1 band-pass outputs under the entry from the int16 audio, the reference's sum in fir_valid_kernel's order.
+struct SweepSource {
+    const int16_t *audio;            // nullptr: d_x is the reference's band-passed stream
+    const double *bpf;
+    int mb;
+    double e_x;                      // |d_x[k] - reference's band-pass output|
+};
+template <bool AUDIO>
 __global__ __launch_bounds__(64) void sweep_exact_kernel(const double *__restrict__ x, const double *__restrict__ mi, const double *__restrict__ mq,
                                                          const double *__restrict__ space, int mc, const double *__restrict__ lpf, int ml,
                                                          SweepArgs P, const unsigned long long *__restrict__ list, const int *__restrict__ count, int cap,
-                                                         int *__restrict__ reset = nullptr, int *__restrict__ mail = nullptr)
+                                                         int *__restrict__ reset, int *__restrict__ mail, SweepSource src)
 {
     // deferred fallback (pm_afsk_sweep_mode): this is the sweep's last launch and clears the next sweep's counter (see d_sweep);
     // it also leaves the counter in a page-locked host word, so that the caller who waits for the recording's event anyway reads it
@@ -941,8 +949,18 @@ __global__ __launch_bounds__(64) void sweep_exact_kernel(const double *__restric
         const int g = (int)(list[e] >> 48);
         const int64_t k = (int64_t)(list[e] & 0xFFFFFFFFFFFFull);
         const double *si = space + (size_t)g * 2 * mc, *sq = si + mc;
+        if (AUDIO) {
+            double *xw = dd + ml;
+            for (int p = lane; p < ml + mc - 1; p += 64) {
+                const int16_t *ap = src.audio + k + p;
+                double acc = 0.0;
+                for (int t = 0; t < src.mb; ++t) acc = __builtin_fma(src.bpf[src.mb - 1 - t], (double)ap[t], acc);
+                xw[p] = acc;
+            }
+            __syncthreads();
+        }
         for (int j = lane; j < ml; j += 64) {
-            const double *xp = x + k + j;
+            const double *xp = AUDIO ? dd + ml + j : x + k + j;
             double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
             for (int t = 0; t < mc; ++t) {
                 const double v = xp[t];
@@ -1344,10 +1362,14 @@ static int afsk_magnitudes(pm_ctx *ctx, const double *d_x, int64_t n, double x_b
 
 static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound, const double *d_mark_i, const double *d_mark_q,
                        const double *d_unit_i, const double *d_unit_q, const double *d_space, const double *h_gains, int groups, int m,
-                       const double *d_lpf, int ml, double lpf_abs_sum, uint64_t *const *h_bits, const pm_afsk_tones *tones)
+                       const double *d_lpf, int ml, double lpf_abs_sum, uint64_t *const *h_bits, const pm_afsk_tones *tones,
+                       const SweepSource *src = nullptr)
 {
     PM_CTX(ctx);
     PM_ARG(d_x && d_mark_i && d_mark_q && d_unit_i && d_unit_q && d_space && h_gains && d_lpf && h_bits);
+    // a band-passed stream that is only near the reference's: certified decisions with the deferred fallback only (the gated exact
+    // launches below read d_x), and the exact recomputation goes back to the audio
+    PM_ARG(!src || (src->audio && src->bpf && src->mb >= 1 && src->e_x >= 0.0 && src->e_x < 1e-6 * x_bound && ctx->sweep_deferred && tones));
     PM_ARG(groups >= 1 && groups <= kSweepMax && m >= 1 && m <= kMaxTaps && ml >= 1 && ml <= kMaxTaps);
     PM_ARG(x_bound > 0.0 && x_bound < 1e300 && lpf_abs_sum > 0.0 && lpf_abs_sum < 1e300);
     PM_ARG(n >= (int64_t)m + ml - 1);
@@ -1407,6 +1429,11 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
         if (!one)
             if (int rc = fir_launch<double>(ctx, M, nc, d_lpf, ml, A, nullptr, 0)) return rc;
     }
+    if (src) {
+        // magnitudes are 1-Lipschitz in the pair of correlator sums, each of which moves by at most m e_x; the sliding sums' own
+        // bound is stated for inputs up to x_bound, which the approximate stream exceeds by at most e_x
+        e_slide = e_slide * (1.0 + src->e_x / x_bound) + 1.4143 * m * src->e_x;
+    }
     const double E = 1e-10 * lpf_abs_sum * (1.0 + gmax) * (double)m * 1.4143 * x_bound + lpf_abs_sum * (1.0 + gmax) * e_slide;
     if (fused) {
         PM_ARG(tones->tap_dev >= 0.0 && tones->tap_dev < 1e-6);
@@ -1453,8 +1480,12 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
     }
     {
         PmProf prof(ctx, PM_K_SIGNS);
-        hipLaunchKernelGGL(sweep_exact_kernel, dim3(1024), dim3(64), (size_t)ml * sizeof(double), ctx->stream, d_x, d_mark_i, d_mark_q, d_space, m,
-                           d_lpf, ml, P, list, count, cap, ctx->sweep_deferred ? count_next : nullptr, mail);
+        if (src)
+            hipLaunchKernelGGL(sweep_exact_kernel<true>, dim3(1024), dim3(64), (size_t)(2 * ml + m - 1) * sizeof(double), ctx->stream, d_x, d_mark_i, d_mark_q,
+                               d_space, m, d_lpf, ml, P, list, count, cap, count_next, mail, *src);
+        else
+            hipLaunchKernelGGL(sweep_exact_kernel<false>, dim3(1024), dim3(64), (size_t)ml * sizeof(double), ctx->stream, d_x, d_mark_i, d_mark_q, d_space, m,
+                               d_lpf, ml, P, list, count, cap, ctx->sweep_deferred ? count_next : nullptr, mail, SweepSource{nullptr, nullptr, 0, 0.0});
     }
     PM_HIP(hipGetLastError());
     // Deferred fallback: the caller looks at the counter once the sweep has finished (pm_afsk_sweep_result) and runs the exact
@@ -1541,6 +1572,14 @@ int pm_afsk_sweep_last(pm_ctx *ctx, int64_t *h_uncertain)
 int pm_afsk_group_run(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const double *d_bpf, int mb, double *d_bpf_out, double x_bound,
                       const pm_afsk_sweep_desc *h_sweeps, int nsweeps, int64_t *h_tickets)
 {
+    return pm_afsk_group_run_plan(ctx, d_audio, n, d_bpf, mb, d_bpf_out, x_bound, h_sweeps, nsweeps, h_tickets, nullptr);
+}
+
+}  // extern "C"
+
+int pm_afsk_group_run_plan(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const double *d_bpf, int mb, double *d_bpf_out, double x_bound,
+                           const pm_afsk_sweep_desc *h_sweeps, int nsweeps, int64_t *h_tickets, const pm_bpf8_plan *plan)
+{
     // The demod stage of a whole AFSK chain group in ONE call: the shared band-pass (afsk.py:151) and every certified sweep on its
     // output (afsk.py:153-166, sign bitmaps only), overflow fallback deferred to the caller (pm_afsk_sweep_results).  The same
     // launches pm_fir_valid_i16 + pm_afsk_sweep_signs[_tones] would make -- a pipelined Python host saves nine boundary crossings
@@ -1551,7 +1590,14 @@ int pm_afsk_group_run(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const doub
     static double acc_us[3] = {0, 0, 0};
     static long calls = 0;
     const auto t_0 = std::chrono::steady_clock::now();
-    if (int rc = fir_launch<int16_t>(ctx, d_audio, n, d_bpf, mb, d_bpf_out, nullptr, 0)) return rc;
+    SweepSource src{d_audio, d_bpf, mb, plan ? pm_bpf8_error(plan) : 0.0};
+    if (plan) {
+        PM_ARG(pm_bpf8_taps(plan) == mb);
+        for (int k = 0; k < nsweeps; ++k) PM_ARG(h_sweeps[k].h_tones != nullptr);
+        if (int rc = pm_bpf8_run(ctx, plan, d_audio, n, d_bpf_out)) return rc;
+    } else if (int rc = fir_launch<int16_t>(ctx, d_audio, n, d_bpf, mb, d_bpf_out, nullptr, 0)) {
+        return rc;
+    }
     const auto t_1 = std::chrono::steady_clock::now();
     const bool was = ctx->sweep_deferred;
     ctx->sweep_deferred = true;
@@ -1559,7 +1605,7 @@ int pm_afsk_group_run(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const doub
     for (int k = 0; k < nsweeps && rc == PM_OK; ++k) {
         const pm_afsk_sweep_desc &w = h_sweeps[k];
         rc = sweep_signs(ctx, d_bpf_out, n - mb + 1, x_bound, w.d_mark_i, w.d_mark_q, w.d_unit_i, w.d_unit_q, w.d_space, w.h_gains, w.groups, w.m,
-                         w.d_lpf, w.ml, w.lpf_abs_sum, w.h_bits, w.h_tones);
+                         w.d_lpf, w.ml, w.lpf_abs_sum, w.h_bits, w.h_tones, plan ? &src : nullptr);
         if (h_tickets) h_tickets[k] = ctx->sweep_seq - 1;
     }
     ctx->sweep_deferred = was;
@@ -1574,6 +1620,8 @@ int pm_afsk_group_run(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const doub
     }
     return rc;
 }
+
+extern "C" {
 
 int pm_afsk_sweep_mode(pm_ctx *ctx, int deferred)
 {

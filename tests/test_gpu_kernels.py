@@ -57,6 +57,62 @@ def test_fir_bit_exact(ctx, m):
     assert np.abs(fir_gpu(ctx, xf, h) - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-300)
 
 
+def fir_limbs_gpu(ctx, x, h):
+    dx = ctx.upload(x)
+    hh = np.ascontiguousarray(h, dtype=np.float64)
+    y = ctx.empty(len(x) - len(h) + 1, np.float64)
+    bound = ctypes.c_double(-1.0)
+    chk(L().pm_fir_valid_i16_limbs(ctx.handle, dx.ptr, len(x), hh.ctypes.data, len(h), y.ptr, ctypes.byref(bound)))
+    return y.download(), bound.value
+
+
+@pytest.mark.parametrize("m", [1, 16, 50, 148, 177])
+def test_fir_int8_limbs_within_its_bound(ctx, m):
+    """The band-pass on the int8 matrix pipe (pm_bpf8.hip): exact integer products of quantised taps, so the distance from the
+    reference's sum is the quantisation + a few roundings, and the entry point states it.  Checked against an integer-exact sum
+    (Python ints / float128-free: the taps as exact fractions), against the bit-exact kernel, and on the inputs that stress the
+    digit split: both ends of the int16 range, alternating signs, ragged lengths around the 4096-output workgroups."""
+    from fractions import Fraction
+    rng = np.random.default_rng(900 + m)
+    from pymodem_amd import taps as T
+    h = T.windowed_sinc(m, [900.0, 2500.0], 48000.0, False) if m >= 50 else rng.standard_normal(m) * 0.1      # afsk.py:126-132 / random
+    h = np.asarray(h, np.float64)
+    scale = float(np.abs(h).sum()) * 32768.0
+    cases = []
+    for n in sorted({m, m + 1, m + 255, m + 4095, m + 4096, m + 4097, 3 * 4096 + m + 17, 70001}):
+        cases.append(np.clip(np.rint(rng.standard_normal(n) * 8000), -32768, 32767).astype(np.int16))
+    n = 9000 + m
+    cases += [np.full(n, 32767, np.int16), np.full(n, -32768, np.int16), np.zeros(n, np.int16),
+              np.where(np.arange(n) % 2 == 0, 32767, -32768).astype(np.int16), rng.integers(-32768, 32768, n).astype(np.int16),
+              np.where(np.sign(h[::-1])[np.arange(n) % m] >= 0, 32767, -32768).astype(np.int16)]      # lines up with the taps: the largest sums
+    for x in cases:
+        y, bound = fir_limbs_gpu(ctx, x, h)
+        assert 0.0 < bound <= 1e-11 * scale, (m, bound, scale)
+        ref = O.fir_canon(x, h)
+        assert np.array_equal(fir_gpu(ctx, x, h), ref)
+        assert np.abs(y - ref).max() <= bound, (m, len(x), np.abs(y - ref).max(), bound)
+    # a handful of outputs against exact rational arithmetic: the bound holds against the true sum too (minus the reference's own share)
+    x = cases[-1]
+    y, bound = fir_limbs_gpu(ctx, x, h)
+    hf = [Fraction(float(v)) for v in h]
+    for k in (0, 1, len(y) // 2, len(y) - 1):
+        exact = sum(hf[m - 1 - t] * int(x[k + t]) for t in range(m))
+        assert abs(Fraction(float(y[k])) - exact) <= Fraction(bound), (m, k)
+
+
+def test_fir_int8_limbs_rejects_what_it_cannot_hold(ctx):
+    x = ctx.upload(noise_i16(5000, 3))
+    y = ctx.empty(5000, np.float64)
+    h = np.zeros(178)
+    h[0] = 1.0
+    b = ctypes.c_double()
+    assert L().pm_fir_valid_i16_limbs(ctx.handle, x.ptr, 5000, h.ctypes.data, 178, y.ptr, ctypes.byref(b)) != 0      # more than 177 taps
+    z = np.zeros(8)
+    assert L().pm_fir_valid_i16_limbs(ctx.handle, x.ptr, 5000, z.ctypes.data, 8, y.ptr, ctypes.byref(b)) != 0        # all-zero taps
+    assert L().pm_fir_valid_i16_limbs(ctx.handle, x.ptr, 5, h.ctypes.data, 8, y.ptr, ctypes.byref(b)) != 0            # fewer samples than taps
+    assert L().pm_fir_valid_i16_limbs(ctx.handle, ctypes.c_void_p(x.ptr.value + 2), 4000, h.ctypes.data, 8, y.ptr, ctypes.byref(b)) != 0     # input not 16-byte aligned
+
+
 def test_fir_rejects_bad_arguments(ctx):
     from pymodem_amd import NativeError
     x = ctx.upload(np.zeros(4))
