@@ -203,6 +203,71 @@ int pm_bpf8_run(pm_ctx *ctx, const pm_bpf8_plan *p, const int16_t *d_audio, int6
     return PM_OK;
 }
 
+// ---- the low-pass plan of the certified sweeps (kernel: afsk_slide_lpf8_kernel, pm_fir.hip) ---------------------------------------
+int pm_lpf8_plan_create(pm_ctx *ctx, const double *h_taps, int ml, pm_lpf8_plan **out)
+{
+    PM_CTX(ctx);
+    PM_ARG(h_taps != nullptr && out != nullptr && ml >= 1);
+    *out = nullptr;
+    constexpr int kD = 5, kB = 2;
+    if (ml + 15 > 64 * kB) return pm_set_error(PM_ERR_ARG, "int8 low-pass: %d taps do not fit the %d-column band", ml, 64 * kB);
+    double hmax = 0.0;
+    for (int t = 0; t < ml; ++t) {
+        if (!std::isfinite(h_taps[t])) return pm_set_error(PM_ERR_ARG, "int8 low-pass: tap %d is not finite", t);
+        hmax = std::max(hmax, std::fabs(h_taps[t]));
+    }
+    if (hmax == 0.0) return pm_set_error(PM_ERR_ARG, "int8 low-pass: all taps are zero");
+    int e = 0;
+    (void)std::frexp(hmax, &e);
+    pm_lpf8_plan *p = new pm_lpf8_plan();
+    p->ml = ml;
+    p->S = 38 - e;                                           // |q| <= 2^38: five balanced digits reach +-2^39
+    p->hmax = hmax;
+    p->device = ctx->device;
+    std::vector<int8_t> dig((size_t)kD * ml);
+    for (int t = 0; t < ml; ++t) {
+        const double scaled = std::ldexp(h_taps[t], p->S);
+        const int64_t q = (int64_t)std::llrint(scaled);
+        p->tapq += std::fabs(scaled - (double)q);
+        p->qsum += q;
+        int64_t v = q;
+        for (int b = 0; b < kD; ++b) {
+            const int64_t d = ((v + 128) & 255) - 128;
+            dig[(size_t)b * ml + t] = (int8_t)d;
+            v = (v - d) / 256;
+        }
+        if (v != 0) { delete p; return pm_set_error(PM_ERR_ARG, "int8 low-pass: tap %d does not fit five digits", t); }
+    }
+    p->tapq = std::ldexp(p->tapq, -p->S) * 1.000001;
+    std::vector<int8_t> tab((size_t)kD * kB * 64 * 16, 0);
+    for (int b = 0; b < kD; ++b)
+        for (int kb = 0; kb < kB; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 16; ++i) {
+                    const int c = 64 * kb + 16 * (lane >> 4) + i, idx = c - (lane & 15);
+                    if (idx >= 0 && idx < ml) tab[(((size_t)b * kB + kb) * 64 + lane) * 16 + i] = dig[(size_t)b * ml + (ml - 1 - idx)];
+                }
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc(&p->d_btab, tab.size()) != hipSuccess) {
+        delete p;
+        return pm_set_error(PM_ERR_HIP, "int8 low-pass: no device memory for the band table");
+    }
+    if (hipMemcpy(p->d_btab, tab.data(), tab.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(p->d_btab);
+        delete p;
+        return pm_set_error(PM_ERR_HIP, "int8 low-pass: copying the band table failed");
+    }
+    *out = p;
+    return PM_OK;
+}
+
+void pm_lpf8_plan_destroy(pm_lpf8_plan *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->d_btab) (void)hipFree(p->d_btab);
+    delete p;
+}
+
 extern "C" int pm_fir_valid_i16_limbs(pm_ctx *ctx, const int16_t *d_x, int64_t n, const double *h_taps, int m, double *d_y, double *h_bound)
 {
     pm_bpf8_plan *p = nullptr;

@@ -87,9 +87,22 @@ void pm_bpf8_plan_destroy(pm_bpf8_plan *p);
 double pm_bpf8_error(const pm_bpf8_plan *p);
 int pm_bpf8_taps(const pm_bpf8_plan *p);
 int pm_bpf8_run(pm_ctx *ctx, const pm_bpf8_plan *p, const int16_t *d_audio, int64_t n, double *d_y);      // d_audio 16-byte aligned
-// pm_afsk_group_run with the band-pass from a plan (nullptr: the reference's sum); every sweep must then carry tones
+// The certified sweeps' low-pass on the same pipe (afsk_slide_lpf8_kernel in pm_fir.hip): taps as five signed base-256 digits
+// q = rint(h 2^S), the Toeplitz band as MFMA B operands [digit][block][lane] on the device.  ml <= 113.
+struct pm_lpf8_plan {
+    int ml = 0, S = 0, device = 0;
+    long long qsum = 0;              // sum of the quantised taps
+    double tapq = 0;                 // sum |h - q 2^-S|
+    double hmax = 0;
+    void *d_btab = nullptr;
+};
+int pm_lpf8_plan_create(pm_ctx *ctx, const double *h_taps, int ml, pm_lpf8_plan **out);
+void pm_lpf8_plan_destroy(pm_lpf8_plan *p);
+// pm_afsk_group_run with the band-pass from a plan (nullptr: the reference's sum); every sweep must then carry tones.
+// lpf8: nullptr or one plan per sweep (entries may be nullptr): that sweep's low-passes on the matrix pipe
 int pm_afsk_group_run_plan(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const double *d_bpf, int mb, double *d_bpf_out, double x_bound,
-                           const pm_afsk_sweep_desc *h_sweeps, int nsweeps, int64_t *h_tickets, const pm_bpf8_plan *plan);
+                           const pm_afsk_sweep_desc *h_sweeps, int nsweeps, int64_t *h_tickets, const pm_bpf8_plan *plan,
+                           const pm_lpf8_plan *const *lpf8 = nullptr);
 
 // ---- launchers shared between translation units (what the batch engine pm_loopbatch.hip strings together) ---------------------
 // `rows` FIRs with the same taps over equal-length streams in one launch (pm_fir.hip).  Input row r: d_x + r * x_stride, or

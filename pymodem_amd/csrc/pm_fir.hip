@@ -16,6 +16,8 @@
 // the global stores are coalesced (lane-contiguous 8 B).
 #include "pm_common.h"
 #include <chrono>
+#include <cmath>
+#include <vector>
 #include <type_traits>
 #include <algorithm>
 #include <cstdlib>
@@ -38,6 +40,7 @@ __host__ __device__ __forceinline__ int slot(int p) { return p + p / R; }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 typedef double double2v __attribute__((ext_vector_type(2)));
+typedef int int4v __attribute__((ext_vector_type(4)));
 typedef short short8v __attribute__((ext_vector_type(8)));
 
 // Stage inputs [tile0, tile0 + span) of x into the padded LDS image, 16 bytes per global load.  Input pairs (f64) / octets
@@ -915,6 +918,172 @@ __global__ __launch_bounds__(kThreads) void afsk_slide_lpf_kernel(const double *
     sweep_combine<R, ONE>(a, b, go, nout, G, P, E, list, count, cap);
 }
 
+// The same kernel with its low-passes on the int8 matrix pipe (v_mfma_i32_16x16x64_i8; the band-pass went there first: pm_bpf8.hip).
+// The low-pass sums are 2/3 of afsk_slide_lpf_kernel's vector instructions and feed nothing but the certified decision, and the int8
+// MFMA is the one matrix instruction that was measured to run BESIDE vector f64 work (tools/ubench/mfma_i8.hip).  So: the magnitudes a
+// run leaves in registers are rounded to 32-bit integers (scale 2^s from the caller's bound on x: quantum 2^-s <= bound 2^-31) and
+// written as four planes of signed base-256 digits; the taps come as five digits (pm_lpf8_plan: |h - q 2^-S| <= hmax 2^-38); a tile of
+// 256 outputs is  out[16 i + j] = sum_c A[i][c] B[c][j],  A[i][c] = digit plane [tile + 16 i + c] (one ds_read_b128 per lane),
+// B = the Toeplitz band of a tap digit -- 2 blocks x 4 x 5 digit pairs = 40 MFMA per stream and tile, eight int32 sums by weight
+// a + b, recombined in binary64 (pairs first: |W_w + 256 W_(w+1)| < 2^31).  The integer sums are exact, so what separates the value
+// from the reference's low-pass output is  sum|h| * quantum/2  +  sum|h - q 2^-S| * max magnitude  + a few roundings, all of which
+// sweep_signs adds to E.  Lane (r, g) of a tile holds outputs 64 g + 16 v + r, v = 0..3: sign and bound tests become four ballots
+// per modem, and the tile's four bitmap words are put together from their 16-bit pieces.
+constexpr int kL8Plane = 2176;           // bytes of a digit plane: 2048 outputs + (ml - 1 <= 112) + what the last tile's band reads beyond
+struct Lpf8Args {
+    double scale;                        // 2^s
+    double wgt[4];                       // 2^(16 p - S - s)
+    double c0;                           // the digits' offsets: (128 (2^32 - 1) / 255 [- 2^31]) sum q 2^-(S + s)
+    const int4v *btab;
+};
+
+template <bool ONE>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void afsk_slide_lpf8_kernel(const double *__restrict__ x, int64_t n, const double *__restrict__ mi,
+                                                                   const double *__restrict__ mq, const double *__restrict__ ui,
+                                                                   const double *__restrict__ uq, int m, SlideTones T, Lpf8Args Q, int ml,
+                                                                   int64_t nout, int G, SweepArgs P, double E, unsigned long long *__restrict__ list,
+                                                                   int *__restrict__ count, int cap, int region0)
+{
+    extern __shared__ double xs[];
+    constexpr int L = kFuseRun, TILE = kThreads * 8;
+    const int t = threadIdx.x;
+    const int64_t tile0 = (int64_t)blockIdx.x * TILE;
+    const int nmag = TILE + ml - 1, nruns = (nmag + L - 1) / L, xspan = nruns * L + m - 1;
+    double *tp = xs + region0;
+    if (((uintptr_t)x & 15) == 0 && tile0 + TILE <= n) {
+        double2v v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const double2v *>(x + tile0 + 2 * (q * kThreads + t));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int s0 = slide_slot<L>(2 * (q * kThreads + t));
+            xs[s0] = v[q].x;
+            xs[s0 + 1] = v[q].y;
+        }
+        for (int p = TILE + t; p < xspan; p += kThreads) {
+            const int64_t gi = tile0 + p;
+            xs[slide_slot<L>(p)] = gi < n ? x[gi] : 0.0;
+        }
+    } else {
+        for (int p = t; p < xspan; p += kThreads) {
+            const int64_t gi = tile0 + p;
+            xs[slide_slot<L>(p)] = gi < n ? x[gi] : 0.0;
+        }
+    }
+    for (int i = t; i < m; i += kThreads) {
+        tp[4 * i + 0] = mi[m - 1 - i];
+        tp[4 * i + 1] = mq[m - 1 - i];
+        tp[4 * i + 2] = ui[m - 1 - i];
+        tp[4 * i + 3] = uq[m - 1 - i];
+    }
+    lds_barrier();
+    double mv[L], sv[L];
+    if (t < nruns) slide_run<L>(xs, tp, t, m, T, mv, sv);
+    lds_barrier();                                           // every lane is done with the window of x: the planes take its place
+    unsigned char *planes = reinterpret_cast<unsigned char *>(xs);
+    if (t < nruns) {
+        static_assert(L % 4 == 0, "four magnitudes per plane word");
+        const double g0 = P.gain[0];
+        auto put = [&](const double (&val)[L], int stream) {
+#pragma unroll
+            for (int q = 0; q < L / 4; ++q) {
+                unsigned w[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double sc = __builtin_fma(val[4 * q + i], Q.scale, 0.5);
+                    w[i] = ONE ? (unsigned)(int)sc ^ 0x00808080u : (unsigned)sc ^ 0x80808080u;      // digits of the offset value, each minus 128
+                }
+                const unsigned lo01 = __builtin_amdgcn_perm(w[1], w[0], 0x05010400u), lo23 = __builtin_amdgcn_perm(w[3], w[2], 0x05010400u);
+                const unsigned hi01 = __builtin_amdgcn_perm(w[1], w[0], 0x07030602u), hi23 = __builtin_amdgcn_perm(w[3], w[2], 0x07030602u);
+                unsigned char *at = planes + (size_t)stream * 4 * kL8Plane + L * t + 4 * q;
+                *reinterpret_cast<unsigned *>(at) = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u);
+                *reinterpret_cast<unsigned *>(at + kL8Plane) = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);
+                *reinterpret_cast<unsigned *>(at + 2 * kL8Plane) = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u);
+                *reinterpret_cast<unsigned *>(at + 3 * kL8Plane) = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
+            }
+        };
+        if (ONE) {
+#pragma unroll
+            for (int i = 0; i < L; ++i) mv[i] = __builtin_fma(-g0, sv[i], mv[i]);       // afsk.py:162 on the approximate magnitudes
+            put(mv, 0);
+        } else {
+            put(mv, 0);
+            put(sv, 1);
+        }
+    }
+    const int lane = t & 63, wave = t >> 6, r = lane & 15, g4 = lane >> 4;
+    // the band operands (5 digits x 2 blocks x 64 lanes x 16 bytes) behind the templates: in registers they cost 40 per lane and a wave
+    // of occupancy
+    int4v *bl = reinterpret_cast<int4v *>(tp + 4 * m);
+    for (int i = t; i < 10 * 64; i += kThreads) bl[i] = Q.btab[i];
+    lds_barrier();
+    const int64_t nout64 = ((nout + 63) >> 6) * 64;
+#pragma unroll 1
+    for (int q = 0; q < 2; ++q) {
+        const int tl = (wave * 2 + q) * 256;
+        const int64_t go = tile0 + tl;
+        if (go >= nout64) break;
+        double a[4], b[4];
+#pragma unroll
+        for (int stream = 0; stream < (ONE ? 1 : 2); ++stream) {
+            int4v acc[8];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) acc[w] = int4v{0, 0, 0, 0};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const unsigned char *at = planes + (size_t)stream * 4 * kL8Plane + tl + 16 * r + 64 * kb + 16 * g4;
+                int4v d[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d[i] = *reinterpret_cast<const int4v *>(at + i * kL8Plane);
+#pragma unroll
+                for (int bb = 0; bb < 5; ++bb) {
+                    const int4v band = bl[(bb * 2 + kb) * 64 + lane];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i + bb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(d[i], band, acc[i + bb], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                double val = Q.c0;
+#pragma unroll
+                for (int pq = 0; pq < 4; ++pq) val = __builtin_fma((double)(acc[2 * pq][v] + acc[2 * pq + 1][v] * 256), Q.wgt[pq], val);
+                if (stream == 0) a[v] = val; else b[v] = val;
+            }
+            __builtin_amdgcn_sched_barrier(0);               // one stream after the other: interleaved they keep 64 accumulators alive
+        }
+        // lane (r, g4) holds outputs go + 64 g4 + 16 v + r
+        const int64_t left = nout - go - (64 * g4 + r);
+        const int lim = left > 1024 ? 1024 : (int)left;          // output v is inside the stream iff 16 v < lim
+        unsigned long long in[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) in[v] = __ballot(16 * v < lim);
+        for (int g = 0; g < G; ++g) {
+            const double mg = -P.gain[g];
+            double y[4];
+            unsigned long long pos[4], uns = 0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                y[v] = ONE ? a[v] : __builtin_fma(mg, b[v], a[v]);
+                pos[v] = __ballot(y[v] >= 0.0) & in[v];
+                uns |= ~__ballot(fabs(y[v]) > E) & in[v];                     // cannot be certified (NaN lands here too)
+            }
+            const int sh = 16 * (lane & 3);
+            const unsigned lo = ((unsigned)(pos[0] >> sh) & 0xFFFFu) | ((unsigned)(pos[1] >> sh) << 16);
+            const unsigned hi = ((unsigned)(pos[2] >> sh) & 0xFFFFu) | ((unsigned)(pos[3] >> sh) << 16);
+            if (lane < 4 && go + 64 * lane < nout64)
+                reinterpret_cast<unsigned long long *>(P.bits[g])[(go >> 6) + lane] = (unsigned long long)lo | ((unsigned long long)hi << 32);
+            if (uns) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (16 * v < lim && !(fabs(y[v]) > E)) {
+                        const int idx = atomicAdd(count, 1);
+                        if (idx < cap) list[idx] = ((unsigned long long)g << 48) | (unsigned long long)(go + 64 * g4 + 16 * v + r);
+                    }
+            }
+        }
+    }
+}
+
 // The exact chain for single samples: correlator bank of modem g at the ml positions the low-pass needs, then the low-pass, every
 // sum in the canonical order of afsk_correlate_kernel / fir_valid_kernel.  Runs after fir_sweep_kernel (its bitmap bytes are final).
 // AUDIO: the band-passed stream the sweep saw was itself a value with a bound (pm_bpf8.hip), so the recomputation starts one stage
@@ -948,6 +1117,7 @@ __global__ __launch_bounds__(64) void sweep_exact_kernel(const double *__restric
     for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
         const int g = (int)(list[e] >> 48);
         const int64_t k = (int64_t)(list[e] & 0xFFFFFFFFFFFFull);
+        if (g >= kSweepMax || P.bits[g] == nullptr) continue;                    // not an entry of this sweep (cannot happen: see sweep_signs)
         const double *si = space + (size_t)g * 2 * mc, *sq = si + mc;
         if (AUDIO) {
             double *xw = dd + ml;
@@ -1363,13 +1533,17 @@ static int afsk_magnitudes(pm_ctx *ctx, const double *d_x, int64_t n, double x_b
 static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound, const double *d_mark_i, const double *d_mark_q,
                        const double *d_unit_i, const double *d_unit_q, const double *d_space, const double *h_gains, int groups, int m,
                        const double *d_lpf, int ml, double lpf_abs_sum, uint64_t *const *h_bits, const pm_afsk_tones *tones,
-                       const SweepSource *src = nullptr)
+                       const SweepSource *src = nullptr, const pm_lpf8_plan *lpf8 = nullptr)
 {
     PM_CTX(ctx);
     PM_ARG(d_x && d_mark_i && d_mark_q && d_unit_i && d_unit_q && d_space && h_gains && d_lpf && h_bits);
     // a band-passed stream that is only near the reference's: certified decisions with the deferred fallback only (the gated exact
     // launches below read d_x), and the exact recomputation goes back to the audio
     PM_ARG(!src || (src->audio && src->bpf && src->mb >= 1 && src->e_x >= 0.0 && src->e_x < 1e-6 * x_bound && ctx->sweep_deferred && tones));
+    // everything that can refuse the call is checked before the counter ring moves on: a sweep that takes its slot and then launches
+    // nothing leaves the NEXT sweep's slot uncleared (each sweep's last launch clears it), and that sweep would start from whatever
+    // count the slot held 64 sweeps ago -- up to 65536 stale list entries to "recompute"
+    PM_ARG(!tones || (tones->tap_dev >= 0.0 && tones->tap_dev < 1e-6));
     PM_ARG(groups >= 1 && groups <= kSweepMax && m >= 1 && m <= kMaxTaps && ml >= 1 && ml <= kMaxTaps);
     PM_ARG(x_bound > 0.0 && x_bound < 1e300 && lpf_abs_sum > 0.0 && lpf_abs_sum < 1e300);
     PM_ARG(n >= (int64_t)m + ml - 1);
@@ -1407,6 +1581,11 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
     int *mail = ctx->sweep_deferred ? ctx->h_sweep + (ctx->sweep_seq % kSweepRing) : nullptr;
     ctx->sweep_mail[ctx->sweep_seq % kSweepRing] = mail ? ctx->sweep_seq + 1 : 0;
     ctx->sweep_seq++;
+    // a sweep that fails from here on has not run its last launch: the next sweep's counter is cleared by hand
+    struct RingGuard {
+        hipStream_t st; int *next; bool ok;
+        ~RingGuard() { if (!ok) (void)hipMemsetAsync(next, 0, sizeof(int), st); }
+    } ring{ctx->stream, count_next, false};
     double *d_w = (double *)(base + 2 * b_m + b_a + b_list + 256);
     double *C = (double *)(base + 2 * b_m + b_a + b_list + 256 + b_w);
     ctx->sweep_count = count;
@@ -1434,8 +1613,61 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
         // bound is stated for inputs up to x_bound, which the approximate stream exceeds by at most e_x
         e_slide = e_slide * (1.0 + src->e_x / x_bound) + 1.4143 * m * src->e_x;
     }
-    const double E = 1e-10 * lpf_abs_sum * (1.0 + gmax) * (double)m * 1.4143 * x_bound + lpf_abs_sum * (1.0 + gmax) * e_slide;
-    if (fused) {
+    double E = 1e-10 * lpf_abs_sum * (1.0 + gmax) * (double)m * 1.4143 * x_bound + lpf_abs_sum * (1.0 + gmax) * e_slide;
+    // Low-passes on the int8 matrix pipe (afsk_slide_lpf8_kernel): a per-call plan for tests and measurements (PM_AFSK_LPF8=1), the
+    // pipeline's own otherwise
+    pm_lpf8_plan *own8 = nullptr;
+    if (fused && !lpf8 && frun == kFuseRun && ml + 15 <= 128) {
+        const char *e8 = getenv("PM_AFSK_LPF8");
+        if (e8 && e8[0] == '1') {
+            std::vector<double> hl((size_t)ml);
+            PM_HIP(hipMemcpyAsync(hl.data(), d_lpf, hl.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            PM_HIP(hipStreamSynchronize(ctx->stream));
+            if (int rc = pm_lpf8_plan_create(ctx, hl.data(), ml, &own8)) return rc;
+            lpf8 = own8;
+        }
+    }
+    struct Own8 { pm_ctx *c; pm_lpf8_plan *p; ~Own8() { if (p) { (void)hipStreamSynchronize(c->stream); pm_lpf8_plan_destroy(p); } } } own8_guard{ctx, own8};
+    if (fused && lpf8 && frun == kFuseRun && lpf8->ml == ml && ml + 15 <= 128) {
+        PM_ARG(tones->tap_dev >= 0.0 && tones->tap_dev < 1e-6);
+        SlideTones T{tones->mark_rot[0], tones->mark_rot[1], tones->mark_end[0], tones->mark_end[1],
+                     tones->space_rot[0], tones->space_rot[1], tones->space_end[0], tones->space_end[1]};
+        // the largest magnitude (sliding value, so its bound on top), and for one chain the largest |M - g S|
+        const double mb = 1.4143 * m * x_bound * 1.000001 + e_slide, top = one ? std::max(1.0, P.gain[0]) * mb : mb;
+        int et = 0;
+        (void)std::frexp(top, &et);                          // top < 2^et
+        const int s2 = (one ? 31 : 32) - et;                 // |value| 2^s2 < 2^31 resp. 2^32
+        Lpf8Args Q;
+        Q.scale = std::ldexp(1.0, s2);
+        for (int pq = 0; pq < 4; ++pq) Q.wgt[pq] = std::ldexp(1.0, 16 * pq - lpf8->S - s2);
+        const long double off = one ? 2155905152.0L - 2147483648.0L : 2155905152.0L;      // 128 (2^32 - 1) / 255 [- 2^31]
+        Q.c0 = (double)std::ldexp(off * (long double)lpf8->qsum, -(lpf8->S + s2));
+        Q.btab = (const int4v *)lpf8->d_btab;
+        // on top of E: the magnitudes' quantum (half a unit; one chain: truncation of a signed value, a whole unit), the taps' quantisation
+        // times the largest value, and the roundings of c0 and of the four recombining fma (terms below 8.1 ml hmax top, see pm_bpf8.hip)
+        const double u = 1.1102230246251565e-16;
+        const double quantum = (one ? 1.0 : 0.5) / Q.scale;
+        const double extra = lpf_abs_sum * quantum + lpf8->tapq * top + 16.0 * u * (std::fabs(Q.c0) + 8.1 * ml * lpf8->hmax * top);
+        E += (one ? 1.0 : 1.0 + gmax) * extra * 1.000001;
+        const int64_t ntiles = pm_cdiv(nl, (int64_t)kThreads * 8);
+        PM_ARG(ntiles < (1LL << 31));
+        const int nmag = kThreads * 8 + ml - 1, nruns = (nmag + kFuseRun - 1) / kFuseRun, pspan = nruns * kFuseRun + m - 1;
+        const size_t xdoubles = (size_t)pspan + pspan / kFuseRun + 2, pdoubles = (size_t)(one ? 4 : 8) * kL8Plane / 8;
+        const int region0 = (int)((std::max(xdoubles, pdoubles) + 1) / 2 * 2);
+        const size_t lds = ((size_t)region0 + 4 * (size_t)m) * sizeof(double) + 10 * 64 * 16;      // x window | planes, templates, band operands
+        PmProf prof(ctx, PM_K_FIR_F64);
+        const double nlp = one ? 1.0 : 2.0;
+        prof.work((double)n * 8 + (double)groups * nl / 8,
+                  (4.0 * m / kFuseRun + 18.0) * (double)nc + nlp * 2.0 * ml * (double)nl + 2.0 * groups * (double)nl);
+        auto go8 = [&](auto kernel) -> int {
+            if (int rc = allow_lds(kernel, lds)) return rc;
+            hipLaunchKernelGGL(kernel, dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, d_x, n, d_mark_i, d_mark_q, d_unit_i, d_unit_q, m, T,
+                               Q, ml, nl, groups, P, E, list, count, cap, region0);
+            return PM_OK;
+        };
+        if (int rc = one ? go8(afsk_slide_lpf8_kernel<true>) : go8(afsk_slide_lpf8_kernel<false>)) return rc;
+        PM_HIP(hipGetLastError());
+    } else if (fused) {
         PM_ARG(tones->tap_dev >= 0.0 && tones->tap_dev < 1e-6);
         SlideTones T{tones->mark_rot[0], tones->mark_rot[1], tones->mark_end[0], tones->mark_end[1],
                      tones->space_rot[0], tones->space_rot[1], tones->space_end[0], tones->space_end[1]};
@@ -1491,7 +1723,7 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
     // Deferred fallback: the caller looks at the counter once the sweep has finished (pm_afsk_sweep_result) and runs the exact
     // chains itself in the (degenerate) overflow case; the three gated launches below -- which in the normal case only look at
     // the counter and leave, but cost the demod stream three dispatches per sweep -- are not enqueued.
-    if (ctx->sweep_deferred) return PM_OK;
+    if (ctx->sweep_deferred) { ring.ok = true; return PM_OK; }
     // More uncertain samples than the list holds (degenerate input: silence, amplitudes far below the caller's bound): the exact
     // chain of every modem runs after all -- the same launches as pm_afsk_correlate_group + pm_fir_signs_f64_batch, each workgroup
     // of which first looks at the counter and leaves at once in the normal case.  No host round trip either way.
@@ -1523,6 +1755,7 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
         }
     }
     PM_HIP(hipGetLastError());
+    ring.ok = true;
     return PM_OK;
 }
 
@@ -1572,13 +1805,14 @@ int pm_afsk_sweep_last(pm_ctx *ctx, int64_t *h_uncertain)
 int pm_afsk_group_run(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const double *d_bpf, int mb, double *d_bpf_out, double x_bound,
                       const pm_afsk_sweep_desc *h_sweeps, int nsweeps, int64_t *h_tickets)
 {
-    return pm_afsk_group_run_plan(ctx, d_audio, n, d_bpf, mb, d_bpf_out, x_bound, h_sweeps, nsweeps, h_tickets, nullptr);
+    return pm_afsk_group_run_plan(ctx, d_audio, n, d_bpf, mb, d_bpf_out, x_bound, h_sweeps, nsweeps, h_tickets, nullptr, nullptr);
 }
 
 }  // extern "C"
 
 int pm_afsk_group_run_plan(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const double *d_bpf, int mb, double *d_bpf_out, double x_bound,
-                           const pm_afsk_sweep_desc *h_sweeps, int nsweeps, int64_t *h_tickets, const pm_bpf8_plan *plan)
+                           const pm_afsk_sweep_desc *h_sweeps, int nsweeps, int64_t *h_tickets, const pm_bpf8_plan *plan,
+                           const pm_lpf8_plan *const *lpf8)
 {
     // The demod stage of a whole AFSK chain group in ONE call: the shared band-pass (afsk.py:151) and every certified sweep on its
     // output (afsk.py:153-166, sign bitmaps only), overflow fallback deferred to the caller (pm_afsk_sweep_results).  The same
@@ -1605,7 +1839,7 @@ int pm_afsk_group_run_plan(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const
     for (int k = 0; k < nsweeps && rc == PM_OK; ++k) {
         const pm_afsk_sweep_desc &w = h_sweeps[k];
         rc = sweep_signs(ctx, d_bpf_out, n - mb + 1, x_bound, w.d_mark_i, w.d_mark_q, w.d_unit_i, w.d_unit_q, w.d_space, w.h_gains, w.groups, w.m,
-                         w.d_lpf, w.ml, w.lpf_abs_sum, w.h_bits, w.h_tones, plan ? &src : nullptr);
+                         w.d_lpf, w.ml, w.lpf_abs_sum, w.h_bits, w.h_tones, plan ? &src : nullptr, lpf8 ? lpf8[k] : nullptr);
         if (h_tickets) h_tickets[k] = ctx->sweep_seq - 1;
     }
     ctx->sweep_deferred = was;

@@ -71,6 +71,8 @@ struct pm_pipe {
     pm_ctx *ctx = nullptr;               // the caller's context: the first demod stream
     std::vector<pm_ctx *> demod;         // demod streams, recordings take turns (demod[0] == ctx, the others are the pipeline's)
     std::vector<double *> d_bpf_outs;    // one band-passed stream per demod context
+    pm_bpf8_plan *bpf8 = nullptr;        // the band-pass on the int8 matrix pipe (every sweep certified, <= 177 taps; PM_PIPE_BPF8=0: off)
+    std::vector<pm_lpf8_plan *> lpf8;    // per sweep: its low-pass there too (tones, <= 113 taps; PM_PIPE_LPF8=0: off), else nullptr
     std::vector<hipEvent_t> handover;    // per slot: the point of the caller's stream a recording submitted to another demod stream starts behind
     std::vector<pm_ctx *> side;          // slicer streams, one per worker
     int nchains = 0, nsweeps = 0, slots = 16, group = 4, min_group = 4, host_threads = 3, decode_threads = 8;
@@ -474,6 +476,8 @@ int pm_pipe_destroy(pm_pipe *p)
     for (size_t i = 1; i < p->demod.size(); ++i) (void)pm_ctx_sync(p->demod[i]);
     for (double *b : p->d_bpf_outs)
         if (b) (void)pm_free(ctx, b);
+    pm_bpf8_plan_destroy(p->bpf8);
+    for (pm_lpf8_plan *q : p->lpf8) pm_lpf8_plan_destroy(q);
     for (size_t i = 1; i < p->demod.size(); ++i) (void)pm_ctx_destroy(p->demod[i]);
     for (hipEvent_t e : p->handover)
         if (e) (void)hipEventDestroy(e);
@@ -558,6 +562,33 @@ int pm_pipe_create(pm_ctx *ctx, const pm_pipe_desc *desc, pm_pipe **out)
         }
         for (int k = 0; k < nd && !rc; ++k)
             if (!(rc = pm_malloc(ctx, (size_t)nb * sizeof(double), &q))) p->d_bpf_outs.push_back((double *)q);
+        if (rc) break;
+        {
+            // every consumer of the band-passed stream is a certified sweep: it may be a value with a bound (pm_bpf8.hip)
+            bool all = true;
+            for (int s = 0; s < d.nsweeps; ++s) all = all && p->has_tones[s];
+            const char *e = getenv("PM_PIPE_BPF8");
+            if (all && d.mb + 15 <= 192 && !(e && e[0] == '0')) {
+                std::vector<double> h((size_t)d.mb);
+                if (hipMemcpy(h.data(), d.d_bpf, h.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+                    rc = pm_set_error(PM_ERR_HIP, "pm_pipe_create: reading the band-pass taps back failed");
+                else
+                    rc = pm_bpf8_plan_create(ctx, h.data(), d.mb, &p->bpf8);
+            }
+        }
+        p->lpf8.assign(d.nsweeps, nullptr);
+        {
+            const char *e = getenv("PM_PIPE_LPF8");
+            for (int s = 0; s < d.nsweeps && !rc && !(e && e[0] == '0'); ++s) {
+                const pm_afsk_sweep_desc &w = p->sweeps[s];
+                if (!p->has_tones[s] || w.ml + 15 > 128 || w.m < 2) continue;
+                std::vector<double> h((size_t)w.ml);
+                if (hipMemcpy(h.data(), w.d_lpf, h.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+                    rc = pm_set_error(PM_ERR_HIP, "pm_pipe_create: reading the low-pass taps back failed");
+                else
+                    rc = pm_lpf8_plan_create(ctx, h.data(), w.ml, &p->lpf8[s]);
+            }
+        }
         if (rc) break;
         p->bits_words = (size_t)(d.max_samples + 63) / 64 + 2;
         p->d_bits.assign((size_t)p->slots * d.nchains, nullptr);
@@ -647,7 +678,9 @@ int pm_pipe_submit(pm_pipe *p, const int16_t *d_audio, int64_t n, int64_t *h_tic
         if (hipEventRecord(p->handover[r->slot], p->ctx->stream) != hipSuccess || hipStreamWaitEvent(r->dctx->stream, p->handover[r->slot], 0) != hipSuccess)
             rc = pm_set_error(PM_ERR_HIP, "handing the recording to demod stream %zu failed", di);
     }
-    if (!rc) rc = pm_afsk_group_run(r->dctx, d_audio, n, p->d_bpf, p->mb, p->d_bpf_outs[di], p->x_bound, sw.data(), p->nsweeps, r->sweep_tickets.data());
+    if (!rc)
+        rc = pm_afsk_group_run_plan(r->dctx, d_audio, n, p->d_bpf, p->mb, p->d_bpf_outs[di], p->x_bound, sw.data(), p->nsweeps, r->sweep_tickets.data(),
+                                    ((uintptr_t)d_audio & 15) == 0 ? p->bpf8 : nullptr, p->lpf8.data());
     if (!rc && hipEventRecord(p->slot_event[r->slot], r->dctx->stream) != hipSuccess) rc = pm_set_error(PM_ERR_HIP, "hipEventRecord failed");
     r->demod_done = p->slot_event[r->slot];
     if (rc) {

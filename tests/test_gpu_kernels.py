@@ -702,7 +702,7 @@ def _sweep(ctx, x, x_bound, mark, unit, gains, lpf, sliding=False):
     return out, redo.value, space
 
 
-@pytest.mark.parametrize("sliding", [False, True, "unfused"])
+@pytest.mark.parametrize("sliding", [False, True, "unfused", "lpf8"])
 def test_afsk_gain_sweep_signs_are_the_exact_chain_s(ctx, sliding, monkeypatch):
     """pm_afsk_sweep_signs / pm_afsk_sweep_signs_tones (sliding correlator sums, fused with the low-passes or not): bitmaps of a space_gain sweep from ONE unit space correlator pair and two low-passes, certified against
     the exact chain -- every bit must equal pm_afsk_correlate + pm_fir_signs_f64 with that modem's own (gain-scaled) taps, on an
@@ -711,6 +711,8 @@ def test_afsk_gain_sweep_signs_are_the_exact_chain_s(ctx, sliding, monkeypatch):
     from pymodem_amd import taps as T
     if sliding == "unfused":           # sliding sums, low-passes and combine as three kernels (the path long filters fall back to)
         monkeypatch.setenv("PM_AFSK_UNFUSED", "1")
+    if sliding == "lpf8":              # the fused kernel with its low-passes as int8 digit products on the matrix pipe (what pm_pipe_* runs)
+        monkeypatch.setenv("PM_AFSK_LPF8", "1")
     rng = np.random.default_rng(1200)
     mi, mq, ui, uq = T.afsk_tone_correlators(48000.0, 1200.0, 1300.0, 2100.0, 1.0, 1.5, 0.0)
     lpf = T.windowed_sinc(100, 900.0, 48000.0, pass_zero=True)
@@ -774,7 +776,7 @@ def test_sliding_correlator_sums_stay_within_their_bound(ctx, rate, baud, mark, 
         assert worst <= e.value / 8.0, (n, amp, worst, e.value)
 
 
-@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("fused", [True, False, "lpf8"])
 @pytest.mark.parametrize("gain", [1.0, 2.25])
 @pytest.mark.parametrize("rate,baud,mark,space,span", [(48000.0, 1200.0, 1600.0, 1800.0, 1.0), (8000.0, 300.0, 1600.0, 1800.0, 1.0)])
 def test_one_chain_certified_signs_are_the_exact_chain_s(ctx, rate, baud, mark, space, span, gain, fused, monkeypatch):
@@ -783,6 +785,8 @@ def test_one_chain_certified_signs_are_the_exact_chain_s(ctx, rate, baud, mark, 
     from pymodem_amd import taps as T
     if not fused:
         monkeypatch.setenv("PM_AFSK_UNFUSED", "1")
+    if fused == "lpf8":
+        monkeypatch.setenv("PM_AFSK_LPF8", "1")
     rng = np.random.default_rng(int(rate + 10 * gain))
     mi, mq, ui, uq = T.afsk_tone_correlators(rate, baud, mark, space, 1.0, span, 0.0)
     lpf = T.windowed_sinc(round(rate * 2.5 / baud) | 1, 0.75 * baud, rate, pass_zero=True)
@@ -795,6 +799,39 @@ def test_one_chain_certified_signs_are_the_exact_chain_s(ctx, rate, baud, mark, 
         want = _exact_afsk_signs(ctx, x, (mi, mq), (space_taps[0, 0], space_taps[0, 1]), lpf)
         assert np.array_equal(got[0], want), (name, int(np.count_nonzero(got[0] != want)), redo)
         assert redo > 65536 if name == "silence" else (redo <= 65536 or name == "quiet"), (name, redo)
+
+
+def test_refused_sweep_leaves_no_stale_counter_behind(ctx):
+    """The counters of uncertain samples live in a ring of 64; a sweep's last launch clears the NEXT slot.  A call that took its slot
+    and was then refused launched nothing, and the sweep after it started from what its slot held 64 sweeps earlier -- up to 65536
+    stale list entries handed to the exact recomputation (found as a GPU fault when the test order changed).  Refusals are now
+    decided before the ring moves, and a sweep that fails later clears the next slot by hand: every third sweep here is refused,
+    every third leaves a large count, and the ones in between must stay exact and report their own count, all the way round the ring."""
+    from pymodem_amd import NativeError
+    from pymodem_amd import taps as T
+    mi, mq, ui, uq = T.afsk_tone_correlators(48000.0, 1200.0, 1300.0, 2100.0, 1.0, 1.5, 0.0)
+    lpf = T.windowed_sinc(100, 900.0, 48000.0, pass_zero=True)
+    rng = np.random.default_rng(64)
+    x = 3000.0 * rng.standard_normal(12000)
+    z = np.zeros(12000)
+    want = None
+    bad = _tones((mi, mq), (ui, uq))
+    bad.tap_dev = 1e-3
+    for it in range(70):
+        got, redo, space = _sweep(ctx, z, 4.0e4, (mi, mq), (ui, uq), [1.5], lpf, sliding=True)          # nothing certifiable: a large count
+        assert redo > 10000 and got[0].all()
+        dx, dl = ctx.upload(x), ctx.upload(lpf)
+        t = [ctx.upload(v) for v in (mi, mq, ui, uq)]
+        ds = ctx.upload(np.stack([1.5 * ui, 1.5 * uq]).reshape(-1))
+        bits = ctx.empty(len(x) // 64 + 2, np.uint64)
+        args = (ctx.handle, dx.ptr, len(x), 4.0e4, t[0].ptr, t[1].ptr, t[2].ptr, t[3].ptr, ds.ptr, (ctypes.c_double * 1)(1.5), 1, len(mi), dl.ptr,
+                len(lpf), float(np.abs(lpf).sum()), (ctypes.c_void_p * 1)(bits.ptr.value))
+        with pytest.raises(NativeError):
+            chk(L().pm_afsk_sweep_signs_tones(*args, ctypes.byref(bad)))                                  # refused
+        got, redo, space = _sweep(ctx, x, 4.0e4, (mi, mq), (ui, uq), [1.5], lpf, sliding=True)
+        if want is None:
+            want = _exact_afsk_signs(ctx, x, (mi, mq), (space[0, 0], space[0, 1]), lpf)
+        assert redo < 100 and np.array_equal(got[0], want), (it, redo)
 
 
 def test_sweep_tones_rejects_templates_that_are_not_tones(ctx):
