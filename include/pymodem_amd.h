@@ -541,7 +541,7 @@ typedef struct pm_pipe_desc {
     int32_t slice_group;             /* most recordings per slicer batch (0 = 4) */
     int32_t slice_min_group;         /* a batch waits for this many recordings while later ones are queued (0 = slice_group) */
     int32_t demod_streams;           /* recordings take turns on this many demod streams: the context's own and further ones of the
-                                        pipeline's, each with its own band-passed stream and sweep state (0 = 3) */
+                                        pipeline's, each with its own band-passed stream and sweep state (0 = 2) */
     int32_t host_threads;            /* recordings in the host stage at once (0 = as chain_execute.RecordingPipeline chooses) */
     int32_t decode_threads;          /* threads inside one recording's host stage (0 = one per chain) */
     double address_distance;         /* PacketMetaArray.Correlate (packet_meta.py:230); < 0: no de-dup here (the chains are a part of

@@ -906,7 +906,7 @@ class NativePipeline:
         self._h = h
         self.nchains = n
         self.done_at_ms = {}                                # ticket -> when it left the last stage (host clock since the pipeline was made)
-        self.slots = max(2, min(int(slots) if slots else 16, 32, 60 // len(planned) * (min(int(demod_streams), 4) if demod_streams else 3)))     # as pm_pipe_create settles it
+        self.slots = max(2, min(int(slots) if slots else 16, 32, 60 // len(planned) * (min(int(demod_streams), 4) if demod_streams else 2)))     # as pm_pipe_create settles it
 
     def prefetch(self, host_audio):
         """Start copying a recording (host int16 array) into HBM on a copy stream; returns a handle for submit().  Called one

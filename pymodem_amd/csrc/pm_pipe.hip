@@ -507,7 +507,9 @@ int pm_pipe_create(pm_ctx *ctx, const pm_pipe_desc *desc, pm_pipe **out)
     p->nchains = d.nchains;
     p->nsweeps = d.nsweeps;
     p->slots = d.slots > 0 ? std::min(d.slots, 32) : 16;
-    const int nd = d.demod_streams > 0 ? std::min(d.demod_streams, 4) : 3;
+    // two: with the sweeps' sums on the matrix pipe three recordings' demod kernels at once take longer than three in a row
+    // (demod alone 0.67 ms per recording with three streams, 0.49 with two, 0.84 with one)
+    const int nd = d.demod_streams > 0 ? std::min(d.demod_streams, 4) : 2;
     p->slots = std::max(2, std::min(p->slots, 60 / d.nsweeps * nd));  // a sweep's counter stays readable for 63 further sweeps of its context
     p->group = d.slice_group > 0 ? std::min(d.slice_group, 16) : 4;
     p->min_group = d.slice_min_group > 0 ? std::min(d.slice_min_group, p->group) : p->group;
@@ -616,9 +618,15 @@ int pm_pipe_create(pm_ctx *ctx, const pm_pipe_desc *desc, pm_pipe **out)
         p->work.resize(workers);
         for (int wk = 0; wk < workers && !rc; ++wk) {
             pm_ctx *s = nullptr;
+            // (confining the slicer streams to 4 / 8 / 12 / 16 CUs per XCD was measured: 1.64 / 1.13 / 0.98 / 0.89 ms per step against
+            // 0.81 -- the walkers need the width; at 8 per XCD they alone take 1.1 ms per recording, i.e. the slicers are worth a
+            // third of the whole GPU's time per recording)
             if (!(rc = pm_ctx_create_prio(ctx->device, 1, &s))) {
                 p->side.push_back(s);
                 rc = pm_slicer_tune(s, 16384);
+                // walkers of 32 k samples: the slicers are a third of the GPU's work now, and a walker re-walks its merge length
+                // (10-20 k samples) whatever the chunk -- 1 + m/L lane-steps per sample; longer chunks cost depth, not work
+                if (!rc) rc = pm_slicer_limits(s, 512);
             }
         }
         if (rc) break;
