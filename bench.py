@@ -795,7 +795,10 @@ def measure(args, env):
         out = {
             "metric": "Msamples/s through demod_chain", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            # the native executor's certified sweeps: band-pass and low-pass sums as exact int8 digit products (matrix pipe) under a proven
+            # bound, recombined in f64; everything else (sliding sums, combine, exact recomputation, every other executor) in f64
+            "dtype": "f64+i8" if native_exec[0] else "f64", "data": "synthetic",
             "value_with_h2d_overlapped": None if h2d_overlapped is None else round(float(args.samples) * nchains * args.steps / h2d_overlapped / 1e6, 3),
             "steady_state_ms_per_step": steady.get("ms_per_step"),
             "steady_state_value": None if not steady else round(float(args.samples) * nchains / (steady["ms_per_step"] * 1e-3) / 1e6, 3),
@@ -831,8 +834,8 @@ def measure(args, env):
                              "achieved_over_busy_time": round(dom_bytes / (spans[dom]["busy_ms"] * 1e-3) / 1e9, 2),
                              "frac_over_busy_time": round(dom_bytes / (spans[dom]["busy_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                              "tflops_f64_over_busy_time": round(dom_flops / (spans[dom]["busy_ms"] * 1e-3) / 1e12, 3),
-                             "note": "the executor runs this class on several streams at once (recordings take turns on three demod streams): "
-                                     "a launch that shares the GPU with two others of its kind takes longer, so `achieved` (bytes of a launch / "
+                             "note": "the executor runs this class on several streams at once (recordings take turns on the demod streams: two in the "
+                                     "native executor): a launch that shares the GPU with others of its kind takes longer, so `achieved` (bytes of a launch / "
                                      "its own duration, what a kernel trace shows) falls as throughput rises.  Over-busy-time figures divide the "
                                      "class's bytes and flops by the time during which at least one of its launches was running (union of the "
                                      "HIP-event intervals of all streams)"},
@@ -848,14 +851,20 @@ def measure(args, env):
                                  "sweep): it reads the band-passed stream once and writes sign bits only, so its algorithmic bytes are 8 B "
                                  "per sample for work that is 32 B per sample AND CHAIN stage by stage (SURVEY 8d) -- a low HBM fraction "
                                  "here means little traffic, not idle hardware; its HBM-bound parts measured on their own: sliding sums "
-                                 "61 % and 8-tap FIR 71-79 % of peak (DESIGN.md 4.2c, 6)"},
+                                 "61 % and 8-tap FIR 71-79 % of peak (DESIGN.md 4.2c, 6).  Native executor, round 3: the band-pass (class fir_i16) "
+                                 "and the fused kernel's low-passes run as int8 digit products on the matrix pipe (pm_bpf8.hip, "
+                                 "afsk_slide_lpf8_kernel); bytes per launch are unchanged"},
             "roofline_fp64": {"bound": "valu_f64", "kernel": dom, "achieved": round(tflops, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(tflops / FP64_PEAK_TFLOPS, 5), "algorithmic_flops_per_launch": round(per_launch_flops),
                               "alone_frac": None if alone_ms is None else round(per_launch_flops / (alone_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5),
                               "sustained_peak_measured": FP64_SUSTAINED_TFLOPS,
                               "alone_frac_of_sustained": None if alone_ms is None else round(per_launch_flops / (alone_ms * 1e-3) / 1e12 / FP64_SUSTAINED_TFLOPS, 5),
                               "note": "2 flops per fma of the FIR sums (epilogue sqrt / sign tests not counted) / the same HIP-event time; "
-                                      "sustained_peak_measured is the rate a pure v_fma_f64 register loop holds on this chip (clock under f64 load)"},
+                                      "sustained_peak_measured is the rate a pure v_fma_f64 register loop holds on this chip (clock under f64 load)"
+                                      + ("; NATIVE EXECUTOR: the low-pass and band-pass sums counted here are computed as int8 digit products on "
+                                         "the matrix pipe (20 resp. 12 int8 products per tap and sample, exact, recombined in f64): `achieved` is "
+                                         "the rate of the f64 sums they stand for, an EQUIVALENT rate -- it may exceed what the vector pipe "
+                                         "sustains and is not a utilisation of it" if native_exec[0] else "")},
             "roofline_by_class": {k: {"avg_kernel_ms": round(prof[k][0] / prof[k][1], 5), "launches": prof[k][1],
                                       "algorithmic_bytes_per_launch": round(work[k][0] / prof[k][1]),
                                       "achieved_GBps": round(work[k][0] / (prof[k][0] * 1e-3) / 1e9, 1),

@@ -36,8 +36,8 @@ for name, ctr in [("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")]:
     for k, (n, v) in agg.items():
         res.setdefault(k, {})[ctr + "_KB_avg_per_launch"] = round(v / n, 1)
         res[k][ctr + "_launches"] = n
-CLASSES = {"fir_i16": ["fir_valid_kernel<short", "fir_short_signs_i16_kernel", "fir_rows_kernel<short"],
-           "fir_f64": ["fir_valid_kernel<double", "fir_sweep_kernel", "afsk_slide_lpf_kernel", "fir_rows_kernel<double"],
+CLASSES = {"fir_i16": ["fir_valid_kernel<short", "fir_short_signs_i16_kernel", "fir_rows_kernel<short", "bpf8_kernel"],
+           "fir_f64": ["fir_valid_kernel<double", "fir_sweep_kernel", "afsk_slide_lpf_kernel", "afsk_slide_lpf8_kernel", "fir_rows_kernel<double"],
            "loop": ["loop_kernel"], "agc": ["agc_rows_kernel", "rows_max_kernel", "rows_max_fold_kernel", "agc_rows_prepare_kernel", "agc_iter_kernel",
                                             "max_partial_kernel", "agc_scale_kernel"],
            "afsk_correlate": ["afsk_correlate_kernel", "afsk_slide_kernel"],
