@@ -252,7 +252,7 @@ def also_workloads(args, env, cpu_also=None):
     # (the carrier-loop workloads: one full engine run each -- 8192 recordings x 1 chain, 2048 x 8 chains; a run takes as long as
     # its recordings are, however many there are)
     for name, steps, warm in (("fsk_9600", 300, 10), ("bpsk_300", 8192, 1), ("qpsk_2400", 2048, 1)):
-        if name == args.workload:
+        if name == args.workload or (os.environ.get("BENCH_ALSO_ONLY") and name not in os.environ["BENCH_ALSO_ONLY"].split(",")):
             continue
         a = copy.copy(args)
         a.workload, a.steps, a.warmup, a.no_cpu_baseline, a.chains_per_gpu = name, steps, warm, True, 0

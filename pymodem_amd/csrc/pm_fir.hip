@@ -1120,17 +1120,51 @@ __global__ __launch_bounds__(64) void sweep_exact_kernel(const double *__restric
         if (g >= kSweepMax || P.bits[g] == nullptr) continue;                    // not an entry of this sweep (cannot happen: see sweep_signs)
         const double *si = space + (size_t)g * 2 * mc, *sq = si + mc;
         if (AUDIO) {
-            double *xw = dd + ml;
-            for (int p = lane; p < ml + mc - 1; p += 64) {
-                const int16_t *ap = src.audio + k + p;
+            // The audio under the entry and every tap set once, coalesced, into LDS; then the sums from there.  (From global memory --
+            // a tap load in front of every fma of three chained sums -- this kernel took 160-200 us for twenty entries, on the demod
+            // stream, twice per recording.)
+            const int nw = ml + mc - 1, na = nw + src.mb - 1;
+            double *xw = dd + ml, *aw = xw + nw, *tb = aw + na, *tc = tb + src.mb, *tl = tc + 4 * mc;
+            for (int p = lane; p < na; p += 64) aw[p] = (double)src.audio[k + p];
+            for (int t = lane; t < src.mb; t += 64) tb[t] = src.bpf[src.mb - 1 - t];
+            for (int t = lane; t < mc; t += 64) {
+                tc[4 * t + 0] = mi[mc - 1 - t];
+                tc[4 * t + 1] = mq[mc - 1 - t];
+                tc[4 * t + 2] = si[mc - 1 - t];
+                tc[4 * t + 3] = sq[mc - 1 - t];
+            }
+            for (int t = lane; t < ml; t += 64) tl[t] = lpf[ml - 1 - t];
+            __syncthreads();
+            for (int p = lane; p < nw; p += 64) {
                 double acc = 0.0;
-                for (int t = 0; t < src.mb; ++t) acc = __builtin_fma(src.bpf[src.mb - 1 - t], (double)ap[t], acc);
+                for (int t = 0; t < src.mb; ++t) acc = __builtin_fma(tb[t], aw[p + t], acc);
                 xw[p] = acc;
             }
             __syncthreads();
+            for (int j = lane; j < ml; j += 64) {
+                double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+                for (int t = 0; t < mc; ++t) {
+                    const double v = xw[j + t];
+                    a = __builtin_fma(tc[4 * t + 0], v, a);
+                    b = __builtin_fma(tc[4 * t + 1], v, b);
+                    c = __builtin_fma(tc[4 * t + 2], v, c);
+                    d = __builtin_fma(tc[4 * t + 3], v, d);
+                }
+                dd[j] = __builtin_sqrt(a * a + b * b) - __builtin_sqrt(c * c + d * d);
+            }
+            __syncthreads();
+            if (lane == 0) {
+                double acc = 0.0;
+                for (int j = 0; j < ml; ++j) acc = __builtin_fma(tl[j], dd[j], acc);
+                unsigned long long *w = reinterpret_cast<unsigned long long *>(P.bits[g]) + (k >> 6);
+                const unsigned long long bit = 1ull << (k & 63);
+                if (acc >= 0.0) atomicOr(w, bit); else atomicAnd(w, ~bit);
+            }
+            __syncthreads();
+            continue;
         }
         for (int j = lane; j < ml; j += 64) {
-            const double *xp = AUDIO ? dd + ml + j : x + k + j;
+            const double *xp = x + k + j;
             double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
             for (int t = 0; t < mc; ++t) {
                 const double v = xp[t];
@@ -1713,7 +1747,7 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
     {
         PmProf prof(ctx, PM_K_SIGNS);
         if (src)
-            hipLaunchKernelGGL(sweep_exact_kernel<true>, dim3(1024), dim3(64), (size_t)(2 * ml + m - 1) * sizeof(double), ctx->stream, d_x, d_mark_i, d_mark_q,
+            hipLaunchKernelGGL(sweep_exact_kernel<true>, dim3(1024), dim3(64), (size_t)(4 * ml + 6 * m + 2 * src->mb - 3) * sizeof(double), ctx->stream, d_x, d_mark_i, d_mark_q,
                                d_space, m, d_lpf, ml, P, list, count, cap, count_next, mail, *src);
         else
             hipLaunchKernelGGL(sweep_exact_kernel<false>, dim3(1024), dim3(64), (size_t)ml * sizeof(double), ctx->stream, d_x, d_mark_i, d_mark_q, d_space, m,
