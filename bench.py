@@ -502,8 +502,14 @@ def measure(args, env):
                     cur = source
                 packed.put(packers.submit(pack, npipe.submit(cur)))
             packed.put(None)
+            t_sub = time.perf_counter()
+            npipe.drain()
+            t_pipe = time.perf_counter()
             for th in threads:
                 th.join()
+            if os.environ.get("BENCH_EXCHANGE_TAIL"):
+                print(f"[exchange] k={k}: last submit to pipeline drained {1e3 * (t_pipe - t_sub):.2f} ms, then exchange + de-dup tail "
+                      f"{1e3 * (time.perf_counter() - t_pipe):.2f} ms", file=sys.stderr)
         npipe.drain()
         if errors:
             raise errors[0]
