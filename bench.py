@@ -20,6 +20,12 @@ import os
 import sys
 import time
 
+# Before anything loads the HIP runtime: eight hardware queues instead of the default four.  The executor keeps two demod and two slicer
+# streams busy; with an RCCL communicator (its streams made first) and torch's own in the same process, four queues made those streams
+# share queues and their kernels take turns -- the forced one-rank exchange ran at 1.02 ms per step against 0.77 without, and at
+# 0.80 with eight queues.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -215,8 +221,11 @@ def main():
         if args.backend == "nccl":
             # the exchange is a tiny kernel on a GPU kept full by 14 000-workgroup FIR launches: let it jump the queue
             opts = dist.ProcessGroupNCCL.Options()
-            opts.is_high_priority_stream = True
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), pg_options=opts)
+            opts.is_high_priority_stream = os.environ.get("BENCH_NCCL_PRIO", "1") != "0"
+            if os.environ.get("BENCH_NCCL_LAZY"):
+                dist.init_process_group("nccl", pg_options=opts)
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), pg_options=opts)
         else:
             dist.init_process_group(args.backend)
     coll_device = f"cuda:{dev_index}" if (use_dist and args.backend == "nccl") else None
@@ -444,6 +453,8 @@ def measure(args, env):
             t0_ = time.perf_counter()
             rows_ = npipe.rows(t)
             t1_ = time.perf_counter()
+            if os.environ.get("BENCH_EX_SKIP") == "all":
+                return None
             out_ = ex.prepare(dict(zip(my, rows_)))
             acc["wait_rows"] += t1_ - t0_
             acc["pack"] += time.perf_counter() - t1_
@@ -452,6 +463,8 @@ def measure(args, env):
         def timed_dedupe(g):
             x_ = g.result()
             t0_ = time.perf_counter()
+            if os.environ.get("BENCH_EX_SKIP") == "dedupe":
+                return None
             r_ = dedupe(x_)
             acc["dedupe"] += time.perf_counter() - t0_
             return r_
@@ -463,6 +476,8 @@ def measure(args, env):
                     if f is None:
                         break
                     x_ = f.result()
+                    if x_ is None or os.environ.get("BENCH_EX_SKIP") == "step":
+                        continue
                     t0_ = time.perf_counter()
                     gathered.put(ex.step(x_))
                     acc["step"] += time.perf_counter() - t0_
@@ -493,16 +508,34 @@ def measure(args, env):
         threads = [threading.Thread(target=ordered), threading.Thread(target=post)]
         for th in threads:
             th.start()
-        with ThreadPoolExecutor(max_workers=2) as packers:
+        with ThreadPoolExecutor(max_workers=int(os.environ.get("BENCH_PACKERS", "2"))) as packers:
             nxt = npipe.prefetch(source) if (k and not hasattr(source, "ptr")) else None
-            for i in range(k):
+            if nxt is None and k and os.environ.get("BENCH_SUBMIT_MANY", "1") != "0":
+                # resident recordings: all of them from one library call on its own thread -- the submitting thread no longer queues
+                # for the interpreter lock behind the packers, the collectives and rank 0's de-dup after every recording
+                first, join = npipe.submit_many([source] * k)
+                for i in range(k):
+                    packed.put(packers.submit(pack, first + i))
+                join()
+                k_loop = 0
+            else:
+                k_loop = k
+            for i in range(k_loop):
                 if nxt is not None:
                     cur, nxt = nxt, (npipe.prefetch(source) if i + 1 < k else None)
                 else:
                     cur = source
-                packed.put(packers.submit(pack, npipe.submit(cur)))
+                t0_ = time.perf_counter()
+                tk_ = npipe.submit(cur)
+                t1_ = time.perf_counter()
+                packed.put(packers.submit(pack, tk_))
+                acc["submit_call"] = acc.get("submit_call", 0.0) + t1_ - t0_
+                acc["submit_rest"] = acc.get("submit_rest", 0.0) + time.perf_counter() - t1_
             packed.put(None)
             t_sub = time.perf_counter()
+            if os.environ.get("BENCH_EXCHANGE_TAIL") and k and "submit_call" in acc:
+                print(f"[exchange] k={k}: per step the submitting thread spent {1e3 * acc['submit_call'] / k:.3f} ms in pm_pipe_submit (slots) and "
+                      f"{1e3 * acc['submit_rest'] / k:.3f} ms handing the ticket to a packer", file=sys.stderr)
             npipe.drain()
             t_pipe = time.perf_counter()
             for th in threads:

@@ -563,6 +563,12 @@ typedef struct pm_pipe_result {
 typedef struct pm_pipe pm_pipe;
 int pm_pipe_create(pm_ctx *ctx, const pm_pipe_desc *desc, pm_pipe **out);
 int pm_pipe_submit(pm_pipe *pipe, const int16_t *d_audio, int64_t n, int64_t *h_ticket);     /* d_audio stays untouched until the recording is sliced */
+/* `count` recordings in order from one call (blocks as pm_pipe_submit does, for the whole run): tickets *h_first_ticket ..
+ * + count - 1, known before the call returns to anyone who read the next ticket -- pm_pipe_wait on a promised ticket waits for its
+ * submission.  For hosts whose submitting thread would otherwise queue for an interpreter lock between recordings.  One submitter. */
+int pm_pipe_submit_many(pm_pipe *pipe, const int16_t *const *d_audio, const int64_t *n, int count, int64_t *h_first_ticket);
+/* Announces the next `count` tickets (a pm_pipe_submit_many that another thread is about to start): pm_pipe_wait on them waits. */
+int pm_pipe_promise(pm_pipe *pipe, int count, int64_t *h_first_ticket);
 int pm_pipe_wait(pm_pipe *pipe, int64_t ticket, pm_pipe_result *out);
 int pm_pipe_release(pm_pipe *pipe, int64_t ticket);      /* the result's memory */
 int pm_pipe_drain(pm_pipe *pipe);                        /* every recording submitted so far is through */

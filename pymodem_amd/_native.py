@@ -222,6 +222,8 @@ _SIGS = {
     "pm_prof_intervals": ([_vp, _int, _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
     "pm_pipe_create": ([_vp, ctypes.POINTER(PipeDesc), ctypes.POINTER(_vp)], _int),
     "pm_pipe_submit": ([_vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
+    "pm_pipe_submit_many": ([_vp, _vp, _vp, _int, _vp], _int),
+    "pm_pipe_promise": ([_vp, _int, _vp], _int),
     "pm_pipe_wait": ([_vp, _i64, ctypes.POINTER(PipeResult)], _int),
     "pm_pipe_release": ([_vp, _i64], _int),
     "pm_pipe_drain": ([_vp], _int),
@@ -271,6 +273,9 @@ def lib():
         if not os.path.exists(path):
             raise NativeError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950). pymodem_amd has no CPU fallback.")
+        # (takes effect when this is what loads the HIP runtime: streams of several libraries in one process -- RCCL, torch, ours -- share
+        # the default four hardware queues and serialise)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         handle = ctypes.CDLL(path)
         for name, (args, res) in _SIGS.items():
             fn = getattr(handle, name)      # AttributeError here = header and library out of sync

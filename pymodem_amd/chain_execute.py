@@ -939,7 +939,43 @@ class NativePipeline:
             raise ValueError("NativePipeline.submit: an int16 DeviceBuffer")
         t = ctypes.c_int64()
         check(lib().pm_pipe_submit(self._h, audio.ptr, audio.n, ctypes.byref(t)))
+        self._next_ticket = t.value + 1
         return t.value
+
+    def submit_many(self, audios):
+        """Resident recordings, in order, from ONE library call on a thread of its own (pm_pipe_submit_many: the interpreter lock is not
+        needed between recordings) -> (first ticket, join).  Tickets first .. first + len(audios) - 1 may be waited for at once;
+        join() returns when the last recording is submitted and raises what the submission raised.  No other submit meanwhile."""
+        import threading
+        audios = list(audios)
+        for a in audios:
+            if not isinstance(a, DeviceBuffer) or a.dtype != np.dtype(np.int16):
+                raise ValueError("NativePipeline.submit_many: int16 DeviceBuffers")
+        k = len(audios)
+        announced = ctypes.c_int64(-1)
+        check(lib().pm_pipe_promise(self._h, k, ctypes.byref(announced)))      # waits on the new tickets may start before the thread has
+        first = announced.value
+        self._next_ticket = first + k
+        ptrs = (ctypes.c_void_p * k)(*[a.ptr.value for a in audios])
+        ns = (ctypes.c_int64 * k)(*[a.n for a in audios])
+        got, err = ctypes.c_int64(-1), []
+
+        def run():
+            try:
+                check(lib().pm_pipe_submit_many(self._h, ptrs, ns, k, ctypes.byref(got)))
+                if got.value != first:
+                    raise RuntimeError(f"submit_many: tickets start at {got.value}, expected {first}")
+            except BaseException as e:                        # noqa: BLE001
+                err.append(e)
+        th = threading.Thread(target=run)
+        th.start()
+
+        def join():
+            th.join()
+            del audios[:]
+            if err:
+                raise err[0]
+        return first, join
 
     def _wait(self, ticket):
         from ._native import PipeResult
