@@ -117,3 +117,54 @@ def test_native_pipeline_refuses_what_it_does_not_cover(config_lines):
     t = pipe.submit(ok)
     assert pipe.unique(t)[0] == 0
     pipe.close()
+
+
+def test_submit_many_promises_its_tickets(config_lines):
+    """pm_pipe_submit_many: a run's recordings from ONE library call on its own thread; tickets are announced before the first is
+    submitted (pm_pipe_promise) and a wait on one of them waits for its submission.  Forty recordings through sixteen slots, the
+    consumers started before the submitter, results equal to per-recording submits; a refused recording fails the waits behind it."""
+    import threading
+    import pymodem_amd
+    from pymodem_amd import NativeError, chain_builder as cb, chain_execute as ce
+    lines = config_lines(CFG)
+    recs = _recordings()
+    ctx = pymodem_amd.Context.default()
+    order = ["a", "b", "half", "noise", "a", "short", "b", "a"] * 5
+    dev = {k: ctx.upload(recs[k]) for k in set(order)}
+    ctx.sync()
+    pipe = ce.NativePipeline([cb.build_chain(48000, l) for l in lines], max(len(v) for v in recs.values()), 48000 / 40, ctx=ctx)
+    one_by_one = {}
+    for k in set(order):
+        t = pipe.table(pipe.submit(dev[k]))
+        one_by_one[k] = (t.counts, t.CountGood(), t.CountBad(), t.unique_idx.copy())
+    first, join = pipe.submit_many([dev[k] for k in order])
+    got, errors = {}, []
+
+    def consume(lo, hi):
+        try:
+            for i in range(lo, hi):
+                t = pipe.table(first + i)
+                got[i] = (t.counts, t.CountGood(), t.CountBad(), t.unique_idx.copy())
+        except BaseException as e:                            # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=consume, args=(lo, lo + 10)) for lo in range(0, 40, 10)]
+    for th in reversed(threads):                              # the one waiting for the LAST tickets first
+        th.start()
+    join()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for i, k in enumerate(order):
+        w = one_by_one[k]
+        assert got[i][:3] == w[:3] and np.array_equal(got[i][3], w[3]), (i, k)
+    # a recording shorter than the filters stops the run: the submitter reports it, and the waits behind it do not hang
+    tiny = ctx.upload(np.zeros(50, np.int16))
+    first, join = pipe.submit_many([dev["a"], tiny, dev["a"]])
+    assert pipe.table(first).CountGood() == one_by_one["a"][1]
+    with pytest.raises(NativeError):
+        join()
+    with pytest.raises(NativeError):
+        pipe.table(first + 2)
+    t = pipe.table(pipe.submit(dev["b"]))                     # and the pipeline goes on
+    assert t.CountGood() == one_by_one["b"][1]
+    pipe.close()
