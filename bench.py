@@ -252,6 +252,40 @@ ALSO_CPU_SAMPLE = {"fsk_9600": 4_800_000, "bpsk_300": 1_440_000, "qpsk_2400": 1_
 LOOPS_IN_FLIGHT = 16384        # carrier loops per engine run: 64 per stepping wave, one stepping wave per CU
 
 
+INT8_PEAK_TOPS = 5000.0         # MI355X dense int8 matrix peak: 2x the BF16 rate per clock (MI355X_MICROARCH.md, MFMA table), 2 ops per product
+
+
+def matrix_roofline(native, args, modems, my, prof):
+    """The native executor's certified sums as what they are since round 3: int8 products on the matrix pipe.  Algorithmic products per
+    launch = taps x (sample digits x tap digits) x outputs -- 2 x 6 for the band-pass, 4 x 5 per low-pass stream -- against the launch
+    times of the same HIP-event profile (in the pipeline, beside the other stream's kernels and the slicers)."""
+    try:
+        if not native or args.workload != "afsk_1200_super_opt" or os.environ.get("PM_PIPE_LPF8") == "0":
+            return None
+        md = modems[my[0]]
+        ml, mb, n = len(md.output_lpf), len(md.input_bpf), float(args.samples)
+        sweeps = {}
+        for c in my:
+            key = modems[c].mark_key() if hasattr(modems[c], "mark_key") else c
+            sweeps[key] = sweeps.get(key, 0) + 1
+        streams = sum(2 if cnt > 1 else 1 for cnt in sweeps.values())            # low-pass streams per recording: two per sweep, one per lone chain
+        lp_ops, bp_ops = 2.0 * 20 * ml * n * streams, 2.0 * 12 * mb * n
+        out = {"bound": "mfma", "peak": INT8_PEAK_TOPS, "unit": "TOP/s",
+               "note": "int8 digit products of the certified sums (exact int32 accumulation, v_mfma_i32_16x16x64_i8), 2 ops per product, per "
+                       "recording / the class's summed launch time per recording; a micro-benchmark of the instruction alone sustains 2 830 TOP/s "
+                       "on this chip (tools/ubench/mfma_i8.hip); the kernels also run their sliding sums, digit split, recombination and "
+                       "combine on the vector pipe"}
+        for cls, ops in (("fir_f64", lp_ops), ("fir_i16", bp_ops)):
+            ms, nl_ = prof[cls]
+            if nl_ and ms > 0:
+                per_rec_ms = ms / nl_ * (len(sweeps) if cls == "fir_f64" else 1)
+                out[cls] = {"int8_ops_per_recording": round(ops), "class_ms_per_recording": round(per_rec_ms, 5),
+                            "achieved": round(ops / (per_rec_ms * 1e-3) / 1e12, 1), "frac": round(ops / (per_rec_ms * 1e-3) / 1e12 / INT8_PEAK_TOPS, 5)}
+        return out
+    except Exception as e:                                    # noqa: BLE001  (an extra: never allowed to break the line)
+        return {"error": repr(e)}
+
+
 def also_workloads(args, env, cpu_also=None):
     """BASELINE configs[1], [2] and [4] measured after the headline workload in the same process (one GPU only): the single-chain
     BPSK-300 Costas path and the 8-chain QPSK-2400 path are bound by their sequential carrier loops -- one step each
@@ -907,6 +941,7 @@ def measure(args, env):
                                          "the matrix pipe (20 resp. 12 int8 products per tap and sample, exact, recombined in f64): `achieved` is "
                                          "the rate of the f64 sums they stand for, an EQUIVALENT rate -- it may exceed what the vector pipe "
                                          "sustains and is not a utilisation of it" if native_exec[0] else "")},
+            "roofline_matrix": matrix_roofline(native_exec[0], args, modems, my, prof),
             "roofline_by_class": {k: {"avg_kernel_ms": round(prof[k][0] / prof[k][1], 5), "launches": prof[k][1],
                                       "algorithmic_bytes_per_launch": round(work[k][0] / prof[k][1]),
                                       "achieved_GBps": round(work[k][0] / (prof[k][0] * 1e-3) / 1e9, 1),
