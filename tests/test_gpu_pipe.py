@@ -168,3 +168,32 @@ def test_submit_many_promises_its_tickets(config_lines):
     t = pipe.table(pipe.submit(dev["b"]))                     # and the pipeline goes on
     assert t.CountGood() == one_by_one["b"][1]
     pipe.close()
+
+
+@pytest.mark.parametrize("rate", [8000, 44100])
+def test_native_pipeline_at_other_sample_rates(config_lines, rate):
+    """The same comparison at 8 kHz and 44.1 kHz: other band-pass / correlator / low-pass lengths (the matrix-pipe plans are per tap
+    set; 8 kHz leaves the band-pass with two dozen taps), other samples per symbol for the slicers."""
+    import pymodem_amd
+    from pymodem_amd import chain_builder as cb, chain_execute as ce, siggen
+    lines = config_lines(CFG)
+    recs = {"a": siggen.recording("afsk1200_ax25", rate, packets=5, seed=21, noise_sigma=900.0, payload_len=(20, 60))[0],
+            "b": siggen.recording("afsk1200_ax25", rate, packets=2, seed=22, noise_sigma=2500.0, payload_len=(10, 30))[0],
+            "noise": noise_i16(120001), "silence": np.zeros(90000, np.int16)}
+    want = {k: _want(lines, v, rate) for k, v in recs.items()}
+    ctx = pymodem_amd.Context.default()
+    dev = {k: ctx.upload(v) for k, v in recs.items()}
+    ctx.sync()
+    pipe = ce.NativePipeline([cb.build_chain(rate, l) for l in lines], max(len(v) for v in recs.values()), rate / 40, ctx=ctx)
+    order = ["a", "b", "noise", "a", "silence", "b"] * 2
+    for k, t in [(k, pipe.submit(dev[k])) for k in order]:
+        table = pipe.table(t)
+        rows_w, table_w = want[k]
+        at = 0
+        for c in range(len(lines)):
+            got = table.rows[at:at + table.counts[c]]
+            at += table.counts[c]
+            assert len(got) == len(rows_w[c]) and all(np.array_equal(got[f], rows_w[c][f]) for f in got.dtype.names if f != "correlated_count"), (k, c)
+        assert np.array_equal(table.unique_idx, table_w.unique_idx) and table.unique_decoders == table_w.unique_decoders, k
+    assert want["a"][1].CountGood() >= 3
+    pipe.close()
