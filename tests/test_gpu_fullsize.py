@@ -121,3 +121,40 @@ def test_headline_workload_end_to_end_at_full_size(ctx):
         got = [(p.streamaddress, bytes(bytearray(p.data))) for p in pk[c]]
         want = [(p.streamaddress, bytes(bytearray(p.data))) for p in r["packets"]]
         assert got == want, c
+
+
+def test_native_executor_at_full_size_equals_the_group_executor(ctx):
+    """The same recording through pm_pipe_* (band-pass and low-pass sums as int8 digit products on the matrix pipe, exact recomputation
+    of the uncertain decisions from the audio): every packet row of every chain and the de-dup equal to the group executor's, which
+    the test above pins to the oracle.  Two recordings in flight, the second one the buffer shifted by 7 samples (unaligned audio
+    takes the binary64 band-pass)."""
+    import bench
+    from pymodem_amd import chain_builder as cb, chain_execute as ce
+    from pymodem_amd.packet_meta import PacketTable
+
+    class A:
+        pass
+    args = A()
+    args.samples, args.rate, args.workload, args.buffer = N, 48000, "afsk_1200_super_opt", "signal"
+    audio = bench.make_buffer(args)
+    factory, cpg, _ = bench.WORKLOADS[args.workload]
+    lines = [factory(c) for c in range(cpg)]
+    names = [l["object_name"] for l in lines]
+    d0 = ctx.upload(audio)
+    shifted = d0.view(7, len(audio) - 7)
+    ctx.sync()
+    pipe = ce.NativePipeline([cb.build_chain(48000, l) for l in lines], len(audio), 48000 / 40, ctx=ctx)
+    tickets = [pipe.submit(d0), pipe.submit(shifted)]
+    for t, a in zip(tickets, [audio, audio[7:]]):
+        rows = ce.process_chains_table([cb.build_chain(48000, l) for l in lines], a)
+        want = PacketTable(dict(rows), names).correlate(48000 / 40)
+        table = pipe.table(t)
+        assert table.counts == want.counts
+        at = 0
+        for c in range(len(lines)):
+            got = table.rows[at:at + table.counts[c]]
+            at += table.counts[c]
+            assert all(np.array_equal(got[f], rows[c][f]) for f in got.dtype.names if f != "correlated_count"), c
+        assert np.array_equal(table.unique_idx, want.unique_idx) and table.unique_decoders == want.unique_decoders
+    assert table.counts[0] > 600
+    pipe.close()
