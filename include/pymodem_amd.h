@@ -521,8 +521,13 @@ int64_t pm_correlate_strided(void *h_records, int64_t stride, const int64_t *h_c
  *                    pm_pipe_release
  * Results equal process_chain on every chain + PacketMetaArray.Correlate, recording by recording.  One submitting thread.  The
  * device pointers inside the descs (taps) must stay valid for the pipeline's life; host arrays are copied by pm_pipe_create. */
+typedef struct pm_pipe_fir {         /* a sign-FIR group: sign(FIR(int16 audio)) as one bitmap (pm_fir_signs_i16) -- FSKModem.demod, fsk.py:149-159 */
+    const double *d_taps;
+    int32_t m, flags;                /* PM_FIR_NEGATE: the modem's `invert` */
+} pm_pipe_fir;
 typedef struct pm_pipe_chain {
-    int32_t sweep, slot;             /* which sweep of pm_pipe_desc.sweeps demodulates this chain, and its place in it (gain index) */
+    int32_t sweep, slot;             /* which sweep of pm_pipe_desc.sweeps demodulates this chain, and its place in it (gain index);
+                                        sweep = -(f + 1): the chain slices the bitmap of sign-FIR group f (slot ignored) */
     pm_slicer_params slicer;         /* binary slicer */
     uint64_t lfsr_poly;              /* lfsr.py:10-20 */
     int32_t lfsr_invert;
@@ -547,6 +552,8 @@ typedef struct pm_pipe_desc {
     double address_distance;         /* PacketMetaArray.Correlate (packet_meta.py:230); < 0: no de-dup here (the chains are a part of
                                         the config: the rows go to the exchange, rank 0 de-duplicates), unique = 0 */
     int64_t max_samples;             /* longest recording */
+    const pm_pipe_fir *firs;         /* sign-FIR groups (may be the only demodulators: nsweeps = 0, d_bpf / sweeps unused) */
+    int32_t nfirs, reserved;
 } pm_pipe_desc;
 typedef struct pm_pipe_result {
     int64_t ticket;

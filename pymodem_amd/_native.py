@@ -102,13 +102,19 @@ class PipeChain(ctypes.Structure):
                 ("codec_kind", _i32), ("crc", _i32), ("disable_rs", _i32), ("min_dist", _i32), ("sync_tol", _i32), ("source_decoder", _i32)]
 
 
+class PipeFir(ctypes.Structure):
+    """pm_pipe_fir"""
+    _fields_ = [("d_taps", ctypes.c_void_p), ("m", ctypes.c_int32), ("flags", ctypes.c_int32)]
+
+
 class PipeDesc(ctypes.Structure):
     """pm_pipe_desc"""
     _i32 = ctypes.c_int32
     _fields_ = [("d_bpf", ctypes.c_void_p), ("mb", _i32), ("nsweeps", _i32), ("x_bound", ctypes.c_double),
                 ("sweeps", ctypes.POINTER(AfskSweepDesc)), ("chains", ctypes.POINTER(PipeChain)), ("nchains", _i32), ("slots", _i32),
                 ("slice_workers", _i32), ("slice_group", _i32), ("slice_min_group", _i32), ("demod_streams", _i32), ("host_threads", _i32), ("decode_threads", _i32),
-                ("address_distance", ctypes.c_double), ("max_samples", ctypes.c_int64)]
+                ("address_distance", ctypes.c_double), ("max_samples", ctypes.c_int64),
+                ("firs", ctypes.POINTER(PipeFir)), ("nfirs", _i32), ("reserved", _i32)]
 
 
 class PipeResult(ctypes.Structure):

@@ -852,8 +852,9 @@ class NativePipeline:
         slice_group = slice_group or int(os.environ.get("PYMODEM_AMD_PIPE_GROUP", 0))
         slice_min_group = slice_min_group or int(os.environ.get("PYMODEM_AMD_PIPE_MIN_GROUP", 0))
         host_threads = host_threads or int(os.environ.get("PYMODEM_AMD_PIPE_HOST_THREADS", 0))
-        from ._native import AfskSweepDesc, PipeChain, PipeDesc
+        from ._native import AfskSweepDesc, PipeChain, PipeDesc, PipeFir
         from .codecs import _NativeCodec
+        from .modems import FSKModem
         from .lfsr import LFSR
         from .slicer import BinarySlicer
         self._h = None
@@ -862,22 +863,40 @@ class NativePipeline:
         n = len(chains)
         ids = list(range(n)) if chain_ids is None else [int(c) for c in chain_ids]
         self.names = list(names) if names is not None else [ch[0] for ch in chains]
-        if not n or not all(isinstance(ch[1], AFSKModem) and not ch[1].carry_history and isinstance(ch[2], BinarySlicer) and isinstance(ch[3], LFSR)
-                            and isinstance(ch[4], _NativeCodec) for ch in chains):
-            raise ValueError("NativePipeline: AFSK modem + binary slicer + LFSR + AX25/IL2P codec chains only")
-        groups = {}
+        if not n or not all(isinstance(ch[1], (AFSKModem, FSKModem)) and not ch[1].carry_history and isinstance(ch[2], BinarySlicer)
+                            and isinstance(ch[3], LFSR) and isinstance(ch[4], _NativeCodec) for ch in chains):
+            raise ValueError("NativePipeline: AFSK / FSK modem + binary slicer + LFSR + AX25/IL2P codec chains only")
+        groups, fsk_groups = {}, {}
         for k, ch in enumerate(chains):
             ch[1].use_context(ctx)
-            groups.setdefault(ch[1].mark_key(), []).append(k)
-        planned = _plan_sweeps(chains, groups)
-        covered = sorted(k for part, _ in planned for k in part)
-        if covered != list(range(n)) or len({mods[0].front_end_key() for _, mods in planned}) != 1:
-            raise ValueError("NativePipeline: every chain must belong to a certified sweep on one shared band-pass")
-        lead = planned[0][1][0]
-        taps = lead._const("input_bpf", lead.input_bpf)
-        descs = (AfskSweepDesc * len(planned))()
+            if isinstance(ch[1], FSKModem):                   # one sign FIR per distinct modem (fsk.py:149-159), its chains slice that bitmap
+                fsk_groups.setdefault(ch[1].front_end_key(), []).append(k)
+            else:
+                groups.setdefault(ch[1].mark_key(), []).append(k)
+        planned = _plan_sweeps(chains, groups) if groups else []
+        covered = sorted([k for part, _ in planned for k in part] + [k for part in fsk_groups.values() for k in part])
+        if covered != list(range(n)) or len({mods[0].front_end_key() for _, mods in planned}) > 1:
+            raise ValueError("NativePipeline: every AFSK chain must belong to a certified sweep on one shared band-pass")
+        lead = planned[0][1][0] if planned else None
+        taps = lead._const("input_bpf", lead.input_bpf) if planned else None
+        descs = (AfskSweepDesc * max(len(planned), 1))()
         pchains = (PipeChain * n)()
         self._keep = [taps, chains]
+
+        def stages(pc, ch, c):
+            pc.slicer = ch[2]._params()
+            pc.lfsr_poly, pc.lfsr_invert = int(ch[3].polynomial), int(bool(ch[3].invert))
+            pc.codec_kind, pc.crc, pc.disable_rs = int(ch[4]._kind), int(ch[4].collect_trailing_crc), int(ch[4].disable_rs)
+            pc.min_dist, pc.sync_tol, pc.source_decoder = int(ch[4].min_distance), int(ch[4].sync_tolerance), ids[c]
+        firs = (PipeFir * max(len(fsk_groups), 1))()
+        for f, part in enumerate(fsk_groups.values()):
+            md = chains[part[0]][1]
+            ft = md._const("input_lpf", md.input_lpf)
+            self._keep.append(ft)
+            firs[f].d_taps, firs[f].m, firs[f].flags = ft.ptr.value, len(md.input_lpf), 1 if md.invert else 0
+            for c in part:
+                pchains[c].sweep, pchains[c].slot = -(f + 1), 0
+                stages(pchains[c], chains[c], c)
         for j, (part, mods) in enumerate(planned):
             prep = AFSKModem._sweep_prepare(mods)
             k, d = prep["consts"], descs[j]
@@ -888,16 +907,15 @@ class NativePipeline:
             d.h_tones = ctypes.addressof(prep["tones"]) if prep["tones"] is not None else None
             self._keep.append(prep)
             for place, c in enumerate(part):
-                ch, pc = chains[c], pchains[c]
-                pc.sweep, pc.slot, pc.slicer = j, place, ch[2]._params()
-                pc.lfsr_poly, pc.lfsr_invert = int(ch[3].polynomial), int(bool(ch[3].invert))
-                pc.codec_kind, pc.crc, pc.disable_rs = int(ch[4]._kind), int(ch[4].collect_trailing_crc), int(ch[4].disable_rs)
-                pc.min_dist, pc.sync_tol, pc.source_decoder = int(ch[4].min_distance), int(ch[4].sync_tolerance), ids[c]
+                pchains[c].sweep, pchains[c].slot = j, place
+                stages(pchains[c], chains[c], c)
         ctx.sync()                                          # the constants are in place before another stream reads them
         desc = PipeDesc()
-        desc.d_bpf, desc.mb, desc.nsweeps = taps.ptr.value, len(lead.input_bpf), len(planned)
-        desc.x_bound = float(np.abs(lead.input_bpf).sum()) * 32768.0
+        if planned:
+            desc.d_bpf, desc.mb, desc.nsweeps = taps.ptr.value, len(lead.input_bpf), len(planned)
+            desc.x_bound = float(np.abs(lead.input_bpf).sum()) * 32768.0
         desc.sweeps, desc.chains, desc.nchains = descs, pchains, n
+        desc.firs, desc.nfirs = firs, len(fsk_groups)
         desc.slots, desc.slice_workers, desc.slice_group, desc.slice_min_group = int(slots), int(slice_workers), int(slice_group), int(slice_min_group)
         desc.host_threads, desc.decode_threads, desc.demod_streams = int(host_threads), int(decode_threads), int(demod_streams)
         desc.address_distance, desc.max_samples = float(address_distance), int(max_samples)
@@ -906,7 +924,7 @@ class NativePipeline:
         self._h = h
         self.nchains = n
         self.done_at_ms = {}                                # ticket -> when it left the last stage (host clock since the pipeline was made)
-        self.slots = max(2, min(int(slots) if slots else 16, 32, 60 // len(planned) * (min(int(demod_streams), 4) if demod_streams else 2)))     # as pm_pipe_create settles it
+        self.slots = max(2, min(int(slots) if slots else 16, 32, (60 // len(planned) * (min(int(demod_streams), 4) if demod_streams else 2)) if planned else 32))     # as pm_pipe_create settles it
 
     def prefetch(self, host_audio):
         """Start copying a recording (host int16 array) into HBM on a copy stream; returns a handle for submit().  Called one

@@ -81,6 +81,8 @@ struct pm_pipe {
     int mb = 0;
     const double *d_bpf = nullptr;
     std::vector<pm_pipe_chain> chains;
+    std::vector<pm_pipe_fir> firs;                       // sign-FIR groups (FSK modems: fsk.py:149-159): chains with sweep = -(f + 1)
+    std::vector<int> bit_owner;                          // per chain: the chain whose bitmap it reads (itself, or the first chain of its FIR group)
     std::vector<pm_afsk_sweep_desc> sweeps;              // as given (device pointers stay the caller's; h_gains / h_tones copied below)
     std::vector<std::vector<double>> gains;
     std::vector<pm_afsk_tones> tones;
@@ -220,6 +222,7 @@ void slice_worker(pm_pipe *p, int wi)
         for (auto &r : batch) {
             std::vector<int64_t> unc(p->nsweeps);
             int64_t cap = 0;
+            if (!p->nsweeps) break;
             if ((rc = pm_afsk_sweep_results(r->dctx, r->sweep_tickets.data(), p->nsweeps, side, unc.data(), &cap))) { fail(*r, rc); continue; }
             for (int s = 0; s < p->nsweeps && !r->status; ++s) {
                 if (unc[s] <= cap) continue;
@@ -263,7 +266,7 @@ void slice_worker(pm_pipe *p, int wi)
                     pm_slice_job &q = jobs[j];
                     memset(&q, 0, sizeof(q));
                     memset(&states[j], 0, sizeof(pm_slicer_state));
-                    q.d_bits_i = p->d_bits[(size_t)batch[b]->slot * nch + c];
+                    q.d_bits_i = p->d_bits[(size_t)batch[b]->slot * nch + p->bit_owner[c]];
                     q.d_bits_q = nullptr;
                     q.n = batch[b]->nout[c];
                     q.params = p->chains[c].slicer;
@@ -502,8 +505,11 @@ int pm_pipe_create(pm_ctx *ctx, const pm_pipe_desc *desc, pm_pipe **out)
     PM_CTX(ctx);
     PM_ARG(desc != nullptr && out != nullptr);
     const pm_pipe_desc &d = *desc;
-    PM_ARG(d.d_bpf && d.mb >= 1 && d.x_bound > 0 && d.sweeps && d.nsweeps >= 1 && d.nsweeps <= 16 && d.chains && d.nchains >= 1 && d.nchains <= kMaxChains);
-    PM_ARG(d.max_samples >= d.mb);
+    PM_ARG(d.nsweeps >= 0 && d.nsweeps <= 16 && d.nfirs >= 0 && d.nfirs <= 16 && d.nsweeps + d.nfirs >= 1 && d.chains && d.nchains >= 1 && d.nchains <= kMaxChains);
+    PM_ARG(d.nsweeps == 0 || (d.d_bpf && d.mb >= 1 && d.x_bound > 0 && d.sweeps));
+    PM_ARG(d.nfirs == 0 || d.firs != nullptr);
+    for (int f = 0; f < d.nfirs; ++f) PM_ARG(d.firs[f].d_taps != nullptr && d.firs[f].m >= 1 && d.firs[f].m <= d.max_samples);
+    PM_ARG(d.nsweeps == 0 || d.max_samples >= d.mb);
     pm_pipe *p = new pm_pipe();
     p->ctx = ctx;
     p->nchains = d.nchains;
@@ -512,7 +518,7 @@ int pm_pipe_create(pm_ctx *ctx, const pm_pipe_desc *desc, pm_pipe **out)
     // two: with the sweeps' sums on the matrix pipe three recordings' demod kernels at once take longer than three in a row
     // (demod alone 0.67 ms per recording with three streams, 0.49 with two, 0.84 with one)
     const int nd = d.demod_streams > 0 ? std::min(d.demod_streams, 4) : 2;
-    p->slots = std::max(2, std::min(p->slots, 60 / d.nsweeps * nd));  // a sweep's counter stays readable for 63 further sweeps of its context
+    if (d.nsweeps) p->slots = std::max(2, std::min(p->slots, 60 / d.nsweeps * nd));  // a sweep's counter stays readable for 63 further sweeps of its context
     p->group = d.slice_group > 0 ? std::min(d.slice_group, 16) : 4;
     p->min_group = d.slice_min_group > 0 ? std::min(d.slice_min_group, p->group) : p->group;
     p->host_threads = d.host_threads > 0 ? d.host_threads : std::max(2, std::min(8, 24 / d.nchains)) + 1;
@@ -520,10 +526,12 @@ int pm_pipe_create(pm_ctx *ctx, const pm_pipe_desc *desc, pm_pipe **out)
     p->address_distance = d.address_distance;
     p->x_bound = d.x_bound;
     p->max_samples = d.max_samples;
-    p->mb = d.mb;
+    p->mb = d.nsweeps ? d.mb : 1;
     p->d_bpf = d.d_bpf;
+    if (d.nfirs) p->firs.assign(d.firs, d.firs + d.nfirs);
+    p->bit_owner.assign(d.nchains, 0);
     p->chains.assign(d.chains, d.chains + d.nchains);
-    p->sweeps.assign(d.sweeps, d.sweeps + d.nsweeps);
+    if (d.nsweeps) p->sweeps.assign(d.sweeps, d.sweeps + d.nsweeps);
     p->gains.resize(d.nsweeps);
     p->tones.resize(d.nsweeps);
     p->has_tones.assign(d.nsweeps, 0);
@@ -545,9 +553,21 @@ int pm_pipe_create(pm_ctx *ctx, const pm_pipe_desc *desc, pm_pipe **out)
         // every chain names its sweep and its place in it exactly once
         std::vector<std::vector<int>> seen(d.nsweeps);
         for (int s = 0; s < d.nsweeps; ++s) seen[s].assign(p->sweeps[s].groups, -1);
+        std::vector<int> fir_first(d.nfirs, -1);
         for (int c = 0; c < d.nchains && !rc; ++c) {
             const pm_pipe_chain &ch = p->chains[c];
-            if (ch.sweep < 0 || ch.sweep >= d.nsweeps || ch.slot < 0 || ch.slot >= p->sweeps[ch.sweep].groups || seen[ch.sweep][ch.slot] >= 0 ||
+            p->bit_owner[c] = c;
+            if (ch.sweep < 0) {                                  // a sign-FIR group's chain: reads the bitmap of the group's first chain
+                const int f = -ch.sweep - 1;
+                if (f >= d.nfirs || ch.slicer.bits_per_symbol != 1) {
+                    rc = pm_set_error(PM_ERR_ARG, "pm_pipe_create: chain %d does not name a sign-FIR group (or is not a binary-slicer chain)", c);
+                } else {
+                    if (fir_first[f] < 0) fir_first[f] = c;
+                    p->bit_owner[c] = fir_first[f];
+                }
+                continue;
+            }
+            if (ch.sweep >= d.nsweeps || ch.slot < 0 || ch.slot >= p->sweeps[ch.sweep].groups || seen[ch.sweep][ch.slot] >= 0 ||
                 ch.slicer.bits_per_symbol != 1)
                 rc = pm_set_error(PM_ERR_ARG, "pm_pipe_create: chain %d does not name a free place of a sweep (or is not a binary-slicer chain)", c);
             else
@@ -557,7 +577,10 @@ int pm_pipe_create(pm_ctx *ctx, const pm_pipe_desc *desc, pm_pipe **out)
             for (int g = 0; g < p->sweeps[s].groups; ++g)
                 if (seen[s][g] < 0) rc = pm_set_error(PM_ERR_ARG, "pm_pipe_create: place %d of sweep %d has no chain", g, s);
         if (rc) break;
-        const int64_t nb = d.max_samples - d.mb + 1;
+        for (int f = 0; f < d.nfirs && !rc; ++f)
+            if (fir_first[f] < 0) rc = pm_set_error(PM_ERR_ARG, "pm_pipe_create: sign-FIR group %d has no chain", f);
+        if (rc) break;
+        const int64_t nb = d.nsweeps ? d.max_samples - d.mb + 1 : 1;
         void *q = nullptr;
         p->demod.push_back(ctx);
         for (int k = 1; k < nd && !rc; ++k) {
@@ -572,7 +595,7 @@ int pm_pipe_create(pm_ctx *ctx, const pm_pipe_desc *desc, pm_pipe **out)
             bool all = true;
             for (int s = 0; s < d.nsweeps; ++s) all = all && p->has_tones[s];
             const char *e = getenv("PM_PIPE_BPF8");
-            if (all && d.mb + 15 <= 192 && !(e && e[0] == '0')) {
+            if (d.nsweeps && all && d.mb + 15 <= 192 && !(e && e[0] == '0')) {
                 std::vector<double> h((size_t)d.mb);
                 if (hipMemcpy(h.data(), d.d_bpf, h.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
                     rc = pm_set_error(PM_ERR_HIP, "pm_pipe_create: reading the band-pass taps back failed");
@@ -666,8 +689,12 @@ int pm_pipe_submit(pm_pipe *p, const int16_t *d_audio, int64_t n, int64_t *h_tic
     }
     r->nout.resize(p->nchains);
     for (int c = 0; c < p->nchains; ++c) {
-        const pm_afsk_sweep_desc &w = p->sweeps[p->chains[c].sweep];
-        r->nout[c] = nb - w.m - w.ml + 2;
+        if (p->chains[c].sweep < 0) {
+            r->nout[c] = n - p->firs[-p->chains[c].sweep - 1].m + 1;
+        } else {
+            const pm_afsk_sweep_desc &w = p->sweeps[p->chains[c].sweep];
+            r->nout[c] = nb - w.m - w.ml + 2;
+        }
         if (r->nout[c] < 1) {
             std::unique_lock<std::mutex> lk(p->mu);
             p->slot_busy[r->slot] = 0;
@@ -688,9 +715,14 @@ int pm_pipe_submit(pm_pipe *p, const int16_t *d_audio, int64_t n, int64_t *h_tic
         if (hipEventRecord(p->handover[r->slot], p->ctx->stream) != hipSuccess || hipStreamWaitEvent(r->dctx->stream, p->handover[r->slot], 0) != hipSuccess)
             rc = pm_set_error(PM_ERR_HIP, "handing the recording to demod stream %zu failed", di);
     }
-    if (!rc)
+    if (!rc && p->nsweeps)
         rc = pm_afsk_group_run_plan(r->dctx, d_audio, n, p->d_bpf, p->mb, p->d_bpf_outs[di], p->x_bound, sw.data(), p->nsweeps, r->sweep_tickets.data(),
                                     ((uintptr_t)d_audio & 15) == 0 ? p->bpf8 : nullptr, p->lpf8.data());
+    for (int c = 0; c < p->nchains && !rc; ++c)              // sign-FIR groups: one launch per group into its first chain's bitmap (fsk.py:149-159)
+        if (p->chains[c].sweep < 0 && p->bit_owner[c] == c) {
+            const pm_pipe_fir &f = p->firs[-p->chains[c].sweep - 1];
+            rc = pm_fir_signs_i16(r->dctx, d_audio, n, f.d_taps, f.m, p->d_bits[(size_t)r->slot * p->nchains + c], f.flags);
+        }
     if (!rc && hipEventRecord(p->slot_event[r->slot], r->dctx->stream) != hipSuccess) rc = pm_set_error(PM_ERR_HIP, "hipEventRecord failed");
     r->demod_done = p->slot_event[r->slot];
     if (rc) {

@@ -100,7 +100,7 @@ def test_native_pipeline_refuses_what_it_does_not_cover(config_lines):
     from pymodem_amd import chain_builder as cb, chain_execute as ce
     ctx = pymodem_amd.Context.default()
     with pytest.raises(ValueError):
-        ce.NativePipeline([cb.build_chain(48000, l) for l in config_lines("fsk_9600.json")], 100000, 1200.0, ctx=ctx)
+        ce.NativePipeline([cb.build_chain(48000, l) for l in config_lines("bpsk_300.json")], 100000, 1200.0, ctx=ctx)      # a carrier-loop modem
     lines = config_lines(CFG)
     pipe = ce.NativePipeline([cb.build_chain(48000, l) for l in lines], 100000, 1200.0, ctx=ctx)
     with pytest.raises(ValueError):
@@ -196,4 +196,35 @@ def test_native_pipeline_at_other_sample_rates(config_lines, rate):
             assert len(got) == len(rows_w[c]) and all(np.array_equal(got[f], rows_w[c][f]) for f in got.dtype.names if f != "correlated_count"), (k, c)
         assert np.array_equal(table.unique_idx, table_w.unique_idx) and table.unique_decoders == table_w.unique_decoders, k
     assert want["a"][1].CountGood() >= 3
+    pipe.close()
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_native_pipeline_with_fsk_chains(config_lines, mixed):
+    """Sign-FIR groups (pm_pipe_fir): the three chains of configs/fsk_9600.json share one FSK modem -- one pm_fir_signs_i16 per
+    recording, every chain slices that bitmap -- alone and in one pipeline with the AFSK sweeps of the headline config; rows and
+    de-dup equal to the group executor's."""
+    import pymodem_amd
+    from pymodem_amd import chain_builder as cb, chain_execute as ce, siggen
+    lines = config_lines("fsk_9600.json") + (config_lines(CFG) if mixed else [])
+    recs = {"f": siggen.recording("fsk9600_il2p", 48000, packets=6, seed=41, noise_sigma=900.0, payload_len=(20, 80))[0],
+            "a": siggen.recording("afsk1200_ax25", 48000, packets=3, seed=42, noise_sigma=900.0, payload_len=(20, 40))[0],
+            "noise": noise_i16(150001), "silence": np.zeros(100000, np.int16), "short": noise_i16(3000)}
+    want = {k: _want(lines, v) for k, v in recs.items()}
+    ctx = pymodem_amd.Context.default()
+    dev = {k: ctx.upload(v) for k, v in recs.items()}
+    ctx.sync()
+    pipe = ce.NativePipeline([cb.build_chain(48000, l) for l in lines], max(len(v) for v in recs.values()), 48000 / 40, ctx=ctx)
+    order = ["f", "a", "noise", "f", "silence", "short", "f", "a"] * 2
+    for k, t in [(k, pipe.submit(dev[k])) for k in order]:
+        table = pipe.table(t)
+        rows_w, table_w = want[k]
+        assert table.counts == table_w.counts, k
+        at = 0
+        for c in range(len(lines)):
+            got = table.rows[at:at + table.counts[c]]
+            at += table.counts[c]
+            assert all(np.array_equal(got[f], rows_w[c][f]) for f in got.dtype.names if f != "correlated_count"), (k, c)
+        assert np.array_equal(table.unique_idx, table_w.unique_idx) and table.unique_decoders == table_w.unique_decoders, k
+    assert want["f"][1].CountGood() >= 4
     pipe.close()
