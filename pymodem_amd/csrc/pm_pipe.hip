@@ -83,6 +83,7 @@ struct pm_pipe {
     std::vector<pm_pipe_chain> chains;
     std::vector<pm_pipe_fir> firs;                       // sign-FIR groups (FSK modems: fsk.py:149-159): chains with sweep = -(f + 1)
     std::vector<int> bit_owner;                          // per chain: the chain whose bitmap it reads (itself, or the first chain of its FIR group)
+    std::vector<int> job_owner;                          // per chain: the chain whose slicer job it shares (same bitmap, same slicer: fsk_9600's three)
     std::vector<pm_afsk_sweep_desc> sweeps;              // as given (device pointers stay the caller's; h_gains / h_tones copied below)
     std::vector<std::vector<double>> gains;
     std::vector<pm_afsk_tones> tones;
@@ -231,20 +232,28 @@ void slice_worker(pm_pipe *p, int wi)
             }
         }
         // all slicers of the batch in one pm_slice_batch (groups of <= 64 jobs), compact form, one copy to the host
-        std::vector<pm_slice_job> jobs((size_t)nb * nch);
-        std::vector<pm_slicer_state> states((size_t)nb * nch);
+        // (chains that slice the same bitmap with the same slicer share a job: jidx maps (recording, chain) to it)
+        std::vector<std::pair<int, int>> act;
+        std::vector<int> jidx((size_t)nb * nch, -1);
+        for (int b = 0; b < nb; ++b) {
+            for (int c = 0; c < nch; ++c)
+                if (p->job_owner[c] == c) { jidx[(size_t)b * nch + c] = (int)act.size(); act.emplace_back(b, c); }
+            for (int c = 0; c < nch; ++c) jidx[(size_t)b * nch + c] = jidx[(size_t)b * nch + p->job_owner[c]];
+        }
+        std::vector<pm_slice_job> jobs(act.size());
+        std::vector<pm_slicer_state> states(act.size());
         std::vector<int64_t> caps(jobs.size());
         auto lay_out = [&](bool tight) -> size_t {
             size_t at = 0;
-            for (int b = 0; b < nb; ++b)
-                for (int c = 0; c < nch; ++c) {
-                    const pm_slicer_params &sp = p->chains[c].slicer;
-                    const int64_t no = batch[b]->nout[c];
-                    int64_t cap = no * sp.bits_per_symbol / 8 + 5;
-                    if (tight) cap = std::min<int64_t>(cap, (int64_t)(no * sp.bits_per_symbol / (8.0 * sp.samples_per_symbol) * 1.5) + 64);
-                    caps[(size_t)b * nch + c] = cap;
-                    at += (size_t)cap * 8;
-                }
+            for (size_t j = 0; j < act.size(); ++j) {
+                const int b = act[j].first, c = act[j].second;
+                const pm_slicer_params &sp = p->chains[c].slicer;
+                const int64_t no = batch[b]->nout[c];
+                int64_t cap = no * sp.bits_per_symbol / 8 + 5;
+                if (tight) cap = std::min<int64_t>(cap, (int64_t)(no * sp.bits_per_symbol / (8.0 * sp.samples_per_symbol) * 1.5) + 64);
+                caps[j] = cap;
+                at += (size_t)cap * 8;
+            }
             for (size_t j = 0; j < caps.size(); ++j) at += ((size_t)caps[j] + 4 + 7) / 8 * 8;
             return at;
         };
@@ -260,23 +269,22 @@ void slice_worker(pm_pipe *p, int wi)
             }
             size_t a_at = 0, d_at = 0;
             for (size_t j = 0; j < caps.size(); ++j) d_at += (size_t)caps[j] * 8;
-            for (int b = 0; b < nb; ++b)
-                for (int c = 0; c < nch; ++c) {
-                    const size_t j = (size_t)b * nch + c;
-                    pm_slice_job &q = jobs[j];
-                    memset(&q, 0, sizeof(q));
-                    memset(&states[j], 0, sizeof(pm_slicer_state));
-                    q.d_bits_i = p->d_bits[(size_t)batch[b]->slot * nch + p->bit_owner[c]];
-                    q.d_bits_q = nullptr;
-                    q.n = batch[b]->nout[c];
-                    q.params = p->chains[c].slicer;
-                    q.d_addr = (int64_t *)(w.d_out + a_at);
-                    q.d_data = w.d_out + d_at;
-                    q.cap = caps[j];
-                    q.h_state = &states[j];
-                    a_at += (size_t)caps[j] * 8;
-                    d_at += ((size_t)caps[j] + 4 + 7) / 8 * 8;
-                }
+            for (size_t j = 0; j < act.size(); ++j) {
+                const int b = act[j].first, c = act[j].second;
+                pm_slice_job &q = jobs[j];
+                memset(&q, 0, sizeof(q));
+                memset(&states[j], 0, sizeof(pm_slicer_state));
+                q.d_bits_i = p->d_bits[(size_t)batch[b]->slot * nch + p->bit_owner[c]];
+                q.d_bits_q = nullptr;
+                q.n = batch[b]->nout[c];
+                q.params = p->chains[c].slicer;
+                q.d_addr = (int64_t *)(w.d_out + a_at);
+                q.d_data = w.d_out + d_at;
+                q.cap = caps[j];
+                q.h_state = &states[j];
+                a_at += (size_t)caps[j] * 8;
+                d_at += ((size_t)caps[j] + 4 + 7) / 8 * 8;
+            }
             for (size_t j0 = 0; j0 < jobs.size(); j0 += 64) {
                 const int nj = (int)std::min<size_t>(64, jobs.size() - j0);
                 if (int rc2 = pm_slice_batch(side, jobs.data() + j0, nj)) return rc2;
@@ -341,7 +349,7 @@ void slice_worker(pm_pipe *p, int wi)
                 r.count.assign(nch, 0);
                 r.full_addr.assign(nch, {});
                 for (int c = 0; c < nch && !r.status; ++c) {
-                    const size_t j = (size_t)b * nch + c;
+                    const size_t j = (size_t)jidx[(size_t)b * nch + c];
                     r.off[c] = offs[j];
                     r.count[c] = jobs[j].count;
                     const uint8_t *flags = hb->p + offs[j] + 16;
@@ -572,6 +580,15 @@ int pm_pipe_create(pm_ctx *ctx, const pm_pipe_desc *desc, pm_pipe **out)
                 rc = pm_set_error(PM_ERR_ARG, "pm_pipe_create: chain %d does not name a free place of a sweep (or is not a binary-slicer chain)", c);
             else
                 seen[ch.sweep][ch.slot] = c;
+        }
+        p->job_owner.assign(d.nchains, 0);
+        for (int c = 0; c < d.nchains; ++c) {
+            p->job_owner[c] = c;
+            for (int e = 0; e < c; ++e)
+                if (p->bit_owner[e] == p->bit_owner[c] && memcmp(&p->chains[e].slicer, &p->chains[c].slicer, sizeof(pm_slicer_params)) == 0) {
+                    p->job_owner[c] = p->job_owner[e];
+                    break;
+                }
         }
         for (int s = 0; s < d.nsweeps && !rc; ++s)
             for (int g = 0; g < p->sweeps[s].groups; ++g)
