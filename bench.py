@@ -232,6 +232,8 @@ def main():
 
     env = {"rank": rank, "world": world, "dev_index": dev_index, "use_dist": use_dist, "coll_device": coll_device}
     out = measure(args, env)
+    if os.environ.get("BENCH_EX_SKIP"):                       # a diagnostic that drops part of the exchange: the line is not a measurement
+        out["invalid"] = "BENCH_EX_SKIP=" + os.environ["BENCH_EX_SKIP"] + ": part of the packet exchange was skipped"
     if rank == 0:
         if cpu_line is not None:
             out["cpu_baseline"] = cpu_line
