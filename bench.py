@@ -170,7 +170,15 @@ def main():
                     "more than 8192 loops, 131072 from 2048 recordings, else 262144 -- the work buffers are sized by it)")
     ap.add_argument("--also", type=int, default=1, help="1 (default, one GPU only): after the headline workload also measure fsk_9600, "
                     "bpsk_300 and qpsk_2400 (BASELINE configs[2], [1], [4]) briefly and attach them under 'also'")
+    ap.add_argument("--with-exchange", type=int, default=1,
+                    help="1 (default): a one-GPU line also carries value_with_exchange -- the same timed steps with the packet exchange "
+                         "(one-rank RCCL gather + rank 0's de-dup over gathered rows) behind the executor, what every rank of an N > 1 run "
+                         "does -- so that the first step of a 1 -> N curve compares like with like; an N > 1 weak-scaling line also carries "
+                         "`strong`: the config's own chains divided over the ranks (one chain per GPU at N = 8)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and os.environ.get("RANK") is None:
+        sys.exit(self_launch(args))
 
     # A dozen Python threads take turns here (the submitting thread, slicer workers, host, finish and post stages), each mostly inside
     # native calls that release the interpreter lock; with CPython's default 5 ms switch interval a thread coming back from a 20 us
@@ -182,16 +190,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
-        args.gpus = world
+        args.gpus = world                             # the launcher's word: one process per GPU
 
-    # CPU baseline first: it forks one process per chain, which must happen before this process initialises the GPU
+    # CPU baseline first: it forks one process per chain, which must happen before this process initialises the GPU.  Rank 0 of every
+    # run carries it (N > 1: the other ranks wait for rank 0 in the rendezvous meanwhile; a self-launched run has it from the parent).
     cpu_line, cpu_also = None, {}
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        factory, default_cpg, _ = WORKLOADS[args.workload]
-        cpu_line = cpu_baseline(args, [factory(c) for c in range(args.chains_per_gpu or default_cpg)])
-        if args.also:                                 # the same oracle leg, shorter, beside every `also` workload
+    if rank == 0 and not args.no_cpu_baseline:
+        handed = os.environ.get("BENCH_CPU_BASELINE_FILE")
+        if handed and os.path.exists(handed):
+            cpu_line = json.load(open(handed))
+        else:
+            factory, default_cpg, _ = WORKLOADS[args.workload]
+            cpu_line = cpu_baseline(args, [factory(c) for c in range(args.chains_per_gpu or default_cpg)])
+        if args.also and world == 1:                  # the same oracle leg, shorter, beside every `also` workload
             import copy
             for name in ALSO:
                 if name != args.workload:
@@ -212,7 +223,8 @@ def main():
     dev_index = local % ndev                      # more ranks than GPUs only happens in the gloo rehearsal
     torch.cuda.set_device(dev_index)
     use_dist = world > 1 or bool(os.environ.get("PYMODEM_AMD_FORCE_GATHER"))      # the latter: one rank, collectives still run
-    if use_dist:
+
+    def init_dist():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
@@ -228,12 +240,42 @@ def main():
                 dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), pg_options=opts)
         else:
             dist.init_process_group(args.backend)
+    if use_dist:
+        init_dist()
     coll_device = f"cuda:{dev_index}" if (use_dist and args.backend == "nccl") else None
 
     env = {"rank": rank, "world": world, "dev_index": dev_index, "use_dist": use_dist, "coll_device": coll_device}
     out = measure(args, env)
-    if os.environ.get("BENCH_EX_SKIP"):                       # a diagnostic that drops part of the exchange: the line is not a measurement
+    if os.environ.get("BENCH_EX_SKIP") and out is not None:   # a diagnostic that drops part of the exchange: the line is not a measurement
         out["invalid"] = "BENCH_EX_SKIP=" + os.environ["BENCH_EX_SKIP"] + ": part of the packet exchange was skipped"
+    import copy
+    if world == 1 and not use_dist and args.with_exchange and args.overlap == 2:
+        # The same steps once more with the one exchange step behind the executor, as every rank of an N > 1 run has it: rows packed
+        # for the wire, ONE all_gather per 1-4 recordings (here among one rank, over RCCL), rank 0's de-dup over the gathered rows.
+        try:
+            init_dist()
+            use_dist = True
+            a = copy.copy(args)
+            a.no_cpu_baseline = True
+            d2 = measure(a, dict(env, use_dist=True, coll_device=f"cuda:{dev_index}" if args.backend == "nccl" else None))
+            out["value_with_exchange"] = d2["value"]
+            out["with_exchange"] = {"value": d2["value"], "unit": d2["unit"], "ms_per_step": d2["ms_per_step"], "steps": d2["steps"],
+                                    "steady_ms_per_step": (d2.get("steady_state") or {}).get("ms_per_step"), "packets": d2.get("packets"),
+                                    "what": "the timed steps repeated with the packet exchange behind the executor (forced one-rank "
+                                            f"{'RCCL' if args.backend == 'nccl' else args.backend} all_gather of the packed rows + rank 0's "
+                                            "de-dup over them): the N = 1 point of a 1 -> N curve whose other points all exchange"}
+        except Exception as e:                                # noqa: BLE001 -- never allowed to break the main line
+            out["with_exchange"] = {"error": repr(e)[:300]}
+    if world > 1 and args.scaling == "weak" and args.with_exchange:
+        # north_star's own sharding -- the config's chains divided over the GPUs, one chain per GPU at N = 8 -- beside the weak-scaling
+        # figure, same steps, same exchange (every rank runs it: the collectives inside must line up)
+        a = copy.copy(args)
+        a.scaling, a.no_cpu_baseline, a.chains_per_gpu = "strong", True, 0
+        d3 = measure(a, env)
+        if rank == 0:
+            out["strong"] = {"value": d3["value"], "unit": d3["unit"], "ms_per_step": d3["ms_per_step"], "steps": d3["steps"],
+                             "chains_total": d3["config"]["chains_total"], "parallelism": d3["config"]["parallelism"],
+                             "packets": d3.get("packets"), "scaling": "strong"}
     if rank == 0:
         if cpu_line is not None:
             out["cpu_baseline"] = cpu_line
@@ -251,6 +293,7 @@ LOOP_WORKLOADS = ("bpsk_300", "qpsk_2400")
 ALSO_CPU_SAMPLE = {"fsk_9600": 4_800_000, "bpsk_300": 1_440_000, "qpsk_2400": 1_440_000, "afsk_1200_super_opt": 4_800_000}
 
 
+LOOP_DISTINCT_BUFFERS = 256    # carrier-loop workloads: distinct resident copies of the recording an engine run's recordings read (14.7 GB)
 LOOPS_IN_FLIGHT = 16384        # carrier loops per engine run: 64 per stepping wave, one stepping wave per CU
 
 
@@ -286,6 +329,47 @@ def matrix_roofline(native, args, modems, my, prof):
         return out
     except Exception as e:                                    # noqa: BLE001  (an extra: never allowed to break the line)
         return {"error": repr(e)}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) with no launcher around it: this process -- which never touches the GPU -- runs the CPU
+    baseline, then starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <the same arguments>` as a CHILD
+    (never an exec: a process that holds the GPU must not be replaced, and this one may have forked already), relays rank 0's one
+    JSON line and returns the child's exit code.  (pymodem.py:140-166: the reference's own one-process-per-chain launch.)"""
+    import socket
+    import subprocess
+    import tempfile
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    tmp = None
+    if not args.no_cpu_baseline:
+        factory, default_cpg, _ = WORKLOADS[args.workload]
+        cpu_line = cpu_baseline(args, [factory(c) for c in range(args.chains_per_gpu or default_cpg)])
+        fd, tmp = tempfile.mkstemp(prefix="bench_cpu_", suffix=".json")
+        with os.fdopen(fd, "w") as f:
+            json.dump(cpu_line, f)
+        env["BENCH_CPU_BASELINE_FILE"] = tmp
+    with socket.socket() as sk:                               # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    try:
+        child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        line = None
+        for ln in child.stdout:                               # rank 0 prints ONE JSON line; anything else a library wrote goes to stderr
+            t = ln.strip()
+            if t.startswith("{") and '"metric"' in t:
+                line = t
+            elif t:
+                print(t, file=sys.stderr)
+        rc = child.wait()
+    finally:
+        if tmp and os.path.exists(tmp):
+            os.unlink(tmp)
+    if line is not None:
+        print(line, flush=True)
+    return rc if rc or line is not None else 1
 
 
 def also_workloads(args, env, cpu_also=None):
@@ -349,6 +433,20 @@ def measure(args, env):
     audio = make_buffer(args)
     d_audio = ctx.upload(audio)                                   # resident in HBM before the timed region
     ctx.sync()
+    ring = [d_audio]
+
+    def audio_ring(count):
+        """`count` DISTINCT resident copies of the recording (made outside the timed region): successive recordings read different
+        memory, as a service decoding different recordings does -- one buffer submitted over and over stays in L2 / Infinity Cache
+        for whoever comes next.  More than the executor has recordings in flight, so none is still cached when its turn
+        comes again."""
+        from pymodem_amd._native import check, lib
+        while len(ring) < count:
+            b = ctx.empty(len(audio), np.int16)
+            check(lib().pm_d2d(ctx.handle, b.ptr, d_audio.ptr, audio.nbytes))
+            ring.append(b)
+        ctx.sync()
+        return ring[:count]
     modems = {c: cb.ModemConfigurator(args.rate, lines[c]["modem"]) for c in my}     # tap design once (host)
 
     chains_ref = []
@@ -408,7 +506,8 @@ def measure(args, env):
             r = min(batch, k - b0)
             sets = [build_chains(reset=False) for _ in range(r)]
             st = {}
-            rows = lb.process_recordings_device(sets, [audio_dev] * r, ctx, chunk=args.loop_chunk, rows=True, chain_ids=my, stages=st)
+            bufs = audio_ring(min(r, LOOP_DISTINCT_BUFFERS))      # (8192 distinct ten-minute recordings would be 472 GB: each copy serves r / 256 of the run's recordings)
+            rows = lb.process_recordings_device(sets, [bufs[i % len(bufs)] for i in range(r)], ctx, chunk=args.loop_chunk, rows=True, chain_ids=my, stages=st)
             t_f = time.perf_counter()
             if use_dist or len(my) < 4:
                 for rr in rows:                                   # (collectives: in order, on this thread; one chain: nothing to share out)
@@ -444,11 +543,12 @@ def measure(args, env):
             return native_steps_exchange(npipe, k, source)
         tickets, taken = [], 0
         nxt = npipe.prefetch(source) if (k and not hasattr(source, "ptr")) else None
+        bufs = audio_ring(npipe.slots + 2) if hasattr(source, "ptr") else None
         for i in range(k):
             if nxt is not None:
                 cur, nxt = nxt, (npipe.prefetch(source) if i + 1 < k else None)
             else:
-                cur = source
+                cur = bufs[i % len(bufs)]
             tickets.append(npipe.submit(cur))
             while taken < len(tickets) - 48:                  # results do not pile up: 7 MB of packet rows each
                 npipe.unique(tickets[taken])
@@ -549,7 +649,8 @@ def measure(args, env):
             if nxt is None and k and os.environ.get("BENCH_SUBMIT_MANY", "1") != "0":
                 # resident recordings: all of them from one library call on its own thread -- the submitting thread no longer queues
                 # for the interpreter lock behind the packers, the collectives and rank 0's de-dup after every recording
-                first, join = npipe.submit_many([source] * k)
+                bufs = audio_ring(npipe.slots + 2)
+                first, join = npipe.submit_many([bufs[i % len(bufs)] for i in range(k)])
                 for i in range(k):
                     packed.put(packers.submit(pack, first + i))
                 join()
@@ -560,7 +661,8 @@ def measure(args, env):
                 if nxt is not None:
                     cur, nxt = nxt, (npipe.prefetch(source) if i + 1 < k else None)
                 else:
-                    cur = source
+                    bufs = audio_ring(npipe.slots + 2)
+                    cur = bufs[i % len(bufs)]
                 t0_ = time.perf_counter()
                 tk_ = npipe.submit(cur)
                 t1_ = time.perf_counter()
@@ -880,7 +982,7 @@ def measure(args, env):
             "ms_per_step_by_rank": per_rank_ms,
             "config": {"workload": f"{args.workload}: {desc}" + extra_chains_note(args, nchains), "chains_per_gpu": (cpg if args.scaling == "weak" else round(nchains / world, 3)), "chains_total": nchains,
                        "samples_per_recording": args.samples, "sample_rate": args.rate,
-                       "buffer": BUFFER_DESC[args.buffer] + ", resident in HBM",
+                       "buffer": BUFFER_DESC[args.buffer] + f", resident in HBM; successive recordings read DISTINCT copies ({len(ring)} of them in rotation)",
                        "parallelism": (f"chains sharded {cpg}/GPU x {world} GPU, packet gather to rank 0" if args.scaling == "weak" else
                                        f"the config's {nchains} chains divided over {world} GPU (contiguous blocks), packet gather to rank 0"),
                        "dist": dinfo,

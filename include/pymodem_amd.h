@@ -55,6 +55,9 @@ int pm_ctx_create_prio(int device, int high_priority, pm_ctx **out);
  * slicer wave runs at the pace of its slowest wave (its barriers couple the four SIMDs of the CU). */
 int pm_ctx_create_cumask(int device, const uint32_t *cu_mask, int nwords, pm_ctx **out);
 int pm_device_cus(int device);      /* compute units of the device (0 if it cannot be queried) */
+/* Diagnostic switches of a context's launchers (kernel shapes kept for comparison, traces; README.md lists them).  A context reads
+ * its switches from the environment (PM_<NAME>) once, when it is made; this call sets one afterwards.  No switch changes a result. */
+int pm_ctx_tune(pm_ctx *ctx, const char *name, int64_t value);
 int pm_ctx_destroy(pm_ctx *ctx);
 /* Cross-stream ordering without a host wait.  pm_event_record marks the point reached by ctx's stream (creating the event when
  * *event is NULL); pm_event_wait makes everything submitted to ctx AFTER the call wait for that point.  Same device only. */
@@ -482,6 +485,8 @@ typedef struct pm_host_job {
     int32_t status;               /* out */
     const uint16_t *h_addr_delta; /* with h_addr == NULL: the addresses in pm_slice_compact's form, address[i] = addr_first +  */
     int64_t addr_first;           /* delta[0] + ... + delta[i] (delta[0] = 0)                                                   */
+    uint8_t *h_plain;             /* NULL, or n bytes: the LFSR's output is written here (and decoded from here) instead of a    */
+                                  /* library-owned buffer -- for callers that want to see what the codec saw                    */
 } pm_host_job;
 int pm_host_decode_batch(pm_host_job *jobs, int njobs, int threads);
 int pm_codec_fetch_batch(pm_codec *const *codecs, const int64_t *counts, int n, pm_packet *h_out, int threads);
@@ -553,7 +558,9 @@ typedef struct pm_pipe_desc {
                                         the config: the rows go to the exchange, rank 0 de-duplicates), unique = 0 */
     int64_t max_samples;             /* longest recording */
     const pm_pipe_fir *firs;         /* sign-FIR groups (may be the only demodulators: nsweeps = 0, d_bpf / sweeps unused) */
-    int32_t nfirs, reserved;
+    int32_t nfirs;
+    int32_t keep_slices;             /* != 0: every finished recording keeps its slicers' bytes + addresses and the LFSR output of
+                                        every chain for pm_pipe_slices (parity tests of the bitstream, slicer.py:59-107) */
 } pm_pipe_desc;
 typedef struct pm_pipe_result {
     int64_t ticket;
@@ -569,7 +576,9 @@ typedef struct pm_pipe_result {
 } pm_pipe_result;
 typedef struct pm_pipe pm_pipe;
 int pm_pipe_create(pm_ctx *ctx, const pm_pipe_desc *desc, pm_pipe **out);
-int pm_pipe_submit(pm_pipe *pipe, const int16_t *d_audio, int64_t n, int64_t *h_ticket);     /* d_audio stays untouched until the recording is sliced */
+/* d_audio stays untouched until the recording is sliced.  A recording refused for its shape (PM_ERR_ARG) takes no ticket; one whose
+ * launches fail has a ticket (*h_ticket) that is finished with that error: pm_pipe_wait returns it, pm_pipe_release frees it. */
+int pm_pipe_submit(pm_pipe *pipe, const int16_t *d_audio, int64_t n, int64_t *h_ticket);
 /* `count` recordings in order from one call (blocks as pm_pipe_submit does, for the whole run): tickets *h_first_ticket ..
  * + count - 1, known before the call returns to anyone who read the next ticket -- pm_pipe_wait on a promised ticket waits for its
  * submission.  For hosts whose submitting thread would otherwise queue for an interpreter lock between recordings.  One submitter. */
@@ -577,6 +586,11 @@ int pm_pipe_submit_many(pm_pipe *pipe, const int16_t *const *d_audio, const int6
 /* Announces the next `count` tickets (a pm_pipe_submit_many that another thread is about to start): pm_pipe_wait on them waits. */
 int pm_pipe_promise(pm_pipe *pipe, int count, int64_t *h_first_ticket);
 int pm_pipe_wait(pm_pipe *pipe, int64_t ticket, pm_pipe_result *out);
+/* A finished recording's slicer output for one chain (pipelines made with keep_slices): the bytes slicer.slice would return with
+ * their stream addresses (slicer.py:59-107), and what stream_unscramble_8bit made of them (lfsr.py:22-52), *h_count entries each,
+ * in the library's memory until pm_pipe_release.  Any of the three pointers may be NULL. */
+int pm_pipe_slices(pm_pipe *pipe, int64_t ticket, int chain, const uint8_t **h_data, const int64_t **h_addr, const uint8_t **h_plain, int64_t *h_count);
+int pm_pipe_slots(pm_pipe *pipe);                        /* recordings between demod and slicer at most, as pm_pipe_create settled it */
 int pm_pipe_release(pm_pipe *pipe, int64_t ticket);      /* the result's memory */
 int pm_pipe_drain(pm_pipe *pipe);                        /* every recording submitted so far is through */
 int pm_pipe_stats(pm_pipe *pipe, int64_t *h_batches, int64_t *h_batch_recordings, double *h_slice_busy_ms, double *h_host_busy_ms);

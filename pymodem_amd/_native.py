@@ -69,7 +69,7 @@ class HostJob(ctypes.Structure):
     _fields_ = [("codec", ctypes.c_void_p), ("h_data", ctypes.c_void_p), ("h_addr", ctypes.c_void_p), ("n", ctypes.c_int64),
                 ("lfsr_poly", ctypes.c_uint64), ("lfsr_state", ctypes.c_uint64), ("pending", ctypes.c_int64),
                 ("lfsr_invert", ctypes.c_int32), ("status", ctypes.c_int32),
-                ("h_addr_delta", ctypes.c_void_p), ("addr_first", ctypes.c_int64)]
+                ("h_addr_delta", ctypes.c_void_p), ("addr_first", ctypes.c_int64), ("h_plain", ctypes.c_void_p)]
 
 
 class ChainDesc(ctypes.Structure):
@@ -114,7 +114,7 @@ class PipeDesc(ctypes.Structure):
                 ("sweeps", ctypes.POINTER(AfskSweepDesc)), ("chains", ctypes.POINTER(PipeChain)), ("nchains", _i32), ("slots", _i32),
                 ("slice_workers", _i32), ("slice_group", _i32), ("slice_min_group", _i32), ("demod_streams", _i32), ("host_threads", _i32), ("decode_threads", _i32),
                 ("address_distance", ctypes.c_double), ("max_samples", ctypes.c_int64),
-                ("firs", ctypes.POINTER(PipeFir)), ("nfirs", _i32), ("reserved", _i32)]
+                ("firs", ctypes.POINTER(PipeFir)), ("nfirs", _i32), ("keep_slices", _i32)]
 
 
 class PipeResult(ctypes.Structure):
@@ -167,6 +167,7 @@ _SIGS = {
     "pm_last_error": ([ctypes.c_char_p, ctypes.c_size_t], _int),
     "pm_ctx_create": ([_int, ctypes.POINTER(_vp)], _int),
     "pm_ctx_create_prio": ([_int, _int, ctypes.POINTER(_vp)], _int),
+    "pm_ctx_tune": ([_vp, ctypes.c_char_p, _i64], _int),
     "pm_d2d": ([_vp, _vp, _vp, ctypes.c_size_t], _int),
     "pm_host_pin": ([_vp, _vp, ctypes.c_size_t], _int),
     "pm_host_unpin": ([_vp], _int),
@@ -232,6 +233,8 @@ _SIGS = {
     "pm_pipe_promise": ([_vp, _int, _vp], _int),
     "pm_pipe_wait": ([_vp, _i64, ctypes.POINTER(PipeResult)], _int),
     "pm_pipe_release": ([_vp, _i64], _int),
+    "pm_pipe_slices": ([_vp, _i64, _int, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i64)], _int),
+    "pm_pipe_slots": ([_vp], _int),
     "pm_pipe_drain": ([_vp], _int),
     "pm_pipe_stats": ([_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)], _int),
     "pm_pipe_side_ctx": ([_vp, _int], _vp),

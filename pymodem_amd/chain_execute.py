@@ -844,7 +844,7 @@ class NativePipeline:
     raises ValueError for anything else (use RecordingPipeline there)."""
 
     def __init__(self, chains, max_samples, address_distance, ctx=None, names=None, chain_ids=None, slots=0, slice_workers=0, slice_group=0,
-                 host_threads=0, decode_threads=0, slice_min_group=0, demod_streams=0):
+                 host_threads=0, decode_threads=0, slice_min_group=0, demod_streams=0, keep_slices=False):
         import os
         demod_streams = demod_streams or int(os.environ.get("PYMODEM_AMD_PIPE_DEMOD_STREAMS", 0))
         slots = slots or int(os.environ.get("PYMODEM_AMD_PIPE_SLOTS", 0))              # tuning knobs (DESIGN.md 4.4b)
@@ -919,12 +919,13 @@ class NativePipeline:
         desc.slots, desc.slice_workers, desc.slice_group, desc.slice_min_group = int(slots), int(slice_workers), int(slice_group), int(slice_min_group)
         desc.host_threads, desc.decode_threads, desc.demod_streams = int(host_threads), int(decode_threads), int(demod_streams)
         desc.address_distance, desc.max_samples = float(address_distance), int(max_samples)
+        desc.keep_slices = int(bool(keep_slices))
         h = ctypes.c_void_p()
         check(lib().pm_pipe_create(ctx.handle, ctypes.byref(desc), ctypes.byref(h)))
         self._h = h
         self.nchains = n
         self.done_at_ms = {}                                # ticket -> when it left the last stage (host clock since the pipeline was made)
-        self.slots = max(2, min(int(slots) if slots else 16, 32, (60 // len(planned) * (min(int(demod_streams), 4) if demod_streams else 2)) if planned else 32))     # as pm_pipe_create settles it
+        self.slots = int(lib().pm_pipe_slots(h))            # as pm_pipe_create settled it
 
     def prefetch(self, host_audio):
         """Start copying a recording (host int16 array) into HBM on a copy stream; returns a handle for submit().  Called one
@@ -955,8 +956,13 @@ class NativePipeline:
             self._ctx.wait_event(copied)
         if not isinstance(audio, DeviceBuffer) or audio.dtype != np.dtype(np.int16):
             raise ValueError("NativePipeline.submit: an int16 DeviceBuffer")
-        t = ctypes.c_int64()
-        check(lib().pm_pipe_submit(self._h, audio.ptr, audio.n, ctypes.byref(t)))
+        t = ctypes.c_int64(-1)
+        rc = lib().pm_pipe_submit(self._h, audio.ptr, audio.n, ctypes.byref(t))
+        try:
+            check(rc)
+        finally:
+            if rc and t.value >= 0:                          # the launches failed: the ticket is finished with that error, nobody waits for it
+                lib().pm_pipe_release(self._h, t.value)
         self._next_ticket = t.value + 1
         return t.value
 
@@ -1052,6 +1058,22 @@ class NativePipeline:
         table.latency_ms = {"demod_done": res.ms_to_demod_done, "sliced": res.ms_to_sliced, "done": res.ms_to_done}
         self.done_at_ms[int(ticket)] = res.done_at_ms
         return table
+
+    def slices(self, ticket, chain):
+        """A finished recording's bitstream for one chain (pipelines made with keep_slices=True): what chain[2].slice returned --
+        bytes and stream addresses (slicer.py:59-107) -- and what chain[3].stream_unscramble_8bit made of the bytes (lfsr.py:22-52),
+        as copies: (AddressedArray, uint8 array).  Call before the recording's rows are released."""
+        from .data_classes import AddressedArray
+        self._wait(ticket)
+        d, a, q, k = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64()
+        check(lib().pm_pipe_slices(self._h, int(ticket), int(chain), ctypes.byref(d), ctypes.byref(a), ctypes.byref(q), ctypes.byref(k)))
+        n = k.value
+        if not n:
+            return AddressedArray(np.zeros(0, np.uint8), np.zeros(0, np.int64)), np.zeros(0, np.uint8)
+        data = np.ctypeslib.as_array(ctypes.cast(d, ctypes.POINTER(ctypes.c_uint8)), (n,)).copy()
+        addr = np.ctypeslib.as_array(ctypes.cast(a, ctypes.POINTER(ctypes.c_int64)), (n,)).copy()
+        plain = np.ctypeslib.as_array(ctypes.cast(q, ctypes.POINTER(ctypes.c_uint8)), (n,)).copy()
+        return AddressedArray(data, addr), plain
 
     def release(self, ticket):
         check(lib().pm_pipe_release(self._h, int(ticket)))

@@ -35,10 +35,11 @@ constexpr int kPlane = (kSpan + 15) / 16 * 16;
 struct Scales { double s[kWeights]; double c0; };
 
 __global__ __launch_bounds__(256) void bpf8_kernel(const int16_t *__restrict__ x, int64_t n, const i4 *__restrict__ btab, Scales sc,
-                                                   double *__restrict__ y, int64_t nout)
+                                                   double *__restrict__ y, int64_t nout, int *__restrict__ clear, int nclear)
 {
     __shared__ __attribute__((aligned(16))) unsigned char plane[2][kPlane];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (blockIdx.x == 0 && t < nclear) clear[t] = 0;         // the recording's sweep counters (pm_sweep_cells)
     const int64_t wg0 = (int64_t)blockIdx.x * kWgOut;
     // stage: 8 samples per thread and step -> 8 bytes of each digit plane
     for (int p = t * 8; p < kPlane; p += 256 * 8) {
@@ -189,8 +190,9 @@ void pm_bpf8_plan_destroy(pm_bpf8_plan *p)
 double pm_bpf8_error(const pm_bpf8_plan *p) { return p ? p->err : 0.0; }
 int pm_bpf8_taps(const pm_bpf8_plan *p) { return p ? p->m : 0; }
 
-int pm_bpf8_run(pm_ctx *ctx, const pm_bpf8_plan *p, const int16_t *d_audio, int64_t n, double *d_y)
+int pm_bpf8_run(pm_ctx *ctx, const pm_bpf8_plan *p, const int16_t *d_audio, int64_t n, double *d_y, int *d_clear, int nclear)
 {
+    PM_ARG(nclear >= 0 && nclear <= 64 && (nclear == 0 || d_clear != nullptr));
     PM_CTX(ctx);
     PM_ARG(p != nullptr && d_audio != nullptr && d_y != nullptr && n >= p->m && p->device == ctx->device);
     PM_ARG(((uintptr_t)d_audio & 15) == 0);
@@ -198,7 +200,7 @@ int pm_bpf8_run(pm_ctx *ctx, const pm_bpf8_plan *p, const int16_t *d_audio, int6
     PM_ARG(wgs < (1LL << 31));
     PmProf prof(ctx, PM_K_FIR_I16);
     prof.work((double)n * 2 + (double)nout * 8, 2.0 * p->m * (double)nout);       // the flops of the sum it stands for
-    hipLaunchKernelGGL(bpf8_kernel, dim3((unsigned)wgs), dim3(256), 0, ctx->stream, d_audio, n, p->d_btab, p->sc, d_y, nout);
+    hipLaunchKernelGGL(bpf8_kernel, dim3((unsigned)wgs), dim3(256), 0, ctx->stream, d_audio, n, p->d_btab, p->sc, d_y, nout, d_clear, nclear);
     PM_HIP(hipGetLastError());
     return PM_OK;
 }

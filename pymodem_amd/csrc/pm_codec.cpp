@@ -476,6 +476,7 @@ struct Il2p : pm_codec {
     int corrected = 0;                                      // NOT cleared when a block fails (il2p.py:203-212)
     bool fail = false;
     std::vector<uint8_t> data;
+    int sync_run = 0;                                       // whole input bytes taken in sync search since it was (re)entered, saturating
 
     const uint8_t *feasible = nullptr;
 
@@ -490,6 +491,7 @@ struct Il2p : pm_codec {
     {
         for (int64_t k = 0; k < n; ++k) {
             if (state != kSync) {
+                sync_run = 0;
                 // inside a packet: an input byte completes exactly one packet byte, nbits bits into it.  Unless that byte ends a
                 // block (header, payload block, CRC) nothing else can happen in this input byte: take it in one step.
                 const int needed = state == kHeader ? 15 : state == kCrc ? 4 : block_size + 16;
@@ -503,8 +505,11 @@ struct Il2p : pm_codec {
             }
             // Between packets nearly every byte fails the feasibility test below, which reads nothing but the two input bytes in front
             // of it: skip ahead on the input itself -- no shift register carried from byte to byte -- and rebuild the register (the last
-            // 32 bits seen) where the run of infeasible bytes ends.
-            if (feasible && k >= 4 && k + 1 < n) {
+            // 32 bits seen) where the run of infeasible bytes ends.  Only once the register IS the last 32 input bits: the reference keeps
+            // eight bits of it while it is inside a packet (il2p.py:146-152 with mask 0xFF) and starts with 0xFFFFFF (il2p.py:119), so
+            // for the first four bytes of a sync search the register holds zeros (ones) where the input had bits, and a sync word that
+            // overlaps the tail of a header or packet must be judged on the register, byte by byte, as below.
+            if (feasible && sync_run >= 4 && k >= 4 && k + 1 < n) {
                 int64_t j = k;
                 while (j < n && !feasible[((unsigned)d[j - 2] << 8) | d[j - 1]]) ++j;
                 if (j > k) {
@@ -519,6 +524,7 @@ struct Il2p : pm_codec {
             const uint64_t win = ((uint64_t)word << 8) | d[k];
             // The two bytes before the current one lie wholly inside all eight candidate windows, so one table lookup on them
             // tells which bit offsets can still be within sync_tol of either pattern -- almost always none
+            if (sync_run < 4) ++sync_run;
             if (feasible && !feasible[(win >> 8) & 0xFFFF]) {
                 word = (uint32_t)win;
                 nbits += 8;
@@ -1012,7 +1018,7 @@ int pm_host_decode_batch(pm_host_job *jobs, int njobs, int threads)
         pm_host_job &q = jobs[j];
         thread_local std::vector<uint8_t> plain;
         thread_local std::vector<int64_t> wide;
-        if ((int64_t)plain.size() < q.n) plain.resize((size_t)q.n);
+        if (!q.h_plain && (int64_t)plain.size() < q.n) plain.resize((size_t)q.n);
         const int64_t *addr = q.h_addr;
         if (!addr && q.n > 0) {                 // the compact form of pm_slice_compact: first address + 16-bit steps
             if ((int64_t)wide.size() < q.n) wide.resize((size_t)q.n);
@@ -1020,8 +1026,9 @@ int pm_host_decode_batch(pm_host_job *jobs, int njobs, int threads)
             for (int64_t i = 0; i < q.n; ++i) wide[(size_t)i] = (a += q.h_addr_delta[i]);
             addr = wide.data();
         }
-        q.status = pm_lfsr_unscramble(q.h_data, q.n, q.lfsr_poly, q.lfsr_invert, &q.lfsr_state, plain.data());
-        if (q.status == PM_OK) q.status = pm_codec_decode(q.codec, plain.data(), addr, q.n, &q.pending);
+        uint8_t *out = q.h_plain ? q.h_plain : plain.data();
+        q.status = pm_lfsr_unscramble(q.h_data, q.n, q.lfsr_poly, q.lfsr_invert, &q.lfsr_state, out);
+        if (q.status == PM_OK) q.status = pm_codec_decode(q.codec, out, addr, q.n, &q.pending);
     });
     for (int j = 0; j < njobs; ++j)
         if (jobs[j].status != PM_OK) return jobs[j].status;

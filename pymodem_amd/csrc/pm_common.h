@@ -9,8 +9,36 @@
 
 constexpr size_t PM_PINNED_BYTES = 256 * 1024;
 constexpr int kSweepRing = 64;
+constexpr int kSweepCap = 65536;        // uncertain (sample, modem) pairs a certified sweep's list holds; more: the exact chains take over
+
+// Counter and mailbox words of the certified sweeps of ONE recording, owned by whoever runs recordings side by side (pm_pipe.hip):
+// sweep k counts its uncertain samples in d_count[k] and its last launch leaves the count in the page-locked h_mail[k].  The
+// words belong to the recording from its submission until its owner has read the mail -- no ring, no arithmetic on sequence numbers.
+struct pm_sweep_cells {
+    int *d_count = nullptr;
+    int *h_mail = nullptr;
+};
+
+// Diagnostic switches of the launchers: read from the environment ONCE, when a context is made (pm_tuning_from_env in
+// pm_runtime.hip), or set per context with pm_ctx_tune -- no launch path calls getenv.  README.md lists what each one is for.
+struct pm_tuning {
+    int fir_no_short = 0;              // PM_FIR_NO_SHORT: short-tap sign FIR through the LDS kernel
+    int fuse_run = 0;                  // PM_FUSE_RUN: 16 = round 1's run length in the fused AFSK kernel (0: the default)
+    int afsk_unfused = 0;              // PM_AFSK_UNFUSED: certified AFSK path as separate kernels
+    int afsk_lpf8 = 0;                 // PM_AFSK_LPF8: pm_afsk_sweep_signs_tones with a per-call matrix-pipe low-pass plan
+    int loop_wide = -1;                // PM_LOOP_WIDE: carrier-loop kernel shape 0 / 1 / 2 (-1: by size)
+    int64_t loop_lds_min = 0;          // PM_LOOP_LDS_MIN
+    int lbatch_tail = -1;              // PM_LBATCH_TAIL: matched filters behind (0) or beside the next chunk's loops
+    int agc_trace = 0;                 // PM_AGC_TRACE
+    int slicer_max_chunk_words = 0, slicer_chunk_words = 0, slicer_quantum_words = 0;      // PM_SLICER_*_WORDS (0: the defaults)
+    int slicer_compare_step = 0, slicer_mask_step = 0, slicer_compiled_step = 0;           // older forms of the slicer step
+    int slicer_trace = 0, slicer_no_setprio = 0;
+    int fir8 = 1;                      // PM_FIR8=0: the batch engine's matched filters in binary64 on the vector pipe
+};
+pm_tuning pm_tuning_from_env();
 
 struct pm_ctx {
+    pm_tuning tune = pm_tuning_from_env();
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -86,7 +114,9 @@ int pm_bpf8_plan_create(pm_ctx *ctx, const double *h_taps, int m, pm_bpf8_plan *
 void pm_bpf8_plan_destroy(pm_bpf8_plan *p);
 double pm_bpf8_error(const pm_bpf8_plan *p);
 int pm_bpf8_taps(const pm_bpf8_plan *p);
-int pm_bpf8_run(pm_ctx *ctx, const pm_bpf8_plan *p, const int16_t *d_audio, int64_t n, double *d_y);      // d_audio 16-byte aligned
+// d_audio 16-byte aligned; d_clear: nclear (<= 64) ints the launch zeroes (a recording's sweep counters: the band-pass is the first
+// launch of its demod stage, the sweeps behind it on the same stream start from zero without a memset of their own)
+int pm_bpf8_run(pm_ctx *ctx, const pm_bpf8_plan *p, const int16_t *d_audio, int64_t n, double *d_y, int *d_clear = nullptr, int nclear = 0);
 // The certified sweeps' low-pass on the same pipe (afsk_slide_lpf8_kernel in pm_fir.hip): taps as five signed base-256 digits
 // q = rint(h 2^S), the Toeplitz band as MFMA B operands [digit][block][lane] on the device.  ml <= 113.
 struct pm_lpf8_plan {
@@ -100,9 +130,11 @@ int pm_lpf8_plan_create(pm_ctx *ctx, const double *h_taps, int ml, pm_lpf8_plan 
 void pm_lpf8_plan_destroy(pm_lpf8_plan *p);
 // pm_afsk_group_run with the band-pass from a plan (nullptr: the reference's sum); every sweep must then carry tones.
 // lpf8: nullptr or one plan per sweep (entries may be nullptr): that sweep's low-passes on the matrix pipe
+// cells: nullptr (the context's counter ring, results through pm_afsk_sweep_results) or the recording's own counters (nsweeps of
+// each; h_tickets is not written then): the counts arrive in cells->h_mail[k] when the recording's demod stage has finished
 int pm_afsk_group_run_plan(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const double *d_bpf, int mb, double *d_bpf_out, double x_bound,
                            const pm_afsk_sweep_desc *h_sweeps, int nsweeps, int64_t *h_tickets, const pm_bpf8_plan *plan,
-                           const pm_lpf8_plan *const *lpf8 = nullptr);
+                           const pm_lpf8_plan *const *lpf8 = nullptr, const pm_sweep_cells *cells = nullptr);
 
 // ---- launchers shared between translation units (what the batch engine pm_loopbatch.hip strings together) ---------------------
 // `rows` FIRs with the same taps over equal-length streams in one launch (pm_fir.hip).  Input row r: d_x + r * x_stride, or

@@ -1226,7 +1226,7 @@ int fir_launch2(pm_ctx *ctx, const InT *d_x, int64_t n, const double *d_taps, in
     PmProf prof(ctx, sizeof(InT) == 2 ? PM_K_FIR_I16 : PM_K_FIR_F64);
     prof.work((double)n * sizeof(InT) + (d_bits ? (double)nout / 8 : (double)nout * 8), 2.0 * m * (double)nout);
     const bool vec = (((uintptr_t)d_x | (uintptr_t)d_y) & 15) == 0;          // 16-byte loads and stores
-    if (sizeof(InT) == 2 && d_bits && !d_y && vec && m >= 2 && m <= 8 && !getenv("PM_FIR_NO_SHORT")) {
+    if (sizeof(InT) == 2 && d_bits && !d_y && vec && m >= 2 && m <= 8 && !ctx->tune.fir_no_short) {
         // the register path for short taps (fir_short_signs_i16_kernel): one lane per bitmap byte
         const int64_t lanes = ((nout + 63) >> 6) * 8;
         const unsigned grid = (unsigned)pm_cdiv(lanes, (int64_t)kThreads * kShortIter);
@@ -1567,9 +1567,12 @@ static int afsk_magnitudes(pm_ctx *ctx, const double *d_x, int64_t n, double x_b
 static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound, const double *d_mark_i, const double *d_mark_q,
                        const double *d_unit_i, const double *d_unit_q, const double *d_space, const double *h_gains, int groups, int m,
                        const double *d_lpf, int ml, double lpf_abs_sum, uint64_t *const *h_bits, const pm_afsk_tones *tones,
-                       const SweepSource *src = nullptr, const pm_lpf8_plan *lpf8 = nullptr)
+                       const SweepSource *src = nullptr, const pm_lpf8_plan *lpf8 = nullptr, int *own_count = nullptr, int *own_mail = nullptr)
 {
     PM_CTX(ctx);
+    // own_count / own_mail: the caller's counter and mailbox word for this sweep (pm_sweep_cells: zeroed by an earlier launch on this
+    // stream, read by the caller when the stream has passed this sweep); the context's ring stays where it is
+    PM_ARG((own_count == nullptr) == (own_mail == nullptr) && (!own_count || ctx->sweep_deferred));
     PM_ARG(d_x && d_mark_i && d_mark_q && d_unit_i && d_unit_q && d_space && h_gains && d_lpf && h_bits);
     // a band-passed stream that is only near the reference's: certified decisions with the deferred fallback only (the gated exact
     // launches below read d_x), and the exact recomputation goes back to the audio
@@ -1591,7 +1594,7 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
         P.bits[g] = h_bits[g];
         gmax = std::max(gmax, h_gains[g]);
     }
-    const int cap = 65536;                                 // more uncertain samples than this: the gated exact path below takes over
+    const int cap = kSweepCap;                             // more uncertain samples than this: the gated exact path below takes over
     const int F = 2 + 2 * groups;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const int64_t stride = (nc + 63) / 64 * 64;
@@ -1604,34 +1607,36 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
     // The counter of uncertain samples lives in a small ring of its own (not in the scratch block, which the next call on this
     // context re-carves and may re-allocate: pm_afsk_sweep_last reads it later).  All slots start at zero; the last launch of a
     // sweep clears the slot the next sweep will use, so there is no memset on the stream.
-    if (!ctx->d_sweep) {
+    if (!own_count && !ctx->d_sweep) {
         PM_HIP(hipMalloc((void **)&ctx->d_sweep, kSweepRing * sizeof(int)));
         PM_HIP(hipMemset(ctx->d_sweep, 0, kSweepRing * sizeof(int)));
         PM_HIP(hipHostMalloc((void **)&ctx->h_sweep, kSweepRing * sizeof(int), hipHostMallocDefault));
         memset(ctx->h_sweep, 0, kSweepRing * sizeof(int));
     }
-    int *count = ctx->d_sweep + (ctx->sweep_seq % kSweepRing);
-    int *count_next = ctx->d_sweep + ((ctx->sweep_seq + 1) % kSweepRing);
-    int *mail = ctx->sweep_deferred ? ctx->h_sweep + (ctx->sweep_seq % kSweepRing) : nullptr;
-    ctx->sweep_mail[ctx->sweep_seq % kSweepRing] = mail ? ctx->sweep_seq + 1 : 0;
-    ctx->sweep_seq++;
+    int *count = own_count, *count_next = nullptr, *mail = own_mail;
+    if (!own_count) {
+        count = ctx->d_sweep + (ctx->sweep_seq % kSweepRing);
+        count_next = ctx->d_sweep + ((ctx->sweep_seq + 1) % kSweepRing);
+        mail = ctx->sweep_deferred ? ctx->h_sweep + (ctx->sweep_seq % kSweepRing) : nullptr;
+        ctx->sweep_mail[ctx->sweep_seq % kSweepRing] = mail ? ctx->sweep_seq + 1 : 0;
+        ctx->sweep_seq++;
+    }
     // a sweep that fails from here on has not run its last launch: the next sweep's counter is cleared by hand
     struct RingGuard {
         hipStream_t st; int *next; bool ok;
-        ~RingGuard() { if (!ok) (void)hipMemsetAsync(next, 0, sizeof(int), st); }
+        ~RingGuard() { if (!ok && next) (void)hipMemsetAsync(next, 0, sizeof(int), st); }
     } ring{ctx->stream, count_next, false};
     double *d_w = (double *)(base + 2 * b_m + b_a + b_list + 256);
     double *C = (double *)(base + 2 * b_m + b_a + b_list + 256 + b_w);
-    ctx->sweep_count = count;
+    if (!own_count) ctx->sweep_count = count;
     double e_slide = 0.0;
     // One chain with tone templates: its mark - gain * space difference leaves the sliding kernel as ONE stream and takes ONE
     // low-pass (the reference's own dataflow, afsk.py:162-166, on approximate magnitudes); a sweep takes two for all its chains.
     const bool one = groups == 1 && tones && m >= 2;
     const double *lp_in = one ? M : S, *lp_a = one ? nullptr : A;
-    int frun = getenv("PM_FUSE_RUN") ? atoi(getenv("PM_FUSE_RUN")) : kFuseRun;
-    if (frun != 16) frun = kFuseRun;                         // PM_FUSE_RUN=16: round 1's run length, for comparison
+    const int frun = ctx->tune.fuse_run == 16 ? 16 : kFuseRun;      // PM_FUSE_RUN=16: round 1's run length, for comparison
     const bool fused = tones && m >= 2 && (kThreads * 8 + ml - 1 + frun - 1) / frun <= kThreads &&
-                       fuse_lds_bytes(m, ml, frun) <= 120 * 1024 && !getenv("PM_AFSK_UNFUSED");
+                       fuse_lds_bytes(m, ml, frun) <= 120 * 1024 && !ctx->tune.afsk_unfused;
     if (fused) {
         // sliding sums, low-pass(es) and combine in one kernel (afsk_slide_lpf_kernel): nothing but the bitmaps is written
         e_slide = slide_bound(tones, m, x_bound, frun);
@@ -1652,8 +1657,7 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
     // pipeline's own otherwise
     pm_lpf8_plan *own8 = nullptr;
     if (fused && !lpf8 && frun == kFuseRun && ml + 15 <= 128) {
-        const char *e8 = getenv("PM_AFSK_LPF8");
-        if (e8 && e8[0] == '1') {
+        if (ctx->tune.afsk_lpf8 == 1) {
             std::vector<double> hl((size_t)ml);
             PM_HIP(hipMemcpyAsync(hl.data(), d_lpf, hl.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             PM_HIP(hipStreamSynchronize(ctx->stream));
@@ -1846,7 +1850,7 @@ int pm_afsk_group_run(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const doub
 
 int pm_afsk_group_run_plan(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const double *d_bpf, int mb, double *d_bpf_out, double x_bound,
                            const pm_afsk_sweep_desc *h_sweeps, int nsweeps, int64_t *h_tickets, const pm_bpf8_plan *plan,
-                           const pm_lpf8_plan *const *lpf8)
+                           const pm_lpf8_plan *const *lpf8, const pm_sweep_cells *cells)
 {
     // The demod stage of a whole AFSK chain group in ONE call: the shared band-pass (afsk.py:151) and every certified sweep on its
     // output (afsk.py:153-166, sign bitmaps only), overflow fallback deferred to the caller (pm_afsk_sweep_results).  The same
@@ -1859,12 +1863,14 @@ int pm_afsk_group_run_plan(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const
     static long calls = 0;
     const auto t_0 = std::chrono::steady_clock::now();
     SweepSource src{d_audio, d_bpf, mb, plan ? pm_bpf8_error(plan) : 0.0};
+    PM_ARG(!cells || (cells->d_count && cells->h_mail));
     if (plan) {
         PM_ARG(pm_bpf8_taps(plan) == mb);
         for (int k = 0; k < nsweeps; ++k) PM_ARG(h_sweeps[k].h_tones != nullptr);
-        if (int rc = pm_bpf8_run(ctx, plan, d_audio, n, d_bpf_out)) return rc;
-    } else if (int rc = fir_launch<int16_t>(ctx, d_audio, n, d_bpf, mb, d_bpf_out, nullptr, 0)) {
-        return rc;
+        if (int rc = pm_bpf8_run(ctx, plan, d_audio, n, d_bpf_out, cells ? cells->d_count : nullptr, cells ? nsweeps : 0)) return rc;
+    } else {
+        if (cells) PM_HIP(hipMemsetAsync(cells->d_count, 0, sizeof(int) * (size_t)nsweeps, ctx->stream));
+        if (int rc = fir_launch<int16_t>(ctx, d_audio, n, d_bpf, mb, d_bpf_out, nullptr, 0)) return rc;
     }
     const auto t_1 = std::chrono::steady_clock::now();
     const bool was = ctx->sweep_deferred;
@@ -1873,8 +1879,9 @@ int pm_afsk_group_run_plan(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const
     for (int k = 0; k < nsweeps && rc == PM_OK; ++k) {
         const pm_afsk_sweep_desc &w = h_sweeps[k];
         rc = sweep_signs(ctx, d_bpf_out, n - mb + 1, x_bound, w.d_mark_i, w.d_mark_q, w.d_unit_i, w.d_unit_q, w.d_space, w.h_gains, w.groups, w.m,
-                         w.d_lpf, w.ml, w.lpf_abs_sum, w.h_bits, w.h_tones, plan ? &src : nullptr, lpf8 ? lpf8[k] : nullptr);
-        if (h_tickets) h_tickets[k] = ctx->sweep_seq - 1;
+                         w.d_lpf, w.ml, w.lpf_abs_sum, w.h_bits, w.h_tones, plan ? &src : nullptr, lpf8 ? lpf8[k] : nullptr,
+                         cells ? cells->d_count + k : nullptr, cells ? cells->h_mail + k : nullptr);
+        if (h_tickets && !cells) h_tickets[k] = ctx->sweep_seq - 1;
     }
     ctx->sweep_deferred = was;
     if (trace) {
@@ -1920,7 +1927,7 @@ int pm_afsk_sweep_results(pm_ctx *ctx, const int64_t *tickets, int n, pm_ctx *vi
     for (int k = 0; k < n && mailed; ++k) mailed = ctx->sweep_mail[tickets[k] % kSweepRing] == tickets[k] + 1;
     if (mailed) {
         for (int k = 0; k < n; ++k) h_uncertain[k] = ((volatile int *)ctx->h_sweep)[tickets[k] % kSweepRing];
-        if (h_capacity) *h_capacity = 65536;
+        if (h_capacity) *h_capacity = kSweepCap;
         return PM_OK;
     }
     // the caller knows the sweeps have finished; the whole ring (256 bytes) comes over in ONE copy on `via`'s stream (the caller's own:
@@ -1930,7 +1937,7 @@ int pm_afsk_sweep_results(pm_ctx *ctx, const int64_t *tickets, int n, pm_ctx *vi
     PM_HIP(hipMemcpyAsync(h, ctx->d_sweep, kSweepRing * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     PM_HIP(hipStreamSynchronize(c->stream));
     for (int k = 0; k < n; ++k) h_uncertain[k] = h[tickets[k] % kSweepRing];
-    if (h_capacity) *h_capacity = 65536;
+    if (h_capacity) *h_capacity = kSweepCap;
     return PM_OK;
 }
 

@@ -218,7 +218,7 @@ int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings,
                   int64_t bits_stride, int64_t *h_nout)
 {
     PM_ARG(b != nullptr && h_d_audio != nullptr && d_bits_i != nullptr && h_nout != nullptr);
-    static const int tail_mode = getenv("PM_LBATCH_TAIL") ? atoi(getenv("PM_LBATCH_TAIL")) : -1;
+    const int tail_mode = b->back ? b->back->tune.lbatch_tail : -1;
     // The matched filters of chunk t beside the loops of chunk t + 1 (third stream; PM_LBATCH_TAIL=0: behind them on the caller's stream).
     // With the tiled loop shapes this paid only sometimes -- beside a filter those loops ran 1.8-2.8x slower, their LDS traffic queuing
     // behind the filter's -- with the direct shape (no tiles in LDS) it pays everywhere: same box, same minute, third stream on / off:

@@ -447,7 +447,7 @@ int loop_enqueue(pm_ctx *ctx, pm_loop *d_loops, int nloops, int per_row, const d
     // every lane a loop once eight-lane waves would outnumber the CUs (PM_LOOP_WIDE=0 / 1 / 2 forces the shape: tests, measurements;
     // 1 = the tiled 64-loop shape, 2 = the direct one)
     int shape = nloops > 8 * 256 ? 2 : 0;
-    if (const char *e = getenv("PM_LOOP_WIDE")) shape = atoi(e);
+    if (ctx->tune.loop_wide >= 0) shape = ctx->tune.loop_wide;
     if (shape == 2) {
         const size_t lds2 = 516 * 8 + (MODE == kMpsk ? 4096 * 4 : 0);
         PmProf prof(ctx, PM_K_LOOP);
@@ -460,7 +460,7 @@ int loop_enqueue(pm_ctx *ctx, pm_loop *d_loops, int nloops, int per_row, const d
     const int g = wide ? 64 : 8, tile = wide ? 32 : 256;
     const int rows_lds = loop_rows_lds(per_row, nloops, g);
     size_t lds = loop_lds_bytes(MODE, rows_lds, g, tile);
-    if (const char *e = getenv("PM_LOOP_LDS_MIN")) lds = std::max(lds, (size_t)atol(e));     // experiment: one workgroup per CU
+    if (ctx->tune.loop_lds_min > 0) lds = std::max(lds, (size_t)ctx->tune.loop_lds_min);     // experiment: one workgroup per CU
     auto go = [&](auto kernel) -> int {
         if (lds > 64 * 1024) PM_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         PmProf prof(ctx, PM_K_LOOP);
@@ -918,7 +918,7 @@ int pm_agc_apply(pm_ctx *ctx, double *d_buf, int64_t n, const pm_agc_params *hp,
         PM_HIP(hipMemsetAsync(changed, 0, sizeof(int), ctx->stream));
         PM_HIP(hipStreamSynchronize(ctx->stream));
         converged = (*h_flag == 0);
-        if (getenv("PM_AGC_TRACE")) fprintf(stderr, "[agc] after %d iterations: %d start states changed (chunks %lld x %d)\n", iters, *h_flag, (long long)nchunks, lc);
+        if (ctx->tune.agc_trace) fprintf(stderr, "[agc] after %d iterations: %d start states changed (chunks %lld x %d)\n", iters, *h_flag, (long long)nchunks, lc);
         if (!converged && iters > nchunks + 10)
             return pm_set_error(PM_ERR_NOCONVERGE, "AGC fixed point not reached after %d iterations", iters);
     }

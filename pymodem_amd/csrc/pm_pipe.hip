@@ -47,7 +47,10 @@ struct Rec {                             // one recording on its way through
     std::vector<int64_t> nout;                          // per chain: the slicer's input length
     hipEvent_t demod_done = nullptr;
     pm_ctx *dctx = nullptr;                             // the context (stream) that demodulates this recording
-    std::vector<int64_t> sweep_tickets;
+    int cell = -1;                                      // its sweeps' counter / mailbox words (pm_pipe::cells), until the slicer worker has read them
+    // pm_pipe_desc.keep_slices: what the slicer and the LFSR produced, chain by chain (pm_pipe_slices)
+    std::vector<std::vector<uint8_t>> kept_data, kept_plain;
+    std::vector<std::vector<int64_t>> kept_addr;
     // slicer output (compact form inside `block`)
     std::shared_ptr<HostBlock> block;
     std::vector<int64_t> off, count;
@@ -112,7 +115,12 @@ struct pm_pipe {
     std::deque<std::shared_ptr<Rec>> slice_q, host_q;
     std::map<int64_t, std::shared_ptr<Rec>> results;
     std::vector<char> slot_busy;
-    int64_t next_ticket = 0, submitted = 0, finished = 0;
+    // per-recording counter / mailbox words of the certified sweeps: block k = words [k * nsweeps, (k + 1) * nsweeps) of both
+    // arrays; a block is the recording's from pm_pipe_submit until its slicer worker has read the mail, then back on the free list
+    int *d_cells = nullptr, *h_cells = nullptr;
+    std::vector<int> free_cells;
+    bool keep_slices = false, trace = false;
+    int64_t next_ticket = 0, submitted = 0, finished = 0;   // submitted: tickets handed out (each is in `results` from then on)
     int64_t promised = 0;                // pm_pipe_submit_many: tickets below this will exist; pm_pipe_wait waits for them to
     bool promise_failed = false;
     bool closing = false;
@@ -221,12 +229,17 @@ void slice_worker(pm_pipe *p, int wi)
         int rc = PM_OK;
         // certified sweeps that overflowed are redone with the exact kernels, here
         for (auto &r : batch) {
-            std::vector<int64_t> unc(p->nsweeps);
-            int64_t cap = 0;
             if (!p->nsweeps) break;
-            if ((rc = pm_afsk_sweep_results(r->dctx, r->sweep_tickets.data(), p->nsweeps, side, unc.data(), &cap))) { fail(*r, rc); continue; }
+            // the recording's demod event has been waited for: its sweeps' last launches have left their counts in the mailbox words
+            std::vector<int64_t> unc(p->nsweeps);
+            for (int s = 0; s < p->nsweeps; ++s) unc[s] = ((volatile int *)p->h_cells)[(size_t)r->cell * p->nsweeps + s];
+            {
+                std::unique_lock<std::mutex> lk(p->mu);
+                p->free_cells.push_back(r->cell);
+                r->cell = -1;
+            }
             for (int s = 0; s < p->nsweeps && !r->status; ++s) {
-                if (unc[s] <= cap) continue;
+                if (unc[s] <= kSweepCap) continue;
                 for (int c = 0; c < nch && !r->status; ++c)
                     if (p->chains[c].sweep == s && (rc = exact_chain(p, side, w, *r, c))) fail(*r, rc);
             }
@@ -335,9 +348,10 @@ void slice_worker(pm_pipe *p, int wi)
                 if (!rc && hipStreamSynchronize(side->stream) != hipSuccess) rc = pm_set_error(PM_ERR_HIP, "slicer stream failed");
             }
         }
+        // a failed batch may have walkers or copies enqueued that still read the bitmaps: the slots go back when the stream is empty
+        if (rc) (void)hipStreamSynchronize(side->stream);
         const double t1 = now_ms();
-        static const bool trace = getenv("PM_PIPE_TRACE") != nullptr;
-        if (trace)
+        if (p->trace)
             fprintf(stderr, "[pm_pipe] worker %d batch of %d (first %lld): demod done at %.2f, collected %.2f, sweeps checked +%.2f, sliced +%.2f, on the host +%.2f ms\n", wi, nb,
                     (long long)batch[0]->ticket, batch[0]->t_ready - p->t_origin, t0 - p->t_origin, t_a - t0, t_b - t_a, t1 - t_b);
         for (int b = 0; b < nb; ++b) {
@@ -421,9 +435,27 @@ void host_worker(pm_pipe *p)
                 j.lfsr_state = 0;
                 j.lfsr_invert = ch.lfsr_invert;
             }
+            if (!rc && p->keep_slices) {
+                // the slicer's output as it reached the host, addresses in full, and room for the LFSR's bytes (pm_host_job.h_plain)
+                r.kept_data.resize(nch);
+                r.kept_addr.resize(nch);
+                r.kept_plain.resize(nch);
+                for (int c = 0; c < nch; ++c) {
+                    pm_host_job &j = jobs[c];
+                    r.kept_data[c].assign(j.h_data, j.h_data + j.n);
+                    r.kept_addr[c].resize((size_t)j.n);
+                    if (j.h_addr) {
+                        std::copy(j.h_addr, j.h_addr + j.n, r.kept_addr[c].begin());
+                    } else {
+                        int64_t a = j.addr_first;
+                        for (int64_t i = 0; i < j.n; ++i) r.kept_addr[c][(size_t)i] = (a += j.h_addr_delta[i]);
+                    }
+                    r.kept_plain[c].resize((size_t)j.n);
+                    j.h_plain = r.kept_plain[c].data();
+                }
+            }
             if (!rc) rc = pm_host_decode_batch(jobs.data(), nch, p->decode_threads);
-            static const bool trace = getenv("PM_PIPE_TRACE") != nullptr;
-            if (trace) {
+            if (p->trace) {
                 std::string line = "[pm_pipe] recording " + std::to_string(r.ticket) + " rc " + std::to_string(rc) + ": slicer bytes / packets per chain";
                 for (int c = 0; c < nch; ++c) line += " " + std::to_string(r.count[c]) + "/" + std::to_string(jobs[c].pending);
                 line += "; host stage began " + std::to_string(t0 - p->t_origin) + ", decode done " + std::to_string(now_ms() - p->t_origin);
@@ -454,8 +486,7 @@ void host_worker(pm_pipe *p)
             if (c) (void)pm_codec_destroy(c);
         r.block.reset();
         r.t_done = now_ms();
-        static const bool trace_done = getenv("PM_PIPE_TRACE") != nullptr;
-        if (trace_done) fprintf(stderr, "[pm_pipe] recording %lld done at %.2f\n", (long long)r.ticket, r.t_done - p->t_origin);
+        if (p->trace) fprintf(stderr, "[pm_pipe] recording %lld done at %.2f\n", (long long)r.ticket, r.t_done - p->t_origin);
         {
             std::unique_lock<std::mutex> lk(p->mu);
             r.done = true;
@@ -494,7 +525,9 @@ int pm_pipe_destroy(pm_pipe *p)
     for (size_t i = 1; i < p->demod.size(); ++i) (void)pm_ctx_destroy(p->demod[i]);
     for (hipEvent_t e : p->handover)
         if (e) (void)hipEventDestroy(e);
-    for (size_t i = 0; i < p->work.size(); ++i) {
+    if (p->d_cells) (void)hipFree(p->d_cells);
+    if (p->h_cells) (void)hipHostFree(p->h_cells);
+    for (size_t i = 0; i < std::min(p->work.size(), p->side.size()); ++i) {      // (a create that failed half way: fewer contexts than blocks)
         pm_ctx *s = p->side[i];
         for (void *q : {(void *)p->work[i].d_out, (void *)p->work[i].d_dense, (void *)p->work[i].d_tmp})
             if (q) (void)pm_free(s, q);
@@ -526,7 +559,9 @@ int pm_pipe_create(pm_ctx *ctx, const pm_pipe_desc *desc, pm_pipe **out)
     // two: with the sweeps' sums on the matrix pipe three recordings' demod kernels at once take longer than three in a row
     // (demod alone 0.67 ms per recording with three streams, 0.49 with two, 0.84 with one)
     const int nd = d.demod_streams > 0 ? std::min(d.demod_streams, 4) : 2;
-    if (d.nsweeps) p->slots = std::max(2, std::min(p->slots, 60 / d.nsweeps * nd));  // a sweep's counter stays readable for 63 further sweeps of its context
+    p->slots = std::max(2, p->slots);
+    p->keep_slices = d.keep_slices != 0;
+    p->trace = getenv("PM_PIPE_TRACE") != nullptr;
     p->group = d.slice_group > 0 ? std::min(d.slice_group, 16) : 4;
     p->min_group = d.slice_min_group > 0 ? std::min(d.slice_min_group, p->group) : p->group;
     p->host_threads = d.host_threads > 0 ? d.host_threads : std::max(2, std::min(8, 24 / d.nchains)) + 1;
@@ -648,6 +683,17 @@ int pm_pipe_create(pm_ctx *ctx, const pm_pipe_desc *desc, pm_pipe **out)
                 for (int g = 0; g < p->sweeps[s].groups; ++g) p->sweep_bits_store[sl][s][g] = p->d_bits[(size_t)sl * d.nchains + seen[s][g]];
             }
         }
+        if (d.nsweeps) {
+            // one block of counter / mailbox words per recording between submission and its slicer batch: never more than `slots`
+            const size_t words = (size_t)p->slots * d.nsweeps;
+            if (hipMalloc((void **)&p->d_cells, words * sizeof(int)) != hipSuccess || hipMemset(p->d_cells, 0, words * sizeof(int)) != hipSuccess ||
+                hipHostMalloc((void **)&p->h_cells, words * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+                rc = pm_set_error(PM_ERR_HIP, "pm_pipe_create: no memory for the sweep counters");
+                break;
+            }
+            memset(p->h_cells, 0, words * sizeof(int));
+            for (int k = p->slots - 1; k >= 0; --k) p->free_cells.push_back(k);
+        }
         p->slot_busy.assign(p->slots, 0);
         p->slot_event.assign(p->slots, nullptr);
         p->handover.assign(p->slots, nullptr);
@@ -690,20 +736,11 @@ int pm_pipe_submit(pm_pipe *p, const int16_t *d_audio, int64_t n, int64_t *h_tic
     PM_ARG(p != nullptr && d_audio != nullptr && h_ticket != nullptr);
     PM_CTX(p->ctx);
     PM_ARG(n >= p->mb && n <= p->max_samples);
+    // Everything that can refuse the recording by its shape is checked before a ticket exists.
     auto r = std::make_shared<Rec>();
     r->d_audio = d_audio;
     r->n = n;
     const int64_t nb = n - p->mb + 1;
-    {
-        std::unique_lock<std::mutex> lk(p->mu);
-        r->ticket = p->next_ticket++;
-        r->slot = (int)(r->ticket % p->slots);
-        const double tw = now_ms();
-        p->cv_slot.wait(lk, [&] { return !p->slot_busy[r->slot]; });      // the recording that used this slot `slots` submissions ago is sliced
-        p->slot_busy[r->slot] = 1;
-        static const bool trace = getenv("PM_PIPE_TRACE") != nullptr;
-        if (trace) fprintf(stderr, "[pm_pipe] submit %lld at %.2f (waited %.2f ms for its slot)\n", (long long)r->ticket, now_ms() - p->t_origin, now_ms() - tw);
-    }
     r->nout.resize(p->nchains);
     for (int c = 0; c < p->nchains; ++c) {
         if (p->chains[c].sweep < 0) {
@@ -712,17 +749,30 @@ int pm_pipe_submit(pm_pipe *p, const int16_t *d_audio, int64_t n, int64_t *h_tic
             const pm_afsk_sweep_desc &w = p->sweeps[p->chains[c].sweep];
             r->nout[c] = nb - w.m - w.ml + 2;
         }
-        if (r->nout[c] < 1) {
-            std::unique_lock<std::mutex> lk(p->mu);
-            p->slot_busy[r->slot] = 0;
-            p->cv_slot.notify_all();
-            return pm_set_error(PM_ERR_ARG, "pm_pipe_submit: %lld samples are fewer than the filters of chain %d need", (long long)n, c);
-        }
+        if (r->nout[c] < 1) return pm_set_error(PM_ERR_ARG, "pm_pipe_submit: %lld samples are fewer than the filters of chain %d need", (long long)n, c);
     }
+    {
+        // From here on the ticket exists: it is in `results` (a wait finds it), it counts as submitted (drain and destroy wait for
+        // it), and a launch that fails below finishes it with that error instead of leaving a hole in the ticket sequence.
+        std::unique_lock<std::mutex> lk(p->mu);
+        r->ticket = p->next_ticket++;
+        p->results[r->ticket] = r;
+        p->submitted++;
+        r->slot = (int)(r->ticket % p->slots);
+        const double tw = now_ms();
+        p->cv_slot.wait(lk, [&] { return !p->slot_busy[r->slot] && (!p->nsweeps || !p->free_cells.empty()); });      // the recording that used this slot `slots` submissions ago is sliced
+        p->slot_busy[r->slot] = 1;
+        if (p->nsweeps) {
+            r->cell = p->free_cells.back();
+            p->free_cells.pop_back();
+        }
+        if (p->trace) fprintf(stderr, "[pm_pipe] submit %lld at %.2f (waited %.2f ms for its slot)\n", (long long)r->ticket, now_ms() - p->t_origin, now_ms() - tw);
+    }
+    *h_ticket = r->ticket;
+    p->cv_done.notify_all();                                 // waits for a promised ticket: it exists now
     r->t_submit = now_ms();
     std::vector<pm_afsk_sweep_desc> sw(p->sweeps);
     for (int s = 0; s < p->nsweeps; ++s) sw[s].h_bits = p->sweep_bits_store[r->slot][s].data();
-    r->sweep_tickets.assign(p->nsweeps, 0);
     const size_t di = (size_t)(r->ticket % (int64_t)p->demod.size());
     r->dctx = p->demod[di];
     int rc = PM_OK;
@@ -732,9 +782,11 @@ int pm_pipe_submit(pm_pipe *p, const int16_t *d_audio, int64_t n, int64_t *h_tic
         if (hipEventRecord(p->handover[r->slot], p->ctx->stream) != hipSuccess || hipStreamWaitEvent(r->dctx->stream, p->handover[r->slot], 0) != hipSuccess)
             rc = pm_set_error(PM_ERR_HIP, "handing the recording to demod stream %zu failed", di);
     }
-    if (!rc && p->nsweeps)
-        rc = pm_afsk_group_run_plan(r->dctx, d_audio, n, p->d_bpf, p->mb, p->d_bpf_outs[di], p->x_bound, sw.data(), p->nsweeps, r->sweep_tickets.data(),
-                                    ((uintptr_t)d_audio & 15) == 0 ? p->bpf8 : nullptr, p->lpf8.data());
+    if (!rc && p->nsweeps) {
+        const pm_sweep_cells cells{p->d_cells + (size_t)r->cell * p->nsweeps, p->h_cells + (size_t)r->cell * p->nsweeps};
+        rc = pm_afsk_group_run_plan(r->dctx, d_audio, n, p->d_bpf, p->mb, p->d_bpf_outs[di], p->x_bound, sw.data(), p->nsweeps, nullptr,
+                                    ((uintptr_t)d_audio & 15) == 0 ? p->bpf8 : nullptr, p->lpf8.data(), &cells);
+    }
     for (int c = 0; c < p->nchains && !rc; ++c)              // sign-FIR groups: one launch per group into its first chain's bitmap (fsk.py:149-159)
         if (p->chains[c].sweep < 0 && p->bit_owner[c] == c) {
             const pm_pipe_fir &f = p->firs[-p->chains[c].sweep - 1];
@@ -743,19 +795,28 @@ int pm_pipe_submit(pm_pipe *p, const int16_t *d_audio, int64_t n, int64_t *h_tic
     if (!rc && hipEventRecord(p->slot_event[r->slot], r->dctx->stream) != hipSuccess) rc = pm_set_error(PM_ERR_HIP, "hipEventRecord failed");
     r->demod_done = p->slot_event[r->slot];
     if (rc) {
-        std::unique_lock<std::mutex> lk(p->mu);
-        p->slot_busy[r->slot] = 0;
+        // Some of the recording's launches may be on the stream: they write this slot's bitmaps and this block's counters, so both go
+        // back only when the stream has passed them.  The ticket is finished, with the error.
+        fail(*r, rc);
+        (void)hipStreamSynchronize(r->dctx->stream);
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->slot_busy[r->slot] = 0;
+            if (r->cell >= 0) p->free_cells.push_back(r->cell);
+            r->cell = -1;
+            r->done = true;
+            r->t_done = r->t_sliced = r->t_ready = now_ms();
+            p->finished++;
+        }
         p->cv_slot.notify_all();
-        return rc;
+        p->cv_done.notify_all();
+        return pm_set_error(rc, "%s", r->error.c_str());
     }
     {
         std::unique_lock<std::mutex> lk(p->mu);
-        p->results[r->ticket] = r;
         p->slice_q.push_back(r);
-        p->submitted++;
     }
     p->cv_slice.notify_one();
-    *h_ticket = r->ticket;
     return PM_OK;
 }
 
@@ -785,9 +846,9 @@ int pm_pipe_submit_many(pm_pipe *p, const int16_t *const *d_audio, const int64_t
     }
     int rc = PM_OK;
     for (int i = 0; i < count && !rc; ++i) {
-        int64_t t = 0;
+        int64_t t = -1;
         rc = pm_pipe_submit(p, d_audio[i], n[i], &t);
-        p->cv_done.notify_all();
+        if (rc && t >= 0) (void)pm_pipe_release(p, t);       // a ticket that finished with the launch error: nobody will ask for it
     }
     if (rc) {
         char keep[512];
@@ -809,8 +870,9 @@ int pm_pipe_wait(pm_pipe *p, int64_t ticket, pm_pipe_result *out)
     std::shared_ptr<Rec> r;
     {
         std::unique_lock<std::mutex> lk(p->mu);
-        // a ticket pm_pipe_submit_many has promised and not yet reached: wait for its submission first
-        p->cv_done.wait(lk, [&] { return ticket < p->submitted || ticket >= p->promised || p->promise_failed; });      // (submitted: in `results`)
+        // a ticket pm_pipe_submit_many has promised and not yet reached: wait until it exists (every ticket below next_ticket is in
+        // `results` from the moment it was handed out until pm_pipe_release)
+        p->cv_done.wait(lk, [&] { return ticket < p->next_ticket || ticket >= p->promised || p->promise_failed; });
         auto it = p->results.find(ticket);
         if (it == p->results.end()) return pm_set_error(PM_ERR_ARG, "pm_pipe_wait: ticket %lld is unknown (or released)", (long long)ticket);
         r = it->second;
@@ -849,6 +911,25 @@ int pm_pipe_drain(pm_pipe *p)
     PM_ARG(p != nullptr);
     std::unique_lock<std::mutex> lk(p->mu);
     p->cv_done.wait(lk, [&] { return p->finished == p->submitted; });
+    return PM_OK;
+}
+
+int pm_pipe_slots(pm_pipe *p) { return p ? p->slots : 0; }
+
+int pm_pipe_slices(pm_pipe *p, int64_t ticket, int chain, const uint8_t **h_data, const int64_t **h_addr, const uint8_t **h_plain, int64_t *h_count)
+{
+    PM_ARG(p != nullptr && h_count != nullptr && chain >= 0 && chain < p->nchains);
+    if (!p->keep_slices) return pm_set_error(PM_ERR_ARG, "pm_pipe_slices: the pipeline was made without keep_slices");
+    std::unique_lock<std::mutex> lk(p->mu);
+    auto it = p->results.find(ticket);
+    if (it == p->results.end() || !it->second->done) return pm_set_error(PM_ERR_ARG, "pm_pipe_slices: recording %lld is unknown, released or still in flight", (long long)ticket);
+    const Rec &r = *it->second;
+    if (r.status) return pm_set_error(r.status, "%s", r.error.c_str());
+    PM_ARG((size_t)chain < r.kept_data.size());
+    *h_count = (int64_t)r.kept_data[chain].size();
+    if (h_data) *h_data = r.kept_data[chain].data();
+    if (h_addr) *h_addr = r.kept_addr[chain].data();
+    if (h_plain) *h_plain = r.kept_plain[chain].data();
     return PM_OK;
 }
 

@@ -1,6 +1,7 @@
 // Context, memory, error and timer entry points of the C ABI (include/pymodem_amd.h).
 #include "pm_common.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <unistd.h>
 #include <mutex>
@@ -16,9 +17,46 @@ int pm_set_error(int code, const char *fmt, ...)
     return code;
 }
 
+namespace {
+struct TuneKey { const char *name, *env; int pm_tuning::*field; };
+const TuneKey kTuneKeys[] = {
+    {"fir_no_short", "PM_FIR_NO_SHORT", &pm_tuning::fir_no_short}, {"fuse_run", "PM_FUSE_RUN", &pm_tuning::fuse_run},
+    {"afsk_unfused", "PM_AFSK_UNFUSED", &pm_tuning::afsk_unfused}, {"afsk_lpf8", "PM_AFSK_LPF8", &pm_tuning::afsk_lpf8},
+    {"loop_wide", "PM_LOOP_WIDE", &pm_tuning::loop_wide}, {"lbatch_tail", "PM_LBATCH_TAIL", &pm_tuning::lbatch_tail},
+    {"agc_trace", "PM_AGC_TRACE", &pm_tuning::agc_trace},
+    {"slicer_max_chunk_words", "PM_SLICER_MAX_CHUNK_WORDS", &pm_tuning::slicer_max_chunk_words},
+    {"slicer_chunk_words", "PM_SLICER_CHUNK_WORDS", &pm_tuning::slicer_chunk_words},
+    {"slicer_quantum_words", "PM_SLICER_QUANTUM_WORDS", &pm_tuning::slicer_quantum_words},
+    {"slicer_compare_step", "PM_SLICER_COMPARE_STEP", &pm_tuning::slicer_compare_step},
+    {"slicer_mask_step", "PM_SLICER_MASK_STEP", &pm_tuning::slicer_mask_step},
+    {"slicer_compiled_step", "PM_SLICER_COMPILED_STEP", &pm_tuning::slicer_compiled_step},
+    {"slicer_trace", "PM_SLICER_TRACE", &pm_tuning::slicer_trace}, {"slicer_no_setprio", "PM_SLICER_NO_SETPRIO", &pm_tuning::slicer_no_setprio},
+    {"fir8", "PM_FIR8", &pm_tuning::fir8},
+};
+}  // namespace
+
+// The environment is looked at here and nowhere on a launch path.  A variable that is set without a number ("PM_SLICER_TRACE=") counts as 1.
+pm_tuning pm_tuning_from_env()
+{
+    pm_tuning t;
+    for (const TuneKey &k : kTuneKeys)
+        if (const char *e = getenv(k.env)) t.*(k.field) = (*e >= '0' && *e <= '9') || *e == '-' ? atoi(e) : 1;
+    if (const char *e = getenv("PM_LOOP_LDS_MIN")) t.loop_lds_min = atol(e);
+    return t;
+}
+
 extern "C" {
 
 int pm_version(void) { return PM_VERSION; }
+
+int pm_ctx_tune(pm_ctx *c, const char *name, int64_t value)
+{
+    PM_ARG(c != nullptr && name != nullptr);
+    if (!strcmp(name, "loop_lds_min")) { c->tune.loop_lds_min = value; return PM_OK; }
+    for (const TuneKey &k : kTuneKeys)
+        if (!strcmp(name, k.name)) { c->tune.*(k.field) = (int)value; return PM_OK; }
+    return pm_set_error(PM_ERR_ARG, "pm_ctx_tune: no switch named '%s'", name);
+}
 
 int pm_device_count(void)
 {

@@ -643,13 +643,14 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
     // (N (1 + m/L)), i.e. less of the vector ALU taken from the demod kernels beside them, shorter ones a shallower first launch;
     // measured in the pipelined executor (medians of interleaved runs, 20 / 400 steps): 256 words 1.52 / 1.17 ms per step, 384 words
     // 1.45 / 1.16, 512 words 1.48 / 1.25
-    const int64_t lc_max = getenv("PM_SLICER_MAX_CHUNK_WORDS") ? std::max(16, atoi(getenv("PM_SLICER_MAX_CHUNK_WORDS"))) : ctx->sl_max_chunk_words;
+    const pm_tuning &tn = ctx->tune;
+    const int64_t lc_max = tn.slicer_max_chunk_words > 0 ? std::max(16, tn.slicer_max_chunk_words) : ctx->sl_max_chunk_words;
     int64_t lc_words = std::max<int64_t>(16, std::min<int64_t>(pm_cdiv(all_words, ctx->sl_target_lanes), lc_max));
-    if (const char *e = getenv("PM_SLICER_CHUNK_WORDS")) { if (atoi(e) > 0) lc_words = atoi(e); }
+    if (tn.slicer_chunk_words > 0) lc_words = tn.slicer_chunk_words;
     // Words per lockstep launch once the walkers are beyond their own chunks (never more than a chunk: see slice_walk_kernel).
     // A walker that retires mid-launch leaves its lane idle for the rest of it, so short launches waste less; each costs a dispatch.
     int64_t qwords = 32;
-    if (const char *e = getenv("PM_SLICER_QUANTUM_WORDS")) { if (atoi(e) > 0) qwords = atoi(e); }
+    if (tn.slicer_quantum_words > 0) qwords = tn.slicer_quantum_words;
     qwords = std::min(qwords, lc_words);
     const int64_t qtail = std::min<int64_t>(lc_words, 4 * qwords);
     std::vector<JobDev> jd;
@@ -744,7 +745,7 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
                        dim3(kBlock), 0, ctx->stream, d_jobs, nj, (int)lc_words, total_chunks, wclk, wpos, counts, ncounts, tails);
 
     // step32m needs lock_rate - 1 to be exact for every stream of the batch (it is for 0.5 <= lock_rate <= 2) and finite clocks
-    int masks = getenv("PM_SLICER_COMPARE_STEP") ? 0 : 2;
+    int masks = tn.slicer_compare_step ? 0 : 2;
     bool lm0 = true, ns0 = true;                     // low words of lock_rate - 1 / of sps zero in every stream
     for (const JobDev &d : jd) {
         const volatile double lm1 = d.lock - 1.0;
@@ -757,15 +758,15 @@ extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
         lm0 = lm0 && (uint32_t)lb == 0;
         ns0 = ns0 && (uint32_t)sb == 0;
     }
-    bool direct = masks != 0 && !getenv("PM_SLICER_MASK_STEP");          // step32c: the decision from the clock itself
+    bool direct = masks != 0 && !tn.slicer_mask_step;          // step32c: the decision from the clock itself
     for (const JobDev &d : jd) direct = direct && d.tp == d.tp;
-    const bool hand = direct && !getenv("PM_SLICER_COMPILED_STEP");
+    const bool hand = direct && !tn.slicer_compiled_step;
     auto walk_kernel = hand ? (lm0 ? (ns0 ? slice_walk_kernel<8> : slice_walk_kernel<6>) : (ns0 ? slice_walk_kernel<7> : slice_walk_kernel<5>))
                        : direct ? (masks == 2 ? slice_walk_kernel<4> : slice_walk_kernel<3>)
                                 : masks == 2 ? slice_walk_kernel<2> : masks == 1 ? slice_walk_kernel<1> : slice_walk_kernel<0>;
     const unsigned wgrid = (unsigned)pm_cdiv(total_chunks, kBlock);
-    const bool trace = getenv("PM_SLICER_TRACE") != nullptr;
-    const int prio = getenv("PM_SLICER_NO_SETPRIO") ? 0 : 1;
+    const bool trace = tn.slicer_trace != 0;
+    const int prio = tn.slicer_no_setprio ? 0 : 1;
     // How many lockstep launches to enqueue before the emit kernels without asking the device: what the last batches of this
     // shape needed plus a margin (a launch that finds its list empty costs a dispatch and nothing else).  The list sizes come
     // back with the results; if walkers were still alive the rest is launched and the emit kernels run again.

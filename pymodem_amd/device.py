@@ -198,6 +198,13 @@ class Context:
         with self.__dict__.setdefault("_arena_lock", threading.Lock()):
             self.__dict__.setdefault("_arena_free", {}).setdefault(buf.n, []).append(buf.ptr.value)
 
+    def tune(self, **switches):
+        """Diagnostic switches of this context's launchers (pm_ctx_tune; README.md lists them): ctx.tune(afsk_unfused=1).  A context
+        reads the PM_* environment variables of the same names once, when it is made; no launch looks at the environment."""
+        for name, value in switches.items():
+            check(lib().pm_ctx_tune(self.handle, name.encode(), int(value)))
+        return self
+
     def profile(self, on=True):
         check(lib().pm_prof_enable(self._h, int(bool(on))))
 

@@ -44,6 +44,21 @@ def config_lines():
     return load
 
 
+import contextlib
+
+_TUNE_DEFAULTS = {"loop_wide": -1, "lbatch_tail": -1, "fir8": 1}
+
+
+@contextlib.contextmanager
+def tuned(ctx, **switches):
+    """ctx.tune(**switches) for the body, the defaults again afterwards (the contexts of the tests are shared)."""
+    ctx.tune(**switches)
+    try:
+        yield ctx
+    finally:
+        ctx.tune(**{k: _TUNE_DEFAULTS.get(k, 0) for k in switches})
+
+
 def noise_i16(n, seed=1234, sigma=8000.0):
     """The synthetic buffer BASELINE.md prescribes."""
     x = np.random.default_rng(seed).standard_normal(n) * sigma

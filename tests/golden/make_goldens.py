@@ -667,6 +667,51 @@ def gen_reports():
     print("reports.json:", {k: (len(v["raw_bad"]), len(v["report"])) for k, v in out.items()})
 
 
+def gen_il2p_resync():
+    """IL2PCodec.decode (il2p.py:360-519) where a REAL frame's sync word lies in the tail of a FALSE header.  After a sync word the
+    decoder takes 15 header bytes; when their RS check fails it is back in the sync search with a register that holds only the last
+    eight bits (mask 0xFF inside a packet, il2p.py:146-152), so a sync word that began before the false header ended is judged on a
+    register with zeros in it -- found or missed by rules a search over the raw input bits does not reproduce.  Streams (one per
+    sync_tol): random bits, an exact 0xF15E48 / 0x5D57DF7F (the false sync), 120 - o random bits with o in [-8, 30] (o > 0: the next
+    sync word starts o bits before the false header ends), then a valid IL2P frame from the build's generator (pymodem_amd.siggen:
+    data, not reference code) whose sync word carries up to sync_tol + 1 bit errors.  Expected output: the reference's packets --
+    which frames it finds is the pin -- and the address of every header attempt (its 'Syncword:' prints, for diagnosis)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from pymodem_amd import siggen
+    d = {}
+    for tol in (0, 1, 2, 3):
+        rng = np.random.default_rng(4100 + tol)
+        bits = []
+        for k in range(400):
+            bits.append(rng.integers(0, 2, int(rng.integers(200, 700)), dtype=np.uint8))
+            pat, nb = (0xF15E48, 24) if rng.random() < 0.6 else (0x5D57DF7F, 32)
+            bits.append(np.array([(pat >> (nb - 1 - i)) & 1 for i in range(nb)], dtype=np.uint8))
+            o = int(rng.integers(-8, 31))
+            bits.append(rng.integers(0, 2, 120 - o, dtype=np.uint8))
+            info = [int(c) for c in rng.integers(32, 127, int(rng.integers(1, 30)))]
+            frame = np.array(siggen.il2p_frame_bits("CQ", f"N0CAL{k % 10}", info, src_ssid=k % 16, preamble=0), dtype=np.uint8)
+            for f in rng.choice(24, int(rng.integers(0, tol + 2)), replace=False):
+                frame[f] ^= 1
+            bits.append(frame)
+        bits = np.concatenate(bits + [rng.integers(0, 2, 400, dtype=np.uint8)])
+        data = np.packbits(bits[: len(bits) // 8 * 8])
+        addr = np.arange(len(data), dtype=np.int64) * 8 + 5
+        with quiet():
+            codec = ref_il2p.IL2PCodec(ident="resync", crc=True, min_dist=0, disable_rs=False, sync_tol=tol)
+        attempts, pkts = [], []
+        for b, a in zip(data, addr):
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                pkts += codec.decode([AddressedData(int(b), int(a))])
+            attempts += [int(a)] * buf.getvalue().count("Syncword:")
+        d[f"tol{tol}_data"] = data
+        d[f"tol{tol}_addr"] = addr
+        d[f"tol{tol}_attempts"] = np.array(attempts, dtype=np.int64)
+        pkts_to_dict(pkts, f"tol{tol}_pkt", d)
+        print(f"il2p_resync tol {tol}: {len(data)} bytes, {len(attempts)} header attempts, {len(pkts)} packets of 400 planted")
+    np.savez_compressed(os.path.join(OUT, "il2p_resync.npz"), **d)
+
+
 def copy_data_files():
     """Data files (not source): the bundled recording and the JSON-lines configs.  MIT, see the
     reference's LICENSE.  They are inputs of the parity tests; the GPU box only has /root/repo."""
@@ -677,7 +722,9 @@ def copy_data_files():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["taps", "prims", "synth", "wav", "signal", "reports", "copy", "qpsk", "segments", "psk_history"]
+    which = sys.argv[1:] or ["taps", "prims", "synth", "wav", "signal", "reports", "copy", "qpsk", "segments", "psk_history", "il2p_resync"]
+    if "il2p_resync" in which:
+        gen_il2p_resync()
     if "taps" in which:
         gen_taps()
     if "prims" in which:

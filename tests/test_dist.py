@@ -213,3 +213,39 @@ def test_forced_one_rank_rccl_exchange_on_the_gpu(tmp_path, golden):
     assert p.returncode == 0, p.stderr[-3000:]
     tab = json.loads([l for l in p.stdout.splitlines() if l.startswith("TABLE ")][0][6:])
     assert tab["good"] == summ["good"] == 49 and tab["bad"] == summ["bad"] == 6
+
+
+def test_bench_launches_its_own_ranks_and_relays_their_exit_code():
+    """`python bench.py --gpus 2` with no launcher around it starts torch.distributed.run as a child (never an exec, and before this
+    process could have touched a GPU).  Without a GPU the ranks fail loudly -- there is no CPU fallback -- and the parent hands the
+    failure on instead of hanging or printing a line."""
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("the GPU box runs the real thing (test_bench_two_ranks_by_itself)")
+    env = dict(os.environ)
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--also", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert "needs a GPU" in p.stderr and '"metric"' not in p.stdout
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_by_itself():
+    """The scaling bench's command with N = 2 and nothing around it: two ranks share the one GPU of the test box
+    over gloo, rank 0's ONE line comes back through the parent with n_gpus 2, the CPU baseline the parent measured before any rank
+    existed, and the strong-scaling figure beside the weak one."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "4", "--warmup", "1", "--also", "0",
+                        "--cpu-sample", "480000"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
+    assert d["config"]["chains_total"] == 16
+    assert d["strong"]["chains_total"] == 8 and d["strong"]["value"] > 0

@@ -6,7 +6,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from conftest import noise_i16
+from conftest import noise_i16, tuned
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -703,16 +703,19 @@ def _sweep(ctx, x, x_bound, mark, unit, gains, lpf, sliding=False):
 
 
 @pytest.mark.parametrize("sliding", [False, True, "unfused", "lpf8"])
-def test_afsk_gain_sweep_signs_are_the_exact_chain_s(ctx, sliding, monkeypatch):
+def test_afsk_gain_sweep_signs_are_the_exact_chain_s(ctx, sliding):
     """pm_afsk_sweep_signs / pm_afsk_sweep_signs_tones (sliding correlator sums, fused with the low-passes or not): bitmaps of a space_gain sweep from ONE unit space correlator pair and two low-passes, certified against
     the exact chain -- every bit must equal pm_afsk_correlate + pm_fir_signs_f64 with that modem's own (gain-scaled) taps, on an
     AFSK-like signal, on noise at several amplitudes (the smaller the amplitude against the caller's bound, the more samples are
     recomputed exactly, and past 65536 of them the exact chains of all modems run instead, decided on the device)."""
+    # "unfused": sliding sums, low-passes and combine as three kernels (the path long filters fall back to); "lpf8": the fused kernel
+    # with its low-passes as int8 digit products on the matrix pipe (what pm_pipe_* runs)
+    with tuned(ctx, afsk_unfused=int(sliding == "unfused"), afsk_lpf8=int(sliding == "lpf8")):
+        _gain_sweep_cases(ctx, sliding)
+
+
+def _gain_sweep_cases(ctx, sliding):
     from pymodem_amd import taps as T
-    if sliding == "unfused":           # sliding sums, low-passes and combine as three kernels (the path long filters fall back to)
-        monkeypatch.setenv("PM_AFSK_UNFUSED", "1")
-    if sliding == "lpf8":              # the fused kernel with its low-passes as int8 digit products on the matrix pipe (what pm_pipe_* runs)
-        monkeypatch.setenv("PM_AFSK_LPF8", "1")
     rng = np.random.default_rng(1200)
     mi, mq, ui, uq = T.afsk_tone_correlators(48000.0, 1200.0, 1300.0, 2100.0, 1.0, 1.5, 0.0)
     lpf = T.windowed_sinc(100, 900.0, 48000.0, pass_zero=True)
@@ -780,14 +783,15 @@ def test_sliding_correlator_sums_stay_within_their_bound(ctx, rate, baud, mark, 
 @pytest.mark.parametrize("fused", [True, False, "lpf8"])
 @pytest.mark.parametrize("gain", [1.0, 2.25])
 @pytest.mark.parametrize("rate,baud,mark,space,span", [(48000.0, 1200.0, 1600.0, 1800.0, 1.0), (8000.0, 300.0, 1600.0, 1800.0, 1.0)])
-def test_one_chain_certified_signs_are_the_exact_chain_s(ctx, rate, baud, mark, space, span, gain, fused, monkeypatch):
+def test_one_chain_certified_signs_are_the_exact_chain_s(ctx, rate, baud, mark, space, span, gain, fused):
     """pm_afsk_sweep_signs_tones with ONE modem: mark - gain * space from the sliding sums as one stream, one low-pass, certified;
     every bit equals pm_afsk_correlate + pm_fir_signs_f64 (signal, loud and quiet noise, silence -> the gated exact chain)."""
+    with tuned(ctx, afsk_unfused=int(not fused), afsk_lpf8=int(fused == "lpf8")):
+        _one_chain_cases(ctx, rate, baud, mark, space, span, gain)
+
+
+def _one_chain_cases(ctx, rate, baud, mark, space, span, gain):
     from pymodem_amd import taps as T
-    if not fused:
-        monkeypatch.setenv("PM_AFSK_UNFUSED", "1")
-    if fused == "lpf8":
-        monkeypatch.setenv("PM_AFSK_LPF8", "1")
     rng = np.random.default_rng(int(rate + 10 * gain))
     mi, mq, ui, uq = T.afsk_tone_correlators(rate, baud, mark, space, 1.0, span, 0.0)
     lpf = T.windowed_sinc(round(rate * 2.5 / baud) | 1, 0.75 * baud, rate, pass_zero=True)

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, noise_i16
+from conftest import GOLDEN, noise_i16, tuned
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -157,7 +157,7 @@ def group_modems(cfg, rate, carriers=None, take=None):
     ("afsk_300_pll.json", 8000, None, 2048),
 ])
 @pytest.mark.parametrize("wide", [0, 1, 2])
-def test_engine_bitmaps_equal_demod_signs(cfg, rate, carriers, chunk, wide, monkeypatch):
+def test_engine_bitmaps_equal_demod_signs(cfg, rate, carriers, chunk, wide):
     """Every (recording, chain) bitmap of a run equals modem.demod_signs() on that recording: different audio per recording, chunk
     lengths from one FIR tile up, chains per recording that do and do not divide the loops of a wave.  wide: the engine's loop
     launches in the shape for runs of thousands of loops (every lane of the stepping wave a loop, 32-sample tiles: PM_LOOP_WIDE),
@@ -174,10 +174,10 @@ def test_engine_bitmaps_equal_demod_signs(cfg, rate, carriers, chunk, wide, monk
     try:
         for take in (5, 2):                                             # a second run on the same engine starts from fresh states
             dev = [ctx.upload(r) for r in recs[:take]]
-            monkeypatch.setenv("PM_LOOP_WIDE", str(wide))
-            got = eng.run(dev)
-            ctx.sync()
-            monkeypatch.setenv("PM_LOOP_WIDE", "0")
+            with tuned(ctx, loop_wide=wide):
+                got = eng.run(dev)
+                ctx.sync()
+            ctx.tune(loop_wide=0)
             for k in range(take):
                 for c, (line, _) in enumerate(group):
                     from pymodem_amd import chain_builder as cb
@@ -187,11 +187,12 @@ def test_engine_bitmaps_equal_demod_signs(cfg, rate, carriers, chunk, wide, monk
                     if ref.bits_q is not None:
                         assert np.array_equal(bits_of(got[k][c].bits_q, ref.n), bits_of(ref.bits_q, ref.n)), (cfg, k, c, "Q")
     finally:
+        ctx.tune(loop_wide=-1)
         eng.close()
 
 
 @pytest.mark.parametrize("n", [5, 5003])
-def test_loop_kernel_shapes_agree(monkeypatch, n):
+def test_loop_kernel_shapes_agree(n):
     """150 loops in one launch (three workgroups of the 64-loop shape, the last one part full), a length that is no multiple of either
     tile: outputs and end states of the four loop kernels bit for bit the same in both shapes, own input rows and one shared row."""
     import ctypes
@@ -230,7 +231,7 @@ def test_loop_kernel_shapes_agree(monkeypatch, n):
     for name, call in calls.items():
         got = {}
         for wide in (0, 1, 2):
-            monkeypatch.setenv("PM_LOOP_WIDE", str(wide))
+            ctx.tune(loop_wide=wide)
             check(lib().pm_memset(ctx.handle, o1.ptr, 0, n * nl * 8))
             check(lib().pm_memset(ctx.handle, o2.ptr, 0, n * nl * 8))
             lp = fresh()
@@ -240,6 +241,7 @@ def test_loop_kernel_shapes_agree(monkeypatch, n):
         assert np.array_equal(got[0][0], got[2][0]) and np.array_equal(got[0][1], got[2][1]) and got[0][2] == got[2][2], (name, "direct")
         assert got[0][2] == got[1][2], name
         assert np.any(got[0][0] != 0), name
+    ctx.tune(loop_wide=-1)
 
 
 def test_engine_qpsk_modem():

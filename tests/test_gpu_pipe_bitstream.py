@@ -1,0 +1,130 @@
+"""The path bench.py times -- pm_pipe_* (NativePipeline): band-pass and low-pass sums as int8 digit products on the matrix pipe,
+certified sign decisions, exact recomputation of the undecided ones, lockstep slicers, LFSR + codec on the library's threads --
+pinned DIRECTLY at bitstream level (slicer.py:59-107, lfsr.py:22-52, chain_execute.py:30-52): for every chain the slicer's bytes,
+their stream addresses, the LFSR's bytes and the packets against
+  (a) the oracle (canonical FIR order) on the bench's own 28.8 M-sample buffer, all eight chains of the headline config, and
+  (b) the reference's goldens (tests/golden/synth_chains.npz, 240 000 samples of seeded noise: the reference itself produced them)
+      for afsk_1200_ax25_super_opt.json, afsk_1200.json and fsk_9600.json.
+The pipeline keeps what its slicers and LFSRs produced when it is made with keep_slices (pm_pipe_slices): the arrays compared here
+are the ones its codecs consumed, not a second computation."""
+import numpy as np
+import pytest
+
+from conftest import noise_i16
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+N = 28_800_000
+
+
+def _pk(rows):
+    return (rows["streamaddress"].astype(np.int64), rows["bytes_corrected"].astype(np.int64),
+            np.concatenate([r["data"][: r["len"]] for r in rows]).astype(np.uint8) if len(rows) else np.zeros(0, np.uint8))
+
+
+def _rows_by_chain(table, nchains):
+    out, at = [], 0
+    for c in range(nchains):
+        out.append(table.rows[at:at + table.counts[c]])
+        at += table.counts[c]
+    return out
+
+
+@pytest.mark.parametrize("cfg", ["afsk_1200_ax25_super_opt.json", "afsk_1200.json", "fsk_9600.json"])
+def test_native_pipeline_bitstream_equals_the_reference_goldens(golden, config_lines, cfg):
+    import pymodem_amd
+    from pymodem_amd import chain_builder as cb, chain_execute as ce
+    g = golden("synth_chains")
+    lines = config_lines(cfg)
+    audio = noise_i16(240000)
+    ctx = pymodem_amd.Context.default()
+    d = ctx.upload(audio)
+    ctx.sync()
+    pipe = ce.NativePipeline([cb.build_chain(48000, l) for l in lines], len(audio), 48000 / 40, ctx=ctx, keep_slices=True)
+    tickets = [pipe.submit(d) for _ in range(3)]             # three in flight: both demod streams, one slicer batch
+    for t in tickets:
+        table = pipe.table(t)
+        rows = _rows_by_chain(table, len(lines))
+        for ci in range(len(lines)):
+            prefix = f"{cfg[:-5]}__c{ci}__48k_l"
+            sliced, plain = pipe.slices(t, ci)
+            assert np.array_equal(sliced.data, g[prefix + "_slice_data"]), prefix
+            assert np.array_equal(sliced.address, g[prefix + "_slice_addr"]), prefix
+            assert np.array_equal(plain, g[prefix + "_lfsr_data"]), prefix
+            a, c, dd = _pk(rows[ci])
+            assert np.array_equal(a, g[prefix + "_pkt_addr"]) and np.array_equal(dd, g[prefix + "_pkt_data"]), prefix
+            assert np.array_equal(c, g[prefix + "_pkt_corrected"]), prefix
+        del table, rows
+    pipe.close()
+
+
+def test_native_pipeline_bitstream_at_full_size_equals_the_oracle():
+    """The bench's buffer and config, every chain: what the timed path's slicers, LFSRs and codecs produce is what the CPU restatement
+    of the reference produces.  Two recordings in flight (one per demod stream); the second is the buffer negated -- other
+    packets' worth of bits, same statistics -- so that a result cannot come from the wrong slot."""
+    import bench
+    import pymodem_amd
+    from pymodem_amd import chain_builder as cb, chain_execute as ce
+
+    class A:
+        pass
+    args = A()
+    args.samples, args.rate, args.workload, args.buffer = N, 48000, "afsk_1200_super_opt", "signal"
+    audio = bench.make_buffer(args)
+    other = np.negative(np.maximum(audio, -32767))
+    factory, cpg, _ = bench.WORKLOADS[args.workload]
+    lines = [factory(c) for c in range(cpg)]
+    ctx = pymodem_amd.Context.default()
+    dev = [ctx.upload(audio), ctx.upload(other)]
+    ctx.sync()
+    pipe = ce.NativePipeline([cb.build_chain(48000, l) for l in lines], N, 48000 / 40, ctx=ctx, keep_slices=True)
+    tickets = [pipe.submit(b) for b in dev]
+    total = 0
+    for t, a in zip(tickets, (audio, other)):
+        table = pipe.table(t)
+        rows = _rows_by_chain(table, len(lines))
+        for c, line in enumerate(lines):
+            w = O.run_chain(O.build_chain(48000, line), a, canon=True)
+            sliced, plain = pipe.slices(t, c)
+            assert np.array_equal(sliced.data, w["slice_data"]) and np.array_equal(sliced.address, w["slice_addr"]), c
+            assert np.array_equal(plain, np.asarray(w["lfsr"], dtype=np.uint8)), c
+            got_a, got_c, got_d = _pk(rows[c])
+            assert [int(x) for x in got_a] == [int(p.streamaddress) for p in w["packets"]], c
+            assert got_d.tobytes() == b"".join(bytes(bytearray(p.data)) for p in w["packets"]), c
+            assert [int(x) for x in got_c] == [int(p.BytesCorrected) for p in w["packets"]], c
+            total += len(w["packets"])
+            assert len(sliced.data) > 80000
+        del table, rows
+    assert total > 4000
+    pipe.close()
+
+
+def test_a_refused_recording_leaves_no_hole_in_the_tickets(config_lines):
+    """pm_pipe_submit refuses a recording that is long enough for the band-pass but not for a chain's correlator + low-pass
+    (mb <= n < mb + m + ml - 2) before a ticket exists; the submit_many behind it gets consecutive tickets and the wait on its LAST
+    ticket returns (it used to compare the ticket with a count of submissions and hang)."""
+    import threading
+    import pymodem_amd
+    from pymodem_amd import NativeError, chain_builder as cb, chain_execute as ce
+    lines = config_lines("afsk_1200_ax25_super_opt.json")
+    ctx = pymodem_amd.Context.default()
+    chains = [cb.build_chain(48000, l) for l in lines]
+    mb = len(chains[0][1].input_bpf)
+    ok = ctx.upload(noise_i16(120000))
+    starved = ctx.upload(noise_i16(mb + 20))                 # passes the band-pass, starves the correlators and the low-pass
+    ctx.sync()
+    pipe = ce.NativePipeline(chains, 120000, 48000 / 40, ctx=ctx)
+    first = pipe.submit(ok)
+    with pytest.raises(NativeError):
+        pipe.submit(starved)
+    start, join = pipe.submit_many([ok] * 5)
+    assert start == first + 1                                # the refused recording took no ticket
+    got = []
+    waiter = threading.Thread(target=lambda: got.append(pipe.unique(start + 4)))
+    waiter.start()
+    join()
+    waiter.join(60)
+    assert not waiter.is_alive() and got, "pm_pipe_wait on the last promised ticket did not return"
+    for t in [first] + list(range(start, start + 4)):
+        assert pipe.unique(t) == got[0]
+    pipe.close()

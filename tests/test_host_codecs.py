@@ -207,6 +207,34 @@ def test_il2p_sync_search_at_every_bit_offset(tol):
     assert within > 20 and len(want) >= within * (0.9 if tol <= 2 else 0.4)
 
 
+@pytest.mark.parametrize("tol", [0, 1, 2, 3])
+@pytest.mark.parametrize("pieces", [1, 7])
+def test_il2p_sync_word_in_the_tail_of_a_false_header(golden, tol, pieces):
+    """Reference golden (tests/golden/il2p_resync.npz, make_goldens.py gen_il2p_resync): valid frames whose sync word starts up to 30
+    bits before a false header ends.  Back in the sync search the reference's register holds eight bits and zeros above them
+    (il2p.py:146-152), so which of these frames it finds is decided by that register -- the native decoder's skip over infeasible
+    input bytes must not look at (or rebuild the register from) input the reference has forgotten.  The oracle is held to the same
+    golden.  pieces: the stream fed in one call and in seven (the search state carries over)."""
+    from pymodem_amd.codecs import IL2PCodec
+    from pymodem_amd.data_classes import AddressedArray
+    g = golden("il2p_resync")
+    data, addr = g[f"tol{tol}_data"], g[f"tol{tol}_addr"]
+    cuts = np.linspace(0, len(data), pieces + 1).astype(int)
+    c = IL2PCodec(ident="x", crc=True, min_dist=0, sync_tol=tol)
+    o = O.IL2PCodec("x", True, False, 0, tol)
+    got, want = [], []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        got += c.decode(AddressedArray(data[lo:hi], addr[lo:hi]))
+        want += o.decode(data[lo:hi], addr[lo:hi])
+    for name, pkts in (("native", got), ("oracle", want)):
+        a = np.array([int(p.streamaddress) for p in pkts], dtype=np.int64)
+        dd = np.array([int(b) for p in pkts for b in p.data], dtype=np.uint8)
+        cc = np.array([int(p.BytesCorrected) for p in pkts], dtype=np.int64)
+        assert np.array_equal(a, g[f"tol{tol}_pkt_addr"]), (name, tol, len(a), int(g[f"tol{tol}_pkt_n"]))
+        assert np.array_equal(dd, g[f"tol{tol}_pkt_data"]) and np.array_equal(cc, g[f"tol{tol}_pkt_corrected"]), (name, tol)
+    assert int(g[f"tol{tol}_pkt_n"]) >= 60
+
+
 @pytest.mark.parametrize("threads", [1, 3, 16])
 def test_batched_host_stage_equals_the_per_chain_calls(threads, monkeypatch):
     """pm_host_decode_batch + pm_codec_fetch_batch (chain_execute._host_rows) against stream_unscramble_8bit + decode_rows chain by

@@ -98,11 +98,10 @@ for gains in ([1.25, 1.5, 1.75, 2.0, 2.25, 2.5, 2.75], [1.0]):
     args = (ctx.handle, d_f64.ptr, N, xb, dt[0].ptr, dt[1].ptr, dt[2].ptr, dt[3].ptr, ds.ptr, gs, g, mc, dl.ptr, len(lpf), float(np.abs(lpf).sum()), ptrs)
     nlp = 1 if g == 1 else 2
     for label, env in (("fused", None), ("three kernels", "1")):
-        if env:
-            os.environ["PM_AFSK_UNFUSED"] = env
+        ctx.tune(afsk_unfused=1 if env else 0)
         report(f"afsk_sweep_signs_tones g={g} {label} (+ gated fallback launches)",
                timeit(lambda: check(L.pm_afsk_sweep_signs_tones(*args, ctypes.byref(tones)))), (8.0 + g / 8.0) * N, (4 * mc / 16 + 9 + nlp * len(lpf) + g) * N)
-        os.environ.pop("PM_AFSK_UNFUSED", None)
+        ctx.tune(afsk_unfused=0)
     report(f"afsk_sweep_signs g={g} direct sums (+ gated fallback launches)", timeit(lambda: check(L.pm_afsk_sweep_signs(*args))), (8.0 + g / 8.0) * N,
            (4 * mc + 2 * len(lpf) + g) * N)
 
