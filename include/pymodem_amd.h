@@ -141,6 +141,13 @@ int pm_fir_rows_f64(pm_ctx *ctx, const double *d_x, int64_t x_stride, int rows, 
                     int64_t y_stride, int flags);
 int pm_fir_rows_signs_f64(pm_ctx *ctx, const double *d_x, int64_t x_stride, int rows, int64_t n, const double *d_taps, int m, uint64_t *d_bits,
                           int64_t bits_stride, int flags);
+/* The same bitmap for LONG filters whose output feeds only a slicer (BPSK / MPSK matched filters, psk.py:193, :750-751): the sums as
+ * int8 digit products on the matrix pipe, each sign certified against a proven bound, the undecided outputs recomputed with the
+ * canonical binary64 chain (csrc/pm_fir8.hip; 16 <= m <= 1009).  Bit for bit pm_fir_rows_signs_f64's result for every input; this
+ * entry point makes its plan per call (tests, measurements) -- the batch engine keeps one.  *h_recomputed: outputs that took the
+ * exact path. */
+int pm_fir8_rows_signs_f64(pm_ctx *ctx, const double *d_x, int64_t x_stride, int rows, int64_t n, const double *h_taps, int m,
+                           uint64_t *d_bits, int64_t bits_stride, int64_t *h_recomputed);
 
 /* AFSK mark/space quadrature correlators fused with magnitude and difference (afsk.py:153-162):
  * y[k] = sqrt(mi*x ^2 + mq*x ^2) - sqrt(si*x ^2 + sq*x ^2), each product a 'valid' convolution. */

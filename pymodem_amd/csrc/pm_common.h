@@ -34,6 +34,7 @@ struct pm_tuning {
     int slicer_compare_step = 0, slicer_mask_step = 0, slicer_compiled_step = 0;           // older forms of the slicer step
     int slicer_trace = 0, slicer_no_setprio = 0;
     int fir8 = 1;                      // PM_FIR8=0: the batch engine's matched filters in binary64 on the vector pipe
+    int loop_agc = 1;                  // PM_LOOP_AGC=0: the batch engine's BPSK AGC as a pass of its own, not in the loop's lane
 };
 pm_tuning pm_tuning_from_env();
 
@@ -136,6 +137,17 @@ int pm_afsk_group_run_plan(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const
                            const pm_afsk_sweep_desc *h_sweeps, int nsweeps, int64_t *h_tickets, const pm_bpf8_plan *plan,
                            const pm_lpf8_plan *const *lpf8 = nullptr, const pm_sweep_cells *cells = nullptr);
 
+// ---- long matched filters as certified signs on the int8 matrix pipe (pm_fir8.hip): bit k of row r = (canonical FIR sum >= 0), the
+// bitmap pm_fir_rows(..., d_bits, ...) writes, for inputs of any magnitude.  A plan belongs to one tap set (m + 15 <= 1024) and device.
+struct pm_fir8_plan;
+int pm_fir8_plan_create(pm_ctx *ctx, const double *h_taps, int m, pm_fir8_plan **out);
+void pm_fir8_plan_destroy(pm_fir8_plan *p);
+int pm_fir8_taps(const pm_fir8_plan *p);
+// rows of n doubles, pitch x_stride -> rows of n - m + 1 sign bits, pitch bits_stride words (bits past the last output of the last word
+// zero).  d_count: nullptr, or a device counter that gains the number of outputs recomputed exactly (diagnostics).
+int pm_fir8_rows_signs(pm_ctx *ctx, const pm_fir8_plan *p, const double *d_x, int64_t x_stride, int rows, int64_t n, uint64_t *d_bits,
+                       int64_t bits_stride, int *d_count);
+
 // ---- launchers shared between translation units (what the batch engine pm_loopbatch.hip strings together) ---------------------
 // `rows` FIRs with the same taps over equal-length streams in one launch (pm_fir.hip).  Input row r: d_x + r * x_stride, or
 // d_x_ptrs[r] + x_off (d_x_ptrs: DEVICE array of row pointers); x_aligned16: every input row starts on a 16-byte boundary.
@@ -145,6 +157,11 @@ int pm_fir_rows(pm_ctx *ctx, bool i16, const void *d_x, int64_t x_stride, const 
 // nloops carrier loops resident in device memory; loop l reads input row l / per_row (pm_loops.hip).  modem: PM_MODEM_*.
 int pm_loops_rows(pm_ctx *ctx, int modem, pm_loop *d_loops, int nloops, int per_row, const double *d_table, const int32_t *d_pd,
                   const double *d_x0, const double *d_x1, int64_t x_stride, int64_t n, double *d_o0, double *d_o1, int64_t out_stride);
+// BPSK with one chain per recording in the direct loop shape: the loop's lane steps the AGC too (pm_loops_rows_agc reads the BAND-PASSED
+// rows; d_consts / d_state as pm_agc_rows) -- pm_loops_rows_take_agc says whether a launch of this size does
+bool pm_loops_rows_take_agc(const pm_ctx *ctx, int modem, int nloops, int per_row);
+int pm_loops_rows_agc(pm_ctx *ctx, pm_loop *d_loops, int nloops, const double *d_table, const double *d_x, int64_t x_stride, int64_t n, double *d_o,
+                      int64_t out_stride, const pm_agc_params *hp, const double *d_consts, double *d_state);
 // d_running[r] = max(d_running[r], max of row r) (first != 0: = max of row r).  d_partial: rows * pm_rows_max_parts() doubles of work space.
 int pm_rows_max(pm_ctx *ctx, const double *d_x, int64_t x_stride, int rows, int64_t n, double *d_partial, double *d_running, int first);
 int pm_rows_max_parts(void);

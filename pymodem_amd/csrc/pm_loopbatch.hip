@@ -39,6 +39,7 @@ struct pm_lbatch {
     pm_agc_params agc{};
     std::vector<double> h_taps;
     double *d_taps = nullptr;
+    pm_fir8_plan *fir8 = nullptr;            // the output filter as certified signs on the int8 matrix pipe (pm_fir8.hip; PM_FIR8=0: off)
     size_t o_in = 0, o_hil = 0, o_out = 0, o_wave = 0;
     int32_t *d_pd = nullptr;
     std::vector<pm_loop> h_loops;            // R x C: the C initial loops repeated
@@ -116,6 +117,7 @@ int pm_lbatch_destroy(pm_lbatch *b)
         if (p) (void)pm_free(ctx, p);
     for (hipEvent_t e : {b->front_done[0], b->front_done[1], b->back_done[0], b->back_done[1], b->hist_done[0], b->hist_done[1], b->run_done})
         if (e) (void)hipEventDestroy(e);
+    pm_fir8_plan_destroy(b->fir8);
     if (b->front) (void)pm_ctx_destroy(b->front);
     if (b->tail) (void)pm_ctx_destroy(b->tail);
     delete b;
@@ -161,6 +163,9 @@ int pm_lbatch_create(pm_ctx *ctx, const pm_lbatch_desc *desc, pm_lbatch **out)
         if (b->mpsk) b->o_hil = put(b->h_taps, d.hilbert, d.n_hilbert);
         b->o_out = put(b->h_taps, d.output_fir, d.n_output_fir);
         b->o_wave = put(b->h_taps, d.wavetable, 256);
+        // The output filter feeds the slicer's sign test and nothing else (psk.py:193 -> slicer.py:74, psk.py:750-751 -> slicer.py:215):
+        // from 64 taps on its sums go to the matrix pipe with certified signs (the short PLL low-pass stays on the vector pipe)
+        if (ctx->tune.fir8 && d.n_output_fir >= 64 && d.n_output_fir + 15 <= 1024 && (rc = pm_fir8_plan_create(ctx, d.output_fir, d.n_output_fir, &b->fir8))) break;
         if ((rc = dev_alloc(ctx, b->d_taps, b->h_taps.size()))) break;
         if ((rc = pm_h2d(ctx, b->d_taps, b->h_taps.data(), b->h_taps.size() * sizeof(double)))) break;
         if (b->mpsk) {
@@ -270,6 +275,9 @@ int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings,
     const int64_t chunks = pm_cdiv(nout, Lc);
     b->last_chunks = chunks;
     int64_t s_agc = 0, s_loop = 0, prev_cnt_l = 0;
+    // BPSK, one chain per recording (psk.py:168-189): the AGC's only reader is the loop -- its lane steps the follower too (pm_loops.hip)
+    const bool fold_agc = pm_loops_rows_take_agc(B, b->modem, RC, C);
+    int64_t skip_of[2] = {0, 0};
     for (int64_t t = 0; t < chunks; ++t) {
         const int set = (int)(t & 1);
         const int64_t o0 = t * Lc, o1 = std::min(nout, o0 + Lc);
@@ -281,10 +289,14 @@ int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings,
         {
             // band-pass from the 16-byte boundary at or below the first new sample: `skip` outputs are computed again and not used
             const int64_t a0 = s_agc & ~(int64_t)7, skip = s_agc - a0;
+            // (with the AGC in the loop's lane the band-passed samples themselves are the chunk's loop input, `skip` samples in)
             if (int rc = pm_fir_rows(F, true, nullptr, 0, (const void *const *)b->d_audio, a0, aligned, R, cnt_a + skip + mb - 1, T + b->o_in, mb,
-                                     b->tmp, P, nullptr, 0, 0)) return rc;
-            double *agc_out = b->mpsk ? b->awin + b->Hh : b->in0[set];
-            if (int rc = pm_agc_rows(F, b->tmp + skip, P, agc_out, P, R, cnt_a, &b->agc, b->d_consts, b->d_agc_state)) return rc;
+                                     fold_agc ? b->in0[set] : b->tmp, P, nullptr, 0, 0)) return rc;
+            skip_of[set] = skip;
+            if (!fold_agc) {
+                double *agc_out = b->mpsk ? b->awin + b->Hh : b->in0[set];
+                if (int rc = pm_agc_rows(F, b->tmp + skip, P, agc_out, P, R, cnt_a, &b->agc, b->d_consts, b->d_agc_state)) return rc;
+            }
             if (b->mpsk) {
                 // imag = Hilbert FIR over [history | new]; real[k] = a[k + delay] (the delay FIR [1, 0, ..] and [:-delay], psk.py:714-716)
                 const double *hin = t == 0 ? b->awin + b->Hh : b->awin + b->Hh - (mh - 1);
@@ -301,7 +313,10 @@ int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings,
         // and chunk t - 1's history has been taken out of... the OTHER set; both lie behind hist_done of chunk t - 1 on the tail stream.
         PM_HIP(hipStreamWaitEvent(B->stream, b->front_done[set], 0));
         if (t >= 1) PM_HIP(hipStreamWaitEvent(B->stream, b->hist_done[(t - 1) & 1], 0));
-        if (int rc = pm_loops_rows(B, b->modem, b->d_loops, RC, C, T + b->o_wave, b->d_pd, b->in0[set], b->in1[set], P, cnt_l, b->dwin0[set] + b->Ho,
+        if (fold_agc) {
+            if (int rc = pm_loops_rows_agc(B, b->d_loops, RC, T + b->o_wave, b->in0[set] + skip_of[set], P, cnt_l, b->dwin0[set] + b->Ho, P, &b->agc, b->d_consts,
+                                           b->d_agc_state)) return rc;
+        } else if (int rc = pm_loops_rows(B, b->modem, b->d_loops, RC, C, T + b->o_wave, b->d_pd, b->in0[set], b->in1[set], P, cnt_l, b->dwin0[set] + b->Ho,
                                    b->two_out ? b->dwin1[set] + b->Ho : nullptr, P)) return rc;
         PM_HIP(hipEventRecord(b->back_done[set], B->stream));
         // -- tail: the output filter's sign bits for chunk t, beside the loops of chunk t + 1.  Its window is [history | new]: the last
@@ -317,13 +332,13 @@ int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings,
             }
             PM_HIP(hipEventRecord(b->hist_done[set], Tl->stream));
             const double *f0 = b->dwin0[set] + b->Ho - back;
-            if (int rc = pm_fir_rows(Tl, false, f0, P, nullptr, 0, (((uintptr_t)f0) & 15) == 0, RC, fn, T + b->o_out, mo, nullptr, 0, d_bits_i + o0 / 64,
-                                     bits_stride, 0)) return rc;
-            if (b->two_out) {
-                const double *f1 = b->dwin1[set] + b->Ho - back;
-                if (int rc = pm_fir_rows(Tl, false, f1, P, nullptr, 0, (((uintptr_t)f1) & 15) == 0, RC, fn, T + b->o_out, mo, nullptr, 0,
-                                         d_bits_q + o0 / 64, bits_stride, 0)) return rc;
-            }
+            auto signs = [&](const double *f, uint64_t *bits) -> int {
+                if (b->fir8) return pm_fir8_rows_signs(Tl, b->fir8, f, P, RC, fn, bits + o0 / 64, bits_stride, nullptr);
+                return pm_fir_rows(Tl, false, f, P, nullptr, 0, (((uintptr_t)f) & 15) == 0, RC, fn, T + b->o_out, mo, nullptr, 0, bits + o0 / 64, bits_stride, 0);
+            };
+            if (int rc = signs(f0, d_bits_i)) return rc;
+            if (b->two_out)
+                if (int rc = signs(b->dwin1[set] + b->Ho - back, d_bits_q)) return rc;
         }
         prev_cnt_l = cnt_l;
         s_agc = e_agc;

@@ -28,6 +28,24 @@ struct LoopRegs {
     double bb0, bb1, ba1, cx0, cx1, cy0, sx0, sx1, sy0;      // QPSK Costas branch filters
 };
 
+struct AgcDev {
+    double att, dec, sustain_time, sustain_inc, target;
+};
+
+// One sample of the envelope follower (agc.py:26-37), branch-free: the statements in the reference's order.
+__device__ __forceinline__ void agc_step(double s, double &env, double &sustain, const AgcDev &P)
+{
+    const double cmp = fabs(s);
+    const bool attack = cmp > env;                          // agc.py:28-32
+    const double up = fmin(env + P.att, cmp);               // env += att; if env > cmp: env = cmp
+    env = attack ? up : env;
+    sustain = attack ? 0.0 : sustain;
+    const bool decay = sustain >= P.sustain_time;           // agc.py:33-36
+    const double dn = env - P.dec;
+    env = decay ? (dn < 0 ? 0.0 : dn) : env;
+    sustain += P.sustain_inc;                               // agc.py:37
+}
+
 __device__ __forceinline__ double iir1(double b0, double b1, double a1, double &x0, double &x1, double &y0, double sample)
 {
     x1 = x0;                                                             // iir.py:40-42
@@ -345,12 +363,18 @@ __global__ __launch_bounds__(128) void loop_kernel(pm_loop *__restrict__ loops, 
 // Why: beside the engine's FIR kernels the tiled shapes run 1.8-2.8x slower than alone -- their LDS traffic (tile reads and writes of
 // the stepping wave, the I/O wave's copies) queues behind the filters' -- as the LDS form of the AGC rows kernel did (five times).
 // What stays in LDS is what the recurrence looks up by a computed index: the NCO pair table and the phase-detector table.
-template <int MODE>
+// AGC (BPSK with one chain per recording, psk.py:168-189: the AGC's output goes straight into the loop): the row holds the band-passed
+// samples and the lane steps the envelope follower too (agc.py:61-80), one block of eight samples AHEAD of the loop: the follower and
+// the division depend on nothing the loop computes, so their instructions issue in the shadow of the loop's dependent chain -- and the
+// AGC'd stream (230 MB written and read per recording, a kernel of its own on the front stream) never exists.
+template <int MODE, bool AGC = false>
 __global__ __launch_bounds__(64) void loop_direct_kernel(pm_loop *__restrict__ loops, int nloops, int per_row, const double *__restrict__ table,
                                                          const int32_t *__restrict__ pd, const double *__restrict__ x0,
                                                          const double *__restrict__ x1, int64_t x_stride, int64_t n, double *__restrict__ o0,
-                                                         double *__restrict__ o1, int64_t out_stride)
+                                                         double *__restrict__ o1, int64_t out_stride, const double *__restrict__ agc_consts = nullptr,
+                                                         AgcDev P = AgcDev{0, 0, 0, 0, 0}, double2 *__restrict__ agc_state = nullptr)
 {
+    static_assert(!AGC || MODE == kCostas, "the AGC is stepped in the loop's lane for the BPSK Costas loop only");
     extern __shared__ double lds[];
     constexpr bool kTwoOut = MODE == kMpsk || MODE == kQpsk;
     double2v *tab2 = reinterpret_cast<double2v *>(lds);
@@ -377,9 +401,20 @@ __global__ __launch_bounds__(64) void loop_direct_kernel(pm_loop *__restrict__ l
     const int64_t row = l / per_row;
     const double *p0 = x0 + row * x_stride, *p1 = MODE == kMpsk ? x1 + row * x_stride : nullptr;
     double *q0 = o0 + (int64_t)l * out_stride, *q1 = kTwoOut ? o1 + (int64_t)l * out_stride : nullptr;
+    double env = 0.0, sustain = 0.0;
+    if (AGC) {
+        P.att = agc_consts[4 * row + 1];
+        P.dec = agc_consts[4 * row + 2];
+        env = agc_state[row].x;
+        sustain = agc_state[row].y;
+    }
+    auto agc = [&](double sv) -> double {                    // agc.py:69-76: the follower's step, then buffer[i] = target * s / env
+        agc_step(sv, env, sustain, P);
+        return env != 0 ? P.target * sv / env : sv;
+    };
     __builtin_amdgcn_s_setprio(3);
     constexpr int B = 8;
-    double c0[B], c1[B], n0[B], n1[B];
+    double c0[B], c1[B], n0[B], n1[B], f0[B];               // stepped now | the block after it | (AGC) the block in flight from memory
     const int64_t full = n / B * B;
 #pragma unroll
     for (int j = 0; j < B; ++j) {
@@ -387,17 +422,27 @@ __global__ __launch_bounds__(64) void loop_direct_kernel(pm_loop *__restrict__ l
         c0[j] = p0[k];
         c1[j] = MODE == kMpsk ? p1[k] : 0.0;
     }
+    if (AGC) {
+#pragma unroll
+        for (int j = 0; j < B; ++j) n0[j] = p0[min((int64_t)B + j, n - 1)];
+        if (full) {
+#pragma unroll
+            for (int j = 0; j < B; ++j) c0[j] = agc(c0[j]);
+        }
+    }
     for (int64_t k0 = 0; k0 < full; k0 += B) {
 #pragma unroll
         for (int j = 0; j < B; ++j) {
-            const int64_t k = min(k0 + B + j, n - 1);
-            n0[j] = p0[k];
+            const int64_t k = min(k0 + (AGC ? 2 : 1) * B + j, n - 1);
+            (AGC ? f0 : n0)[j] = p0[k];
             n1[j] = MODE == kMpsk ? p1[k] : 0.0;
         }
+        const bool more = k0 + 2 * B <= full;                // (AGC) the next block is a whole one: its samples take their AGC steps now
         double r0[B], r1[B];
 #pragma unroll
         for (int j = 0; j < B; ++j) {
             r1[j] = 0.0;
+            if (AGC && more) n0[j] = agc(n0[j]);             // independent of the loop's chain: fills its issue gaps
             loop_step<MODE>(L, tab2, pdt, c0[j], c1[j], r0[j], r1[j]);
         }
 #pragma unroll
@@ -409,11 +454,13 @@ __global__ __launch_bounds__(64) void loop_direct_kernel(pm_loop *__restrict__ l
         for (int j = 0; j < B; ++j) {
             c0[j] = n0[j];
             c1[j] = n1[j];
+            if (AGC) n0[j] = f0[j];
         }
     }
     for (int64_t k = full; k < n; ++k) {
         double a = 0.0, b = 0.0;
-        loop_step<MODE>(L, tab2, pdt, p0[k], MODE == kMpsk ? p1[k] : 0.0, a, b);
+        const double sv = AGC ? agc(p0[k]) : p0[k];
+        loop_step<MODE>(L, tab2, pdt, sv, MODE == kMpsk ? p1[k] : 0.0, a, b);
         q0[k] = a;
         if (kTwoOut) q1[k] = b;
     }
@@ -421,6 +468,7 @@ __global__ __launch_bounds__(64) void loop_direct_kernel(pm_loop *__restrict__ l
     s.phase = L.phase; s.control = L.control; s.sine = L.sine; s.cosine = L.cosine;
     s.x0 = L.x0; s.x1 = L.x1; s.y0 = L.y0; s.integral = L.integral; s.proportional = L.proportional;
     if (MODE == kQpsk) { s.cx0 = L.cx0; s.cx1 = L.cx1; s.cy0 = L.cy0; s.sx0 = L.sx0; s.sx1 = L.sx1; s.sy0 = L.sy0; }
+    if (AGC) agc_state[row] = make_double2(env, sustain);
 }
 
 // the most distinct input rows the g consecutive loops of one workgroup can touch
@@ -440,14 +488,18 @@ size_t loop_lds_bytes(int mode, int rows_in, int g, int tile)
 
 // The launch itself: d_loops are `nloops` loops in DEVICE memory (parameters and state, read and written); nothing is copied and
 // nothing waits.
+// every lane a loop once eight-lane waves would outnumber the CUs (PM_LOOP_WIDE=0 / 1 / 2 forces the shape: tests, measurements;
+// 1 = the tiled 64-loop shape, 2 = the direct one)
+int loop_shape(const pm_ctx *ctx, int nloops)
+{
+    return ctx->tune.loop_wide >= 0 ? ctx->tune.loop_wide : (nloops > 8 * 256 ? 2 : 0);
+}
+
 template <int MODE>
 int loop_enqueue(pm_ctx *ctx, pm_loop *d_loops, int nloops, int per_row, const double *d_table, const int32_t *d_pd,
                  const double *d_x0, const double *d_x1, int64_t x_stride, int64_t n, double *d_o0, double *d_o1, int64_t out_stride)
 {
-    // every lane a loop once eight-lane waves would outnumber the CUs (PM_LOOP_WIDE=0 / 1 / 2 forces the shape: tests, measurements;
-    // 1 = the tiled 64-loop shape, 2 = the direct one)
-    int shape = nloops > 8 * 256 ? 2 : 0;
-    if (ctx->tune.loop_wide >= 0) shape = ctx->tune.loop_wide;
+    const int shape = loop_shape(ctx, nloops);
     if (shape == 2) {
         const size_t lds2 = 516 * 8 + (MODE == kMpsk ? 4096 * 4 : 0);
         PmProf prof(ctx, PM_K_LOOP);
@@ -515,10 +567,6 @@ __global__ __launch_bounds__(256) void max_partial_kernel(const double *__restri
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
-struct AgcDev {
-    double att, dec, sustain_time, sustain_inc, target;
-};
-
 // ---- AGC as a chunk-parallel fixed point -------------------------------------------------------------------------------
 // The envelope follower (agc.py:26-37) carries two doubles, (envelope, sustain_count).  Whenever a sample exceeds the
 // envelope by less than one attack step the envelope is clamped to |s| and sustain_count restarts, which erases the
@@ -527,19 +575,6 @@ struct AgcDev {
 // iteration stops when no start state changes -- at which point the chunk runs are the sequential run.  Worst case (no
 // common clamp for a long stretch) degrades to sequential cost.  The converged pass writes the envelope, and the division
 // buf[i] = target*s/env (agc.py:75-76), which is not part of the recurrence, runs fully parallel.
-__device__ __forceinline__ void agc_step(double s, double &env, double &sustain, const AgcDev &P)
-{
-    const double cmp = fabs(s);
-    const bool attack = cmp > env;                          // agc.py:28-32
-    const double up = fmin(env + P.att, cmp);               // env += att; if env > cmp: env = cmp
-    env = attack ? up : env;
-    sustain = attack ? 0.0 : sustain;
-    const bool decay = sustain >= P.sustain_time;           // agc.py:33-36
-    const double dn = env - P.dec;
-    env = decay ? (dn < 0 ? 0.0 : dn) : env;
-    sustain += P.sustain_inc;                               // agc.py:37
-}
-
 struct AgcScale {
     double scaled_attack, scaled_decay;
 };
@@ -764,6 +799,29 @@ int pm_loops_rows(pm_ctx *ctx, int modem, pm_loop *d_loops, int nloops, int per_
         return loop_enqueue<kMpsk>(ctx, d_loops, nloops, per_row, d_table, d_pd, d_x0, d_x1, x_stride, n, d_o0, d_o1, out_stride);
     default: return pm_set_error(PM_ERR_ARG, "pm_loops_rows: modem %d has no carrier loop", modem);
     }
+}
+
+bool pm_loops_rows_take_agc(const pm_ctx *ctx, int modem, int nloops, int per_row)
+{
+    return ctx && modem == PM_MODEM_BPSK && per_row == 1 && loop_shape(ctx, nloops) == 2 && ctx->tune.loop_agc != 0;
+}
+
+int pm_loops_rows_agc(pm_ctx *ctx, pm_loop *d_loops, int nloops, const double *d_table, const double *d_x, int64_t x_stride, int64_t n, double *d_o,
+                      int64_t out_stride, const pm_agc_params *hp, const double *d_consts, double *d_state)
+{
+    PM_CTX(ctx);
+    PM_ARG(d_loops && nloops >= 1 && d_table && d_x && d_o && n >= 0 && hp && d_consts && d_state && hp->sample_rate > 0);
+    if (n == 0) return PM_OK;
+    AgcDev P;
+    P.sustain_time = hp->sustain_time;
+    P.sustain_inc = 1 / hp->sample_rate;                            // agc.py:17
+    P.target = hp->target_amplitude;
+    P.att = P.dec = 0;
+    PmProf prof(ctx, PM_K_LOOP);
+    hipLaunchKernelGGL((loop_direct_kernel<kCostas, true>), dim3((unsigned)pm_cdiv(nloops, 64)), dim3(64), 516 * 8, ctx->stream, d_loops, nloops, 1, d_table,
+                       (const int32_t *)nullptr, d_x, (const double *)nullptr, x_stride, n, d_o, (double *)nullptr, out_stride, d_consts, P, (double2 *)d_state);
+    PM_HIP(hipGetLastError());
+    return PM_OK;
 }
 
 int pm_rows_max(pm_ctx *ctx, const double *d_x, int64_t x_stride, int rows, int64_t n, double *d_partial, double *d_running, int first)
