@@ -144,9 +144,10 @@ int pm_fir8_plan_create(pm_ctx *ctx, const double *h_taps, int m, pm_fir8_plan *
 void pm_fir8_plan_destroy(pm_fir8_plan *p);
 int pm_fir8_taps(const pm_fir8_plan *p);
 // rows of n doubles, pitch x_stride -> rows of n - m + 1 sign bits, pitch bits_stride words (bits past the last output of the last word
-// zero).  d_count: nullptr, or a device counter that gains the number of outputs recomputed exactly (diagnostics).
+// zero).  d_count: nullptr, or a device counter that gains the number of outputs recomputed exactly (diagnostics).  x_room: 0, or how
+// many doubles may be READ from each row's start (>= n: rows of a pitched block; whole windows are then loaded without bounds tests)
 int pm_fir8_rows_signs(pm_ctx *ctx, const pm_fir8_plan *p, const double *d_x, int64_t x_stride, int rows, int64_t n, uint64_t *d_bits,
-                       int64_t bits_stride, int *d_count);
+                       int64_t bits_stride, int *d_count, int64_t x_room = 0);
 
 // ---- launchers shared between translation units (what the batch engine pm_loopbatch.hip strings together) ---------------------
 // `rows` FIRs with the same taps over equal-length streams in one launch (pm_fir.hip).  Input row r: d_x + r * x_stride, or

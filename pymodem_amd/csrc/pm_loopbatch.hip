@@ -333,7 +333,8 @@ int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings,
             PM_HIP(hipEventRecord(b->hist_done[set], Tl->stream));
             const double *f0 = b->dwin0[set] + b->Ho - back;
             auto signs = [&](const double *f, uint64_t *bits) -> int {
-                if (b->fir8) return pm_fir8_rows_signs(Tl, b->fir8, f, P, RC, fn, bits + o0 / 64, bits_stride, nullptr);
+                // (a row of the output windows: Ho history slots, the chunk, slack up to the pitch -- all of it the engine's own memory)
+                if (b->fir8) return pm_fir8_rows_signs(Tl, b->fir8, f, P, RC, fn, bits + o0 / 64, bits_stride, nullptr, P - (b->Ho - back));
                 return pm_fir_rows(Tl, false, f, P, nullptr, 0, (((uintptr_t)f) & 15) == 0, RC, fn, T + b->o_out, mo, nullptr, 0, bits + o0 / 64, bits_stride, 0);
             };
             if (int rc = signs(f0, d_bits_i)) return rc;

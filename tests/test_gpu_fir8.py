@@ -70,7 +70,9 @@ def test_certified_signs_equal_the_exact_kernel(ctx, m):
     got, want, redo = _both(ctx, rows, taps)
     assert np.array_equal(got, want), [int(np.sum(got[r] != want[r])) for r in range(len(rows))]
     total = got.size
-    assert 0 <= redo < 0.02 * total, (redo, total)          # the matrix pipe decides nearly everything
+    # the matrix pipe decides nearly everything; what it cannot decide by magnitude are sums that ARE zero (windows of zeros)
+    silent = sum(int(np.sum(np.convolve((rows[r] != 0).astype(np.int64), np.ones(m, np.int64), "valid") == 0)) for r in range(len(rows)))
+    assert 0 <= redo <= silent + 0.02 * total, (redo, silent, total)
 
 
 def test_certification_is_tight_on_the_modems_own_filters(ctx):
@@ -78,7 +80,7 @@ def test_certification_is_tight_on_the_modems_own_filters(ctx):
     quotes these)."""
     from pymodem_amd import chain_builder as cb
     rng = np.random.default_rng(5)
-    for kind, cfg in (("bpsk", "300"), ("mpsk", "2400")):
+    for kind, cfg in (("bpsk", "300"), ("mpsk", "qpsk_2400")):
         md = cb.ModemConfigurator(48000, {"type": kind, "config": cfg, "options": {}})
         taps = np.asarray(md.rrc_taps, dtype=np.float64)
         n = 400000
