@@ -165,7 +165,7 @@ def main():
     ap.add_argument("--loop-batch", type=int, default=0,
                     help="carrier-loop workloads (bpsk_300, qpsk_2400): recordings per engine run (pymodem_amd.loop_batch) -- the loops of all of "
                          "them x the rank's chains advance together, one lane each; a step is still one recording.  0 (default): as many as "
-                         "give 16384 loops in flight (every lane of one stepping wave per CU), 8192 recordings at most, never more than --steps")
+                         "give 16384 loops in flight (every lane of one stepping wave per CU), never more than --steps")
     ap.add_argument("--loop-chunk", type=int, default=0, help="carrier-loop workloads: final-filter outputs per time chunk (0: 65536 for runs of "
                     "more than 8192 loops, 131072 from 2048 recordings, else 262144 -- the work buffers are sized by it)")
     ap.add_argument("--also", type=int, default=1, help="1 (default, one GPU only): after the headline workload also measure fsk_9600, "
@@ -378,9 +378,9 @@ def also_workloads(args, env, cpu_also=None):
     at full size -- and fsk_9600 is the shortest-tap FIR path.  Never allowed to break the main line."""
     import copy
     out = {}
-    # (the carrier-loop workloads: one full engine run each -- 8192 recordings x 1 chain, 2048 x 8 chains; a run takes as long as
+    # (the carrier-loop workloads: one full engine run each -- 16384 recordings x 1 chain, 2048 x 8 chains; a run takes as long as
     # its recordings are, however many there are)
-    for name, steps, warm in (("fsk_9600", 300, 10), ("bpsk_300", 8192, 1), ("qpsk_2400", 2048, 1)):
+    for name, steps, warm in (("fsk_9600", 300, 10), ("bpsk_300", 16384, 1), ("qpsk_2400", 2048, 1)):
         if name == args.workload or (os.environ.get("BENCH_ALSO_ONLY") and name not in os.environ["BENCH_ALSO_ONLY"].split(",")):
             continue
         a = copy.copy(args)
@@ -487,7 +487,7 @@ def measure(args, env):
     loop_info = None
     if loop_wl:
         from pymodem_amd import loop_batch as lb
-        batch = max(1, min(args.loop_batch or min(8192, LOOPS_IN_FLIGHT // max(len(my), 1)), max(args.steps, 1)))
+        batch = max(1, min(args.loop_batch or min(16384, LOOPS_IN_FLIGHT // max(len(my), 1)), max(args.steps, 1)))
         if not args.loop_chunk:
             args.loop_chunk = 65536 if batch * len(my) > 8192 else 131072 if batch >= 2048 else 262144
         engine = lb.engine_for([modems[c] for c in my], batch, ctx, args.loop_chunk)
@@ -506,7 +506,7 @@ def measure(args, env):
             r = min(batch, k - b0)
             sets = [build_chains(reset=False) for _ in range(r)]
             st = {}
-            bufs = audio_ring(min(r, LOOP_DISTINCT_BUFFERS))      # (8192 distinct ten-minute recordings would be 472 GB: each copy serves r / 256 of the run's recordings)
+            bufs = audio_ring(min(r, LOOP_DISTINCT_BUFFERS))      # (16384 distinct ten-minute recordings would be 944 GB: each copy serves r / 256 of the run's recordings)
             rows = lb.process_recordings_device(sets, [bufs[i % len(bufs)] for i in range(r)], ctx, chunk=args.loop_chunk, rows=True, chain_ids=my, stages=st)
             t_f = time.perf_counter()
             if use_dist or len(my) < 4:
@@ -814,7 +814,7 @@ def measure(args, env):
         # any run of the engine takes as long as its recordings are (the loops are sequential in time): warm up on the first seconds
         if args.warmup:
             loop_steps(min(args.warmup, batch), d_audio.view(0, min(args.samples, 1_500_000)))
-        sides.extend([engine.front, engine.tail])
+        sides.extend([engine.front, engine.tail] + ([engine.loop] if engine.loop is not None else []))
     else:
         run_steps(args.warmup)
     fence()
@@ -908,6 +908,8 @@ def measure(args, env):
     if loop_wl:
         sides.remove(engine.front)
         sides.remove(engine.tail)
+        if engine.loop is not None:
+            sides.remove(engine.loop)
         lb.close_engines()                                    # the engine's work buffers and bitmap sets (gigabytes) go back
         chains_ref[:] = []
         import gc

@@ -427,6 +427,7 @@ int pm_lbatch_run(pm_lbatch *batch, const int16_t *const *h_d_audio, int recordi
                   int64_t bits_stride, int64_t *h_nout);
 pm_ctx *pm_lbatch_front_ctx(pm_lbatch *batch);       /* the engine's own contexts, for pm_prof_*: band-pass, AGC, Hilbert of chunk t + 1 ... */
 pm_ctx *pm_lbatch_tail_ctx(pm_lbatch *batch);        /* ... and the matched filters of chunk t - 1, beside the loops of chunk t on the caller's */
+pm_ctx *pm_lbatch_loop_ctx(pm_lbatch *batch);        /* ... or on the engine's loop context, when the loops have compute units of their own (else NULL) */
 int pm_lbatch_destroy(pm_lbatch *batch);
 
 /* ---- host-integer stages (native C++, no GPU) --------------------------------------------------

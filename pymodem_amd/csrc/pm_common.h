@@ -35,6 +35,9 @@ struct pm_tuning {
     int slicer_trace = 0, slicer_no_setprio = 0;
     int fir8 = 1;                      // PM_FIR8=0: the batch engine's matched filters in binary64 on the vector pipe
     int loop_agc = 1;                  // PM_LOOP_AGC=0: the batch engine's BPSK AGC as a pass of its own, not in the loop's lane
+    int loop_vec = 1;                  // PM_LOOP_VEC=0: the direct loop shape moves its blocks with eight-byte accesses, a lane a row
+    int lbatch_loop_cus = -1;          // PM_LBATCH_LOOP_CUS: compute units the batch engine's carrier loops have to themselves (0: none, -1: by size)
+    int agc_rows_prio = 2;             // PM_AGC_ROWS_PRIO: wave priority of the rows AGC (the loops run at 3)
 };
 pm_tuning pm_tuning_from_env();
 

@@ -31,6 +31,8 @@ struct pm_lbatch {
     pm_ctx *back = nullptr;                  // the caller's context: loops and output filter
     pm_ctx *front = nullptr;                 // own context: band-pass, AGC, Hilbert pair of the next chunk
     pm_ctx *tail = nullptr;                  // own context: the matched filter(s) of chunk t beside the loops of chunk t + 1
+    pm_ctx *loop = nullptr;                  // own context on compute units of its own (or nullptr: the loops run on the caller's stream)
+    hipEvent_t loop_go = nullptr, loop_end = nullptr;
     int modem = 0, R = 0, C = 0;
     int mb = 0, mh = 0, mo = 0, delay = 0;
     bool mpsk = false, two_out = false;
@@ -118,6 +120,10 @@ int pm_lbatch_destroy(pm_lbatch *b)
     for (hipEvent_t e : {b->front_done[0], b->front_done[1], b->back_done[0], b->back_done[1], b->hist_done[0], b->hist_done[1], b->run_done})
         if (e) (void)hipEventDestroy(e);
     pm_fir8_plan_destroy(b->fir8);
+    if (b->loop) (void)pm_ctx_sync(b->loop);
+    for (hipEvent_t e : {b->loop_go, b->loop_end})
+        if (e) (void)hipEventDestroy(e);
+    if (b->loop) (void)pm_ctx_destroy(b->loop);
     if (b->front) (void)pm_ctx_destroy(b->front);
     if (b->tail) (void)pm_ctx_destroy(b->tail);
     delete b;
@@ -157,8 +163,36 @@ int pm_lbatch_create(pm_ctx *ctx, const pm_lbatch_desc *desc, pm_lbatch **out)
     b->pitch = (b->Lc + 2 * b->mo + 2 * b->mh + 32 + 7) / 8 * 8;
     int rc = PM_OK;
     do {
-        if ((rc = pm_ctx_create_prio(ctx->device, 0, &b->front))) break;
-        if ((rc = pm_ctx_create_prio(ctx->device, 0, &b->tail))) break;
+        // Compute units for the carrier loops alone.  A loop's wave is one dependent binary64 chain that also fills about half of its
+        // SIMD's issue slots (10 cycles per dependent operation, 5.5 to issue it): a filter wave on the same SIMD -- or an AGC wave, another
+        // chain -- costs it a third to a half of its pace, and a loop launch ends with its slowest wave (measured: loops of a qpsk_2400
+        // chunk 14.2 ms alone, 26-28 ms beside the engine's other streams).  With one wave per SIMD on units the other streams' masks
+        // exclude, the loops keep their pace whatever runs elsewhere -- up to what loop waves cost each other on one unit: measured
+        // (profiles/r04_loop_sweep.txt), qpsk_2400 with 16 384 loops 8.3 / 7.1 / 6.5-6.8 ms per step on 64 / 96 / 128 units (8.0-8.7 without),
+        // bpsk_300 with 16 384 loops 1.30 / 1.48 on 64 / 128 (1.38 without): the two-output loops (two rows in, two out, the phase
+        // detector's table) want two waves per unit, the Costas loop four.  -1: that, at most half the device; 0: no partition.
+        int cus = ctx->tune.lbatch_loop_cus;
+        const int have = pm_device_cus(ctx->device);
+        const int64_t waves = ((int64_t)d.recordings * d.chains + 63) / 64;
+        const bool two = d.modem == PM_MODEM_MPSK || d.modem == PM_MODEM_QPSK;
+        if (cus < 0) cus = waves >= 64 ? (int)std::min<int64_t>(two ? (waves + 1) / 2 : (waves + 3) / 4, have / 2) : 0;
+        cus = std::min(cus, have - 8) / 8 * 8;                // whole rows of the XCDs (bit i of a mask is unit i / 8 of XCD i % 8)
+        if (cus >= 8 && have >= 16 && have <= 1024) {
+            uint32_t mine[32] = {0}, rest[32] = {0};
+            for (int i = 0; i < have; ++i) (i < cus ? mine : rest)[i / 32] |= 1u << (i % 32);
+            const int nw = (have + 31) / 32;
+            if ((rc = pm_ctx_create_cumask(ctx->device, mine, nw, &b->loop))) break;
+            if ((rc = pm_ctx_create_cumask(ctx->device, rest, nw, &b->front))) break;
+            if ((rc = pm_ctx_create_cumask(ctx->device, rest, nw, &b->tail))) break;
+            b->loop->tune = ctx->tune;
+            hipError_t e1 = hipEventCreateWithFlags(&b->loop_go, hipEventDisableTiming), e2 = hipEventCreateWithFlags(&b->loop_end, hipEventDisableTiming);
+            if (e1 != hipSuccess || e2 != hipSuccess) { rc = pm_set_error(PM_ERR_HIP, "hipEventCreate failed"); break; }
+        } else {
+            if ((rc = pm_ctx_create_prio(ctx->device, 0, &b->front))) break;
+            if ((rc = pm_ctx_create_prio(ctx->device, 0, &b->tail))) break;
+        }
+        b->front->tune = ctx->tune;
+        b->tail->tune = ctx->tune;
         b->o_in = put(b->h_taps, d.input_fir, d.n_input_fir);
         if (b->mpsk) b->o_hil = put(b->h_taps, d.hilbert, d.n_hilbert);
         b->o_out = put(b->h_taps, d.output_fir, d.n_output_fir);
@@ -218,6 +252,7 @@ int pm_lbatch_geometry(pm_lbatch *b, int64_t n, int64_t *h_nout, int64_t *h_chun
 
 pm_ctx *pm_lbatch_front_ctx(pm_lbatch *b) { return b ? b->front : nullptr; }
 pm_ctx *pm_lbatch_tail_ctx(pm_lbatch *b) { return b ? b->tail : nullptr; }
+pm_ctx *pm_lbatch_loop_ctx(pm_lbatch *b) { return b ? b->loop : nullptr; }
 
 int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings, int64_t n, uint64_t *d_bits_i, uint64_t *d_bits_q,
                   int64_t bits_stride, int64_t *h_nout)
@@ -230,6 +265,9 @@ int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings,
     // bpsk_300 (8192 x 1) 14 744 / 12 035 Msamples/s, qpsk_2400 2048 x 8 chains 18 616 / 17 438, 256 x 64 chains 22 062 / 18 865.
     const bool use_tail = tail_mode != 0;
     pm_ctx *B = b->back, *F = b->front, *Tl = use_tail ? b->tail : b->back;
+    pm_ctx *Lp = b->loop ? b->loop : B;                       // the loops' stream (the caller's, or the engine's own on its own compute units)
+    for (pm_ctx *c : {b->front, b->tail, b->loop})            // the caller's switches (pm_ctx_tune) hold for the engine's own contexts too
+        if (c) c->tune = B->tune;
     PM_CTX(B);
     PM_ARG(recordings >= 1 && recordings <= b->R);
     PM_ARG(!b->two_out || d_bits_q != nullptr);
@@ -254,6 +292,7 @@ int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings,
         PM_HIP(hipStreamWaitEvent(F->stream, b->run_done, 0));
         PM_HIP(hipStreamWaitEvent(B->stream, b->run_done, 0));
         PM_HIP(hipStreamWaitEvent(Tl->stream, b->run_done, 0));
+        PM_HIP(hipStreamWaitEvent(Lp->stream, b->run_done, 0));
     }
     // the front stream is ordered behind whatever the caller has enqueued on its context so far (e.g. the recordings' uploads)
     PM_HIP(hipEventRecord(b->run_done, B->stream));
@@ -261,6 +300,10 @@ int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings,
     PM_HIP(hipMemcpyAsync(b->d_audio, b->h_audio.data(), sizeof(void *) * (size_t)R, hipMemcpyHostToDevice, F->stream));
     PM_HIP(hipMemsetAsync(b->d_agc_state, 0, sizeof(double) * 2 * (size_t)R, F->stream));          // fresh AGC objects (agc.py:20-21)
     PM_HIP(hipMemcpyAsync(b->d_loops, b->h_loops.data(), sizeof(pm_loop) * (size_t)RC, hipMemcpyHostToDevice, B->stream));
+    if (Lp != B) {                                            // the loops start behind the fresh states
+        PM_HIP(hipEventRecord(b->loop_go, B->stream));
+        PM_HIP(hipStreamWaitEvent(Lp->stream, b->loop_go, 0));
+    }
 
     // ---- pass 1: normal = max(band-passed recording) per row (agc.py:67) ------------------------------------------------------
     for (int64_t at = 0, first = 1; at < na; at += Lc, first = 0) {
@@ -276,7 +319,7 @@ int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings,
     b->last_chunks = chunks;
     int64_t s_agc = 0, s_loop = 0, prev_cnt_l = 0;
     // BPSK, one chain per recording (psk.py:168-189): the AGC's only reader is the loop -- its lane steps the follower too (pm_loops.hip)
-    const bool fold_agc = pm_loops_rows_take_agc(B, b->modem, RC, C);
+    const bool fold_agc = pm_loops_rows_take_agc(Lp, b->modem, RC, C);
     int64_t skip_of[2] = {0, 0};
     for (int64_t t = 0; t < chunks; ++t) {
         const int set = (int)(t & 1);
@@ -311,14 +354,14 @@ int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings,
         }
         // -- back: every loop over the chunk into output set t & 1.  The set is free once the matched filters of chunk t - 2 have read it
         // and chunk t - 1's history has been taken out of... the OTHER set; both lie behind hist_done of chunk t - 1 on the tail stream.
-        PM_HIP(hipStreamWaitEvent(B->stream, b->front_done[set], 0));
-        if (t >= 1) PM_HIP(hipStreamWaitEvent(B->stream, b->hist_done[(t - 1) & 1], 0));
+        PM_HIP(hipStreamWaitEvent(Lp->stream, b->front_done[set], 0));
+        if (t >= 1) PM_HIP(hipStreamWaitEvent(Lp->stream, b->hist_done[(t - 1) & 1], 0));
         if (fold_agc) {
-            if (int rc = pm_loops_rows_agc(B, b->d_loops, RC, T + b->o_wave, b->in0[set] + skip_of[set], P, cnt_l, b->dwin0[set] + b->Ho, P, &b->agc, b->d_consts,
+            if (int rc = pm_loops_rows_agc(Lp, b->d_loops, RC, T + b->o_wave, b->in0[set] + skip_of[set], P, cnt_l, b->dwin0[set] + b->Ho, P, &b->agc, b->d_consts,
                                            b->d_agc_state)) return rc;
-        } else if (int rc = pm_loops_rows(B, b->modem, b->d_loops, RC, C, T + b->o_wave, b->d_pd, b->in0[set], b->in1[set], P, cnt_l, b->dwin0[set] + b->Ho,
+        } else if (int rc = pm_loops_rows(Lp, b->modem, b->d_loops, RC, C, T + b->o_wave, b->d_pd, b->in0[set], b->in1[set], P, cnt_l, b->dwin0[set] + b->Ho,
                                    b->two_out ? b->dwin1[set] + b->Ho : nullptr, P)) return rc;
-        PM_HIP(hipEventRecord(b->back_done[set], B->stream));
+        PM_HIP(hipEventRecord(b->back_done[set], Lp->stream));
         // -- tail: the output filter's sign bits for chunk t, beside the loops of chunk t + 1.  Its window is [history | new]: the last
         // mo - 1 loop outputs of chunk t - 1 come over from the other set first (the loops of chunk t + 1, which overwrite them, wait
         // for that copy: hist_done).
@@ -348,6 +391,10 @@ int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings,
     // the tail stream's last filter ends the run: the caller's context waits for it
     PM_HIP(hipEventRecord(b->hist_done[0], Tl->stream));
     PM_HIP(hipStreamWaitEvent(B->stream, b->hist_done[0], 0));
+    if (Lp != B) {                                            // (the tail's last filter is behind the last loops; the states they left: this)
+        PM_HIP(hipEventRecord(b->loop_end, Lp->stream));
+        PM_HIP(hipStreamWaitEvent(B->stream, b->loop_end, 0));
+    }
     // the run is complete on the caller's context once the back stream gets here; the next run waits for this point on both streams
     PM_HIP(hipEventRecord(b->run_done, B->stream));
     b->ran = true;

@@ -358,16 +358,33 @@ __global__ __launch_bounds__(128) void loop_kernel(pm_loop *__restrict__ loops, 
     }
 }
 
-// The third shape: one wave per workgroup, a loop on every lane, NOTHING but the tables in LDS.  A lane loads eight samples of its input
-// row (the next eight already in flight), steps them, stores its eight outputs: no tiles, no second wave, no barrier after the tables.
-// Why: beside the engine's FIR kernels the tiled shapes run 1.8-2.8x slower than alone -- their LDS traffic (tile reads and writes of
-// the stepping wave, the I/O wave's copies) queues behind the filters' -- as the LDS form of the AGC rows kernel did (five times).
-// What stays in LDS is what the recurrence looks up by a computed index: the NCO pair table and the phase-detector table.
+// The third shape: one wave per workgroup, a loop on every lane, no second wave and no barrier between waves.  A lane steps eight samples
+// of its loop at a time, the next eight already in registers and the eight after them in flight from memory.
+// Why no tiles: beside the engine's FIR kernels the tiled shapes run 1.8-2.8x slower than alone -- their LDS traffic (tile reads and
+// writes of the stepping wave, the I/O wave's copies) queues behind the filters'.  What is in LDS: the tables the recurrence looks up by
+// a computed index (NCO pairs, phase detector) and, round 4, for the two-output loops one 5 KB tile per output through which the wave's
+// eight-sample blocks are TRANSPOSED on their way to memory (VEC).  A lane owns a row, so a plain eight-byte store touches 64 cache lines
+// per instruction and fills each line with eight separate requests; through the tile a store instruction writes 16 whole lines (four
+// lanes per row, 16 bytes each): an eighth of the requests, and fewer memory operations in flight per wave (a wave may have 63).
+// Measured (profiles/r04_loop_sweep.txt): qpsk_2400 7.8 against 8.6 ms per step; the BPSK loop, which would also LOAD through a tile
+// (a row per loop), ran 20 % slower that way -- LDS operations of a wave complete in order, so the NCO's table read, which is on the
+// loop's dependent chain, queues behind the tile's -- and keeps its plain accesses.  Only this wave touches its tiles: no barrier.
 // AGC (BPSK with one chain per recording, psk.py:168-189: the AGC's output goes straight into the loop): the row holds the band-passed
 // samples and the lane steps the envelope follower too (agc.py:61-80), one block of eight samples AHEAD of the loop: the follower and
 // the division depend on nothing the loop computes, so their instructions issue in the shadow of the loop's dependent chain -- and the
 // AGC'd stream (230 MB written and read per recording, a kernel of its own on the front stream) never exists.
-template <int MODE, bool AGC = false>
+constexpr int kTileRow = 10;                 // doubles per row of a transposing tile: eight samples + 16 bytes (rows 80 bytes apart: no bank conflicts for 16-byte accesses)
+
+// Between a tile's writes and its reads by other lanes OF THE SAME WAVE: LDS operations of a wave complete in issue order, so nothing has
+// to be waited for -- the compiler only must not move them across (a __syncthreads() here also waits for every global load and store
+// in flight: the prefetched blocks, i.e. a memory round trip per eight samples on the loop's critical path).
+__device__ __forceinline__ void tile_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int MODE, bool AGC = false, bool VEC = false>
 __global__ __launch_bounds__(64) void loop_direct_kernel(pm_loop *__restrict__ loops, int nloops, int per_row, const double *__restrict__ table,
                                                          const int32_t *__restrict__ pd, const double *__restrict__ x0,
                                                          const double *__restrict__ x1, int64_t x_stride, int64_t n, double *__restrict__ o0,
@@ -379,12 +396,15 @@ __global__ __launch_bounds__(64) void loop_direct_kernel(pm_loop *__restrict__ l
     constexpr bool kTwoOut = MODE == kMpsk || MODE == kQpsk;
     double2v *tab2 = reinterpret_cast<double2v *>(lds);
     int32_t *pdt = (int32_t *)(lds + 516);
+    double *tiles = lds + 516 + (MODE == kMpsk ? 2048 : 0);          // VEC: out0 | out1 (64 rows of kTileRow doubles each)
     for (int i = threadIdx.x; i < 257; i += 64) tab2[i] = double2v{table[i & 255], table[(i + 64) & 255]};
     if (MODE == kMpsk)
         for (int i = threadIdx.x; i < 4096; i += 64) pdt[i] = pd[i];
     __syncthreads();
-    const int l = blockIdx.x * 64 + threadIdx.x;
-    if (l >= nloops) return;
+    const int lane = threadIdx.x, l0 = blockIdx.x * 64;
+    const bool alive = l0 + lane < nloops;
+    if (!VEC && !alive) return;
+    const int l = min(l0 + lane, nloops - 1);                        // (VEC: the lanes past the last loop help moving the tiles and step a copy of it, unsaved)
     LoopRegs L;
     {
         const pm_loop &s = loops[l];
@@ -414,30 +434,56 @@ __global__ __launch_bounds__(64) void loop_direct_kernel(pm_loop *__restrict__ l
     };
     __builtin_amdgcn_s_setprio(3);
     constexpr int B = 8;
-    double c0[B], c1[B], n0[B], n1[B], f0[B];               // stepped now | the block after it | (AGC) the block in flight from memory
     const int64_t full = n / B * B;
-#pragma unroll
-    for (int j = 0; j < B; ++j) {
-        const int64_t k = min((int64_t)j, n - 1);
-        c0[j] = p0[k];
-        c1[j] = MODE == kMpsk ? p1[k] : 0.0;
-    }
-    if (AGC) {
-#pragma unroll
-        for (int j = 0; j < B; ++j) n0[j] = p0[min((int64_t)B + j, n - 1)];
-        if (full) {
-#pragma unroll
-            for (int j = 0; j < B; ++j) c0[j] = agc(c0[j]);
-        }
-    }
-    for (int64_t k0 = 0; k0 < full; k0 += B) {
+    // VEC: lane i moves quarter i % 4 (16 bytes) of the block of loop 16 j + i / 4 in pass j = 0..3: four lanes to a cache line
+    const int sub = lane & 3, grp = lane >> 2;
+    double *t_o0 = tiles, *t_o1 = tiles + 64 * kTileRow;
+    auto fetch = [&](int64_t k, double (&d0)[B], double (&d1)[B]) {          // the block of eight samples at k (clamped into the stream) -> registers
 #pragma unroll
         for (int j = 0; j < B; ++j) {
-            const int64_t k = min(k0 + (AGC ? 2 : 1) * B + j, n - 1);
-            (AGC ? f0 : n0)[j] = p0[k];
-            n1[j] = MODE == kMpsk ? p1[k] : 0.0;
+            const int64_t kk = min(k + j, n - 1);
+            d0[j] = p0[kk];
+            d1[j] = MODE == kMpsk ? p1[kk] : 0.0;
         }
-        const bool more = k0 + 2 * B <= full;                // (AGC) the next block is a whole one: its samples take their AGC steps now
+    };
+    auto put = [&](int64_t k0, const double (&r0)[B], const double (&r1)[B]) {
+        if (VEC) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                *reinterpret_cast<double2v *>(t_o0 + lane * kTileRow + 2 * j) = double2v{r0[2 * j], r0[2 * j + 1]};
+                if (kTwoOut) *reinterpret_cast<double2v *>(t_o1 + lane * kTileRow + 2 * j) = double2v{r1[2 * j], r1[2 * j + 1]};
+            }
+            tile_fence();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ll = l0 + 16 * j + grp;
+                const double2v a = *reinterpret_cast<const double2v *>(t_o0 + (16 * j + grp) * kTileRow + 2 * sub);
+                const double2v b = kTwoOut ? *reinterpret_cast<const double2v *>(t_o1 + (16 * j + grp) * kTileRow + 2 * sub) : double2v{0.0, 0.0};
+                if (ll < nloops) {
+                    *reinterpret_cast<double2v *>(o0 + (int64_t)ll * out_stride + k0 + 2 * sub) = a;
+                    if (kTwoOut) *reinterpret_cast<double2v *>(o1 + (int64_t)ll * out_stride + k0 + 2 * sub) = b;
+                }
+            }
+            tile_fence();
+        } else {
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                q0[k0 + j] = r0[j];
+                if (kTwoOut) q1[k0 + j] = r1[j];
+            }
+        }
+    };
+    // c: stepped now | nx: the block after it (AGC: its AGC steps are taken while c is stepped) | f: the block in flight from memory
+    double c0[B] = {0}, c1[B] = {0}, n0[B] = {0}, n1[B] = {0}, f0[B] = {0}, f1[B] = {0};
+    fetch(0, c0, c1);
+    fetch(B, n0, n1);
+    if (AGC && full) {
+#pragma unroll
+        for (int j = 0; j < B; ++j) c0[j] = agc(c0[j]);
+    }
+    for (int64_t k0 = 0; k0 < full; k0 += B) {
+        fetch(k0 + 2 * B, f0, f1);
+        const bool more = k0 + 2 * B <= full;                // the next block is a whole one: (AGC) its samples take their AGC steps now
         double r0[B], r1[B];
 #pragma unroll
         for (int j = 0; j < B; ++j) {
@@ -445,30 +491,29 @@ __global__ __launch_bounds__(64) void loop_direct_kernel(pm_loop *__restrict__ l
             if (AGC && more) n0[j] = agc(n0[j]);             // independent of the loop's chain: fills its issue gaps
             loop_step<MODE>(L, tab2, pdt, c0[j], c1[j], r0[j], r1[j]);
         }
-#pragma unroll
-        for (int j = 0; j < B; ++j) {
-            q0[k0 + j] = r0[j];
-            if (kTwoOut) q1[k0 + j] = r1[j];
-        }
+        put(k0, r0, r1);
 #pragma unroll
         for (int j = 0; j < B; ++j) {
             c0[j] = n0[j];
             c1[j] = n1[j];
-            if (AGC) n0[j] = f0[j];
+            n0[j] = f0[j];
+            n1[j] = f1[j];
         }
     }
-    for (int64_t k = full; k < n; ++k) {
-        double a = 0.0, b = 0.0;
-        const double sv = AGC ? agc(p0[k]) : p0[k];
-        loop_step<MODE>(L, tab2, pdt, sv, MODE == kMpsk ? p1[k] : 0.0, a, b);
-        q0[k] = a;
-        if (kTwoOut) q1[k] = b;
+    if (alive) {
+        for (int64_t k = full; k < n; ++k) {
+            double a = 0.0, b = 0.0;
+            const double sv = AGC ? agc(p0[k]) : p0[k];
+            loop_step<MODE>(L, tab2, pdt, sv, MODE == kMpsk ? p1[k] : 0.0, a, b);
+            q0[k] = a;
+            if (kTwoOut) q1[k] = b;
+        }
+        pm_loop &s = loops[l];
+        s.phase = L.phase; s.control = L.control; s.sine = L.sine; s.cosine = L.cosine;
+        s.x0 = L.x0; s.x1 = L.x1; s.y0 = L.y0; s.integral = L.integral; s.proportional = L.proportional;
+        if (MODE == kQpsk) { s.cx0 = L.cx0; s.cx1 = L.cx1; s.cy0 = L.cy0; s.sx0 = L.sx0; s.sx1 = L.sx1; s.sy0 = L.sy0; }
+        if (AGC) agc_state[row] = make_double2(env, sustain);
     }
-    pm_loop &s = loops[l];
-    s.phase = L.phase; s.control = L.control; s.sine = L.sine; s.cosine = L.cosine;
-    s.x0 = L.x0; s.x1 = L.x1; s.y0 = L.y0; s.integral = L.integral; s.proportional = L.proportional;
-    if (MODE == kQpsk) { s.cx0 = L.cx0; s.cx1 = L.cx1; s.cy0 = L.cy0; s.sx0 = L.sx0; s.sx1 = L.sx1; s.sy0 = L.sy0; }
-    if (AGC) agc_state[row] = make_double2(env, sustain);
 }
 
 // the most distinct input rows the g consecutive loops of one workgroup can touch
@@ -495,16 +540,27 @@ int loop_shape(const pm_ctx *ctx, int nloops)
     return ctx->tune.loop_wide >= 0 ? ctx->tune.loop_wide : (nloops > 8 * 256 ? 2 : 0);
 }
 
+// the eight-sample blocks of the direct shape as 16-byte pieces through the transposing tiles: every row 16-byte aligned (PM_LOOP_VEC=0: off)
+bool loop_io_vec(const pm_ctx *ctx, const double *d_x0, int64_t x_stride, const double *d_o0, const double *d_o1, int64_t out_stride, int64_t n)
+{
+    return ctx->tune.loop_vec != 0 && d_o1 != nullptr && n >= 8 && (((uintptr_t)d_x0 | (uintptr_t)d_o0 | (uintptr_t)d_o1) & 15) == 0 && x_stride % 2 == 0 && out_stride % 2 == 0;
+}
+
 template <int MODE>
 int loop_enqueue(pm_ctx *ctx, pm_loop *d_loops, int nloops, int per_row, const double *d_table, const int32_t *d_pd,
                  const double *d_x0, const double *d_x1, int64_t x_stride, int64_t n, double *d_o0, double *d_o1, int64_t out_stride)
 {
     const int shape = loop_shape(ctx, nloops);
     if (shape == 2) {
-        const size_t lds2 = 516 * 8 + (MODE == kMpsk ? 4096 * 4 : 0);
+        const bool vec = loop_io_vec(ctx, d_x0, x_stride, d_o0, d_o1, out_stride, n);
+        const size_t lds2 = 516 * 8 + (MODE == kMpsk ? 4096 * 4 : 0) + (vec ? 2 * 64 * kTileRow * 8 : 0);
         PmProf prof(ctx, PM_K_LOOP);
-        hipLaunchKernelGGL((loop_direct_kernel<MODE>), dim3((unsigned)pm_cdiv(nloops, 64)), dim3(64), lds2, ctx->stream, d_loops, nloops, per_row, d_table,
-                           d_pd, d_x0, d_x1, x_stride, n, d_o0, d_o1, out_stride);
+        if (vec)
+            hipLaunchKernelGGL((loop_direct_kernel<MODE, false, true>), dim3((unsigned)pm_cdiv(nloops, 64)), dim3(64), lds2, ctx->stream, d_loops, nloops, per_row,
+                               d_table, d_pd, d_x0, d_x1, x_stride, n, d_o0, d_o1, out_stride);
+        else
+            hipLaunchKernelGGL((loop_direct_kernel<MODE>), dim3((unsigned)pm_cdiv(nloops, 64)), dim3(64), lds2, ctx->stream, d_loops, nloops, per_row, d_table,
+                               d_pd, d_x0, d_x1, x_stride, n, d_o0, d_o1, out_stride);
         PM_HIP(hipGetLastError());
         return PM_OK;
     }
@@ -742,7 +798,7 @@ __global__ void agc_rows_prepare_kernel(const double *__restrict__ running, int 
 // behind theirs.  The rows of a wave are a pitch apart, so a load or store touches 64 cache lines -- at eight bytes per 100 ns and
 // lane that is nothing.
 __global__ __launch_bounds__(64) void agc_rows_kernel(const double *x, int64_t x_stride, double *y, int64_t y_stride, int rows,
-                                                      int64_t n, const double *__restrict__ consts, AgcDev P, double2 *__restrict__ state)
+                                                      int64_t n, const double *__restrict__ consts, AgcDev P, double2 *__restrict__ state, int prio)
 {
     const int64_t r = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (r >= rows) return;
@@ -751,7 +807,11 @@ __global__ __launch_bounds__(64) void agc_rows_kernel(const double *x, int64_t x
     P.att = consts[4 * r + 1];
     P.dec = consts[4 * r + 2];
     double env = state[r].x, sustain = state[r].y;
-    __builtin_amdgcn_s_setprio(3);             // one dependent chain per lane: issue slots lost to the FIR waves of the other streams are time
+    // one dependent chain per lane: issue slots lost to the FIR waves of the other streams are time -- but the carrier loops' chains are
+    // twice as long per sample, so on a SIMD that holds both the loop's wave goes first (priority 3; a kernel ends with its slowest wave)
+    if (prio >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
     constexpr int B = 8;
     double cur[B], nxt[B];
     const int64_t full = n / B * B;
@@ -861,7 +921,7 @@ int pm_agc_rows(pm_ctx *ctx, const double *d_x, int64_t x_stride, double *d_y, i
     P.att = P.dec = 0;
     PmProf prof(ctx, PM_K_AGC);
     hipLaunchKernelGGL(agc_rows_kernel, dim3((unsigned)pm_cdiv(rows, 64)), dim3(64), 0, ctx->stream, d_x, x_stride, d_y, y_stride, rows, n, d_consts, P,
-                       (double2 *)d_state);
+                       (double2 *)d_state, ctx->tune.agc_rows_prio);
     PM_HIP(hipGetLastError());
     return PM_OK;
 }

@@ -100,6 +100,15 @@ class LoopBatch:
             self._tail = Context.borrowed(lib().pm_lbatch_tail_ctx(self._h), self.ctx.device)
         return self._tail
 
+    @property
+    def loop(self):
+        """The engine's loop context when the carrier loops have compute units of their own (csrc/pm_loopbatch.hip), borrowed, for
+        profile_read(); None when they run on the caller's context."""
+        if getattr(self, "_loop", None) is None:
+            h = lib().pm_lbatch_loop_ctx(self._h)
+            self._loop = Context.borrowed(h, self.ctx.device) if h else False
+        return self._loop or None
+
     def _bits(self, r, nout, slot):
         stride = ((nout + 63) // 64 + 1 + 7) // 8 * 8
         streams = r * self.chains

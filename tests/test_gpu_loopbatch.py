@@ -191,7 +191,7 @@ def test_engine_bitmaps_equal_demod_signs(cfg, rate, carriers, chunk, wide):
         eng.close()
 
 
-@pytest.mark.parametrize("n", [5, 5003])
+@pytest.mark.parametrize("n", [5, 5003, 5008])
 def test_loop_kernel_shapes_agree(n):
     """150 loops in one launch (three workgroups of the 64-loop shape, the last one part full), a length that is no multiple of either
     tile: outputs and end states of the four loop kernels bit for bit the same in both shapes, own input rows and one shared row."""
