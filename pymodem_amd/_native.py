@@ -16,7 +16,9 @@ class NativeError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "libpymodem_amd.so")
+    # (PYMODEM_AMD_LIB: another build of the same library -- a kernel variant compiled with different constants -- for A/B measurements
+    # on one box; tools/build_variant.py makes them)
+    return os.environ.get("PYMODEM_AMD_LIB") or os.path.join(_HERE, "libpymodem_amd.so")
 
 
 class AGCParams(ctypes.Structure):

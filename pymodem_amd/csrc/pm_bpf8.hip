@@ -211,7 +211,7 @@ int pm_lpf8_plan_create(pm_ctx *ctx, const double *h_taps, int ml, pm_lpf8_plan 
     PM_CTX(ctx);
     PM_ARG(h_taps != nullptr && out != nullptr && ml >= 1);
     *out = nullptr;
-    constexpr int kD = 5, kB = 2;
+    constexpr int kD = 3, kB = 2;
     if (ml + 15 > 64 * kB) return pm_set_error(PM_ERR_ARG, "int8 low-pass: %d taps do not fit the %d-column band", ml, 64 * kB);
     double hmax = 0.0;
     for (int t = 0; t < ml; ++t) {
@@ -223,24 +223,30 @@ int pm_lpf8_plan_create(pm_ctx *ctx, const double *h_taps, int ml, pm_lpf8_plan 
     (void)std::frexp(hmax, &e);
     pm_lpf8_plan *p = new pm_lpf8_plan();
     p->ml = ml;
-    p->S = 38 - e;                                           // |q| <= 2^38: five balanced digits reach +-2^39
+    p->S = 22 - e;                                           // |q| <= 2^22: three balanced digits reach beyond +-2^23 - 2^15
     p->hmax = hmax;
     p->device = ctx->device;
     std::vector<int8_t> dig((size_t)kD * ml);
+    long double tapq = 0.0L, qabs = 0.0L, d0 = 0.0L, d1 = 0.0L;
     for (int t = 0; t < ml; ++t) {
-        const double scaled = std::ldexp(h_taps[t], p->S);
+        const double scaled = std::ldexp(h_taps[t], p->S);   // exact
         const int64_t q = (int64_t)std::llrint(scaled);
-        p->tapq += std::fabs(scaled - (double)q);
-        p->qsum += q;
+        tapq += std::fabs((long double)scaled - (long double)q);
+        qabs += std::fabs((long double)q);
         int64_t v = q;
         for (int b = 0; b < kD; ++b) {
             const int64_t d = ((v + 128) & 255) - 128;
             dig[(size_t)b * ml + t] = (int8_t)d;
+            if (b == 0) d0 += (long double)std::llabs(d);
+            if (b == 1) d1 += (long double)std::llabs(d);
             v = (v - d) / 256;
         }
-        if (v != 0) { delete p; return pm_set_error(PM_ERR_ARG, "int8 low-pass: tap %d does not fit five digits", t); }
+        if (v != 0) { delete p; return pm_set_error(PM_ERR_ARG, "int8 low-pass: tap %d does not fit three digits", t); }
     }
-    p->tapq = std::ldexp(p->tapq, -p->S) * 1.000001;
+    p->tapq_int = (double)(tapq * 1.000001L);
+    p->qabs = (double)(qabs * 1.000001L);
+    p->dlow = (double)(128.0L * d0 * 1.000001L);             // |x_0 q_0| summed over the taps, |x_0| <= 128: the one digit product the kernel leaves out
+    (void)d1;
     std::vector<int8_t> tab((size_t)kD * kB * 64 * 16, 0);
     for (int b = 0; b < kD; ++b)
         for (int kb = 0; kb < kB; ++kb)

@@ -121,12 +121,13 @@ int pm_bpf8_taps(const pm_bpf8_plan *p);
 // d_audio 16-byte aligned; d_clear: nclear (<= 64) ints the launch zeroes (a recording's sweep counters: the band-pass is the first
 // launch of its demod stage, the sweeps behind it on the same stream start from zero without a memset of their own)
 int pm_bpf8_run(pm_ctx *ctx, const pm_bpf8_plan *p, const int16_t *d_audio, int64_t n, double *d_y, int *d_clear = nullptr, int nclear = 0);
-// The certified sweeps' low-pass on the same pipe (afsk_slide_lpf8_kernel in pm_fir.hip): taps as five signed base-256 digits
-// q = rint(h 2^S), the Toeplitz band as MFMA B operands [digit][block][lane] on the device.  ml <= 113.
+// The certified sweeps' low-pass on the same pipe (afsk_slide_lpf8_kernel in pm_fir.hip): taps as three signed base-256 digits
+// q = rint(h 2^S), |q| <= 2^22, the Toeplitz band as MFMA B operands [digit][block][lane] on the device.  ml <= 113.
 struct pm_lpf8_plan {
     int ml = 0, S = 0, device = 0;
-    long long qsum = 0;              // sum of the quantised taps
-    double tapq = 0;                 // sum |h - q 2^-S|
+    double tapq_int = 0;             // sum |h 2^S - q|
+    double qabs = 0;                 // sum |q|
+    double dlow = 0;                 // bound on the digit product the kernel leaves out: 128 sum|q_0|
     double hmax = 0;
     void *d_btab = nullptr;
 };

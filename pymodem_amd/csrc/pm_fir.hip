@@ -921,24 +921,35 @@ __global__ __launch_bounds__(kThreads) void afsk_slide_lpf_kernel(const double *
 // The same kernel with its low-passes on the int8 matrix pipe (v_mfma_i32_16x16x64_i8; the band-pass went there first: pm_bpf8.hip).
 // The low-pass sums are 2/3 of afsk_slide_lpf_kernel's vector instructions and feed nothing but the certified decision, and the int8
 // MFMA is the one matrix instruction that was measured to run BESIDE vector f64 work (tools/ubench/mfma_i8.hip).  So: the magnitudes a
-// run leaves in registers are rounded to 32-bit integers (scale 2^s from the caller's bound on x: quantum 2^-s <= bound 2^-31) and
-// written as four planes of signed base-256 digits; the taps come as five digits (pm_lpf8_plan: |h - q 2^-S| <= hmax 2^-38); a tile of
-// 256 outputs is  out[16 i + j] = sum_c A[i][c] B[c][j],  A[i][c] = digit plane [tile + 16 i + c] (one ds_read_b128 per lane),
-// B = the Toeplitz band of a tap digit -- 2 blocks x 4 x 5 digit pairs = 40 MFMA per stream and tile, eight int32 sums by weight
-// a + b, recombined in binary64 (pairs first: |W_w + 256 W_(w+1)| < 2^31).  The integer sums are exact, so what separates the value
-// from the reference's low-pass output is  sum|h| * quantum/2  +  sum|h - q 2^-S| * max magnitude  + a few roundings, all of which
-// sweep_signs adds to E.  Lane (r, g) of a tile holds outputs 64 g + 16 v + r, v = 0..3: sign and bound tests become four ballots
-// per modem, and the tile's four bitmap words are put together from their 16-bit pieces.
+// run leaves in registers are rounded to integers |X| <= 2^22 -- scaled by the power of two that fits the WORKGROUP's largest
+// magnitude, so a quiet recording keeps its bits -- and written as three planes of signed base-256 digits; the taps come as three
+// digits (pm_lpf8_plan: q = rint(h 2^S), |q| <= 2^22); a tile of 256 outputs is  out[16 i + j] = sum_c A[i][c] B[c][j],  A[i][c] = digit
+// plane [tile + 16 i + c] (one ds_read_b128 per lane), B = the Toeplitz band of a tap digit -- 2 blocks x the 8 digit pairs of weight
+// 256 and up = 16 MFMA per stream and tile, four int32 sums by weight, recombined exactly in binary64 (an integer below 2^50).
+// The integer sums are exact, so what separates the value from the reference's low-pass output is  sum|h - q 2^-S| * the largest
+// magnitude  +  2^-(S+s2) (sum|q| / 2 + the digit pair left out)  on top of E -- computed by the workgroup from its own scale
+// (Ecmp).  Round 3 had 4 x 5 digits, all 20 pairs, and a scale fixed by the caller's bound on the audio: 40 MFMA per stream and tile,
+// eight accumulators to clear and recombine, 20 uncertain decisions per recording; now several hundred of 230 M (the exact
+// recomputation takes them in its stride) for 40 % of the matrix work and half of the recombination (profiles/r04_sweep_probe.txt;
+// with the six pairs of weight 256^2 and up: 2600 uncertain decisions, and the exact kernel behind them cost what the matrix pipe saved).
+// Lane (r, g) of a tile holds outputs 64 g + 16 v + r, v = 0..3: sign and bound tests become four ballots per modem, and the tile's
+// four bitmap words are put together from their 16-bit pieces.
 constexpr int kL8Plane = 2176;           // bytes of a digit plane: 2048 outputs + (ml - 1 <= 112) + what the last tile's band reads beyond
+constexpr int kL8Dig = 3;                // digits of a magnitude and of a tap
+constexpr int kL8Acc = 4;                // accumulators: the weights 256^1 .. 256^4
 struct Lpf8Args {
-    double scale;                        // 2^s
-    double wgt[4];                       // 2^(16 p - S - s)
-    double c0;                           // the digits' offsets: (128 (2^32 - 1) / 255 [- 2^31]) sum q 2^-(S + s)
+    int S;                               // taps: q = rint(h 2^S)
+    double c_tap;                        // sum |h 2^S - q|: the taps' quantisation, in units of 2^-S
+    double c_q;                          // sum |q| / 2 (the magnitudes' rounding) + the digit product that is left out: units of 2^-(S+s2)
+    double gfac;                         // 1 + the largest gain (two streams: |a - g b|'s error), 1 for one stream
     const int4v *btab;
 };
 
+#ifndef PM_LPF8_WAVES
+#define PM_LPF8_WAVES 4          // waves per SIMD the fused matrix-pipe kernel is compiled for (-DPM_LPF8_WAVES=5: measured, profiles/r04_lpf8_occupancy.txt)
+#endif
 template <bool ONE>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void afsk_slide_lpf8_kernel(const double *__restrict__ x, int64_t n, const double *__restrict__ mi,
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PM_LPF8_WAVES, PM_LPF8_WAVES))) void afsk_slide_lpf8_kernel(const double *__restrict__ x, int64_t n, const double *__restrict__ mi,
                                                                    const double *__restrict__ mq, const double *__restrict__ ui,
                                                                    const double *__restrict__ uq, int m, SlideTones T, Lpf8Args Q, int ml,
                                                                    int64_t nout, int G, SweepArgs P, double E, unsigned long long *__restrict__ list,
@@ -979,43 +990,63 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))
     lds_barrier();
     double mv[L], sv[L];
     if (t < nruns) slide_run<L>(xs, tp, t, m, T, mv, sv);
+    // The largest magnitude of the workgroup (what the planes will hold): the digits are scaled to IT, not to the largest the audio
+    // could produce -- a quiet recording keeps its 22 bits (round 4; a fixed scale cost a bit of certainty per halving of the level)
+    double vmax = 0.0;
+    if (t < nruns) {
+        if (ONE) {
+            const double g0 = P.gain[0];
+#pragma unroll
+            for (int i = 0; i < L; ++i) mv[i] = __builtin_fma(-g0, sv[i], mv[i]);       // afsk.py:162 on the approximate magnitudes
+        }
+#pragma unroll
+        for (int i = 0; i < L; ++i) vmax = fmax(vmax, ONE ? fabs(mv[i]) : fmax(fabs(mv[i]), fabs(sv[i])));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = fmax(vmax, __shfl_xor(vmax, off));
+    __shared__ double wmax[kThreads / 64];
+    if ((t & 63) == 0) wmax[t >> 6] = vmax;
     lds_barrier();                                           // every lane is done with the window of x: the planes take its place
+    vmax = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+    static_assert(kThreads == 256, "four waves");
+    int e2 = 0;
+    (void)frexp(vmax, &e2);                                  // vmax < 2^e2 (0 for no signal at all)
+    const bool scalable = vmax < 1.0e300 && vmax > 1.0e-280;  // (not: NaN, infinities, all zeros -- everything goes to the list then)
+    const int s2 = scalable ? 22 - e2 : 0;
+    const double scale = ldexp(1.0, s2);
+    // |sum h v - 2^-(S+s2) 256 val| <= sum|h - q 2^-S| vmax + 2^-(S+s2) (sum|q| / 2 + the product left out), times 1 + gmax for
+    // a - g b; plus E, what separates sum h v from the reference's low-pass output: all in the units of `val`, rounded up
+    const double Ecmp = scalable ? ceil((ldexp(E, Q.S + s2) + Q.gfac * (Q.c_tap * (vmax * scale) + Q.c_q)) * (1.0 + 1e-9) * (1.0 / 256.0)) + 2.0
+                                 : __builtin_inf();
     unsigned char *planes = reinterpret_cast<unsigned char *>(xs);
     if (t < nruns) {
         static_assert(L % 4 == 0, "four magnitudes per plane word");
-        const double g0 = P.gain[0];
         auto put = [&](const double (&val)[L], int stream) {
 #pragma unroll
             for (int q = 0; q < L / 4; ++q) {
                 unsigned w[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const double sc = __builtin_fma(val[4 * q + i], Q.scale, 0.5);
-                    w[i] = ONE ? (unsigned)(int)sc ^ 0x00808080u : (unsigned)sc ^ 0x80808080u;      // digits of the offset value, each minus 128
+                    // v 2^s2 is exact, |..| <= 2^22; adding 1.5 2^52 leaves its nearest integer in the low word (two's complement);
+                    // the bytes of (X + 0x808080) ^ 0x808080 are X's three balanced base-256 digits
+                    const double sc = scalable ? __builtin_fma(val[4 * q + i], scale, 6755399441055744.0) : 6755399441055744.0;
+                    w[i] = ((unsigned)__double2loint(sc) + 0x808080u) ^ 0x808080u;
                 }
-                const unsigned lo01 = __builtin_amdgcn_perm(w[1], w[0], 0x05010400u), lo23 = __builtin_amdgcn_perm(w[3], w[2], 0x05010400u);
-                const unsigned hi01 = __builtin_amdgcn_perm(w[1], w[0], 0x07030602u), hi23 = __builtin_amdgcn_perm(w[3], w[2], 0x07030602u);
-                unsigned char *at = planes + (size_t)stream * 4 * kL8Plane + L * t + 4 * q;
-                *reinterpret_cast<unsigned *>(at) = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u);
-                *reinterpret_cast<unsigned *>(at + kL8Plane) = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);
-                *reinterpret_cast<unsigned *>(at + 2 * kL8Plane) = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u);
-                *reinterpret_cast<unsigned *>(at + 3 * kL8Plane) = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
+                const unsigned a01 = __builtin_amdgcn_perm(w[1], w[0], 0x05010400u), a23 = __builtin_amdgcn_perm(w[3], w[2], 0x05010400u);
+                unsigned char *at = planes + (size_t)stream * kL8Dig * kL8Plane + L * t + 4 * q;
+                *reinterpret_cast<unsigned *>(at) = __builtin_amdgcn_perm(a23, a01, 0x05040100u);
+                *reinterpret_cast<unsigned *>(at + kL8Plane) = __builtin_amdgcn_perm(a23, a01, 0x07060302u);
+                *reinterpret_cast<unsigned *>(at + 2 * kL8Plane) =
+                    __builtin_amdgcn_perm(w[1], w[0], 0x0c0c0602u) | __builtin_amdgcn_perm(w[3], w[2], 0x06020c0cu);
             }
         };
-        if (ONE) {
-#pragma unroll
-            for (int i = 0; i < L; ++i) mv[i] = __builtin_fma(-g0, sv[i], mv[i]);       // afsk.py:162 on the approximate magnitudes
-            put(mv, 0);
-        } else {
-            put(mv, 0);
-            put(sv, 1);
-        }
+        put(mv, 0);
+        if (!ONE) put(sv, 1);
     }
     const int lane = t & 63, wave = t >> 6, r = lane & 15, g4 = lane >> 4;
-    // the band operands (5 digits x 2 blocks x 64 lanes x 16 bytes) behind the templates: in registers they cost 40 per lane and a wave
-    // of occupancy
+    // the band operands (3 digits x 2 blocks x 64 lanes x 16 bytes) behind the templates
     int4v *bl = reinterpret_cast<int4v *>(tp + 4 * m);
-    for (int i = t; i < 10 * 64; i += kThreads) bl[i] = Q.btab[i];
+    for (int i = t; i < 2 * kL8Dig * 64; i += kThreads) bl[i] = Q.btab[i];
     lds_barrier();
     const int64_t nout64 = ((nout + 63) >> 6) * 64;
 #pragma unroll 1
@@ -1026,30 +1057,32 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))
         double a[4], b[4];
 #pragma unroll
         for (int stream = 0; stream < (ONE ? 1 : 2); ++stream) {
-            int4v acc[8];
+            // the eight digit products of weight 256 and up (accumulator i + j - 1); the ninth, x_0 q_0, is bounded in c_q
+            int4v acc[kL8Acc];
 #pragma unroll
-            for (int w = 0; w < 8; ++w) acc[w] = int4v{0, 0, 0, 0};
+            for (int w = 0; w < kL8Acc; ++w) acc[w] = int4v{0, 0, 0, 0};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                const unsigned char *at = planes + (size_t)stream * 4 * kL8Plane + tl + 16 * r + 64 * kb + 16 * g4;
-                int4v d[4];
+                const unsigned char *at = planes + (size_t)stream * kL8Dig * kL8Plane + tl + 16 * r + 64 * kb + 16 * g4;
+                int4v d[kL8Dig];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) d[i] = *reinterpret_cast<const int4v *>(at + i * kL8Plane);
+                for (int i = 0; i < kL8Dig; ++i) d[i] = *reinterpret_cast<const int4v *>(at + i * kL8Plane);
 #pragma unroll
-                for (int bb = 0; bb < 5; ++bb) {
+                for (int bb = 0; bb < kL8Dig; ++bb) {
                     const int4v band = bl[(bb * 2 + kb) * 64 + lane];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i + bb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(d[i], band, acc[i + bb], 0, 0, 0);
+                    for (int i = 0; i < kL8Dig; ++i)
+                        if (i + bb >= 1)
+                            acc[i + bb - 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(d[i], band, acc[i + bb - 1], 0, 0, 0);
                 }
             }
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                double val = Q.c0;
-#pragma unroll
-                for (int pq = 0; pq < 4; ++pq) val = __builtin_fma((double)(acc[2 * pq][v] + acc[2 * pq + 1][v] * 256), Q.wgt[pq], val);
+                // W_1 + 256 W_2 + 256^2 W_3 + 256^3 W_4: an integer below 2^50, exact
+                const double val = __builtin_fma(__builtin_fma(__builtin_fma((double)acc[3][v], 256.0, (double)acc[2][v]), 256.0, (double)acc[1][v]), 256.0,
+                                                 (double)acc[0][v]);
                 if (stream == 0) a[v] = val; else b[v] = val;
             }
-            __builtin_amdgcn_sched_barrier(0);               // one stream after the other: interleaved they keep 64 accumulators alive
         }
         // lane (r, g4) holds outputs go + 64 g4 + 16 v + r
         const int64_t left = nout - go - (64 * g4 + r);
@@ -1065,7 +1098,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))
             for (int v = 0; v < 4; ++v) {
                 y[v] = ONE ? a[v] : __builtin_fma(mg, b[v], a[v]);
                 pos[v] = __ballot(y[v] >= 0.0) & in[v];
-                uns |= ~__ballot(fabs(y[v]) > E) & in[v];                     // cannot be certified (NaN lands here too)
+                uns |= ~__ballot(fabs(y[v]) > Ecmp) & in[v];                  // cannot be certified (NaN lands here too)
             }
             const int sh = 16 * (lane & 3);
             const unsigned lo = ((unsigned)(pos[0] >> sh) & 0xFFFFu) | ((unsigned)(pos[1] >> sh) << 16);
@@ -1075,7 +1108,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))
             if (uns) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
-                    if (16 * v < lim && !(fabs(y[v]) > E)) {
+                    if (16 * v < lim && !(fabs(y[v]) > Ecmp)) {
                         const int idx = atomicAdd(count, 1);
                         if (idx < cap) list[idx] = ((unsigned long long)g << 48) | (unsigned long long)(go + 64 * g4 + 16 * v + r);
                     }
@@ -1564,6 +1597,10 @@ static int afsk_magnitudes(pm_ctx *ctx, const double *d_x, int64_t n, double x_b
     return PM_OK;
 }
 
+// one wave per uncertain decision at a time: as many workgroups as a sweep usually has entries (several hundred; an idle one costs a
+// dispatch slot for a microsecond), so that the launch lasts one entry's latency and not three
+constexpr int kExactGrid = 4096;
+
 static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound, const double *d_mark_i, const double *d_mark_q,
                        const double *d_unit_i, const double *d_unit_q, const double *d_space, const double *h_gains, int groups, int m,
                        const double *d_lpf, int ml, double lpf_abs_sum, uint64_t *const *h_bits, const pm_afsk_tones *tones,
@@ -1670,29 +1707,20 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
         PM_ARG(tones->tap_dev >= 0.0 && tones->tap_dev < 1e-6);
         SlideTones T{tones->mark_rot[0], tones->mark_rot[1], tones->mark_end[0], tones->mark_end[1],
                      tones->space_rot[0], tones->space_rot[1], tones->space_end[0], tones->space_end[1]};
-        // the largest magnitude (sliding value, so its bound on top), and for one chain the largest |M - g S|
-        const double mb = 1.4143 * m * x_bound * 1.000001 + e_slide, top = one ? std::max(1.0, P.gain[0]) * mb : mb;
-        int et = 0;
-        (void)std::frexp(top, &et);                          // top < 2^et
-        const int s2 = (one ? 31 : 32) - et;                 // |value| 2^s2 < 2^31 resp. 2^32
+        // What the matrix pipe adds to E depends on the workgroup's own largest magnitude (its digits are scaled to it): the kernel
+        // computes it from these constants (afsk_slide_lpf8_kernel, Ecmp)
         Lpf8Args Q;
-        Q.scale = std::ldexp(1.0, s2);
-        for (int pq = 0; pq < 4; ++pq) Q.wgt[pq] = std::ldexp(1.0, 16 * pq - lpf8->S - s2);
-        const long double off = one ? 2155905152.0L - 2147483648.0L : 2155905152.0L;      // 128 (2^32 - 1) / 255 [- 2^31]
-        Q.c0 = (double)std::ldexp(off * (long double)lpf8->qsum, -(lpf8->S + s2));
+        Q.S = lpf8->S;
+        Q.c_tap = lpf8->tapq_int;
+        Q.c_q = 0.5 * lpf8->qabs + lpf8->dlow;
+        Q.gfac = one ? 1.0 : 1.0 + gmax;
         Q.btab = (const int4v *)lpf8->d_btab;
-        // on top of E: the magnitudes' quantum (half a unit; one chain: truncation of a signed value, a whole unit), the taps' quantisation
-        // times the largest value, and the roundings of c0 and of the four recombining fma (terms below 8.1 ml hmax top, see pm_bpf8.hip)
-        const double u = 1.1102230246251565e-16;
-        const double quantum = (one ? 1.0 : 0.5) / Q.scale;
-        const double extra = lpf_abs_sum * quantum + lpf8->tapq * top + 16.0 * u * (std::fabs(Q.c0) + 8.1 * ml * lpf8->hmax * top);
-        E += (one ? 1.0 : 1.0 + gmax) * extra * 1.000001;
         const int64_t ntiles = pm_cdiv(nl, (int64_t)kThreads * 8);
         PM_ARG(ntiles < (1LL << 31));
         const int nmag = kThreads * 8 + ml - 1, nruns = (nmag + kFuseRun - 1) / kFuseRun, pspan = nruns * kFuseRun + m - 1;
-        const size_t xdoubles = (size_t)pspan + pspan / kFuseRun + 2, pdoubles = (size_t)(one ? 4 : 8) * kL8Plane / 8;
+        const size_t xdoubles = (size_t)pspan + pspan / kFuseRun + 2, pdoubles = (size_t)(one ? 1 : 2) * kL8Dig * kL8Plane / 8;
         const int region0 = (int)((std::max(xdoubles, pdoubles) + 1) / 2 * 2);
-        const size_t lds = ((size_t)region0 + 4 * (size_t)m) * sizeof(double) + 10 * 64 * 16;      // x window | planes, templates, band operands
+        const size_t lds = ((size_t)region0 + 4 * (size_t)m) * sizeof(double) + 2 * kL8Dig * 64 * 16;      // x window | planes, templates, band operands
         PmProf prof(ctx, PM_K_FIR_F64);
         const double nlp = one ? 1.0 : 2.0;
         prof.work((double)n * 8 + (double)groups * nl / 8,
@@ -1751,10 +1779,10 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
     {
         PmProf prof(ctx, PM_K_SIGNS);
         if (src)
-            hipLaunchKernelGGL(sweep_exact_kernel<true>, dim3(1024), dim3(64), (size_t)(4 * ml + 6 * m + 2 * src->mb - 3) * sizeof(double), ctx->stream, d_x, d_mark_i, d_mark_q,
+            hipLaunchKernelGGL(sweep_exact_kernel<true>, dim3(kExactGrid), dim3(64), (size_t)(4 * ml + 6 * m + 2 * src->mb - 3) * sizeof(double), ctx->stream, d_x, d_mark_i, d_mark_q,
                                d_space, m, d_lpf, ml, P, list, count, cap, count_next, mail, *src);
         else
-            hipLaunchKernelGGL(sweep_exact_kernel<false>, dim3(1024), dim3(64), (size_t)ml * sizeof(double), ctx->stream, d_x, d_mark_i, d_mark_q, d_space, m,
+            hipLaunchKernelGGL(sweep_exact_kernel<false>, dim3(kExactGrid), dim3(64), (size_t)ml * sizeof(double), ctx->stream, d_x, d_mark_i, d_mark_q, d_space, m,
                                d_lpf, ml, P, list, count, cap, ctx->sweep_deferred ? count_next : nullptr, mail, SweepSource{nullptr, nullptr, 0, 0.0});
     }
     PM_HIP(hipGetLastError());
