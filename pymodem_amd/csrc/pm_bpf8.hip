@@ -6,16 +6,18 @@
 // slots; f64 and f32 MFMA were measured earlier and do not run beside vector f64 work.  The int8 MFMA does (tools/ubench/mfma_i8.hip:
 // 1.4 P mac/s alone, 0.9 P beside 28 T vector fma/s from the same waves), and integer products need no rounding analysis:
 //
-//   taps      h[t] ~ q[t] 2^-S,  q[t] a 48-bit integer written in six balanced base-256 digits  q = sum_b d_b 256^b,  d_b in [-128, 127]
+//   taps      h[t] ~ q[t] 2^-S,  q[t] a 32-bit integer written in four balanced base-256 digits  q = sum_b d_b 256^b,  d_b in [-128, 127]
+//             (round 3: 48 bits in six digits, 36 products per tile; the error this adds to the sweeps' bound is a hundredth of what
+//             their own low-pass digits add, profiles/r04_sweep_probe.txt)
 //   samples   x = 256 s1 + s0 + 128  with  s1 = x >> 8  and  s0 = (x & 255) - 128,  both in [-128, 127]
 //   y[k] = sum_t h[K-1-t] x[k+t]  ~  2^-S ( sum_w 256^w W_w[k] )  +  128 2^-S sum_t q[t],     W_w = sum_t ( d_w s0 + d_(w-1) s1 )[k+t]
 //
-// The seven W_w are exact int32 sums (|W_w| < 148 * 2 * 2^14): 12 int8 products per tap and sample instead of one f64 fma, 36
-// v_mfma_i32_16x16x64_i8 per 256 outputs (576 matrix cycles against 2368 vector cycles).  As a matrix product: the tile's outputs
+// The five W_w are exact int32 sums (|W_w| < 148 * 2 * 2^14): 8 int8 products per tap and sample instead of one f64 fma, 24
+// v_mfma_i32_16x16x64_i8 per 256 outputs (384 matrix cycles against 2368 vector cycles).  As a matrix product: the tile's outputs
 // y[T + 16 i + j] = sum_c A[i][c] B[c][j] with A[i][c] = s[T + 16 i + c] (16 consecutive bytes of a digit plane per lane: one
 // ds_read_b128) and the Toeplitz band B[c][j] = d[c - j], c < 192, prepared once per tap set by the host and held in registers.
-// What separates the result from the reference's sum:  sum_t |h[t] - q[t] 2^-S| * 32768  (quantisation, ~148 * 2^-49 * 32768)  +  the
-// seven roundings of the recombination  +  the reference's own (K + 1) u sum|h| 32768: pm_bpf8_error() returns the sum, the sweep adds
+// What separates the result from the reference's sum:  sum_t |h[t] - q[t] 2^-S| * 32768  (quantisation, ~148 * 2^-33 * 32768)  +  the
+// roundings of the recombination  +  the reference's own (K + 1) u sum|h| 32768: pm_bpf8_error() returns the sum, the sweep adds
 // sqrt2 m times that to the bound of its sliding magnitudes -- 0.1 % of the certified decision's slack, no sample more goes to the
 // exact recomputation, which now starts from the audio (sweep_exact_kernel<true>).
 #include "pm_common.h"
@@ -27,7 +29,7 @@ namespace {
 
 typedef int i4 __attribute__((ext_vector_type(4)));
 
-constexpr int kDigits = 6, kBlocks = 3, kWeights = kDigits + 1;
+constexpr int kDigits = 4, kBlocks = 3, kWeights = kDigits + 1;
 constexpr int kTilesPerWave = 4, kWaves = 4, kWgOut = 256 * kTilesPerWave * kWaves;      // 4096 outputs per workgroup
 constexpr int kSpan = kWgOut + 64 * kBlocks + 240 - 256 + 16;                            // bytes of a digit plane a workgroup reads
 constexpr int kPlane = (kSpan + 15) / 16 * 16;
@@ -121,7 +123,7 @@ int pm_bpf8_plan_create(pm_ctx *ctx, const double *h_taps, int m, pm_bpf8_plan *
     if (hmax == 0.0) return pm_set_error(PM_ERR_ARG, "int8 band-pass: all taps are zero");
     int e = 0;
     (void)std::frexp(hmax, &e);                              // hmax = f 2^e, f in [0.5, 1)
-    const int S = 46 - e;                                    // |q| <= 2^46 (+ 1/2): six balanced digits reach +-2^47
+    const int S = 8 * kDigits - 2 - e;                       // |q| <= 2^30 (+ 1/2): four balanced digits reach +-2^31
     std::vector<int64_t> q(m);
     double quant = 0.0;
     int64_t qsum = 0;
@@ -138,7 +140,7 @@ int pm_bpf8_plan_create(pm_ctx *ctx, const double *h_taps, int m, pm_bpf8_plan *
             dig[(size_t)b * m + t] = (int8_t)d;
             v = (v - d) / 256;
         }
-        if (v != 0) return pm_set_error(PM_ERR_ARG, "int8 band-pass: tap %d does not fit six digits", t);
+        if (v != 0) return pm_set_error(PM_ERR_ARG, "int8 band-pass: tap %d does not fit its digits", t);
     }
     pm_bpf8_plan *p = new pm_bpf8_plan();
     p->m = m;
@@ -155,8 +157,8 @@ int pm_bpf8_plan_create(pm_ctx *ctx, const double *h_taps, int m, pm_bpf8_plan *
     p->sc.c0 = std::ldexp((double)(128 * qsum), -S);             // |128 sum q| < 2^62; its conversion is one of the nine roundings below
     part += std::fabs(p->sc.c0);
     const double u = 1.1102230246251565e-16;
-    // quantisation (|x| <= 32768) + the constant's and the seven fma's roundings + the reference's own sum (K + 1) u sum|h| 32768
-    p->err = (std::ldexp(quant, -S) * 32768.0 + 9.0 * u * part + (m + 1) * u * habs * 32768.0) * 1.000001;      // (the bound's own roundings)
+    // quantisation (|x| <= 32768) + the constant's and the kWeights fma's roundings + the reference's own sum (K + 1) u sum|h| 32768
+    p->err = (std::ldexp(quant, -S) * 32768.0 + (kWeights + 2.0) * u * part + (m + 1) * u * habs * 32768.0) * 1.000001;      // (the bound's own roundings)
     // B[c][j] = hr[c - j], hr[t] = h[m - 1 - t] (the reference's sum ascends through the input): lane (j, g), bytes c = 64 kb + 16 g + 0..15
     std::vector<int8_t> tab((size_t)kDigits * kBlocks * 64 * 16, 0);
     for (int b = 0; b < kDigits; ++b)

@@ -87,7 +87,7 @@ def test_fir_int8_limbs_within_its_bound(ctx, m):
               np.where(np.sign(h[::-1])[np.arange(n) % m] >= 0, 32767, -32768).astype(np.int16)]      # lines up with the taps: the largest sums
     for x in cases:
         y, bound = fir_limbs_gpu(ctx, x, h)
-        assert 0.0 < bound <= 1e-11 * scale, (m, bound, scale)
+        assert 0.0 < bound <= 1e-8 * scale, (m, bound, scale)      # (32-bit taps: ~2^-31 of the largest sum)
         ref = O.fir_canon(x, h)
         assert np.array_equal(fir_gpu(ctx, x, h), ref)
         assert np.abs(y - ref).max() <= bound, (m, len(x), np.abs(y - ref).max(), bound)
