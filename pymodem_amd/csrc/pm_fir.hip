@@ -1136,6 +1136,13 @@ __global__ __launch_bounds__(64) void sweep_exact_kernel(const double *__restric
     // deferred fallback (pm_afsk_sweep_mode): this is the sweep's last launch and clears the next sweep's counter (see d_sweep);
     // it also leaves the counter in a page-locked host word, so that the caller who waits for the recording's event anyway reads it
     // without a copy and a stream wait of its own
+#ifndef PM_EXACT_PRIO
+#define PM_EXACT_PRIO 3
+#endif
+    // a few hundred lone waves, each a chain of dependent sums, between a recording's two sweeps on the demod stream: every issue slot
+    // they lose to the filter and slicer waves beside them is time the whole recording waits (measured in the pipeline: 0.10 ms per
+    // launch at the default priority against 0.011 alone)
+    __builtin_amdgcn_s_setprio(PM_EXACT_PRIO);
     if (reset && blockIdx.x == 0 && threadIdx.x == 0) *reset = 0;
     if (mail && blockIdx.x == 0 && threadIdx.x == 0) {
         *mail = *count;
