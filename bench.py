@@ -831,6 +831,20 @@ def measure(args, env):
             sc.profile(True)
     if os.environ.get("BENCH_TIMELINE"):
         print("[timeline] timed region begins", file=sys.stderr, flush=True)
+    def thread_cpu():
+        """{tid: (name, cpu seconds)} of every thread of this process (diagnostic: BENCH_THREAD_CPU=1)"""
+        out = {}
+        tick = os.sysconf("SC_CLK_TCK")
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                st = open(f"/proc/self/task/{tid}/stat").read()
+                name = st[st.index("(") + 1:st.rindex(")")]
+                f = st[st.rindex(")") + 2:].split()
+                out[int(tid)] = (name, (int(f[11]) + int(f[12])) / tick)
+            except OSError:
+                pass
+        return out
+    tcpu0 = thread_cpu() if os.environ.get("BENCH_THREAD_CPU") else None
     t0 = time.perf_counter()
     cpu0 = time.process_time()
     if os.environ.get("BENCH_PYPROFILE") == "all":            # every thread's interpreter time (diagnostic, stderr): one profiler per thread
@@ -867,6 +881,16 @@ def measure(args, env):
     if os.environ.get("BENCH_TIMELINE"):
         print("[timeline] timed region ends", file=sys.stderr, flush=True)
     host_cpu_ms = (time.process_time() - cpu0) / max(args.steps, 1) * 1e3     # all threads of this process, native ones included
+    if tcpu0 is not None:                                     # which threads the host CPU of a step goes to, by thread name
+        now, by = thread_cpu(), {}
+        for tid, (name, cpu) in now.items():
+            d = cpu - tcpu0.get(tid, (name, 0.0))[1]
+            if d > 0:
+                by.setdefault(name, [0, 0.0])
+                by[name][0] += 1
+                by[name][1] += d
+        print("[thread cpu] ms per step by thread name (threads): " +
+              ", ".join(f"{k} {v[1] / max(args.steps, 1) * 1e3:.2f} ({v[0]})" for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])), file=sys.stderr)
     if os.environ.get("BENCH_NO_PROF"):                   # diagnostic: the step time without the HIP-event bracketing the roofline needs
         print(json.dumps({"ms_per_step_without_profiling": round(elapsed / args.steps * 1e3, 3), "stages": stage_ms}), file=sys.stderr)
         sys.exit(0)

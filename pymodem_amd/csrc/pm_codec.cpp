@@ -18,6 +18,7 @@
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <pthread.h>
 #include <thread>
 #include <unistd.h>
 #include <unordered_map>
@@ -70,17 +71,26 @@ void finalize(pm_packet &p)
     p.correlated_count = 0;
 }
 
+// Decoded packets wait here until pm_codec_fetch takes them: their bytes one behind the other in ONE block (a vector per packet was an
+// allocation and a free per packet: 5800 of each per ten-minute recording of the headline config)
 struct Queued {
     int64_t addr;
     int corrected;
-    std::vector<uint8_t> data;
+    size_t off, len;                 // bytes[off .. off + len)
 };
 
 struct Sink {
     std::vector<Queued> q;
+    std::vector<uint8_t> bytes;
     void push(const std::vector<uint8_t> &data, int64_t addr, int corrected, int /*source*/)
     {
-        q.push_back(Queued{addr, corrected, data});
+        q.push_back(Queued{addr, corrected, bytes.size(), data.size()});
+        bytes.insert(bytes.end(), data.begin(), data.end());
+    }
+    void drop_front(size_t take)
+    {
+        q.erase(q.begin(), q.begin() + (ptrdiff_t)take);
+        if (q.empty()) bytes.clear();                        // (offsets of what is left stay valid otherwise)
     }
 };
 
@@ -815,7 +825,7 @@ public:
                     ++workers_;
                 }
             }
-            cv_.notify_all();
+            for (int h = 0; h < helpers; ++h) cv_.notify_one();      // one sleeper per queued share, not the whole pool for a handful of tasks
         }
         work(*st);
         std::unique_lock<std::mutex> g(st->m);
@@ -849,6 +859,7 @@ private:
     }
     void loop()
     {
+        (void)pthread_setname_np(pthread_self(), "pm-decode");
         for (;;) {
             std::shared_ptr<Batch> b;
             {
@@ -974,35 +985,40 @@ int pm_codec_decode(pm_codec *c, const uint8_t *h_data, const int64_t *h_addr, i
     return PM_OK;
 }
 
-int pm_codec_fetch(pm_codec *c, pm_packet *h_out, int64_t cap, int64_t *h_count)
+// clean: h_out's rows hold zeros wherever this call does not write (a row block kept zero-tailed by its owner, pm_pipe.hip): the
+// 1280-byte payload field costs what the packet is long, not what the row is
+static int codec_fetch(pm_codec *c, pm_packet *h_out, int64_t cap, int64_t *h_count, bool clean)
 {
     if (!c || cap < 0 || (cap > 0 && !h_out) || !h_count) return pm_set_error(PM_ERR_ARG, "pm_codec_fetch: bad argument");
     const int64_t take = std::min<int64_t>(cap, (int64_t)c->sink.q.size());
     for (int64_t k = 0; k < take; ++k) {
         const Queued &src = c->sink.q[(size_t)k];
+        const uint8_t *bytes = c->sink.bytes.data() + src.off;
         pm_packet &p = h_out[k];
         memset(&p, 0, offsetof(pm_packet, data));            // h_out may be uninitialised memory: every byte of the row is written
         p.streamaddress = src.addr;
-        p.len = (int32_t)std::min<size_t>(src.data.size(), PM_PKT_MAX);
+        p.len = (int32_t)std::min<size_t>(src.len, PM_PKT_MAX);
         p.bytes_corrected = src.corrected;
         p.source_decoder = c->source;
-        memcpy(p.data, src.data.data(), (size_t)p.len);
-        memset(p.data + p.len, 0, sizeof(p.data) - (size_t)p.len);
+        memcpy(p.data, bytes, (size_t)p.len);
+        if (!clean) memset(p.data + p.len, 0, sizeof(p.data) - (size_t)p.len);
         finalize(p);
-        if (src.data.size() > PM_PKT_MAX) {
+        if (src.len > PM_PKT_MAX) {
             // A frame longer than a row: the reference's AX.25 decoder never drops collected bytes when its byte counter wraps at 1023
             // (ax25.py:41-47), so a flag after a long stretch without one can close a frame of any length.  The row keeps its first
             // PM_PKT_MAX bytes; CRC and validity are those of the WHOLE frame, as PacketMeta.CalcCRC would find them.
-            const size_t L = src.data.size();
-            p.carried_crc = src.data[L - 1] * 256 + src.data[L - 2];
-            p.calculated_crc = crc16(src.data.data(), (int)(L - 2));
+            const size_t L = src.len;
+            p.carried_crc = bytes[L - 1] * 256 + bytes[L - 2];
+            p.calculated_crc = crc16(bytes, (int)(L - 2));
             p.valid_crc = p.carried_crc == p.calculated_crc;
         }
     }
-    c->sink.q.erase(c->sink.q.begin(), c->sink.q.begin() + take);
+    c->sink.drop_front((size_t)take);
     *h_count = take;
     return PM_OK;
 }
+
+int pm_codec_fetch(pm_codec *c, pm_packet *h_out, int64_t cap, int64_t *h_count) { return codec_fetch(c, h_out, cap, h_count, false); }
 
 int pm_host_decode_batch(pm_host_job *jobs, int njobs, int threads)
 {
@@ -1035,7 +1051,16 @@ int pm_host_decode_batch(pm_host_job *jobs, int njobs, int threads)
     return PM_OK;
 }
 
+static int codec_fetch_batch(pm_codec *const *codecs, const int64_t *counts, int n, pm_packet *h_out, int threads, bool clean);
 int pm_codec_fetch_batch(pm_codec *const *codecs, const int64_t *counts, int n, pm_packet *h_out, int threads)
+{
+    return codec_fetch_batch(codecs, counts, n, h_out, threads, false);
+}
+int pm_codec_fetch_batch_clean(pm_codec *const *codecs, const int64_t *counts, int n, pm_packet *h_out, int threads)
+{
+    return codec_fetch_batch(codecs, counts, n, h_out, threads, true);
+}
+static int codec_fetch_batch(pm_codec *const *codecs, const int64_t *counts, int n, pm_packet *h_out, int threads, bool clean)
 {
     if (n < 0 || (n > 0 && (!codecs || !counts)) || threads < 1) return pm_set_error(PM_ERR_ARG, "pm_codec_fetch_batch: bad argument");
     std::vector<int64_t> at((size_t)n + 1, 0);
@@ -1048,7 +1073,7 @@ int pm_codec_fetch_batch(pm_codec *const *codecs, const int64_t *counts, int n, 
     std::vector<int> rc((size_t)n, PM_OK);
     HostPool::get().run(n, threads, [&](int j) {
         int64_t got = 0;
-        if (counts[j] > 0) rc[(size_t)j] = pm_codec_fetch(codecs[j], h_out + at[(size_t)j], counts[j], &got);
+        if (counts[j] > 0) rc[(size_t)j] = codec_fetch(codecs[j], h_out + at[(size_t)j], counts[j], &got, clean);
     });
     for (int j = 0; j < n; ++j)
         if (rc[(size_t)j] != PM_OK) return rc[(size_t)j];

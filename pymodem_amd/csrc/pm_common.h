@@ -141,6 +141,10 @@ int pm_afsk_group_run_plan(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const
                            const pm_afsk_sweep_desc *h_sweeps, int nsweeps, int64_t *h_tickets, const pm_bpf8_plan *plan,
                            const pm_lpf8_plan *const *lpf8 = nullptr, const pm_sweep_cells *cells = nullptr);
 
+// pm_codec_fetch_batch into rows whose payload fields are already zero wherever a packet will not write (pm_pipe.hip keeps its row blocks
+// that way): per packet the bytes it has, not the 1280 of the field
+extern "C" int pm_codec_fetch_batch_clean(pm_codec *const *codecs, const int64_t *counts, int n, pm_packet *h_out, int threads);
+
 // ---- long matched filters as certified signs on the int8 matrix pipe (pm_fir8.hip): bit k of row r = (canonical FIR sum >= 0), the
 // bitmap pm_fir_rows(..., d_bits, ...) writes, for inputs of any magnitude.  A plan belongs to one tap set (m + 15 <= 1024) and device.
 struct pm_fir8_plan;

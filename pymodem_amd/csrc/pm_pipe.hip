@@ -20,6 +20,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <pthread.h>
 #include <thread>
 #include <vector>
 
@@ -56,9 +57,12 @@ struct Rec {                             // one recording on its way through
     std::vector<int64_t> off, count;
     std::vector<std::vector<int64_t>> full_addr;        // per chain: addresses in full when a step did not fit 16 bits (else empty)
     // result
-    pm_packet *rows = nullptr;                          // malloc'd: the codecs write every row in full, nothing to clear first
+    // the packet rows: a block out of the pipeline's pool, whose rows hold zeros wherever no packet has written (RowBlock)
+    struct RowBlock *rowblock = nullptr;
+    pm_packet *rows = nullptr;
     int64_t nrows = 0;
-    ~Rec() { free(rows); }
+    pm_pipe *owner = nullptr;
+    ~Rec();
     std::vector<int64_t> counts, unique_idx;
     std::vector<int32_t> corr;
     int64_t unique = 0;
@@ -66,6 +70,17 @@ struct Rec {                             // one recording on its way through
     std::string error;
     double t_submit = 0, t_ready = 0, t_sliced = 0, t_done = 0;
     bool done = false;
+};
+
+// Packet rows are 1320 bytes each (a 1280-byte payload field) and a recording of the headline config has 5800 of them: 7.7 MB that
+// malloc handed out untouched and munmap took back, every recording, with every payload field's tail zeroed by hand in between --
+// more host time than the decoding itself (tools/host_stage_probe.py: fetch 7.7 ms against decode 4.3 ms per recording on one core).
+// A block stays with the pipeline instead, and stays CLEAN: zero wherever no packet has written.  Giving it back costs the bytes the
+// packets had (their headers and payloads are zeroed again), taking it costs nothing.
+struct RowBlock {
+    pm_packet *rows = nullptr;
+    int64_t cap = 0, used = 0;
+    ~RowBlock() { free(rows); }
 };
 
 }  // namespace
@@ -107,6 +122,7 @@ struct pm_pipe {
     // one made in front of a copy costs 8-20 ms there (touch + pin), so they are made once and go round
     std::mutex pool_mu;
     std::vector<HostBlock *> pool;
+    std::vector<RowBlock *> row_pool;    // clean row blocks (pool_mu)
     std::vector<Work> work;
     // queues
     std::mutex mu;
@@ -131,6 +147,49 @@ struct pm_pipe {
 };
 
 namespace {
+
+RowBlock *rows_get(pm_pipe *p, int64_t need)
+{
+    RowBlock *b = nullptr;
+    {
+        std::unique_lock<std::mutex> lk(p->pool_mu);
+        for (size_t i = 0; i < p->row_pool.size(); ++i)
+            if (p->row_pool[i]->cap >= need) {
+                b = p->row_pool[i];
+                p->row_pool.erase(p->row_pool.begin() + (ptrdiff_t)i);
+                break;
+            }
+    }
+    if (!b) {
+        b = new RowBlock();
+        b->cap = std::max<int64_t>(need + need / 4, 64);
+        b->rows = (pm_packet *)calloc((size_t)b->cap, sizeof(pm_packet));
+        if (!b->rows) { delete b; return nullptr; }
+    }
+    b->used = need;
+    return b;
+}
+
+void rows_put(pm_pipe *p, RowBlock *b)
+{
+    // clean again: what the packets wrote -- the header and len bytes of payload per row -- back to zero
+    for (int64_t k = 0; k < b->used; ++k) {
+        pm_packet &q = b->rows[k];
+        const int32_t len = q.len < 0 ? 0 : q.len > PM_PKT_MAX ? PM_PKT_MAX : q.len;
+        memset(q.data, 0, (size_t)len);
+        memset(&q, 0, offsetof(pm_packet, data));
+    }
+    b->used = 0;
+    std::unique_lock<std::mutex> lk(p->pool_mu);
+    if (p->row_pool.size() < 64) p->row_pool.push_back(b);
+    else delete b;
+}
+
+Rec::~Rec()
+{
+    if (rowblock && owner) rows_put(owner, rowblock);
+    else delete rowblock;
+}
 
 int fail(Rec &r, int rc)
 {
@@ -192,6 +251,7 @@ int exact_chain(pm_pipe *p, pm_ctx *side, pm_pipe::Work &w, const Rec &r, int ch
 
 void slice_worker(pm_pipe *p, int wi)
 {
+    (void)pthread_setname_np(pthread_self(), "pm-slice");
     pm_ctx *side = p->side[wi];
     pm_pipe::Work &w = p->work[wi];
     (void)hipSetDevice(side->device);
@@ -395,6 +455,7 @@ void slice_worker(pm_pipe *p, int wi)
 
 void host_worker(pm_pipe *p)
 {
+    (void)pthread_setname_np(pthread_self(), "pm-host");
     for (;;) {
         std::shared_ptr<Rec> rp;
         {
@@ -465,10 +526,12 @@ void host_worker(pm_pipe *p)
                 r.counts.resize(nch);
                 int64_t total = 0;
                 for (int c = 0; c < nch; ++c) total += (r.counts[c] = jobs[c].pending);
-                r.rows = (pm_packet *)malloc((size_t)std::max<int64_t>(total, 1) * sizeof(pm_packet));
+                r.owner = p;
+                r.rowblock = rows_get(p, std::max<int64_t>(total, 1));
+                r.rows = r.rowblock ? r.rowblock->rows : nullptr;
                 r.nrows = total;
                 if (!r.rows) rc = pm_set_error(PM_ERR_ARG, "out of host memory for %lld packet rows", (long long)total);
-                if (!rc) rc = pm_codec_fetch_batch(codecs.data(), r.counts.data(), nch, r.rows, p->decode_threads);
+                if (!rc) rc = pm_codec_fetch_batch_clean(codecs.data(), r.counts.data(), nch, r.rows, p->decode_threads);
                 if (!rc) {
                     // PacketMetaArray.Correlate over the chains in config order (packet_meta.py:230-271)
                     r.unique_idx.resize((size_t)std::max<int64_t>(total, 1));
@@ -537,6 +600,7 @@ int pm_pipe_destroy(pm_pipe *p)
     for (pm_ctx *s : p->side) (void)pm_ctx_destroy(s);
     p->results.clear();
     for (HostBlock *b : p->pool) delete b;
+    for (RowBlock *b : p->row_pool) delete b;
     delete p;
     return PM_OK;
 }
