@@ -573,12 +573,13 @@ def measure(args, env):
         import queue
         import threading
         from concurrent.futures import ThreadPoolExecutor
-        # four recordings per collective: the ordered thread's half-dozen torch calls cost about the same per CALL whatever they carry
-        # (forced one-rank RCCL exchange, 400 steps: 1.31 ms per step with one recording per collective, 1.06-1.08 with four or eight,
-        # 0.93 without the exchange)
+        # eight recordings per collective: the ordered thread's half-dozen torch calls and rank 0's indexing + de-dup cost about the same per
+        # CALL whatever they carry (forced one-rank RCCL exchange, 400 steps, round 3: 1.31 ms per step with one recording per collective,
+        # 1.06-1.08 with four or eight, 0.93 without the exchange; round 4, with the executor at 0.65-0.66: 0.80 with four, 0.69 with eight --
+        # and 0.66 with rank 0's de-dup skipped, 0.65 with the collective skipped: profiles/r04_exchange_probe.txt)
         # (short runs -- the driver's 20 steps -- one per collective and one outstanding: what is gained per call there is lost in the
         # drain, 1.48-1.50 against 1.50-1.62 ms per step)
-        ex = pdist.Exchanger(nchains, coll_device, batch=int(os.environ.get("PYMODEM_AMD_EXCHANGE_BATCH", "4" if k >= 64 else "1")))
+        ex = pdist.Exchanger(nchains, coll_device, batch=int(os.environ.get("PYMODEM_AMD_EXCHANGE_BATCH", "8" if k >= 64 else "1")))
         if "PYMODEM_AMD_EXCHANGE_DEPTH" not in os.environ:
             ex.depth = 2 if k >= 64 else 1
         packed, gathered, out, errors = queue.Queue(), queue.Queue(), {}, []
