@@ -244,6 +244,54 @@ def test_loop_kernel_shapes_agree(n):
     ctx.tune(loop_wide=-1)
 
 
+@pytest.mark.parametrize("cfg,rate,carriers,switches", [
+    ("bpsk_300.json", 48000, [1500.0], dict(lbatch_loop_cus=16, loop_wide=2)),                 # loops on 16 units of their own, AGC in the loop's lane
+    ("bpsk_300.json", 48000, [1500.0], dict(lbatch_loop_cus=0, loop_wide=2, loop_agc=0)),       # the AGC as a pass of its own again
+    ("bpsk_300.json", 48000, [1500.0], dict(fir8=0, loop_wide=2)),                              # the matched filter in binary64 on the vector pipe
+    ("qpsk_2400.json", 48000, [1475.0, 1500.0, 1525.0], dict(lbatch_loop_cus=32, loop_wide=2)),  # two-output loops, tiles, own units
+    ("qpsk_2400.json", 48000, [1475.0, 1500.0, 1525.0], dict(loop_wide=2, loop_vec=0)),          # plain eight-byte stores
+])
+def test_engine_shapes_of_round_4_agree(cfg, rate, carriers, switches):
+    """What round 4 added to the engine -- compute units reserved for the loops (CU-masked streams), the BPSK AGC stepped in the
+    loop's lane, two-output loops storing through transposing tiles, matched filters on the matrix pipe -- each switched on and off
+    (pm_ctx_tune): every bitmap still equals modem.demod_signs() on that recording."""
+    import pymodem_amd
+    from pymodem_amd import chain_builder as cb
+    from pymodem_amd.loop_batch import LoopBatch
+    ctx = pymodem_amd.Context.default()
+    group = group_modems(cfg, rate, carriers)
+    n = 30000
+    recs = [noise_i16(n, seed=300 + k, sigma=2500.0 + 3000.0 * k) for k in range(4)]
+    recs[2][n // 3:] //= 8
+    def reference(line, audio):                               # (its bitmaps live in pooled work buffers: read them before the next call)
+        r = cb.ModemConfigurator(rate, line["modem"]).demod_signs(audio)
+        return r.n, bits_of(r.bits_i, r.n), None if r.bits_q is None else bits_of(r.bits_q, r.n)
+    want = [[reference(line, recs[k]) for line, _ in group] for k in range(len(recs))]
+    with tuned(ctx, **switches):
+        eng = LoopBatch([m for _, m in group], recordings=4, ctx=ctx, chunk=4096)
+        try:
+            assert (eng.loop is not None) == (switches.get("lbatch_loop_cus", 0) > 0)
+            got = eng.run([ctx.upload(r) for r in recs])
+            ctx.sync()
+            for k in range(len(recs)):
+                for c in range(len(group)):
+                    n_ref, bi, bq = want[k][c]
+                    assert got[k][c].n == n_ref
+                    assert np.array_equal(bits_of(got[k][c].bits_i, n_ref), bi), (cfg, switches, k, c, "I")
+                    if bq is not None:
+                        assert np.array_equal(bits_of(got[k][c].bits_q, n_ref), bq), (cfg, switches, k, c, "Q")
+        finally:
+            eng.close()
+
+
+def test_context_switches_are_named():
+    import pymodem_amd
+    ctx = pymodem_amd.Context.default()
+    ctx.tune(slicer_trace=0)
+    with pytest.raises(pymodem_amd.NativeError):
+        ctx.tune(no_such_switch=1)
+
+
 def test_engine_qpsk_modem():
     """QPSKModem (psk.py:197-476, chain_builder type 'qpsk'): one input, two low-passed arms."""
     import pymodem_amd
