@@ -240,8 +240,18 @@ def main():
                 dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), pg_options=opts)
         else:
             dist.init_process_group(args.backend)
-    if use_dist:
-        init_dist()
+    exchange_leg = world == 1 and not use_dist and bool(args.with_exchange) and args.overlap == 2
+    comm_up = False
+    if use_dist or (exchange_leg and os.environ.get("BENCH_EXCHANGE_COMM_FIRST", "1") != "0"):
+        # (the one-GPU line's exchange leg: its communicator comes up HERE, before the first stream of the executor exists, as in every
+        # rank of an N > 1 run -- made afterwards it leaves the exchange 30 % slower, profiles/r04_exchange_probe.txt; the headline steps
+        # below do not use it)
+        try:
+            init_dist()
+            comm_up = True
+        except Exception:                                     # noqa: BLE001 -- the leg reports its own failure below
+            if use_dist:
+                raise
     coll_device = f"cuda:{dev_index}" if (use_dist and args.backend == "nccl") else None
 
     env = {"rank": rank, "world": world, "dev_index": dev_index, "use_dist": use_dist, "coll_device": coll_device}
@@ -249,12 +259,13 @@ def main():
     if os.environ.get("BENCH_EX_SKIP") and out is not None:   # a diagnostic that drops part of the exchange: the line is not a measurement
         out["invalid"] = "BENCH_EX_SKIP=" + os.environ["BENCH_EX_SKIP"] + ": part of the packet exchange was skipped"
     import copy
-    if world == 1 and not use_dist and args.with_exchange and args.overlap == 2:
+    if exchange_leg:
         # The same steps once more with the one exchange step behind the executor, as every rank of an N > 1 run has it: rows packed
-        # for the wire, ONE all_gather per 1-4 recordings (here among one rank, over RCCL), rank 0's de-dup over the gathered rows.
+        # for the wire, ONE all_gather per 1-8 recordings (here among one rank, over RCCL), rank 0's de-dup over the gathered rows.
         try:
-            init_dist()
-            use_dist = True
+            if not comm_up:
+                init_dist()
+                comm_up = True
             a = copy.copy(args)
             a.no_cpu_baseline = True
             d2 = measure(a, dict(env, use_dist=True, coll_device=f"cuda:{dev_index}" if args.backend == "nccl" else None))
@@ -283,7 +294,7 @@ def main():
             out["also"] = also_workloads(args, env, cpu_also)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())         # the ONE line of this run's stdout
-    if use_dist:
+    if comm_up:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
