@@ -945,6 +945,9 @@ struct Lpf8Args {
     const int4v *btab;
 };
 
+#ifndef PM_LPF8_RECOMB32
+#define PM_LPF8_RECOMB32 1       // pairs of accumulators recombined as 32-bit integers first (two conversions per output instead of four): 0.206 -> 0.203 ms
+#endif
 #ifndef PM_LPF8_WAVES
 #define PM_LPF8_WAVES 4          // waves per SIMD the fused matrix-pipe kernel is compiled for (-DPM_LPF8_WAVES=5: measured, profiles/r04_lpf8_occupancy.txt)
 #endif
@@ -1078,9 +1081,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PM_LPF
             }
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                // W_1 + 256 W_2 + 256^2 W_3 + 256^3 W_4: an integer below 2^50, exact
+                // W_1 + 256 W_2 + 256^2 W_3 + 256^3 W_4, an integer below 2^50, exact: the pairs first, as 32-bit integers (ml <= 113
+                // taps and at most three digit pairs per weight keep |W_w| below 5.6 M, so W + 256 W' stays inside 2^31) -- two
+                // integer-to-double conversions per output instead of four (they are quarter-rate instructions)
+#if PM_LPF8_RECOMB32
+                const int lo = acc[0][v] + acc[1][v] * 256, hi = acc[2][v] + acc[3][v] * 256;
+                const double val = __builtin_fma((double)hi, 65536.0, (double)lo);
+#else
                 const double val = __builtin_fma(__builtin_fma(__builtin_fma((double)acc[3][v], 256.0, (double)acc[2][v]), 256.0, (double)acc[1][v]), 256.0,
                                                  (double)acc[0][v]);
+#endif
                 if (stream == 0) a[v] = val; else b[v] = val;
             }
         }
@@ -1100,6 +1110,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PM_LPF
                 pos[v] = __ballot(y[v] >= 0.0) & in[v];
                 uns |= ~__ballot(fabs(y[v]) > Ecmp) & in[v];                  // cannot be certified (NaN lands here too)
             }
+            // the tile's four bitmap words from the 16-bit pieces of the four ballots: scalar arithmetic (the ballots are uniform), then
+            // lane w < 4 picks word w -- with per-lane shifts of 64-bit values this was a dozen vector instructions per modem and tile
+            // (putting the words together with scalar arithmetic and a select per lane, as fir8_kernel does for its one bitmap, was measured
+            // here and is slower: seven modems' worth of 64-bit scalar shifts per tile, 0.233 against 0.206 ms -- profiles/r04_sweep_probe.txt)
             const int sh = 16 * (lane & 3);
             const unsigned lo = ((unsigned)(pos[0] >> sh) & 0xFFFFu) | ((unsigned)(pos[1] >> sh) << 16);
             const unsigned hi = ((unsigned)(pos[2] >> sh) & 0xFFFFu) | ((unsigned)(pos[3] >> sh) << 16);
