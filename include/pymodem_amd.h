@@ -112,10 +112,17 @@ int pm_prof_intervals(pm_ctx *ctx, int kernel_class, double *h_start_ms, double 
 #define PM_FIR_NEGATE 1
 int pm_fir_valid_i16(pm_ctx *ctx, const int16_t *d_x, int64_t n, const double *d_taps, int m, double *d_y, int flags);
 /* The same sum for callers that need a value with a bound, not the reference's rounding (the certified AFSK sweeps inside pm_pipe_*):
- * taps quantised to 48-bit integers, samples and taps as signed base-256 digits, exact int32 products on the int8 matrix pipe
- * (v_mfma_i32_16x16x64_i8), recombined in binary64.  |d_y[k] - reference sum| <= *h_bound (~1e-13 of sum|taps| * 32768).  m <= 177,
+ * taps quantised to 32-bit integers, samples and taps as signed base-256 digits, exact int32 products on the int8 matrix pipe
+ * (v_mfma_i32_16x16x64_i8), recombined in binary64.  |d_y[k] - reference sum| <= *h_bound (~1e-9 of sum|taps| * 32768).  m <= 241,
  * d_x 16-byte aligned, h_taps on the HOST; synchronous (plans its tables per call: the pipeline keeps them).  Test and measurement entry. */
 int pm_fir_valid_i16_limbs(pm_ctx *ctx, const int16_t *d_x, int64_t n, const double *h_taps, int m, double *d_y, double *h_bound);
+/* max(numpy.convolve(row, h, 'valid')) per row -- AGC.apply's `normal` (agc.py:67) over the band-passed recording (psk.py:165, :710) --
+ * WITHOUT writing the band-passed rows: matrix-pipe values with the bound above pick the outputs that could be the maximum, the
+ * reference's own sum (one fma per tap, ascending input index) decides among them; h_max[r] is bit for bit max() of pm_fir_valid_i16.
+ * Rows x_stride samples apart (a multiple of 8) from a 16-byte aligned d_x; *h_redone (may be null) = outputs recomputed.  m <= 241.
+ * Test and measurement entry: pm_lbatch_* keeps a plan for its band-pass. */
+int pm_bpf8_rows_max_i16(pm_ctx *ctx, const int16_t *d_x, int64_t x_stride, int rows, int64_t n, const double *h_taps, int m, double *h_max,
+                         int64_t *h_redone);
 int pm_fir_valid_f64(pm_ctx *ctx, const double *d_x, int64_t n, const double *d_taps, int m, double *d_y, int flags);
 
 /* The same FIRs fused with the slicer's sign test: only the (y >= 0) bitmap of the n-m+1 outputs is written (bit k of the

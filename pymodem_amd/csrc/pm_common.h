@@ -34,6 +34,7 @@ struct pm_tuning {
     int slicer_compare_step = 0, slicer_mask_step = 0, slicer_compiled_step = 0;           // older forms of the slicer step
     int slicer_trace = 0, slicer_no_setprio = 0;
     int fir8 = 1;                      // PM_FIR8=0: the batch engine's matched filters in binary64 on the vector pipe
+    int bpf8_max = 1;                  // PM_BPF8_MAX=0: the batch engine's pass for the AGC's `normal` as the reference's sums + a maximum
     int loop_agc = 1;                  // PM_LOOP_AGC=0: the batch engine's BPSK AGC as a pass of its own, not in the loop's lane
     int loop_vec = 1;                  // PM_LOOP_VEC=0: the direct loop shape moves its blocks with eight-byte accesses, a lane a row
     int lbatch_loop_cus = -1;          // PM_LBATCH_LOOP_CUS: compute units the batch engine's carrier loops have to themselves (0: none, -1: by size)
@@ -114,13 +115,18 @@ static inline int64_t pm_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // ---- the group band-pass on the int8 matrix pipe (pm_bpf8.hip): a value within pm_bpf8_error() of the reference's sum, for the
 // certified sweeps only.  A plan belongs to one tap set (host copy given once) and one device.
 struct pm_bpf8_plan;
-int pm_bpf8_plan_create(pm_ctx *ctx, const double *h_taps, int m, pm_bpf8_plan **out);      // PM_ERR_ARG: more than 177 taps
+int pm_bpf8_plan_create(pm_ctx *ctx, const double *h_taps, int m, pm_bpf8_plan **out, int digits = 4);   // digits: 4, or pm_bpf8_max_digits() for pm_bpf8_rows_max
+int pm_bpf8_max_digits(void);      // PM_ERR_ARG: more than 241 taps
 void pm_bpf8_plan_destroy(pm_bpf8_plan *p);
 double pm_bpf8_error(const pm_bpf8_plan *p);
 int pm_bpf8_taps(const pm_bpf8_plan *p);
 // d_audio 16-byte aligned; d_clear: nclear (<= 64) ints the launch zeroes (a recording's sweep counters: the band-pass is the first
 // launch of its demod stage, the sweeps behind it on the same stream start from zero without a memset of their own)
 int pm_bpf8_run(pm_ctx *ctx, const pm_bpf8_plan *p, const int16_t *d_audio, int64_t n, double *d_y, int *d_clear = nullptr, int nclear = 0);
+// d_out[r] = max(band-pass of row r), the reference's value exactly (matrix-pipe values pick the candidates, the canonical chain decides);
+// d_keys: rows words of work space; d_redone: null or a counter of the outputs that took the exact chain.  Rows 16-byte aligned.
+int pm_bpf8_rows_max(pm_ctx *ctx, const pm_bpf8_plan *p, const int16_t *const *d_rows, int rows, int64_t n, unsigned long long *d_keys, double *d_out,
+                     unsigned long long *d_redone = nullptr);
 // The certified sweeps' low-pass on the same pipe (afsk_slide_lpf8_kernel in pm_fir.hip): taps as three signed base-256 digits
 // q = rint(h 2^S), |q| <= 2^22, the Toeplitz band as MFMA B operands [digit][block][lane] on the device.  ml <= 113.
 struct pm_lpf8_plan {

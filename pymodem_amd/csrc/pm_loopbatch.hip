@@ -23,6 +23,7 @@
 // the stage objects' demod() for every chunk length (tests/test_gpu_loopbatch.py).
 #include "pm_common.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -41,6 +42,8 @@ struct pm_lbatch {
     pm_agc_params agc{};
     std::vector<double> h_taps;
     double *d_taps = nullptr;
+    pm_bpf8_plan *bpf8 = nullptr;            // the band-pass on the matrix pipe, for the pass that finds the AGC's `normal` (pm_bpf8.hip; PM_BPF8_MAX=0: off)
+    unsigned long long *d_keys = nullptr;
     pm_fir8_plan *fir8 = nullptr;            // the output filter as certified signs on the int8 matrix pipe (pm_fir8.hip; PM_FIR8=0: off)
     size_t o_in = 0, o_hil = 0, o_out = 0, o_wave = 0;
     int32_t *d_pd = nullptr;
@@ -115,11 +118,12 @@ int pm_lbatch_destroy(pm_lbatch *b)
     if (ctx) (void)pm_ctx_sync(ctx);
     for (void *p : {(void *)b->d_taps, (void *)b->d_pd, (void *)b->d_loops, (void *)b->tmp, (void *)b->awin, (void *)b->in0[0], (void *)b->in0[1],
                     (void *)b->in1[0], (void *)b->in1[1], (void *)b->dwin0[0], (void *)b->dwin0[1], (void *)b->dwin1[0], (void *)b->dwin1[1], (void *)b->d_running, (void *)b->d_partial,
-                    (void *)b->d_consts, (void *)b->d_agc_state, (void *)b->d_audio})
+                    (void *)b->d_consts, (void *)b->d_agc_state, (void *)b->d_audio, (void *)b->d_keys})
         if (p) (void)pm_free(ctx, p);
     for (hipEvent_t e : {b->front_done[0], b->front_done[1], b->back_done[0], b->back_done[1], b->hist_done[0], b->hist_done[1], b->run_done})
         if (e) (void)hipEventDestroy(e);
     pm_fir8_plan_destroy(b->fir8);
+    pm_bpf8_plan_destroy(b->bpf8);
     if (b->loop) (void)pm_ctx_sync(b->loop);
     for (hipEvent_t e : {b->loop_go, b->loop_end})
         if (e) (void)hipEventDestroy(e);
@@ -169,13 +173,17 @@ int pm_lbatch_create(pm_ctx *ctx, const pm_lbatch_desc *desc, pm_lbatch **out)
         // chunk 14.2 ms alone, 26-28 ms beside the engine's other streams).  With one wave per SIMD on units the other streams' masks
         // exclude, the loops keep their pace whatever runs elsewhere -- up to what loop waves cost each other on one unit: measured
         // (profiles/r04_loop_sweep.txt), qpsk_2400 with 16 384 loops 8.3 / 7.1 / 6.5-6.8 ms per step on 64 / 96 / 128 units (8.0-8.7 without),
-        // bpsk_300 with 16 384 loops 1.30 / 1.48 on 64 / 128 (1.38 without): the two-output loops (two rows in, two out, the phase
-        // detector's table) want two waves per unit, the Costas loop four.  -1: that, at most half the device; 0: no partition.
+        // bpsk_300 with 16 384 loops 1.30 / 1.48 on 64 / 128 (1.38 without).  Since the pass for the AGC's `normal` left the vector pipe
+        // (pm_bpf8.hip) the filters need fewer units and the balance moved: bpsk_300, 16 384 loops, 0.97 / 0.77-0.80 / 0.96 ms per step on
+        // 64 / 96 / 128 -- the loops' own time goes 0.73 / 0.53 / 0.50 ms with four / three / two waves on a unit (80 and 88 units still
+        // leave four on some), the filters' 0.88 / 0.89 / 1.12; qpsk_2400 5.44-5.48 on 128 and on 160, 6.9-7.1 on 176
+        // (profiles/r04_loop_sweep.txt).  So: two-output loops (two rows in, two out, the phase detector's table) two waves per unit, the
+        // Costas loop eight on three.  -1: that, at most half the device; 0: no partition.
         int cus = ctx->tune.lbatch_loop_cus;
         const int have = pm_device_cus(ctx->device);
         const int64_t waves = ((int64_t)d.recordings * d.chains + 63) / 64;
         const bool two = d.modem == PM_MODEM_MPSK || d.modem == PM_MODEM_QPSK;
-        if (cus < 0) cus = waves >= 64 ? (int)std::min<int64_t>(two ? (waves + 1) / 2 : (waves + 3) / 4, have / 2) : 0;
+        if (cus < 0) cus = waves >= 64 ? (int)std::min<int64_t>(two ? (waves + 1) / 2 : (3 * waves + 7) / 8, have / 2) : 0;
         cus = std::min(cus, have - 8) / 8 * 8;                // whole rows of the XCDs (bit i of a mask is unit i / 8 of XCD i % 8)
         if (cus >= 8 && have >= 16 && have <= 1024) {
             uint32_t mine[32] = {0}, rest[32] = {0};
@@ -200,6 +208,13 @@ int pm_lbatch_create(pm_ctx *ctx, const pm_lbatch_desc *desc, pm_lbatch **out)
         // The output filter feeds the slicer's sign test and nothing else (psk.py:193 -> slicer.py:74, psk.py:750-751 -> slicer.py:215):
         // from 64 taps on its sums go to the matrix pipe with certified signs (the short PLL low-pass stays on the vector pipe)
         if (ctx->tune.fir8 && d.n_output_fir >= 64 && d.n_output_fir + 15 <= 1024 && (rc = pm_fir8_plan_create(ctx, d.output_fir, d.n_output_fir, &b->fir8))) break;
+        // max(band-passed recording) needs no band-passed recording (pm_bpf8.hip: bpf8_max_kernel); up to 241 taps
+        if (ctx->tune.bpf8_max && d.n_input_fir + 15 <= 256) {
+            bool finite = true, some = false;
+            for (int t = 0; t < d.n_input_fir; ++t) finite = finite && std::isfinite(d.input_fir[t]), some = some || d.input_fir[t] != 0.0;
+            if (finite && some && (rc = pm_bpf8_plan_create(ctx, d.input_fir, d.n_input_fir, &b->bpf8, pm_bpf8_max_digits()))) break;
+            if (b->bpf8 && (rc = dev_alloc(ctx, b->d_keys, (size_t)b->R))) break;
+        }
         if ((rc = dev_alloc(ctx, b->d_taps, b->h_taps.size()))) break;
         if ((rc = pm_h2d(ctx, b->d_taps, b->h_taps.data(), b->h_taps.size() * sizeof(double)))) break;
         if (b->mpsk) {
@@ -294,10 +309,18 @@ int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings,
         PM_HIP(hipStreamWaitEvent(Tl->stream, b->run_done, 0));
         PM_HIP(hipStreamWaitEvent(Lp->stream, b->run_done, 0));
     }
+    // ---- pass 1: normal = max(band-passed recording) per row (agc.py:67).  On the matrix pipe (pm_bpf8.hip) it needs no band-passed
+    // recording, and runs on the caller's stream: nothing else of this run can start before it, and that stream has every compute unit
+    // (the engine's own may be masked to their share)
+    const bool max8 = b->bpf8 && aligned && B->tune.bpf8_max && pm_cdiv(na, (int64_t)4096) <= 65535;
+    if (max8) {
+        PM_HIP(hipMemcpyAsync(b->d_audio, b->h_audio.data(), sizeof(void *) * (size_t)R, hipMemcpyHostToDevice, B->stream));
+        if (int rc = pm_bpf8_rows_max(B, b->bpf8, b->d_audio, R, n, b->d_keys, b->d_running)) return rc;
+    }
     // the front stream is ordered behind whatever the caller has enqueued on its context so far (e.g. the recordings' uploads)
     PM_HIP(hipEventRecord(b->run_done, B->stream));
     PM_HIP(hipStreamWaitEvent(F->stream, b->run_done, 0));
-    PM_HIP(hipMemcpyAsync(b->d_audio, b->h_audio.data(), sizeof(void *) * (size_t)R, hipMemcpyHostToDevice, F->stream));
+    if (!max8) PM_HIP(hipMemcpyAsync(b->d_audio, b->h_audio.data(), sizeof(void *) * (size_t)R, hipMemcpyHostToDevice, F->stream));
     PM_HIP(hipMemsetAsync(b->d_agc_state, 0, sizeof(double) * 2 * (size_t)R, F->stream));          // fresh AGC objects (agc.py:20-21)
     PM_HIP(hipMemcpyAsync(b->d_loops, b->h_loops.data(), sizeof(pm_loop) * (size_t)RC, hipMemcpyHostToDevice, B->stream));
     if (Lp != B) {                                            // the loops start behind the fresh states
@@ -305,8 +328,8 @@ int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings,
         PM_HIP(hipStreamWaitEvent(Lp->stream, b->loop_go, 0));
     }
 
-    // ---- pass 1: normal = max(band-passed recording) per row (agc.py:67) ------------------------------------------------------
-    for (int64_t at = 0, first = 1; at < na; at += Lc, first = 0) {
+    // (pass 1 the reference's way: its sums over every chunk, then their maxima)
+    for (int64_t at = 0, first = 1; at < na && !max8; at += Lc, first = 0) {
         const int64_t cnt = std::min(Lc, na - at);
         if (int rc = pm_fir_rows(F, true, nullptr, 0, (const void *const *)b->d_audio, at, aligned, R, cnt + mb - 1, T + b->o_in, mb, b->tmp, P, nullptr,
                                  0, 0)) return rc;

@@ -46,7 +46,7 @@ def config_lines():
 
 import contextlib
 
-_TUNE_DEFAULTS = {"loop_wide": -1, "lbatch_tail": -1, "fir8": 1, "lbatch_loop_cus": -1, "loop_agc": 1, "loop_vec": 1, "agc_rows_prio": 2}
+_TUNE_DEFAULTS = {"loop_wide": -1, "lbatch_tail": -1, "fir8": 1, "bpf8_max": 1, "lbatch_loop_cus": -1, "loop_agc": 1, "loop_vec": 1, "agc_rows_prio": 2}
 
 
 @contextlib.contextmanager

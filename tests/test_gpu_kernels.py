@@ -66,7 +66,7 @@ def fir_limbs_gpu(ctx, x, h):
     return y.download(), bound.value
 
 
-@pytest.mark.parametrize("m", [1, 16, 50, 148, 177])
+@pytest.mark.parametrize("m", [1, 16, 50, 148, 177, 178, 241])
 def test_fir_int8_limbs_within_its_bound(ctx, m):
     """The band-pass on the int8 matrix pipe (pm_bpf8.hip): exact integer products of quantised taps, so the distance from the
     reference's sum is the quantisation + a few roundings, and the entry point states it.  Checked against an integer-exact sum
@@ -103,14 +103,62 @@ def test_fir_int8_limbs_within_its_bound(ctx, m):
 def test_fir_int8_limbs_rejects_what_it_cannot_hold(ctx):
     x = ctx.upload(noise_i16(5000, 3))
     y = ctx.empty(5000, np.float64)
-    h = np.zeros(178)
+    h = np.zeros(242)
     h[0] = 1.0
     b = ctypes.c_double()
-    assert L().pm_fir_valid_i16_limbs(ctx.handle, x.ptr, 5000, h.ctypes.data, 178, y.ptr, ctypes.byref(b)) != 0      # more than 177 taps
+    assert L().pm_fir_valid_i16_limbs(ctx.handle, x.ptr, 5000, h.ctypes.data, 242, y.ptr, ctypes.byref(b)) != 0      # more than 241 taps
     z = np.zeros(8)
     assert L().pm_fir_valid_i16_limbs(ctx.handle, x.ptr, 5000, z.ctypes.data, 8, y.ptr, ctypes.byref(b)) != 0        # all-zero taps
     assert L().pm_fir_valid_i16_limbs(ctx.handle, x.ptr, 5, h.ctypes.data, 8, y.ptr, ctypes.byref(b)) != 0            # fewer samples than taps
     assert L().pm_fir_valid_i16_limbs(ctx.handle, ctypes.c_void_p(x.ptr.value + 2), 4000, h.ctypes.data, 8, y.ptr, ctypes.byref(b)) != 0     # input not 16-byte aligned
+
+
+def rows_max_gpu(ctx, rows2d, h):
+    rows, n = rows2d.shape
+    stride = (n + 7) // 8 * 8
+    flat = np.zeros((rows, stride), np.int16)
+    flat[:, :n] = rows2d
+    dx = ctx.upload(flat.reshape(-1))
+    hh = np.ascontiguousarray(h, dtype=np.float64)
+    out = np.full(rows, np.nan)
+    redone = ctypes.c_int64(-1)
+    chk(L().pm_bpf8_rows_max_i16(ctx.handle, dx.ptr, stride, rows, n, hh.ctypes.data, len(h), out.ctypes.data, ctypes.byref(redone)))
+    return out, redone.value
+
+
+@pytest.mark.parametrize("m", [1, 16, 148, 177, 178, 240, 241])
+def test_band_pass_maximum_is_the_reference_sums_maximum(ctx, m):
+    """AGC.apply's `normal` = max(band-passed recording) (agc.py:67, psk.py:165-168) without the band-passed recording
+    (pm_bpf8.hip: bpf8_max_kernel): values from the matrix pipe choose the candidates, the canonical chain decides -- the result is
+    max() of the oracle's FIR bit for bit, on noise, tones, silence (whole and partial), full-scale constants, the alignment
+    that makes the largest sums, periodic inputs whose maximum repeats thousands of times, and ragged lengths."""
+    from pymodem_amd import taps as T
+    rng = np.random.default_rng(40 + m)
+    h = np.asarray(T.windowed_sinc(m, [1200.0, 1800.0], 48000.0, False) if m >= 50 else rng.standard_normal(m) * 0.1, np.float64)
+    for n in (m, m + 1, m + 4095, m + 4096, m + 4097, 5 * 4096 + m + 3, 150001):
+        t = np.arange(n)
+        rows = [
+            np.clip(np.rint(rng.standard_normal(n) * 6000), -32768, 32767),
+            np.rint(9000 * np.sin(2 * np.pi * 1500.0 * t / 48000.0) + 200 * rng.standard_normal(n)),
+            np.zeros(n),
+            np.where((t // 5000) % 2 == 0, 0, np.rint(rng.standard_normal(n) * 3000)),
+            np.full(n, 32767), np.full(n, -32768),
+            np.where(np.sign(h[::-1])[t % m] >= 0, 32767, -32768),
+            np.rint(12000 * np.sin(2 * np.pi * (t % 32) / 32.0)),                      # 1500 Hz exactly: every period the same sums
+            np.where(t < n // 2, np.rint(rng.standard_normal(n) * 100), 0),
+            -np.abs(np.rint(rng.standard_normal(n) * 50)) * (np.abs(h).sum() > 0),
+        ]
+        x = np.stack(rows).astype(np.int16)
+        got, redone = rows_max_gpu(ctx, x, h)
+        want = np.array([O.fir_canon(r, h).max() for r in x])
+        assert got.tobytes() == want.tobytes(), (m, n, got, want)
+        assert redone >= 1
+    # what goes through the exact chain on a recording-like input is a handful of outputs per row
+    n = 2_000_000
+    x = np.clip(np.rint(rng.standard_normal((4, n)) * 4000), -32768, 32767).astype(np.int16)
+    got, redone = rows_max_gpu(ctx, x, h)
+    assert got.tobytes() == np.array([O.fir_canon(r, h).max() for r in x]).tobytes()
+    assert redone < 4 * 4000, redone                            # (at most about one per workgroup of the first wave of workgroups)
 
 
 def test_fir_rejects_bad_arguments(ctx):

@@ -248,6 +248,8 @@ def test_loop_kernel_shapes_agree(n):
     ("bpsk_300.json", 48000, [1500.0], dict(lbatch_loop_cus=16, loop_wide=2)),                 # loops on 16 units of their own, AGC in the loop's lane
     ("bpsk_300.json", 48000, [1500.0], dict(lbatch_loop_cus=0, loop_wide=2, loop_agc=0)),       # the AGC as a pass of its own again
     ("bpsk_300.json", 48000, [1500.0], dict(fir8=0, loop_wide=2)),                              # the matched filter in binary64 on the vector pipe
+    ("bpsk_300.json", 48000, [1500.0], dict(bpf8_max=0, loop_wide=2)),                          # the AGC's `normal` from the reference's sums, chunk by chunk
+    ("qpsk_2400.json", 48000, [1475.0, 1500.0, 1525.0], dict(bpf8_max=0, loop_wide=2)),
     ("qpsk_2400.json", 48000, [1475.0, 1500.0, 1525.0], dict(lbatch_loop_cus=32, loop_wide=2)),  # two-output loops, tiles, own units
     ("qpsk_2400.json", 48000, [1475.0, 1500.0, 1525.0], dict(loop_wide=2, loop_vec=0)),          # plain eight-byte stores
 ])
