@@ -502,7 +502,10 @@ def measure(args, env):
         if not args.loop_chunk:
             args.loop_chunk = 65536 if batch * len(my) > 8192 else 131072 if batch >= 2048 else 262144
         engine = lb.engine_for([modems[c] for c in my], batch, ctx, args.loop_chunk)
-        engine.reserve(batch, args.samples, slot=(0, 0))
+        if os.environ.get("PYMODEM_AMD_LOOP_FUSED_SLICERS", "1") != "0":      # the slicers inside the engine: rows of bytes, no bitmaps
+            engine.reserve_sliced(batch, args.samples, [ch[2] for ch in build_chains(reset=False)], slot=(0, 0))
+        else:
+            engine.reserve(batch, args.samples, slot=(0, 0))
         nout_, chunk_, chunks_ = engine.geometry(args.samples)
         loop_info = {"recordings_per_run": batch, "loops_in_flight": batch * len(my), "chunk_outputs": chunk_, "chunks_per_recording": chunks_,
                      "note": "all carrier loops of the run's recordings x this rank's chains advance together, one lane each, state carried "

@@ -432,6 +432,25 @@ int pm_lbatch_geometry(pm_lbatch *batch, int64_t n, int64_t *h_nout, int64_t *h_
  * bits_stride >= (nout + 63) / 64 + 1 words. */
 int pm_lbatch_run(pm_lbatch *batch, const int16_t *const *h_d_audio, int recordings, int64_t n, uint64_t *d_bits_i, uint64_t *d_bits_q,
                   int64_t bits_stride, int64_t *h_nout);
+/* The same run with the slicers inside it (slicer.py:59-107, :193-242): every stream (recording r, chain c: row r * chains + c) is
+ * sliced chunk by chunk behind its matched filter by a lane of its own that carries the slicer's state through the run, so no sign
+ * bitmap of a whole recording exists (16 384 streams of ten minutes: 59 GB each for I and Q) and nothing is left to slice when the run
+ * ends.  h_params: one parameter set per chain; every stream starts from the just-tuned slicer state.  Output, per row: up to `cap`
+ * (a multiple of 8) data bytes at d_data + row * cap, their address steps (address[i] - address[i-1], the first 0) at d_steps + row * cap,
+ * and the row's record: count (bytes produced -- beyond cap they are counted, not stored, and flags has bit 1), the first and last
+ * address, the slicer's end state (pm_slicer_state's fields) and flags (bit 0: a step did not fit 16 bits -- slice that run the
+ * other way).  Results equal pm_lbatch_run + pm_slice_batch on every stream, byte for byte and address for address. */
+typedef struct pm_rowslice_rec {
+    int64_t count, first_addr, last_addr, seen;      /* seen: samples consumed (streamaddress) */
+    double clk;                                      /* phase_clock */
+    int32_t li_neg, lq_neg, wbyte, wbits, sreg, flags;
+} pm_rowslice_rec;
+int pm_lbatch_run_sliced(pm_lbatch *batch, const int16_t *const *h_d_audio, int recordings, int64_t n, const pm_slicer_params *h_params, int nparams,
+                         uint8_t *d_data, uint16_t *d_steps, int64_t cap, pm_rowslice_rec *d_recs, int64_t *h_nout);
+/* Rows [row0, row0 + nrows) of such a run as one dense block for the way to the host: row k at the sum of the sizes before it, its
+ * min(count, cap) steps (padded to 8 bytes) then its data bytes (padded to 8).  On the ctx stream; nrows <= 4096. */
+int pm_rows_gather(pm_ctx *ctx, const pm_rowslice_rec *d_recs, const uint8_t *d_data, const uint16_t *d_steps, int64_t cap, int64_t row0, int nrows,
+                   void *d_block, size_t block_bytes);
 pm_ctx *pm_lbatch_front_ctx(pm_lbatch *batch);       /* the engine's own contexts, for pm_prof_*: band-pass, AGC, Hilbert of chunk t + 1 ... */
 pm_ctx *pm_lbatch_tail_ctx(pm_lbatch *batch);        /* ... and the matched filters of chunk t - 1, beside the loops of chunk t on the caller's */
 pm_ctx *pm_lbatch_loop_ctx(pm_lbatch *batch);        /* ... or on the engine's loop context, when the loops have compute units of their own (else NULL) */

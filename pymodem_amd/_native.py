@@ -53,6 +53,19 @@ class SlicerState(ctypes.Structure):
                 ("reserved", ctypes.c_int32), ("streamaddress", ctypes.c_int64)]
 
 
+class RowSliceRec(ctypes.Structure):
+    """pm_rowslice_rec: a stream's record of a sliced engine run (pm_lbatch_run_sliced)"""
+    _fields_ = [("count", ctypes.c_int64), ("first_addr", ctypes.c_int64), ("last_addr", ctypes.c_int64), ("seen", ctypes.c_int64),
+                ("clk", ctypes.c_double), ("li_neg", ctypes.c_int32), ("lq_neg", ctypes.c_int32), ("wbyte", ctypes.c_int32),
+                ("wbits", ctypes.c_int32), ("sreg", ctypes.c_int32), ("flags", ctypes.c_int32)]
+
+
+def rowslice_dtype():
+    import numpy as np
+    return np.dtype([("count", "<i8"), ("first_addr", "<i8"), ("last_addr", "<i8"), ("seen", "<i8"), ("clk", "<f8"), ("li_neg", "<i4"),
+                     ("lq_neg", "<i4"), ("wbyte", "<i4"), ("wbits", "<i4"), ("sreg", "<i4"), ("flags", "<i4")])
+
+
 class SliceJob(ctypes.Structure):
     """pm_slice_job"""
     _fields_ = [("d_bits_i", ctypes.c_void_p), ("d_bits_q", ctypes.c_void_p), ("n", ctypes.c_int64), ("params", SlicerParams),
@@ -226,6 +239,8 @@ _SIGS = {
     "pm_rows_max_f64": ([_vp, _vp, _i64, _int, _i64, ctypes.POINTER(_dbl)], _int),
     "pm_lbatch_create": ([_vp, ctypes.POINTER(LBatchDesc), ctypes.POINTER(_vp)], _int),
     "pm_lbatch_geometry": ([_vp, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64)], _int),
+    "pm_lbatch_run_sliced": ([_vp, ctypes.POINTER(_vp), _int, _i64, _vp, _int, _vp, _vp, _i64, _vp, ctypes.POINTER(_i64)], _int),
+    "pm_rows_gather": ([_vp, _vp, _vp, _vp, _i64, _i64, _int, _vp, ctypes.c_size_t], _int),
     "pm_lbatch_run": ([_vp, ctypes.POINTER(_vp), _int, _i64, _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
     "pm_lbatch_front_ctx": ([_vp], _vp),
     "pm_lbatch_tail_ctx": ([_vp], _vp),

@@ -151,6 +151,15 @@ int pm_afsk_group_run_plan(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const
 // that way): per packet the bytes it has, not the 1280 of the field
 extern "C" int pm_codec_fetch_batch_clean(pm_codec *const *codecs, const int64_t *counts, int n, pm_packet *h_out, int threads);
 
+// ---- the batch engine's slicers: one lane per stream, a chunk per launch, state carried in d_recs (pm_slicer.hip: rowslice_kernel)
+struct pm_rowslice;
+int pm_rowslice_create(pm_ctx *ctx, const pm_slicer_params *h_params, int chains, pm_rowslice **out);
+void pm_rowslice_destroy(pm_rowslice *rs);
+bool pm_rowslice_made_for(const pm_rowslice *rs, const pm_slicer_params *h_params, int chains);
+// samples [first, first + count) of every row (first a multiple of 64): bit k of d_bi[row * stride + k / 64] is sample first + k
+int pm_rowslice_chunk(pm_ctx *ctx, const pm_rowslice *rs, int rows, int quad, const uint64_t *d_bi, const uint64_t *d_bq, int64_t stride, int64_t first,
+                      int64_t count, pm_rowslice_rec *d_recs, uint8_t *d_data, uint16_t *d_steps, int64_t cap);
+
 // ---- long matched filters as certified signs on the int8 matrix pipe (pm_fir8.hip): bit k of row r = (canonical FIR sum >= 0), the
 // bitmap pm_fir_rows(..., d_bits, ...) writes, for inputs of any magnitude.  A plan belongs to one tap set (m + 15 <= 1024) and device.
 struct pm_fir8_plan;

@@ -44,6 +44,9 @@ struct pm_lbatch {
     double *d_taps = nullptr;
     pm_bpf8_plan *bpf8 = nullptr;            // the band-pass on the matrix pipe, for the pass that finds the AGC's `normal` (pm_bpf8.hip; PM_BPF8_MAX=0: off)
     unsigned long long *d_keys = nullptr;
+    pm_rowslice *rs = nullptr;               // pm_lbatch_run_sliced: the slicers' parameter table ...
+    uint64_t *cbits_i = nullptr, *cbits_q = nullptr;      // ... and ONE chunk of sign bits per stream (rows of cstride words)
+    int64_t cstride = 0;
     pm_fir8_plan *fir8 = nullptr;            // the output filter as certified signs on the int8 matrix pipe (pm_fir8.hip; PM_FIR8=0: off)
     size_t o_in = 0, o_hil = 0, o_out = 0, o_wave = 0;
     int32_t *d_pd = nullptr;
@@ -124,6 +127,9 @@ int pm_lbatch_destroy(pm_lbatch *b)
         if (e) (void)hipEventDestroy(e);
     pm_fir8_plan_destroy(b->fir8);
     pm_bpf8_plan_destroy(b->bpf8);
+    pm_rowslice_destroy(b->rs);
+    if (b->cbits_i) (void)pm_free(ctx, b->cbits_i);
+    if (b->cbits_q) (void)pm_free(ctx, b->cbits_q);
     if (b->loop) (void)pm_ctx_sync(b->loop);
     for (hipEvent_t e : {b->loop_go, b->loop_end})
         if (e) (void)hipEventDestroy(e);
@@ -269,10 +275,58 @@ pm_ctx *pm_lbatch_front_ctx(pm_lbatch *b) { return b ? b->front : nullptr; }
 pm_ctx *pm_lbatch_tail_ctx(pm_lbatch *b) { return b ? b->tail : nullptr; }
 pm_ctx *pm_lbatch_loop_ctx(pm_lbatch *b) { return b ? b->loop : nullptr; }
 
+namespace {
+struct SliceOut {                      // pm_lbatch_run_sliced: where the rows' bytes, steps and records go
+    uint8_t *data;
+    uint16_t *steps;
+    int64_t cap;
+    pm_rowslice_rec *recs;
+};
+int run_impl(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings, int64_t n, uint64_t *d_bits_i, uint64_t *d_bits_q, int64_t bits_stride,
+             int64_t *h_nout, const SliceOut *so);
+}  // namespace
+
 int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings, int64_t n, uint64_t *d_bits_i, uint64_t *d_bits_q,
                   int64_t bits_stride, int64_t *h_nout)
 {
     PM_ARG(b != nullptr && h_d_audio != nullptr && d_bits_i != nullptr && h_nout != nullptr);
+    return run_impl(b, h_d_audio, recordings, n, d_bits_i, d_bits_q, bits_stride, h_nout, nullptr);
+}
+
+int pm_lbatch_run_sliced(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings, int64_t n, const pm_slicer_params *h_params, int nparams,
+                         uint8_t *d_data, uint16_t *d_steps, int64_t cap, pm_rowslice_rec *d_recs, int64_t *h_nout)
+{
+    PM_ARG(b != nullptr && h_d_audio != nullptr && h_params != nullptr && d_data != nullptr && d_steps != nullptr && d_recs != nullptr && h_nout != nullptr);
+    PM_ARG(nparams == b->C && cap >= 8 && cap % 8 == 0);
+    pm_ctx *ctx = b->back;
+    PM_CTX(ctx);
+    if (!pm_rowslice_made_for(b->rs, h_params, nparams)) {
+        if (b->rs) {                                          // (a run with the old table may still be in flight)
+            if (int rc = pm_ctx_sync(b->tail)) return rc;
+            pm_rowslice_destroy(b->rs);
+            b->rs = nullptr;
+        }
+        if (int rc = pm_rowslice_create(ctx, h_params, nparams, &b->rs)) return rc;
+    }
+    if (!b->cbits_i) {
+        b->cstride = b->Lc / 64 + 8;
+        const size_t words = (size_t)b->R * (size_t)b->C * (size_t)b->cstride;
+        void *q = nullptr;
+        if (int rc = pm_malloc(ctx, words * 8, &q)) return rc;
+        b->cbits_i = (uint64_t *)q;
+        if (b->two_out) {
+            if (int rc = pm_malloc(ctx, words * 8, &q)) return rc;
+            b->cbits_q = (uint64_t *)q;
+        }
+    }
+    const SliceOut so{d_data, d_steps, cap, d_recs};
+    return run_impl(b, h_d_audio, recordings, n, b->cbits_i, b->cbits_q, b->cstride, h_nout, &so);
+}
+
+namespace {
+int run_impl(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings, int64_t n, uint64_t *d_bits_i, uint64_t *d_bits_q, int64_t bits_stride,
+             int64_t *h_nout, const SliceOut *so)
+{
     const int tail_mode = b->back ? b->back->tune.lbatch_tail : -1;
     // The matched filters of chunk t beside the loops of chunk t + 1 (third stream; PM_LBATCH_TAIL=0: behind them on the caller's stream).
     // With the tiled loop shapes this paid only sometimes -- beside a filter those loops ran 1.8-2.8x slower, their LDS traffic queuing
@@ -293,7 +347,7 @@ int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings,
     if (nout < 1)
         return pm_set_error(PM_ERR_ARG, "pm_lbatch_run: %lld samples are fewer than the filters need for one output (%d + %d + %d taps)",
                             (long long)n, mb, mh, mo);
-    PM_ARG(bits_stride >= (nout + 63) / 64);
+    PM_ARG(bits_stride >= (std::min(nout, so ? Lc : nout) + 63) / 64);
     *h_nout = nout;
     const double *T = b->d_taps;
     bool aligned = true;
@@ -323,6 +377,7 @@ int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings,
     if (!max8) PM_HIP(hipMemcpyAsync(b->d_audio, b->h_audio.data(), sizeof(void *) * (size_t)R, hipMemcpyHostToDevice, F->stream));
     PM_HIP(hipMemsetAsync(b->d_agc_state, 0, sizeof(double) * 2 * (size_t)R, F->stream));          // fresh AGC objects (agc.py:20-21)
     PM_HIP(hipMemcpyAsync(b->d_loops, b->h_loops.data(), sizeof(pm_loop) * (size_t)RC, hipMemcpyHostToDevice, B->stream));
+    if (so) PM_HIP(hipMemsetAsync(so->recs, 0, sizeof(pm_rowslice_rec) * (size_t)RC, B->stream));      // just-tuned slicers (slicer.py:49-56, :193-202)
     if (Lp != B) {                                            // the loops start behind the fresh states
         PM_HIP(hipEventRecord(b->loop_go, B->stream));
         PM_HIP(hipStreamWaitEvent(Lp->stream, b->loop_go, 0));
@@ -398,14 +453,18 @@ int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings,
             }
             PM_HIP(hipEventRecord(b->hist_done[set], Tl->stream));
             const double *f0 = b->dwin0[set] + b->Ho - back;
+            const int64_t word0 = so ? 0 : o0 / 64;            // sliced runs keep one chunk of sign bits, not the recording's
             auto signs = [&](const double *f, uint64_t *bits) -> int {
                 // (a row of the output windows: Ho history slots, the chunk, slack up to the pitch -- all of it the engine's own memory)
-                if (b->fir8) return pm_fir8_rows_signs(Tl, b->fir8, f, P, RC, fn, bits + o0 / 64, bits_stride, nullptr, P - (b->Ho - back));
-                return pm_fir_rows(Tl, false, f, P, nullptr, 0, (((uintptr_t)f) & 15) == 0, RC, fn, T + b->o_out, mo, nullptr, 0, bits + o0 / 64, bits_stride, 0);
+                if (b->fir8) return pm_fir8_rows_signs(Tl, b->fir8, f, P, RC, fn, bits + word0, bits_stride, nullptr, P - (b->Ho - back));
+                return pm_fir_rows(Tl, false, f, P, nullptr, 0, (((uintptr_t)f) & 15) == 0, RC, fn, T + b->o_out, mo, nullptr, 0, bits + word0, bits_stride, 0);
             };
             if (int rc = signs(f0, d_bits_i)) return rc;
             if (b->two_out)
                 if (int rc = signs(b->dwin1[set] + b->Ho - back, d_bits_q)) return rc;
+            if (so)
+                if (int rc = pm_rowslice_chunk(Tl, b->rs, RC, b->two_out ? 1 : 0, d_bits_i, d_bits_q, bits_stride, o0, o1 - o0, so->recs, so->data, so->steps,
+                                               so->cap)) return rc;
         }
         prev_cnt_l = cnt_l;
         s_agc = e_agc;
@@ -423,5 +482,6 @@ int pm_lbatch_run(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings,
     b->ran = true;
     return PM_OK;
 }
+}  // namespace
 
 }  // extern "C"

@@ -611,6 +611,171 @@ double symbol_clock_threshold(double thr)
     return NAN;
 }
 
+
+// ---- one lane per stream, a chunk of the stream per launch (the carrier-loop batch engine, pm_loopbatch.hip) -------------------------
+// The engine advances thousands of streams together, a time chunk at a time, and its loops are sequential in exactly the way the
+// slicer's clock is: here the parallelism is across the streams, so every stream gets ONE lane that carries the true state from chunk
+// to chunk -- no walkers, no merging, no symbol bitmap, and no sign bitmaps of whole recordings either (59 GB for 16 384 streams of ten
+// minutes: the engine keeps one chunk of them).  Per 64-sample word the lane runs the same 64 steps as a walker (the step forms above:
+// the reference's operations in the reference's order), then turns the word's symbols into bits as slice_pack_kernel does
+// (slicer.py:85-96, :210-228), and stores a byte and its address step whenever eight bits are full.  A wave of 64 such lanes is bound
+// by its dependent chain, ~2 us per word: a 65 536-sample chunk takes ~2.5 ms beside the 18-20 ms of the chunk's carrier loops.
+struct RowParams {
+    double thr, sps, lock, tp;
+    int bps, mask;
+    unsigned long long demap4;       // demap[16], four bits each
+};
+
+template <int STEP>
+__global__ __launch_bounds__(64) void rowslice_kernel(const RowParams *__restrict__ params, int chains, int rows, int quad,
+                                                      const uint64_t *__restrict__ bits_i, const uint64_t *__restrict__ bits_q, int64_t stride,
+                                                      int64_t first, int64_t count, pm_rowslice_rec *__restrict__ recs,
+                                                      uint8_t *__restrict__ data, uint16_t *__restrict__ steps, int64_t cap)
+{
+    const int row = (int)(blockIdx.x * 64 + threadIdx.x);
+    if (row >= rows) return;
+    typedef const uint64_t __attribute__((address_space(1))) *gptr_c;
+    const RowParams P = params[row % chains];
+    pm_rowslice_rec R = recs[row];
+    const gptr_c bi = (gptr_c)(bits_i + (int64_t)row * stride);
+    const gptr_c bq = quad ? (gptr_c)(bits_q + (int64_t)row * stride) : bi;
+    const double thr = P.thr, sps = P.sps, lock = P.lock, tp = P.tp, neg_sps = -P.sps, lm1 = P.lock - 1.0;
+    const int bps = P.bps;
+    const uint32_t mask = (uint32_t)P.mask;
+    const unsigned long long demap4 = P.demap4;
+    double clk = R.clk;
+    uint64_t li = R.li_neg ? 0ull : 1ull, lq = R.lq_neg ? 0ull : 1ull;
+    uint32_t byte = (uint32_t)R.wbyte, prev = (uint32_t)R.sreg & 3u, flags = (uint32_t)R.flags;
+    int nbits = R.wbits;
+    int64_t cnt = R.count, last_addr = R.last_addr, first_addr = R.first_addr;
+    uint8_t *const out_d = data + (int64_t)row * cap;
+    uint16_t *const out_s = steps + (int64_t)row * cap;
+    const int64_t nwords = (count + 63) >> 6;
+    uint64_t si_n = 0, sq_n = 0;
+    if (nwords > 0) {
+        si_n = bi[0];
+        sq_n = bq[0];
+    }
+    for (int64_t w = 0; w < nwords; ++w) {
+        const uint64_t si = si_n, sq = sq_n;
+        const int64_t wn = min(w + 1, nwords - 1);
+        si_n = bi[wn];                                       // a word ahead: its latency under this word's 64 steps
+        sq_n = bq[wn];
+        uint64_t zc = si ^ ((si << 1) | li);
+        if (quad) zc |= sq ^ ((sq << 1) | lq);
+        const int64_t left = count - (w << 6);
+        uint64_t sym;
+        if (left >= 64) {
+            li = si >> 63;
+            lq = sq >> 63;
+            uint32_t lo, hi;
+            if (STEP >= 5) {
+                lo = step32a<((STEP - 5) & 1) != 0, ((STEP - 5) & 2) != 0>(clk, __brev((uint32_t)zc), tp, neg_sps, lm1);
+                hi = step32a<((STEP - 5) & 1) != 0, ((STEP - 5) & 2) != 0>(clk, __brev((uint32_t)(zc >> 32)), tp, neg_sps, lm1);
+            } else if (STEP == 4) {
+                lo = step32c<true, true>(clk, __brev((uint32_t)zc), tp, neg_sps, lm1);
+                hi = step32c<true, true>(clk, __brev((uint32_t)(zc >> 32)), tp, neg_sps, lm1);
+            } else if (STEP == 3) {
+                lo = step32c<false, false>(clk, __brev((uint32_t)zc), tp, neg_sps, lm1);
+                hi = step32c<false, false>(clk, __brev((uint32_t)(zc >> 32)), tp, neg_sps, lm1);
+            } else if (STEP == 2) {
+                lo = step32m<true, true>(clk, __brev((uint32_t)zc), thr, neg_sps, lm1);
+                hi = step32m<true, true>(clk, __brev((uint32_t)(zc >> 32)), thr, neg_sps, lm1);
+            } else if (STEP == 1) {
+                lo = step32m<false, false>(clk, __brev((uint32_t)zc), thr, neg_sps, lm1);
+                hi = step32m<false, false>(clk, __brev((uint32_t)(zc >> 32)), thr, neg_sps, lm1);
+            } else {
+                lo = step32(clk, __brev((uint32_t)zc), thr, neg_sps, lock);
+                hi = step32(clk, __brev((uint32_t)(zc >> 32)), thr, neg_sps, lock);
+            }
+            sym = ((uint64_t)__brev(hi) << 32) | (uint64_t)__brev(lo);
+        } else {                                             // the stream's last, partial word (bits past the end are not samples)
+            li = (si >> (left - 1)) & 1;
+            lq = (sq >> (left - 1)) & 1;
+            sym = 0;
+            for (int b = 0; b < (int)left; ++b) {
+                clk += 1.0;
+                if (clk >= thr) {
+                    clk -= sps;
+                    sym |= 1ull << b;
+                }
+                if ((zc >> b) & 1) clk = clk * lock;
+            }
+        }
+        while (sym) {
+            const int b = __ffsll((long long)sym) - 1;
+            sym &= sym - 1;
+            uint32_t v;
+            if (quad) {
+                const uint32_t cur = (uint32_t)((((si >> b) & 1) << 1) | ((sq >> b) & 1));
+                v = (uint32_t)(demap4 >> (4 * (((prev << 2) | cur) & mask))) & 15u;          // slicer.py:210-217
+                prev = cur;
+            } else {
+                v = (uint32_t)((si >> b) & 1);                                              // slicer.py:85-90
+            }
+            byte = ((byte << bps) | v) & 0xFFu;
+            nbits += bps;
+            if (nbits >= 8) {                                                               // slicer.py:91-96, :219-228
+                nbits = 0;
+                const int64_t a = first + (w << 6) + b + 1;                                 // 1-based address of the byte's last symbol
+                if (cnt < cap) {
+                    const int64_t step = cnt ? a - last_addr : 0;
+                    if (step > 65535) flags |= 1u;
+                    out_d[cnt] = (uint8_t)byte;
+                    out_s[cnt] = (uint16_t)step;
+                } else {
+                    flags |= 2u;
+                }
+                if (cnt == 0) first_addr = a;
+                last_addr = a;
+                ++cnt;
+            }
+        }
+    }
+    R.clk = clk;
+    R.li_neg = li ? 0 : 1;
+    R.lq_neg = quad ? (lq ? 0 : 1) : 0;
+    R.wbits = nbits;
+    R.wbyte = nbits ? (int32_t)(byte & ((1u << nbits) - 1u)) : 0;
+    R.sreg = (int32_t)prev;
+    R.flags = (int32_t)flags;
+    R.count = cnt;
+    R.first_addr = first_addr;
+    R.last_addr = last_addr;
+    R.seen = first + count;
+    recs[row] = R;
+}
+
+// rows of a sliced run -> one dense block: row k (of this call's rows) at the sum of the rows' sizes before it, count[k] address steps
+// (uint16, padded to 8 bytes) then count[k] data bytes (padded to 8)
+__global__ __launch_bounds__(256) void rows_gather_kernel(const pm_rowslice_rec *__restrict__ recs, const uint8_t *__restrict__ data,
+                                                          const uint16_t *__restrict__ steps, int64_t cap, int64_t row0, uint8_t *__restrict__ block,
+                                                          size_t block_bytes)
+{
+    __shared__ unsigned long long part[256];
+    const int k = blockIdx.x, t = threadIdx.x;
+    unsigned long long mine = 0;
+    for (int j = t; j < k; j += 256) {
+        const unsigned long long c = (unsigned long long)min(recs[row0 + j].count, cap);
+        mine += ((2 * c + 7) & ~7ull) + ((c + 7) & ~7ull);
+    }
+    part[t] = mine;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) part[t] += part[t + s];
+        __syncthreads();
+    }
+    const unsigned long long off = part[0];
+    const unsigned long long c = (unsigned long long)min(recs[row0 + k].count, cap);
+    const unsigned long long sw = (2 * c + 7) >> 3, dw = (c + 7) >> 3;
+    if (off + 8 * (sw + dw) > block_bytes) return;           // (the host sized the block from the same counts)
+    const uint64_t *src_s = reinterpret_cast<const uint64_t *>(steps + (row0 + k) * cap);      // cap is a multiple of 8: rows are aligned
+    const uint64_t *src_d = reinterpret_cast<const uint64_t *>(data + (row0 + k) * cap);
+    uint64_t *dst = reinterpret_cast<uint64_t *>(block + off);
+    for (unsigned long long i = t; i < sw; i += 256) dst[i] = src_s[i];
+    for (unsigned long long i = t; i < dw; i += 256) dst[sw + i] = src_d[i];
+}
+
 }  // namespace
 
 extern "C" int pm_slice_batch(pm_ctx *ctx, pm_slice_job *jobs, int njobs)
@@ -996,3 +1161,115 @@ int pm_slicer_stats(pm_ctx *ctx, int32_t *iterations, int32_t *chunk_len, int64_
 }
 
 }  // extern "C"
+
+// ---- the batch engine's row slicers (rowslice_kernel) ----------------------------------------------------------------------------
+struct pm_rowslice {
+    int chains = 0, step = 0, device = 0;
+    RowParams *d_params = nullptr;
+    std::vector<pm_slicer_params> made_for;
+};
+
+int pm_rowslice_create(pm_ctx *ctx, const pm_slicer_params *h_params, int chains, pm_rowslice **out)
+{
+    PM_CTX(ctx);
+    PM_ARG(h_params != nullptr && out != nullptr && chains >= 1 && chains <= 4096);
+    *out = nullptr;
+    std::vector<RowParams> rp((size_t)chains);
+    const pm_tuning &tn = ctx->tune;
+    int masks = tn.slicer_compare_step ? 0 : 2;              // the choice of pm_slice_batch, over the chains' parameter sets
+    bool lm0 = true, ns0 = true, direct = true;
+    for (int c = 0; c < chains; ++c) {
+        const pm_slicer_params &q = h_params[c];
+        PM_ARG(q.bits_per_symbol == 1 || q.bits_per_symbol == 2);
+        PM_ARG(q.samples_per_symbol > 0.0 && q.lock_rate == q.lock_rate);
+        RowParams &d = rp[(size_t)c];
+        d.sps = q.samples_per_symbol;
+        d.thr = (q.samples_per_symbol / 2.0) - 0.5;          // slicer.py:52
+        d.tp = symbol_clock_threshold(d.thr);
+        d.lock = q.lock_rate;
+        d.bps = q.bits_per_symbol;
+        d.mask = q.state_mask;
+        d.demap4 = 0;
+        for (int i = 0; i < 16; ++i) {
+            PM_ARG(q.demap[i] >= 0 && q.demap[i] < (1 << q.bits_per_symbol));
+            d.demap4 |= (unsigned long long)q.demap[i] << (4 * i);
+        }
+        const volatile double lm1 = d.lock - 1.0;
+        if (!(lm1 + 1.0 == d.lock) || !(d.sps - d.sps == 0.0)) masks = 0;
+        uint64_t lb, sb;
+        const double l1 = lm1;
+        memcpy(&lb, &l1, 8);
+        memcpy(&sb, &d.sps, 8);
+        if (masks == 2 && ((uint32_t)lb || (uint32_t)sb)) masks = 1;
+        lm0 = lm0 && (uint32_t)lb == 0;
+        ns0 = ns0 && (uint32_t)sb == 0;
+        direct = direct && d.tp == d.tp;
+    }
+    direct = direct && masks != 0 && !tn.slicer_mask_step;
+    const bool hand = direct && !tn.slicer_compiled_step;
+    pm_rowslice *rs = new pm_rowslice();
+    rs->chains = chains;
+    rs->device = ctx->device;
+    rs->step = hand ? (lm0 ? (ns0 ? 8 : 6) : (ns0 ? 7 : 5)) : direct ? (masks == 2 ? 4 : 3) : masks;
+    rs->made_for.assign(h_params, h_params + chains);
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void **)&rs->d_params, sizeof(RowParams) * (size_t)chains) != hipSuccess) {
+        delete rs;
+        return pm_set_error(PM_ERR_HIP, "row slicers: no device memory for the parameter table");
+    }
+    if (hipMemcpy(rs->d_params, rp.data(), sizeof(RowParams) * (size_t)chains, hipMemcpyHostToDevice) != hipSuccess) {
+        pm_rowslice_destroy(rs);
+        return pm_set_error(PM_ERR_HIP, "row slicers: copying the parameter table failed");
+    }
+    *out = rs;
+    return PM_OK;
+}
+
+void pm_rowslice_destroy(pm_rowslice *rs)
+{
+    if (!rs) return;
+    (void)hipSetDevice(rs->device);
+    if (rs->d_params) (void)hipFree(rs->d_params);
+    delete rs;
+}
+
+bool pm_rowslice_made_for(const pm_rowslice *rs, const pm_slicer_params *h_params, int chains)
+{
+    return rs && rs->chains == chains && memcmp(rs->made_for.data(), h_params, sizeof(pm_slicer_params) * (size_t)chains) == 0;
+}
+
+int pm_rowslice_chunk(pm_ctx *ctx, const pm_rowslice *rs, int rows, int quad, const uint64_t *d_bi, const uint64_t *d_bq, int64_t stride, int64_t first,
+                      int64_t count, pm_rowslice_rec *d_recs, uint8_t *d_data, uint16_t *d_steps, int64_t cap)
+{
+    PM_CTX(ctx);
+    PM_ARG(rs != nullptr && rows >= 1 && d_bi != nullptr && (!quad || d_bq != nullptr) && d_recs != nullptr && d_data != nullptr && d_steps != nullptr);
+    PM_ARG(first >= 0 && first % 64 == 0 && count >= 1 && stride >= (count + 63) / 64 && cap >= 8 && cap % 8 == 0 && rs->device == ctx->device);
+    PmProf prof(ctx, PM_K_SLICE_ITER);
+    const dim3 grid((unsigned)pm_cdiv(rows, 64)), block(64);
+#define PM_ROWSLICE(S) hipLaunchKernelGGL(rowslice_kernel<S>, grid, block, 0, ctx->stream, rs->d_params, rs->chains, rows, quad, d_bi, d_bq, stride, first, count, \
+                                          d_recs, d_data, d_steps, cap)
+    switch (rs->step) {
+    case 8: PM_ROWSLICE(8); break;
+    case 7: PM_ROWSLICE(7); break;
+    case 6: PM_ROWSLICE(6); break;
+    case 5: PM_ROWSLICE(5); break;
+    case 4: PM_ROWSLICE(4); break;
+    case 3: PM_ROWSLICE(3); break;
+    case 2: PM_ROWSLICE(2); break;
+    case 1: PM_ROWSLICE(1); break;
+    default: PM_ROWSLICE(0); break;
+    }
+#undef PM_ROWSLICE
+    PM_HIP(hipGetLastError());
+    return PM_OK;
+}
+
+extern "C" int pm_rows_gather(pm_ctx *ctx, const pm_rowslice_rec *d_recs, const uint8_t *d_data, const uint16_t *d_steps, int64_t cap, int64_t row0, int nrows,
+                              void *d_block, size_t block_bytes)
+{
+    PM_CTX(ctx);
+    PM_ARG(d_recs != nullptr && d_data != nullptr && d_steps != nullptr && d_block != nullptr && cap >= 8 && cap % 8 == 0 && row0 >= 0 && nrows >= 1 &&
+           nrows <= 4096 && ((uintptr_t)d_block & 7) == 0);
+    hipLaunchKernelGGL(rows_gather_kernel, dim3((unsigned)nrows), dim3(256), 0, ctx->stream, d_recs, d_data, d_steps, cap, row0, (uint8_t *)d_block, block_bytes);
+    PM_HIP(hipGetLastError());
+    return PM_OK;
+}

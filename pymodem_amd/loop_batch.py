@@ -151,6 +151,47 @@ class LoopBatch:
             out.append(row)
         return out
 
+    def _sliced_room(self, r, nout, slicers, slot):
+        # room per stream: 1.5 x the nominal byte count (a clock pulled by its crossings runs at most twice nominal; real streams stay
+        # within a few percent); a row that needs more says so in its record and the caller slices that run the other way
+        nominal = max(nout * sl.bits_per_symbol / (8.0 * sl.samples_per_symbol) for sl in slicers)
+        cap = (int(nominal * 1.5) + 64 + 7) // 8 * 8
+        rows = r * self.chains
+        data = self.ctx.scratch(("lbatch", id(self), slot, "sliced-data"), rows * cap, np.uint8)
+        steps = self.ctx.scratch(("lbatch", id(self), slot, "sliced-steps"), rows * cap, np.uint16)
+        recs = self.ctx.scratch(("lbatch", id(self), slot, "sliced-recs"), rows * ctypes.sizeof(N.RowSliceRec), np.uint8)
+        return cap, rows, data, steps, recs
+
+    def reserve_sliced(self, recordings, n, slicers, slot=0):
+        """reserve() for run_sliced(): the rows' output blocks for `recordings` recordings of n samples, now."""
+        nout = self.geometry(n)[0]
+        if nout >= 1:
+            self._sliced_room(int(recordings), nout, slicers, slot)
+
+    def run_sliced(self, audios, slicers, slot=0):
+        """run() with the slicers inside the engine (pm_lbatch_run_sliced): every stream is sliced chunk by chunk behind its matched
+        filter by a lane of its own, no sign bitmap of a whole recording is kept and nothing is left to slice when the run ends.
+        `slicers`: one slicer object per chain -- its parameters; every stream starts from the just-tuned state (slicer.py:49-56).
+        -> SlicedRun (complete when this context's stream gets there)."""
+        r = len(audios)
+        if not 1 <= r <= self.recordings:
+            raise ValueError(f"LoopBatch.run_sliced: {r} recordings, the engine was made for {self.recordings}")
+        if len(slicers) != self.chains:
+            raise ValueError("LoopBatch.run_sliced: one slicer per chain")
+        n = audios[0].n
+        for a in audios:
+            if not isinstance(a, DeviceBuffer) or a.dtype != np.dtype(np.int16) or a.n != n:
+                raise ValueError("LoopBatch.run_sliced: recordings must be int16 DeviceBuffers of equal length")
+        nout = self.geometry(n)[0]
+        if nout < 1:
+            raise ValueError(f"input of {n} samples is shorter than the filters of the chain")
+        params = (N.SlicerParams * self.chains)(*[sl._params() for sl in slicers])
+        cap, rows, data, steps, recs = self._sliced_room(r, nout, slicers, slot)
+        ptrs = (ctypes.c_void_p * r)(*[a.ptr.value for a in audios])
+        got = ctypes.c_int64()
+        check(lib().pm_lbatch_run_sliced(self._h, ptrs, r, n, params, self.chains, data.ptr, steps.ptr, cap, recs.ptr, ctypes.byref(got)))
+        return SlicedRun(self.ctx, data, steps, recs, cap, rows, got.value)
+
     def close(self):
         if self._h:
             lib().pm_lbatch_destroy(self._h)                 # waits for both of the engine's streams
@@ -165,6 +206,55 @@ class LoopBatch:
             self.close()
         except Exception:
             pass
+
+
+class SlicedRun:
+    """What a sliced engine run left in device memory: per stream (row = recording * chains + chain) its data bytes, address steps and
+    record.  records() and fetch() want the run complete (synchronise the context it ran on first)."""
+
+    def __init__(self, ctx, data, steps, recs, cap, rows, nout):
+        self.ctx, self.data, self.steps, self.recs, self.cap, self.rows, self.nout = ctx, data, steps, recs, cap, rows, nout
+        self._records = None
+
+    def records(self):
+        if self._records is None:
+            self._records = self.recs.download(self.rows * ctypes.sizeof(N.RowSliceRec)).view(N.rowslice_dtype())
+        return self._records
+
+    def ok(self):
+        """False if a row overflowed its room or took an address step beyond 16 bits: slice that run with slice_batch instead."""
+        return not self.records()["flags"].any()
+
+    def state_into(self, row, slicer):
+        """The end state of the row's slicer, as slice() would have left it in the object."""
+        rec, st = self.records()[row], slicer._state
+        st.phase_clock, st.last_i_negative, st.last_q_negative = float(rec["clk"]), int(rec["li_neg"]), int(rec["lq_neg"])
+        st.working_byte, st.working_bits, st.state_register, st.streamaddress = int(rec["wbyte"]), int(rec["wbits"]), int(rec["sreg"]), int(rec["seen"])
+        slicer.phase_clock, slicer.streamaddress = st.phase_clock, st.streamaddress
+
+    def fetch(self, row0, nrows, copy_ctx=None, tag=None):
+        """-> [AddressedArray of row row0, row0 + 1, ...]: one gather launch and ONE copy to the host for the lot (on copy_ctx's stream)."""
+        from .data_classes import AddressedArray
+        ctx = copy_ctx or self.ctx
+        recs = self.records()[row0:row0 + nrows]
+        counts = np.minimum(recs["count"], self.cap)
+        sizes = (2 * counts + 7) // 8 * 8 + (counts + 7) // 8 * 8
+        offs = np.concatenate(([0], np.cumsum(sizes)))
+        used = int(offs[-1])
+        out = []
+        if used:
+            room = nrows * 3 * self.cap
+            block = ctx.scratch((tag if tag is not None else ("sliced-run", id(self)), "dense"), room, np.uint8)
+            check(lib().pm_rows_gather(ctx.handle, self.recs.ptr, self.data.ptr, self.steps.ptr, self.cap, row0, nrows, block.ptr, block.n))
+            host = block.download(used, recycle=True, ctx=ctx, room=room)
+        for k in range(nrows):
+            c, o = int(counts[k]), int(offs[k])
+            if c == 0:
+                out.append(AddressedArray(np.zeros(0, np.uint8), np.zeros(0, np.int64)))
+                continue
+            sw = (2 * c + 7) // 8 * 8
+            out.append(AddressedArray.from_steps(host[o + sw:o + sw + c], host[o:o + 2 * c].view(np.uint16), int(recs["first_addr"][k])))
+        return out
 
 
 _ENGINES = {}
@@ -219,8 +309,60 @@ def process_recordings_device(chain_sets, audios, ctx=None, chunk=0, rows=False,
     for cs in chain_sets:
         if len(cs) != nchains or any(group_key(cs[c][1]) != k for k, members in groups.items() for c in members):
             raise ValueError("every recording must bring the same group of chains")
+    import os
     import time
     t0 = time.perf_counter()
+    # One group of chains, every slicer just tuned and the same from recording to recording (a service's chains are made from one config
+    # per recording): the slicers run INSIDE the engine, a lane per stream (pm_lbatch_run_sliced).  PYMODEM_AMD_LOOP_FUSED_SLICERS=0, or
+    # anything else about the slicers: the engine leaves sign bitmaps and pm_slice_batch slices them afterwards, as before.
+    from ._native import SlicerState
+    fresh = bytes(SlicerState())
+    if (len(groups) == 1 and os.environ.get("PYMODEM_AMD_LOOP_FUSED_SLICERS", "1") != "0"
+            and all(hasattr(ch[2], "_params_bytes") and bytes(ch[2]._state) == fresh for cs in chain_sets for ch in cs)
+            and all(cs[c][2]._params_bytes() == chain_sets[0][c][2]._params_bytes() for cs in chain_sets for c in range(nchains))):
+        eng = engine_for([ch[1] for ch in chain_sets[0]], r, ctx, chunk)
+        run = eng.run_sliced(dev, [ch[2] for ch in chain_sets[0]], slot=(slot, 0))
+        ctx.sync_relaxed()
+        t1 = time.perf_counter()
+        if run.ok():
+            for rec in range(r):
+                for c in range(nchains):
+                    sl = chain_sets[rec][c][2]
+                    sl._ctx = sl._ctx or ctx
+                    run.state_into(rec * nchains + c, sl)
+            # to the host a few hundred streams at a time (one gather, one copy), several copies in flight on streams of their own, and a
+            # recording whose streams are there goes to the host stage at once, beside the copies still to come
+            parts = max(1, min(int(os.environ.get("PYMODEM_AMD_LOOP_SLICE_STREAMS", "8")), r))
+            per = max(1, 256 // nchains)
+            cuts = [r * p // parts for p in range(parts + 1)]
+            sides = [Context.side(ctx.device, 400 + p) for p in range(parts)]
+            early = {}
+
+            def part(p):
+                out = []
+                for lo in range(cuts[p], cuts[p + 1], per):
+                    hi = min(lo + per, cuts[p + 1])
+                    got = run.fetch(lo * nchains, (hi - lo) * nchains, sides[p], tag=("loop-sliced", p))
+                    out += got
+                    for rec in range(lo, hi):
+                        if rows:
+                            early[rec] = _pool().submit(_host_rows, chain_sets[rec], got[(rec - lo) * nchains:(rec - lo + 1) * nchains], chain_ids)
+                return out
+            futs = [_pool().submit(part, p) for p in range(parts)]
+            sliced = [x for f in futs for x in f.result()]
+            t2 = time.perf_counter()
+            if stages is not None:
+                stages["sliced"] = [sliced[rec * nchains:(rec + 1) * nchains] for rec in range(r)]
+                stages["seconds"] = {"engine": t1 - t0, "slicers": t2 - t1}
+                stages["fused_slicers"] = True
+            if rows:
+                out = [early[rec].result() for rec in range(r)]
+                if stages is not None:
+                    stages["seconds"]["host"] = time.perf_counter() - t2
+                return out
+            futs = [[_pool().submit(_host_stages, ch, sl) for ch, sl in zip(chain_sets[rec], sliced[rec * nchains:(rec + 1) * nchains])] for rec in range(r)]
+            return [[f.result() for f in futs[rec]] for rec in range(r)]
+        t0 = time.perf_counter()                # (a row outgrew its room or its 16-bit steps: the whole run again, the other way)
     bitmaps = [[None] * nchains for _ in range(r)]
     for gi, (k, members) in enumerate(groups.items()):
         eng = engine_for([chain_sets[0][c][1] for c in members], r, ctx, chunk)

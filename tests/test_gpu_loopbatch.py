@@ -315,13 +315,72 @@ def test_engine_qpsk_modem():
         eng.close()
 
 
+@pytest.mark.parametrize("cfg,rate,carriers,chunk,n", [
+    ("bpsk_300.json", 48000, [1500.0], 2048, 30000),
+    ("bpsk_300.json", 48000, [1490.0, 1500.0, 1512.5], 4096, 41234),
+    ("bpsk_1200.json", 8000, [1500.0, 1510.0], 2048, 12000),
+    ("qpsk_2400.json", 48000, [1500.0 + 3.125 * k for k in range(-4, 4)], 6144, 30001),
+    ("qpsk_600.json", 44100, [1500.0], 0, 30000),
+    ("afsk_300_pll.json", 8000, None, 2048, 12000),
+])
+def test_sliced_run_equals_run_then_slice_batch(cfg, rate, carriers, chunk, n):
+    """pm_lbatch_run_sliced -- the slicers inside the engine, one lane per stream, state carried from chunk to chunk -- against the same
+    engine's bitmaps sliced by pm_slice_batch (itself pinned to the oracle's slicers in tests/test_gpu_slicer.py): bytes, addresses and
+    the slicer objects' end states, for binary and quadrature slicers, several chunks and a ragged last word, noise (a crossing
+    at nearly every sample) and level steps."""
+    import pymodem_amd
+    from pymodem_amd import chain_builder as cb
+    from pymodem_amd.loop_batch import LoopBatch
+    from pymodem_amd.slicer import slice_batch
+    ctx = pymodem_amd.Context.default()
+    group = group_modems(cfg, rate, carriers, take=1 if carriers is None else None)
+    modems = [m for _, m in group]
+    recs = [noise_i16(n, seed=500 + k, sigma=2000.0 + 2500.0 * k) for k in range(5)]
+    recs[1][n // 2:] //= 16
+    t = np.arange(n)
+    recs[2] = (6000 * np.sin(2 * np.pi * 1500.0 * t / rate) * np.sign(np.sin(2 * np.pi * 37.0 * t / rate))).astype(np.int16)      # a keyed carrier
+    def slicers():
+        return [cb.build_chain(rate, line)[2] for line, _ in group]
+    eng = LoopBatch(modems, recordings=5, ctx=ctx, chunk=chunk)
+    try:
+        dev = [ctx.upload(r) for r in recs]
+        run = eng.run_sliced(dev, slicers())
+        ctx.sync()
+        assert run.ok()
+        got = run.fetch(0, run.rows)
+        bitmaps = eng.run(dev)
+        ctx.sync()
+        C = len(group)
+        assert run.rows == 5 * C and run.nout == bitmaps[0][0].n
+        produced = 0
+        for k in range(5):
+            sls = slicers()
+            want = slice_batch(sls, [sl.sign_bitmaps(bitmaps[k][c]) for c, sl in enumerate(sls)], ctx)
+            for c in range(C):
+                g, w = got[k * C + c], want[c]
+                assert np.array_equal(g.data, w.data), (cfg, k, c, len(g.data), len(w.data))
+                assert np.array_equal(g.address, w.address), (cfg, k, c)
+                mine = slicers()[c]
+                run.state_into(k * C + c, mine)
+                assert bytes(mine._state) == bytes(sls[c]._state), (cfg, k, c)
+                produced += len(w.data)
+        assert produced > 0
+        # pieces of the rows come back the same as the whole
+        some = run.fetch(C, 2 * C)
+        for j in range(2 * C):
+            assert np.array_equal(some[j].data, got[C + j].data) and np.array_equal(some[j].address, got[C + j].address)
+    finally:
+        eng.close()
+
+
 def pk(pkts):
     return (np.array([p.streamaddress for p in pkts], dtype=np.int64), np.array([len(p.data) for p in pkts], dtype=np.int64),
             np.array([p.BytesCorrected for p in pkts], dtype=np.int64), np.array([b for p in pkts for b in p.data], dtype=np.uint8))
 
 
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("mode,cfg", [("qpsk2400_il2p", "qpsk_2400.json"), ("bpsk300_il2p", "bpsk_300.json")])
-def test_recordings_executor_matches_the_oracle_on_packet_bearing_audio(mode, cfg):
+def test_recordings_executor_matches_the_oracle_on_packet_bearing_audio(mode, cfg, fused, monkeypatch):
     """process_recordings_device on four different packet-bearing recordings: slicer bytes, addresses and packets of every chain of
     every recording equal the oracle's (which the reference's goldens pin)."""
     from pymodem_amd import chain_builder as cb, siggen
@@ -336,7 +395,9 @@ def test_recordings_executor_matches_the_oracle_on_packet_bearing_audio(mode, cf
     recs = [r[:n] for r in recs]
     chain_sets = [[cb.build_chain(rate, line) for line in lines] for _ in recs]
     stages = {}
+    monkeypatch.setenv("PYMODEM_AMD_LOOP_FUSED_SLICERS", str(fused))      # the slicers inside the engine / pm_slice_batch afterwards
     got = process_recordings_device(chain_sets, recs, chunk=8192, stages=stages)
+    assert bool(stages.get("fused_slicers")) == bool(fused)
     decoded = 0
     for k, audio in enumerate(recs):
         for c, line in enumerate(lines):
