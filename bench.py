@@ -391,7 +391,8 @@ def also_workloads(args, env, cpu_also=None):
     out = {}
     # (the carrier-loop workloads: one full engine run each -- 16384 recordings x 1 chain, 2048 x 8 chains; a run takes as long as
     # its recordings are, however many there are)
-    for name, steps, warm in (("fsk_9600", 300, 10), ("bpsk_300", 16384, 1), ("qpsk_2400", 2048, 1)):
+    # -- two runs each, one after the other: the host's share of the first lies beside the GPU's run of the second (loop_steps)
+    for name, steps, warm in (("fsk_9600", 300, 10), ("bpsk_300", 32768, 1), ("qpsk_2400", 4096, 1)):
         if name == args.workload or (os.environ.get("BENCH_ALSO_ONLY") and name not in os.environ["BENCH_ALSO_ONLY"].split(",")):
             continue
         a = copy.copy(args)
@@ -503,38 +504,88 @@ def measure(args, env):
             args.loop_chunk = 65536 if batch * len(my) > 8192 else 131072 if batch >= 2048 else 262144
         engine = lb.engine_for([modems[c] for c in my], batch, ctx, args.loop_chunk)
         if os.environ.get("PYMODEM_AMD_LOOP_FUSED_SLICERS", "1") != "0":      # the slicers inside the engine: rows of bytes, no bitmaps
-            engine.reserve_sliced(batch, args.samples, [ch[2] for ch in build_chains(reset=False)], slot=(0, 0))
+            for sl_ in range(2 if args.steps > batch else 1):     # (two sets of output rows when batches follow each other: see loop_steps)
+                engine.reserve_sliced(batch, args.samples, [ch[2] for ch in build_chains(reset=False)], slot=(sl_, 0))
         else:
             engine.reserve(batch, args.samples, slot=(0, 0))
         nout_, chunk_, chunks_ = engine.geometry(args.samples)
-        loop_info = {"recordings_per_run": batch, "loops_in_flight": batch * len(my), "chunk_outputs": chunk_, "chunks_per_recording": chunks_,
+        loop_info = {"recordings_per_run": batch, "runs": -(-max(args.steps, 1) // batch), "loops_in_flight": batch * len(my), "chunk_outputs": chunk_,
+                     "chunks_per_recording": chunks_,
+                     "slicers": "inside the engine, one lane per stream (pm_lbatch_run_sliced)" if os.environ.get("PYMODEM_AMD_LOOP_FUSED_SLICERS", "1") != "0"
+                     else "pm_slice_batch over the run's sign bitmaps",
+                     "between_runs": "the host's share of a run (rows to the host, LFSR + codec, de-dup) beside the GPU's next run; the phase times "
+                                     "below then overlap and add up to more than the step",
                      "note": "all carrier loops of the run's recordings x this rank's chains advance together, one lane each, state carried "
                              "in device memory from chunk to chunk; band-pass/AGC/Hilbert of chunk t+1 on a second stream beside the loops of chunk t"}
 
     loop_phase_s = {}
 
     def loop_steps(k, audio_dev):
-        res = None
+        import threading
+        res = [None]
         loop_phase_s.clear()
-        for b0 in range(0, k, batch):
-            r = min(batch, k - b0)
-            sets = [build_chains(reset=False) for _ in range(r)]
-            st = {}
-            bufs = audio_ring(min(r, LOOP_DISTINCT_BUFFERS))      # (16384 distinct ten-minute recordings would be 944 GB: each copy serves r / 256 of the run's recordings)
-            rows = lb.process_recordings_device(sets, [bufs[i % len(bufs)] for i in range(r)], ctx, chunk=args.loop_chunk, rows=True, chain_ids=my, stages=st)
+
+        failed = []
+
+        def after(rest, st):
+            """what follows a batch's engine run: its rows to the host, LFSR + codec, de-dup"""
+            try:
+                after_(rest, st)
+            except BaseException as e:                            # noqa: BLE001  (raised again on the submitting thread)
+                failed.append(e)
+
+        def after_(rest, st):
+            rows = rest()
             t_f = time.perf_counter()
             if use_dist or len(my) < 4:
                 for rr in rows:                                   # (collectives: in order, on this thread; one chain: nothing to share out)
-                    res = finish(rr)
+                    res[0] = finish(rr)
             else:
                 # the recordings' de-dups do not depend on each other (PacketTable + pm_correlate, mostly native): four at a time
                 from concurrent.futures import ThreadPoolExecutor
                 with ThreadPoolExecutor(max_workers=4) as fin:
-                    for res in fin.map(finish, rows):
-                        pass
+                    for got in fin.map(finish, rows):
+                        res[0] = got
             for k2, v in dict(st.get("seconds", {}), finish=time.perf_counter() - t_f).items():
                 loop_phase_s[k2] = loop_phase_s.get(k2, 0.0) + v
-        return res
+
+        # Successive batches as a service would run them: the host's share of batch i (rows to the host, LFSR + codec, de-dup) on a
+        # thread of its own beside the GPU's run of batch i + 1 (two sets of output rows in rotation).  One batch: nothing to overlap.
+        # With an exchange the finish is a collective: in order, on this thread.
+        prev = None
+        starts = list(range(0, k, batch))
+        built = {}
+
+        def build(bi):                                            # a batch's stage objects, made while the batch before it runs
+            built[bi] = [build_chains(reset=False) for _ in range(min(batch, k - starts[bi]))]
+        build(0)
+        for bi, b0 in enumerate(starts):
+            r = min(batch, k - b0)
+            sets = built.pop(bi)
+            ahead = None
+            if bi + 1 < len(starts):
+                ahead = threading.Thread(target=build, args=(bi + 1,), name="bench-build-chains")
+                ahead.start()
+            st = {}
+            bufs = audio_ring(min(r, LOOP_DISTINCT_BUFFERS))      # (16384 distinct ten-minute recordings would be 944 GB: each copy serves r / 256 of the run's recordings)
+            rest = lb.process_recordings_device(sets, [bufs[i % len(bufs)] for i in range(r)], ctx, chunk=args.loop_chunk, rows=True, chain_ids=my, stages=st,
+                                                slot=bi & 1, defer=True)
+            if prev is not None:
+                prev.join()
+            if ahead is not None:
+                ahead.join()
+            if failed:
+                raise failed[0]
+            if use_dist:
+                after(rest, st)
+            else:
+                prev = threading.Thread(target=after, args=(rest, st), name="bench-after-run")
+                prev.start()
+        if prev is not None:
+            prev.join()
+        if failed:
+            raise failed[0]
+        return res[0]
 
     native_sides = []
     exchanging = use_dist or bool(os.environ.get("PYMODEM_AMD_FORCE_GATHER"))

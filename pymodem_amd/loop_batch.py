@@ -216,9 +216,9 @@ class SlicedRun:
         self.ctx, self.data, self.steps, self.recs, self.cap, self.rows, self.nout = ctx, data, steps, recs, cap, rows, nout
         self._records = None
 
-    def records(self):
+    def records(self, copy_ctx=None):
         if self._records is None:
-            self._records = self.recs.download(self.rows * ctypes.sizeof(N.RowSliceRec)).view(N.rowslice_dtype())
+            self._records = self.recs.download(self.rows * ctypes.sizeof(N.RowSliceRec), ctx=copy_ctx).view(N.rowslice_dtype())
         return self._records
 
     def ok(self):
@@ -243,7 +243,9 @@ class SlicedRun:
         used = int(offs[-1])
         out = []
         if used:
-            room = nrows * 3 * self.cap
+            # (host blocks in 8 MB size classes: streams run within a few percent of their nominal counts, so the groups of a run ask
+            # for the same class and the page-locked blocks go round; the worst case, 1.5 x that, would be filled and pinned for nothing)
+            room = (used + (8 << 20) - 1) // (8 << 20) * (8 << 20)
             block = ctx.scratch((tag if tag is not None else ("sliced-run", id(self)), "dense"), room, np.uint8)
             check(lib().pm_rows_gather(ctx.handle, self.recs.ptr, self.data.ptr, self.steps.ptr, self.cap, row0, nrows, block.ptr, block.n))
             host = block.download(used, recycle=True, ctx=ctx, room=room)
@@ -278,17 +280,20 @@ def close_engines():
     _ENGINES.clear()
 
 
-def process_recordings_device(chain_sets, audios, ctx=None, chunk=0, rows=False, chain_ids=None, stages=None, slot=0):
+def process_recordings_device(chain_sets, audios, ctx=None, chunk=0, rows=False, chain_ids=None, stages=None, slot=0, defer=False):
     """chain_sets[k] = the chains [name, modem, slicer, stream, codec] of recording k (every recording brings the same group of
     chains, as a service decoding successive recordings with one config does), audios[k] its int16 samples (host array or
     DeviceBuffer; equal lengths).  -> [[packets of chain 0, ...] per recording], identical to chain_execute.process_chain on each
-    (rows=True: pm_packet rows instead of PacketMeta lists).  All carrier loops of all recordings advance together."""
+    (rows=True: pm_packet rows instead of PacketMeta lists).  All carrier loops of all recordings advance together.
+    defer=True: returns when the engine's run is complete, with a function that does the rest (the rows to the host, LFSR + codec) and
+    returns the result -- a service calls it on another thread while this one starts the next batch's run (with the other `slot`): the
+    host's work on batch k then lies beside the GPU's on batch k + 1 instead of behind it."""
     from .chain_execute import _host_rows, _host_stages, _pool
     from .slicer import slice_batch
     ctx = ctx or Context.default()
     r = len(chain_sets)
     if r == 0:
-        return []
+        return (lambda: []) if defer else []
     dev = []
     for a in audios:
         if isinstance(a, DeviceBuffer):
@@ -324,49 +329,52 @@ def process_recordings_device(chain_sets, audios, ctx=None, chunk=0, rows=False,
         run = eng.run_sliced(dev, [ch[2] for ch in chain_sets[0]], slot=(slot, 0))
         ctx.sync_relaxed()
         t1 = time.perf_counter()
+        run.records(Context.side(ctx.device, 399))          # (not on the context's own stream: the next run may be queued on it by now)
         if run.ok():
-            for rec in range(r):
-                for c in range(nchains):
-                    sl = chain_sets[rec][c][2]
-                    sl._ctx = sl._ctx or ctx
-                    run.state_into(rec * nchains + c, sl)
-            # to the host a few hundred streams at a time (one gather, one copy), several copies in flight on streams of their own, and a
-            # recording whose streams are there goes to the host stage at once, beside the copies still to come
-            parts = max(1, min(int(os.environ.get("PYMODEM_AMD_LOOP_SLICE_STREAMS", "8")), r))
-            per = max(1, 256 // nchains)
-            cuts = [r * p // parts for p in range(parts + 1)]
-            sides = [Context.side(ctx.device, 400 + p) for p in range(parts)]
-            early = {}
+            def rest():
+                for rec in range(r):
+                    for c in range(nchains):
+                        sl = chain_sets[rec][c][2]
+                        sl._ctx = sl._ctx or ctx
+                        run.state_into(rec * nchains + c, sl)
+                # to the host a few hundred streams at a time (one gather, one copy), several copies in flight on streams of their own, and a
+                # recording whose streams are there goes to the host stage at once, beside the copies still to come
+                parts = max(1, min(int(os.environ.get("PYMODEM_AMD_LOOP_SLICE_STREAMS", "8")), r))
+                per = max(1, int(os.environ.get("PYMODEM_AMD_LOOP_FETCH_ROWS", "256")) // nchains)
+                cuts = [r * p // parts for p in range(parts + 1)]
+                sides = [Context.side(ctx.device, 400 + p) for p in range(parts)]
+                early = {}
 
-            def part(p):
-                out = []
-                for lo in range(cuts[p], cuts[p + 1], per):
-                    hi = min(lo + per, cuts[p + 1])
-                    got = run.fetch(lo * nchains, (hi - lo) * nchains, sides[p], tag=("loop-sliced", p))
-                    out += got
-                    for rec in range(lo, hi):
-                        if rows:
-                            early[rec] = _pool().submit(_host_rows, chain_sets[rec], got[(rec - lo) * nchains:(rec - lo + 1) * nchains], chain_ids)
-                return out
-            futs = [_pool().submit(part, p) for p in range(parts)]
-            sliced = [x for f in futs for x in f.result()]
-            t2 = time.perf_counter()
-            if stages is not None:
-                stages["sliced"] = [sliced[rec * nchains:(rec + 1) * nchains] for rec in range(r)]
-                stages["seconds"] = {"engine": t1 - t0, "slicers": t2 - t1}
-                stages["fused_slicers"] = True
-            if rows:
-                out = [early[rec].result() for rec in range(r)]
+                def part(p):
+                    out = []
+                    for lo in range(cuts[p], cuts[p + 1], per):
+                        hi = min(lo + per, cuts[p + 1])
+                        got = run.fetch(lo * nchains, (hi - lo) * nchains, sides[p], tag=("loop-sliced", p))
+                        out += got
+                        for rec in range(lo, hi):
+                            if rows:
+                                early[rec] = _pool().submit(_host_rows, chain_sets[rec], got[(rec - lo) * nchains:(rec - lo + 1) * nchains], chain_ids)
+                    return out
+                futs = [_pool().submit(part, p) for p in range(parts)]
+                sliced = [x for f in futs for x in f.result()]
+                t2 = time.perf_counter()
                 if stages is not None:
-                    stages["seconds"]["host"] = time.perf_counter() - t2
-                return out
-            futs = [[_pool().submit(_host_stages, ch, sl) for ch, sl in zip(chain_sets[rec], sliced[rec * nchains:(rec + 1) * nchains])] for rec in range(r)]
-            return [[f.result() for f in futs[rec]] for rec in range(r)]
+                    stages["sliced"] = [sliced[rec * nchains:(rec + 1) * nchains] for rec in range(r)]
+                    stages["seconds"] = {"engine": t1 - t0, "slicers": t2 - t1}
+                    stages["fused_slicers"] = True
+                if rows:
+                    out = [early[rec].result() for rec in range(r)]
+                    if stages is not None:
+                        stages["seconds"]["host"] = time.perf_counter() - t2
+                    return out
+                futs = [[_pool().submit(_host_stages, ch, sl) for ch, sl in zip(chain_sets[rec], sliced[rec * nchains:(rec + 1) * nchains])] for rec in range(r)]
+                return [[f.result() for f in futs[rec]] for rec in range(r)]
+            return rest if defer else rest()
         t0 = time.perf_counter()                # (a row outgrew its room or its 16-bit steps: the whole run again, the other way)
     bitmaps = [[None] * nchains for _ in range(r)]
     for gi, (k, members) in enumerate(groups.items()):
         eng = engine_for([chain_sets[0][c][1] for c in members], r, ctx, chunk)
-        got = eng.run(dev, slot=(slot, gi))
+        got = eng.run(dev, slot=(0 if defer else slot, gi))    # (this way everything is over when the call returns: one bitmap set will do)
         for rec in range(r):
             for j, c in enumerate(members):
                 sl = chain_sets[rec][c][2]
@@ -424,8 +432,8 @@ def process_recordings_device(chain_sets, audios, ctx=None, chunk=0, rows=False,
         out = [f.result() for f in futs]
         if stages is not None:
             stages["seconds"]["host"] = time.perf_counter() - t2
-        return out
+        return (lambda: out) if defer else out
     futs = [[_pool().submit(_host_stages, ch, sl) for ch, sl in zip(chain_sets[rec], sliced[rec * nchains:(rec + 1) * nchains])] for rec in range(r)]
     for rec in range(r):
         out.append([f.result() for f in futs[rec]])
-    return out
+    return (lambda: out) if defer else out
