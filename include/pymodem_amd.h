@@ -116,6 +116,10 @@ int pm_fir_valid_i16(pm_ctx *ctx, const int16_t *d_x, int64_t n, const double *d
  * (v_mfma_i32_16x16x64_i8), recombined in binary64.  |d_y[k] - reference sum| <= *h_bound (~1e-9 of sum|taps| * 32768).  m <= 241,
  * d_x 16-byte aligned, h_taps on the HOST; synchronous (plans its tables per call: the pipeline keeps them).  Test and measurement entry. */
 int pm_fir_valid_i16_limbs(pm_ctx *ctx, const int16_t *d_x, int64_t n, const double *h_taps, int m, double *d_y, double *h_bound);
+/* What the certified AFSK sweeps' binary32 roots rely on (csrc/pm_fir.hip: slide_run_f32): the largest error of the device's v_sqrt_f32
+ * over ALL 2^24 binary32 values of the binades 2^exponent and 2^(exponent + 1), in units of the result's last place x 1024 (rounded up),
+ * against the correctly rounded binary64 root.  Test entry. */
+int pm_ubench_sqrt_f32(pm_ctx *ctx, int exponent, int64_t *h_worst_ulp_1024);
 /* max(numpy.convolve(row, h, 'valid')) per row -- AGC.apply's `normal` (agc.py:67) over the band-passed recording (psk.py:165, :710) --
  * WITHOUT writing the band-passed rows: matrix-pipe values with the bound above pick the outputs that could be the maximum, the
  * reference's own sum (one fma per tap, ascending input index) decides among them; h_max[r] is bit for bit max() of pm_fir_valid_i16.

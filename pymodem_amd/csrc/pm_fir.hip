@@ -572,6 +572,57 @@ __device__ __forceinline__ void slide_run(const double *__restrict__ xs, const d
     }
 }
 
+// The same run with the two roots in binary32: v_sqrt_f32 of the binary64 sum of squares rounded to binary32 -- for afsk_slide_lpf8_kernel,
+// whose magnitudes end as integers of 22 bits anyway.  What that costs in accuracy is a relative 2^-23 (the instruction: within one unit
+// in the last place for every one of the 2^24 significands of a binade, checked exhaustively on the device by
+// tests/test_gpu_kernels.py::test_v_sqrt_f32_is_within_one_ulp, pm_ubench_sqrt_f32) + 2^-25 (the conversion of the radicand), which the
+// kernel adds to its bound in units of its integers; what it saves is the binary64 reciprocal-square-root seed and its Newton step (six
+// instructions of which one is quarter-rate) -- twice per sample.  Radicands below binary32's normal range give roots below 2^-63 either
+// way: the kernel only scales workgroups whose largest magnitude is above 2^-21, so that is below 2^-20 of a unit.
+template <int L>
+__device__ __forceinline__ void slide_run_f32(const double *__restrict__ xs, const double *__restrict__ tp, int run, int m, const SlideTones &T,
+                                              float (&mv)[L], float (&sv)[L])
+{
+    const double *xr = xs + run * (L + 1);
+    double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+    {
+        const double2v *tq = reinterpret_cast<const double2v *>(tp);
+        int i = 0;
+        for (; i + 4 <= m; i += 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double v = xr[slide_slot<L>(i + q)];
+                const double2v h01 = tq[2 * (i + q)], h23 = tq[2 * (i + q) + 1];
+                a = __builtin_fma(h01.x, v, a);
+                b = __builtin_fma(h01.y, v, b);
+                c = __builtin_fma(h23.x, v, c);
+                d = __builtin_fma(h23.y, v, d);
+            }
+        }
+        for (; i < m; ++i) {
+            const double v = xr[slide_slot<L>(i)];
+            const double2v h01 = tq[2 * i], h23 = tq[2 * i + 1];
+            a = __builtin_fma(h01.x, v, a);
+            b = __builtin_fma(h01.y, v, b);
+            c = __builtin_fma(h23.x, v, c);
+            d = __builtin_fma(h23.y, v, d);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        mv[i] = __builtin_amdgcn_sqrtf((float)__builtin_fma(a, a, b * b));       // afsk.py:157
+        sv[i] = __builtin_amdgcn_sqrtf((float)__builtin_fma(c, c, d * d));
+        if (i + 1 < L) {
+            const double xk = xr[i], xn = xr[slide_slot<L>(i + m)];
+            const double a2 = __builtin_fma(T.mr, a, __builtin_fma(-T.ms, b, __builtin_fma(-T.mer, xk, xn)));
+            const double b2 = __builtin_fma(T.ms, a, __builtin_fma(T.mr, b, -T.mes * xk));
+            const double c2 = __builtin_fma(T.sr, c, __builtin_fma(-T.ss, d, __builtin_fma(-T.ser, xk, xn)));
+            const double d2 = __builtin_fma(T.ss, c, __builtin_fma(T.sr, d, -T.ses * xk));
+            a = a2; b = b2; c = c2; d = d2;
+        }
+    }
+}
+
 template <int L>
 __global__ __launch_bounds__(kSlideThreads) void afsk_slide_kernel(const double *__restrict__ x, int64_t n, const double *__restrict__ mi,
                                                                    const double *__restrict__ mq, const double *__restrict__ ui,
@@ -942,8 +993,13 @@ struct Lpf8Args {
     double c_tap;                        // sum |h 2^S - q|: the taps' quantisation, in units of 2^-S
     double c_q;                          // sum |q| / 2 (the magnitudes' rounding) + the digit product that is left out: units of 2^-(S+s2)
     double gfac;                         // 1 + the largest gain (two streams: |a - g b|'s error), 1 for one stream
+    double qabs;                         // sum |q|: what a unit of error in every magnitude's integer costs (PM_LPF8_F32MAG: the binary32 roots)
     const int4v *btab;
 };
+
+#ifndef PM_LPF8_F32MAG
+#define PM_LPF8_F32MAG 1         // the sliding sums' roots in binary32 (slide_run_f32): g = 7 0.203 -> 0.188 ms, g = 1 0.133 -> 0.124, 752 -> 891 / 20 -> 221 uncertain decisions
+#endif
 
 #ifndef PM_LPF8_RECOMB32
 #define PM_LPF8_RECOMB32 1       // pairs of accumulators recombined as 32-bit integers first (two conversions per output instead of four): 0.206 -> 0.203 ms
@@ -991,6 +1047,55 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PM_LPF
         tp[4 * i + 3] = uq[m - 1 - i];
     }
     lds_barrier();
+#if PM_LPF8_F32MAG
+    float mv[L], sv[L];
+    if (t < nruns) slide_run_f32<L>(xs, tp, t, m, T, mv, sv);
+    // the workgroup's largest value (what the planes will hold) and, for one stream, the largest mark + gain * space (what its roots'
+    // errors scale with: the difference may be far smaller than either)
+    float vmaxf = 0.0f, vsumf = 0.0f;
+    if (t < nruns) {
+        if (ONE) {
+            const float g0 = (float)P.gain[0], ag0 = fabsf(g0);
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                vsumf = fmaxf(vsumf, fmaf(ag0, sv[i], mv[i]));
+                mv[i] = fmaf(-g0, sv[i], mv[i]);             // afsk.py:162 on the approximate magnitudes
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < L; ++i) vmaxf = fmaxf(vmaxf, ONE ? fabsf(mv[i]) : fmaxf(mv[i], sv[i]));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        vmaxf = fmaxf(vmaxf, __shfl_xor(vmaxf, off));
+        if (ONE) vsumf = fmaxf(vsumf, __shfl_xor(vsumf, off));
+    }
+    __shared__ float wmaxf[2][kThreads / 64];
+    if ((t & 63) == 0) {
+        wmaxf[0][t >> 6] = vmaxf;
+        wmaxf[1][t >> 6] = vsumf;
+    }
+    lds_barrier();                                           // every lane is done with the window of x: the planes take its place
+    static_assert(kThreads == 256, "four waves");
+    const double vmax = (double)fmaxf(fmaxf(wmaxf[0][0], wmaxf[0][1]), fmaxf(wmaxf[0][2], wmaxf[0][3]));
+    const double vsum = ONE ? (double)fmaxf(fmaxf(wmaxf[1][0], wmaxf[1][1]), fmaxf(wmaxf[1][2], wmaxf[1][3])) : vmax;
+    int e2 = 0;
+    (void)frexp(vmax, &e2);                                  // vmax < 2^e2
+    // (not: NaN, infinities, all zeros, and what binary32 cannot carry: magnitudes below 2^-21 or above 2^60 -- everything goes to the list then)
+    const bool scalable = vmax < 1.0e18 && vmax > 4.8e-7 && vsum < 1.0e18;
+    const int s2 = scalable ? 22 - e2 : 0;
+    const double scale = ldexp(1.0, s2);
+    const float scalef = (float)scale;
+    // A root is within (2^-23 + 2^-25) of itself of the true one (slide_run_f32), the one-stream difference adds the gain's and its own
+    // binary32 roundings (2^-24 each, of mark + gain space at most): in units of the integers, per magnitude; 1e-6: vmax and vsum are
+    // themselves rounded values
+    const double root_units = (ONE ? 2.13 : 1.13) * 1.1920928955078125e-07 * (vsum * scale) * (1.0 + 1e-6) + 1e-5;
+    // |sum h v - 2^-(S+s2) 256 val| <= sum|h - q 2^-S| vmax + 2^-(S+s2) (sum|q| (1/2 + the roots' share) + the product left out), times
+    // 1 + gmax for a - g b; plus E, what separates sum h v from the reference's low-pass output: all in the units of `val`, rounded up
+    const double Ecmp = scalable ? ceil((ldexp(E, Q.S + s2) + Q.gfac * (Q.c_tap * (vmax * scale) * (1.0 + 1e-6) + Q.c_q + Q.qabs * root_units)) *
+                                        (1.0 + 1e-9) * (1.0 / 256.0)) + 2.0
+                                 : __builtin_inf();
+#else
     double mv[L], sv[L];
     if (t < nruns) slide_run<L>(xs, tp, t, m, T, mv, sv);
     // The largest magnitude of the workgroup (what the planes will hold): the digits are scaled to IT, not to the largest the audio
@@ -1021,10 +1126,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PM_LPF
     // a - g b; plus E, what separates sum h v from the reference's low-pass output: all in the units of `val`, rounded up
     const double Ecmp = scalable ? ceil((ldexp(E, Q.S + s2) + Q.gfac * (Q.c_tap * (vmax * scale) + Q.c_q)) * (1.0 + 1e-9) * (1.0 / 256.0)) + 2.0
                                  : __builtin_inf();
+#endif
     unsigned char *planes = reinterpret_cast<unsigned char *>(xs);
     if (t < nruns) {
         static_assert(L % 4 == 0, "four magnitudes per plane word");
-        auto put = [&](const double (&val)[L], int stream) {
+        auto put = [&](const auto (&val)[L], int stream) {
 #pragma unroll
             for (int q = 0; q < L / 4; ++q) {
                 unsigned w[4];
@@ -1032,8 +1138,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PM_LPF
                 for (int i = 0; i < 4; ++i) {
                     // v 2^s2 is exact, |..| <= 2^22; adding 1.5 2^52 leaves its nearest integer in the low word (two's complement);
                     // the bytes of (X + 0x808080) ^ 0x808080 are X's three balanced base-256 digits
+#if PM_LPF8_F32MAG
+                    // (binary32: 1.5 2^23, the integer in the low 23 bits of the significand)
+                    const float sc = scalable ? fmaf(val[4 * q + i], scalef, 12582912.0f) : 12582912.0f;
+                    w[i] = ((unsigned)((int)__float_as_uint(sc) - 0x4B400000) + 0x808080u) ^ 0x808080u;
+#else
                     const double sc = scalable ? __builtin_fma(val[4 * q + i], scale, 6755399441055744.0) : 6755399441055744.0;
                     w[i] = ((unsigned)__double2loint(sc) + 0x808080u) ^ 0x808080u;
+#endif
                 }
                 const unsigned a01 = __builtin_amdgcn_perm(w[1], w[0], 0x05010400u), a23 = __builtin_amdgcn_perm(w[3], w[2], 0x05010400u);
                 unsigned char *at = planes + (size_t)stream * kL8Dig * kL8Plane + L * t + 4 * q;
@@ -1735,6 +1847,7 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
         Q.c_tap = lpf8->tapq_int;
         Q.c_q = 0.5 * lpf8->qabs + lpf8->dlow;
         Q.gfac = one ? 1.0 : 1.0 + gmax;
+        Q.qabs = lpf8->qabs;
         Q.btab = (const int4v *)lpf8->d_btab;
         const int64_t ntiles = pm_cdiv(nl, (int64_t)kThreads * 8);
         PM_ARG(ntiles < (1LL << 31));
@@ -2012,3 +2125,47 @@ int pm_signs_f64(pm_ctx *ctx, const double *d_x, int64_t n, uint64_t *d_bits)
 }
 
 }  // extern "C"
+
+// ---- what slide_run_f32 relies on: v_sqrt_f32 within one unit in the last place, for EVERY significand ---------------------------------
+// All 2^23 significands of the binades 2^e and 2^(e+1) (a root's significand depends on the radicand's significand and on the parity of
+// its exponent only): the largest |v_sqrt_f32(x) - sqrt(x)| in units of the result's last place, sqrt(x) in binary64 (correctly rounded,
+// 29 bits to spare).  *h_worst_ulp_1024 = that, times 1024, rounded up.
+namespace {
+__global__ __launch_bounds__(256) void sqrt_f32_ulp_kernel(int e, unsigned long long *worst)
+{
+    const unsigned k = blockIdx.x * 256u + threadIdx.x;       // 2^24 threads: significand k & (2^23 - 1), exponent e + (k >> 23)
+    const unsigned bits = ((unsigned)(e + (int)(k >> 23) + 127) << 23) | (k & 0x7FFFFFu);
+    const float x = __uint_as_float(bits);
+    const float r = __builtin_amdgcn_sqrtf(x);
+    const double exact = __builtin_sqrt((double)x);
+    int re = 0;
+    (void)frexp((double)r, &re);                              // r = f 2^re, f in [0.5, 1): its last place is 2^(re - 24)
+    const double ulps = fabs((double)r - exact) * ldexp(1.0, 24 - re);
+    unsigned long long mine = (unsigned long long)ceil(ulps * 1024.0);
+    if (!(ulps == ulps)) mine = ~0ull;
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(mine, off);
+        mine = o > mine ? o : mine;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(worst, mine);
+}
+}  // namespace
+
+extern "C" int pm_ubench_sqrt_f32(pm_ctx *ctx, int exponent, int64_t *h_worst_ulp_1024)
+{
+    PM_CTX(ctx);
+    PM_ARG(h_worst_ulp_1024 != nullptr && exponent >= -125 && exponent <= 125);
+    void *q = nullptr;
+    if (int rc = pm_malloc(ctx, 8, &q)) return rc;
+    int rc = PM_OK;
+    unsigned long long worst = 0;
+    if (hipMemsetAsync(q, 0, 8, ctx->stream) != hipSuccess) rc = pm_set_error(PM_ERR_HIP, "pm_ubench_sqrt_f32: memset failed");
+    if (!rc) {
+        hipLaunchKernelGGL(sqrt_f32_ulp_kernel, dim3(1u << 16), dim3(256), 0, ctx->stream, exponent, (unsigned long long *)q);
+        if (hipMemcpyAsync(&worst, q, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+            rc = pm_set_error(PM_ERR_HIP, "pm_ubench_sqrt_f32: the launch failed");
+    }
+    (void)pm_free(ctx, q);
+    *h_worst_ulp_1024 = (int64_t)worst;
+    return rc;
+}

@@ -113,6 +113,17 @@ def test_fir_int8_limbs_rejects_what_it_cannot_hold(ctx):
     assert L().pm_fir_valid_i16_limbs(ctx.handle, ctypes.c_void_p(x.ptr.value + 2), 4000, h.ctypes.data, 8, y.ptr, ctypes.byref(b)) != 0     # input not 16-byte aligned
 
 
+@pytest.mark.parametrize("exponent", [-60, -21, -1, 0, 1, 24, 59, 100])
+def test_v_sqrt_f32_is_within_one_ulp(ctx, exponent):
+    """slide_run_f32 (csrc/pm_fir.hip) takes the roots of the certified sweeps' magnitudes with v_sqrt_f32 and prices the instruction at
+    one unit in the last place in its bound: here the device evaluates it on every one of the 2^24 binary32 values of two neighbouring
+    binades (a root's significand depends on the radicand's significand and its exponent's parity only) against the correctly rounded
+    binary64 root."""
+    worst = ctypes.c_int64(-1)
+    chk(L().pm_ubench_sqrt_f32(ctx.handle, exponent, ctypes.byref(worst)))
+    assert 0 < worst.value <= 1024, worst.value / 1024.0
+
+
 def rows_max_gpu(ctx, rows2d, h):
     rows, n = rows2d.shape
     stride = (n + 7) // 8 * 8
