@@ -1114,8 +1114,8 @@ def measure(args, env):
                              "frac": round(per_launch_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                              "note": "same kernel class in three extra sequential steps after the timed region, no other stream on the GPU"
                                      + (" -- through the Python-sequenced path, i.e. the BINARY64 kernels of this class; the native executor's "
-                                        "matrix-pipe kernels alone: 0.245 ms (seven-chain sweep) and 0.152 ms (one chain), 0.086 ms for the band-pass "
-                                        "(tools/sweep_probe.py with PM_AFSK_LPF8=1, tools/bpf8_probe.py; DESIGN.md 4.2d)" if native_exec[0] else "")},
+                                        "matrix-pipe kernels alone: 0.188 ms (seven-chain sweep) and 0.124 ms (one chain), 0.06 ms for the band-pass "
+                                        "(tools/sweep_probe.py with PM_AFSK_LPF8=1, tools/bpf8_probe.py; DESIGN.md 4.2, profiles/r04_sweep_probe.txt)" if native_exec[0] else "")},
                          "note": "achieved = algorithmic bytes of the timed launches / their HIP-event time inside the timed region (where "
                                  "the slicer streams share the CUs).  Above ~40 taps a FIR is bound by the vector-f64 FMA pipe, not by "
                                  "HBM: see roofline_fp64 for that fraction (DESIGN.md 4.1-4.2).  For the AFSK workloads the class fir_f64 is "
