@@ -408,3 +408,47 @@ def test_recordings_executor_matches_the_oracle_on_packet_bearing_audio(mode, cf
                 assert np.array_equal(a, b), (cfg, k, c)
             decoded += len(want["packets"])
     assert decoded > 0
+
+
+def test_recordings_executor_deferred_batches_and_the_way_back(monkeypatch):
+    """defer=True: the call returns when the GPU is through and hands the host's share back as a function -- two batches with their
+    output rows in two slots, the first one's share run after the second batch's engine run, equal what the plain call returns.  And
+    the way back: when a stream's output outgrows its room (forced here: room for eight bytes) the run is sliced from its sign bitmaps
+    instead, with the same result."""
+    from pymodem_amd import chain_builder as cb, siggen
+    from pymodem_amd import loop_batch as lbm
+    from pymodem_amd.loop_batch import process_recordings_device
+    rate = 48000
+    lines = lines_of("bpsk_300.json")
+    recs = []
+    for k in range(4):
+        audio, _ = siggen.recording("bpsk300_il2p", rate, packets=2, seed=80 + k, noise_sigma=1000.0, payload_len=(20, 40))
+        recs.append(audio)
+    n = min(len(r) for r in recs)
+    recs = [r[:n] for r in recs]
+
+    def chains(count):
+        return [[cb.build_chain(rate, line) for line in lines] for _ in range(count)]
+    want = process_recordings_device(chains(4), recs, chunk=8192)
+    assert sum(len(p) for rec in want for p in rec) > 0
+    first = process_recordings_device(chains(2), recs[:2], chunk=8192, slot=0, defer=True)
+    second = process_recordings_device(chains(2), recs[2:], chunk=8192, slot=1, defer=True)
+    got = first() + second()
+    for k in range(4):
+        for c in range(len(lines)):
+            for a, b in zip(pk(got[k][c]), pk(want[k][c])):
+                assert np.array_equal(a, b), (k, c)
+    # no room: every row flags it, the executor goes the other way
+    real = lbm.LoopBatch._sliced_room
+
+    def tiny(self, r, nout, slicers, slot):
+        cap, rows, data, steps, recs_ = real(self, r, nout, slicers, slot)
+        return 8, rows, data, steps, recs_
+    monkeypatch.setattr(lbm.LoopBatch, "_sliced_room", tiny)
+    stages = {}
+    again = process_recordings_device(chains(4), recs, chunk=8192, stages=stages)
+    assert not stages.get("fused_slicers")
+    for k in range(4):
+        for c in range(len(lines)):
+            for a, b in zip(pk(again[k][c]), pk(want[k][c])):
+                assert np.array_equal(a, b), (k, c)
