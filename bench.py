@@ -305,7 +305,10 @@ ALSO_CPU_SAMPLE = {"fsk_9600": 4_800_000, "bpsk_300": 1_440_000, "qpsk_2400": 1_
 
 
 LOOP_DISTINCT_BUFFERS = 256    # carrier-loop workloads: distinct resident copies of the recording an engine run's recordings read (14.7 GB)
-LOOPS_IN_FLIGHT = 16384        # carrier loops per engine run: 64 per stepping wave, one stepping wave per CU
+LOOPS_IN_FLIGHT = 16384        # carrier loops per engine run, one-output loops: 256 waves, eight on three of the loops' 96 CUs
+LOOPS_IN_FLIGHT_TWO = 24576    # two-output loops (MPSK, QPSK): 384 waves, three on each of their 128 CUs -- what the sign bitmaps of whole
+                               # recordings (118 GB at 16384 loops) used to forbid; measured 2048 / 2560 / 3072 / 3584 / 4096 recordings of 8
+                               # chains per run: 5.10 / 4.40 / 4.43 / 4.47 / 4.59 ms per step (profiles/r04_loop_sweep.txt)
 
 
 INT8_PEAK_TOPS = 5000.0         # MI355X dense int8 matrix peak: 2x the BF16 rate per clock (MI355X_MICROARCH.md, MFMA table), 2 ops per product
@@ -389,10 +392,10 @@ def also_workloads(args, env, cpu_also=None):
     at full size -- and fsk_9600 is the shortest-tap FIR path.  Never allowed to break the main line."""
     import copy
     out = {}
-    # (the carrier-loop workloads: one full engine run each -- 16384 recordings x 1 chain, 2048 x 8 chains; a run takes as long as
+    # (the carrier-loop workloads: full engine runs -- 16384 recordings x 1 chain, 3072 x 8 chains; a run takes as long as
     # its recordings are, however many there are)
     # -- two runs each, one after the other: the host's share of the first lies beside the GPU's run of the second (loop_steps)
-    for name, steps, warm in (("fsk_9600", 300, 10), ("bpsk_300", 32768, 1), ("qpsk_2400", 4096, 1)):
+    for name, steps, warm in (("fsk_9600", 300, 10), ("bpsk_300", 32768, 1), ("qpsk_2400", 6144, 1)):
         if name == args.workload or (os.environ.get("BENCH_ALSO_ONLY") and name not in os.environ["BENCH_ALSO_ONLY"].split(",")):
             continue
         a = copy.copy(args)
@@ -410,13 +413,13 @@ def also_workloads(args, env, cpu_also=None):
             if d["config"].get("loop_batch"):
                 out[name]["loop_batch"] = d["config"]["loop_batch"]
             if name == "qpsk_2400":
-                # configs[4] has 64 chains: the whole config on ONE GPU, 256 recordings in flight (the same 16384 loops per launch as 2048
+                # configs[4] has 64 chains: the whole config on ONE GPU, 384 recordings in flight (the same 24576 loops per launch as 3072
                 # recordings x 8 chains), for comparison with the 8-chains-per-GPU sharding
                 a64 = copy.copy(a)
-                a64.chains_per_gpu, a64.steps, a64.warmup, a64.loop_batch, a64.loop_chunk = 64, 256, 1, 0, 0
+                a64.chains_per_gpu, a64.steps, a64.warmup, a64.loop_batch, a64.loop_chunk = 64, 384, 1, 0, 0
                 d64 = measure(a64, env)
                 out[name]["all_64_chains_on_one_gpu"] = {"value": d64["value"], "unit": d64["unit"], "ms_per_step": d64["ms_per_step"], "chains_per_gpu": 64,
-                                                         "steps": 256, "loop_batch": d64["config"]["loop_batch"],
+                                                         "steps": 384, "loop_batch": d64["config"]["loop_batch"],
                                                          "gpu_kernel_ms_per_step": d64["gpu_kernel_ms_per_step"], "packets": d64["packets"]}
         except Exception as e:                                   # noqa: BLE001
             out.setdefault(name, {})["error"] = repr(e)[:300]
@@ -499,7 +502,8 @@ def measure(args, env):
     loop_info = None
     if loop_wl:
         from pymodem_amd import loop_batch as lb
-        batch = max(1, min(args.loop_batch or min(16384, LOOPS_IN_FLIGHT // max(len(my), 1)), max(args.steps, 1)))
+        in_flight = LOOPS_IN_FLIGHT_TWO if args.workload in ("qpsk_2400",) and os.environ.get("PYMODEM_AMD_LOOP_FUSED_SLICERS", "1") != "0" else LOOPS_IN_FLIGHT
+        batch = max(1, min(args.loop_batch or min(16384, in_flight // max(len(my), 1)), max(args.steps, 1)))
         if not args.loop_chunk:
             args.loop_chunk = 65536 if batch * len(my) > 8192 else 131072 if batch >= 2048 else 262144
         engine = lb.engine_for([modems[c] for c in my], batch, ctx, args.loop_chunk)
@@ -880,7 +884,7 @@ def measure(args, env):
         # any run of the engine takes as long as its recordings are (the loops are sequential in time): warm up on the first seconds
         if args.warmup:
             loop_steps(min(args.warmup, batch), d_audio.view(0, min(args.samples, 1_500_000)))
-        sides.extend([engine.front, engine.tail] + ([engine.loop] if engine.loop is not None else []))
+        sides.extend([engine.front, engine.tail, engine.slicing] + ([engine.loop] if engine.loop is not None else []))
     else:
         run_steps(args.warmup)
     fence()
@@ -998,6 +1002,7 @@ def measure(args, env):
     if loop_wl:
         sides.remove(engine.front)
         sides.remove(engine.tail)
+        sides.remove(engine.slicing)
         if engine.loop is not None:
             sides.remove(engine.loop)
         lb.close_engines()                                    # the engine's work buffers and bitmap sets (gigabytes) go back

@@ -458,6 +458,7 @@ int pm_rows_gather(pm_ctx *ctx, const pm_rowslice_rec *d_recs, const uint8_t *d_
 pm_ctx *pm_lbatch_front_ctx(pm_lbatch *batch);       /* the engine's own contexts, for pm_prof_*: band-pass, AGC, Hilbert of chunk t + 1 ... */
 pm_ctx *pm_lbatch_tail_ctx(pm_lbatch *batch);        /* ... and the matched filters of chunk t - 1, beside the loops of chunk t on the caller's */
 pm_ctx *pm_lbatch_loop_ctx(pm_lbatch *batch);        /* ... or on the engine's loop context, when the loops have compute units of their own (else NULL) */
+pm_ctx *pm_lbatch_slice_ctx(pm_lbatch *batch);       /* ... and the slicers of a sliced run, beside the matched filters of the next chunk */
 int pm_lbatch_destroy(pm_lbatch *batch);
 
 /* ---- host-integer stages (native C++, no GPU) --------------------------------------------------

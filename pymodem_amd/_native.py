@@ -246,6 +246,7 @@ _SIGS = {
     "pm_lbatch_front_ctx": ([_vp], _vp),
     "pm_lbatch_tail_ctx": ([_vp], _vp),
     "pm_lbatch_loop_ctx": ([_vp], _vp),
+    "pm_lbatch_slice_ctx": ([_vp], _vp),
     "pm_lbatch_destroy": ([_vp], _int),
     "pm_prof_intervals": ([_vp, _int, _vp, _vp, _i64, ctypes.POINTER(_i64)], _int),
     "pm_pipe_create": ([_vp, ctypes.POINTER(PipeDesc), ctypes.POINTER(_vp)], _int),

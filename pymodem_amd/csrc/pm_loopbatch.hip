@@ -45,8 +45,10 @@ struct pm_lbatch {
     pm_bpf8_plan *bpf8 = nullptr;            // the band-pass on the matrix pipe, for the pass that finds the AGC's `normal` (pm_bpf8.hip; PM_BPF8_MAX=0: off)
     unsigned long long *d_keys = nullptr;
     pm_rowslice *rs = nullptr;               // pm_lbatch_run_sliced: the slicers' parameter table ...
-    uint64_t *cbits_i = nullptr, *cbits_q = nullptr;      // ... and ONE chunk of sign bits per stream (rows of cstride words)
-    int64_t cstride = 0;
+    uint64_t *cbits_i = nullptr, *cbits_q = nullptr;      // ... and two chunks of sign bits per stream in rotation (rows of cstride words; set s at
+    int64_t cstride = 0, cset = 0;                        // + s * cset): the slicers of chunk t run on a stream of their own beside the matched
+    pm_ctx *slice = nullptr;                              // filters of chunk t + 1
+    hipEvent_t bits_done[2] = {nullptr, nullptr}, slice_done[2] = {nullptr, nullptr};
     pm_fir8_plan *fir8 = nullptr;            // the output filter as certified signs on the int8 matrix pipe (pm_fir8.hip; PM_FIR8=0: off)
     size_t o_in = 0, o_hil = 0, o_out = 0, o_wave = 0;
     int32_t *d_pd = nullptr;
@@ -118,6 +120,7 @@ int pm_lbatch_destroy(pm_lbatch *b)
     pm_ctx *ctx = b->back;
     if (b->front) (void)pm_ctx_sync(b->front);
     if (b->tail) (void)pm_ctx_sync(b->tail);
+    if (b->slice) (void)pm_ctx_sync(b->slice);
     if (ctx) (void)pm_ctx_sync(ctx);
     for (void *p : {(void *)b->d_taps, (void *)b->d_pd, (void *)b->d_loops, (void *)b->tmp, (void *)b->awin, (void *)b->in0[0], (void *)b->in0[1],
                     (void *)b->in1[0], (void *)b->in1[1], (void *)b->dwin0[0], (void *)b->dwin0[1], (void *)b->dwin1[0], (void *)b->dwin1[1], (void *)b->d_running, (void *)b->d_partial,
@@ -136,6 +139,9 @@ int pm_lbatch_destroy(pm_lbatch *b)
     if (b->loop) (void)pm_ctx_destroy(b->loop);
     if (b->front) (void)pm_ctx_destroy(b->front);
     if (b->tail) (void)pm_ctx_destroy(b->tail);
+    if (b->slice) (void)pm_ctx_destroy(b->slice);
+    for (hipEvent_t e : {b->bits_done[0], b->bits_done[1], b->slice_done[0], b->slice_done[1]})
+        if (e) (void)hipEventDestroy(e);
     delete b;
     return PM_OK;
 }
@@ -198,15 +204,18 @@ int pm_lbatch_create(pm_ctx *ctx, const pm_lbatch_desc *desc, pm_lbatch **out)
             if ((rc = pm_ctx_create_cumask(ctx->device, mine, nw, &b->loop))) break;
             if ((rc = pm_ctx_create_cumask(ctx->device, rest, nw, &b->front))) break;
             if ((rc = pm_ctx_create_cumask(ctx->device, rest, nw, &b->tail))) break;
+            if ((rc = pm_ctx_create_cumask(ctx->device, rest, nw, &b->slice))) break;
             b->loop->tune = ctx->tune;
             hipError_t e1 = hipEventCreateWithFlags(&b->loop_go, hipEventDisableTiming), e2 = hipEventCreateWithFlags(&b->loop_end, hipEventDisableTiming);
             if (e1 != hipSuccess || e2 != hipSuccess) { rc = pm_set_error(PM_ERR_HIP, "hipEventCreate failed"); break; }
         } else {
             if ((rc = pm_ctx_create_prio(ctx->device, 0, &b->front))) break;
             if ((rc = pm_ctx_create_prio(ctx->device, 0, &b->tail))) break;
+            if ((rc = pm_ctx_create_prio(ctx->device, 0, &b->slice))) break;
         }
         b->front->tune = ctx->tune;
         b->tail->tune = ctx->tune;
+        b->slice->tune = ctx->tune;
         b->o_in = put(b->h_taps, d.input_fir, d.n_input_fir);
         if (b->mpsk) b->o_hil = put(b->h_taps, d.hilbert, d.n_hilbert);
         b->o_out = put(b->h_taps, d.output_fir, d.n_output_fir);
@@ -274,6 +283,7 @@ int pm_lbatch_geometry(pm_lbatch *b, int64_t n, int64_t *h_nout, int64_t *h_chun
 pm_ctx *pm_lbatch_front_ctx(pm_lbatch *b) { return b ? b->front : nullptr; }
 pm_ctx *pm_lbatch_tail_ctx(pm_lbatch *b) { return b ? b->tail : nullptr; }
 pm_ctx *pm_lbatch_loop_ctx(pm_lbatch *b) { return b ? b->loop : nullptr; }
+pm_ctx *pm_lbatch_slice_ctx(pm_lbatch *b) { return b ? b->slice : nullptr; }
 
 namespace {
 struct SliceOut {                      // pm_lbatch_run_sliced: where the rows' bytes, steps and records go
@@ -302,7 +312,7 @@ int pm_lbatch_run_sliced(pm_lbatch *b, const int16_t *const *h_d_audio, int reco
     PM_CTX(ctx);
     if (!pm_rowslice_made_for(b->rs, h_params, nparams)) {
         if (b->rs) {                                          // (a run with the old table may still be in flight)
-            if (int rc = pm_ctx_sync(b->tail)) return rc;
+            if (int rc = pm_ctx_sync(b->slice)) return rc;
             pm_rowslice_destroy(b->rs);
             b->rs = nullptr;
         }
@@ -310,7 +320,10 @@ int pm_lbatch_run_sliced(pm_lbatch *b, const int16_t *const *h_d_audio, int reco
     }
     if (!b->cbits_i) {
         b->cstride = b->Lc / 64 + 8;
-        const size_t words = (size_t)b->R * (size_t)b->C * (size_t)b->cstride;
+        b->cset = (int64_t)b->R * b->C * b->cstride;
+        const size_t words = 2 * (size_t)b->cset;
+        for (hipEvent_t *ev : {&b->bits_done[0], &b->bits_done[1], &b->slice_done[0], &b->slice_done[1]})
+            if (!*ev && hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) return pm_set_error(PM_ERR_HIP, "hipEventCreate failed");
         void *q = nullptr;
         if (int rc = pm_malloc(ctx, words * 8, &q)) return rc;
         b->cbits_i = (uint64_t *)q;
@@ -335,7 +348,7 @@ int run_impl(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings, int6
     const bool use_tail = tail_mode != 0;
     pm_ctx *B = b->back, *F = b->front, *Tl = use_tail ? b->tail : b->back;
     pm_ctx *Lp = b->loop ? b->loop : B;                       // the loops' stream (the caller's, or the engine's own on its own compute units)
-    for (pm_ctx *c : {b->front, b->tail, b->loop})            // the caller's switches (pm_ctx_tune) hold for the engine's own contexts too
+    for (pm_ctx *c : {b->front, b->tail, b->loop, b->slice})  // the caller's switches (pm_ctx_tune) hold for the engine's own contexts too
         if (c) c->tune = B->tune;
     PM_CTX(B);
     PM_ARG(recordings >= 1 && recordings <= b->R);
@@ -453,7 +466,10 @@ int run_impl(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings, int6
             }
             PM_HIP(hipEventRecord(b->hist_done[set], Tl->stream));
             const double *f0 = b->dwin0[set] + b->Ho - back;
-            const int64_t word0 = so ? 0 : o0 / 64;            // sliced runs keep one chunk of sign bits, not the recording's
+            // sliced runs keep two chunks of sign bits in rotation, not the recording's: chunk t's go to set t & 1, free once the
+            // slicers of chunk t - 2 are through with it
+            const int64_t word0 = so ? (t & 1) * b->cset : o0 / 64;
+            if (so && t >= 2) PM_HIP(hipStreamWaitEvent(Tl->stream, b->slice_done[t & 1], 0));
             auto signs = [&](const double *f, uint64_t *bits) -> int {
                 // (a row of the output windows: Ho history slots, the chunk, slack up to the pitch -- all of it the engine's own memory)
                 if (b->fir8) return pm_fir8_rows_signs(Tl, b->fir8, f, P, RC, fn, bits + word0, bits_stride, nullptr, P - (b->Ho - back));
@@ -462,9 +478,15 @@ int run_impl(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings, int6
             if (int rc = signs(f0, d_bits_i)) return rc;
             if (b->two_out)
                 if (int rc = signs(b->dwin1[set] + b->Ho - back, d_bits_q)) return rc;
-            if (so)
-                if (int rc = pm_rowslice_chunk(Tl, b->rs, RC, b->two_out ? 1 : 0, d_bits_i, d_bits_q, bits_stride, o0, o1 - o0, so->recs, so->data, so->steps,
-                                               so->cap)) return rc;
+            if (so) {
+                // ... on a stream of their own: a lane per stream and a dependent chain per sample, nothing a matched filter has to wait behind
+                pm_ctx *Sl = b->slice;
+                PM_HIP(hipEventRecord(b->bits_done[t & 1], Tl->stream));
+                PM_HIP(hipStreamWaitEvent(Sl->stream, b->bits_done[t & 1], 0));
+                if (int rc = pm_rowslice_chunk(Sl, b->rs, RC, b->two_out ? 1 : 0, d_bits_i + word0, b->two_out ? d_bits_q + word0 : nullptr, bits_stride, o0,
+                                               o1 - o0, so->recs, so->data, so->steps, so->cap)) return rc;
+                PM_HIP(hipEventRecord(b->slice_done[t & 1], Sl->stream));
+            }
         }
         prev_cnt_l = cnt_l;
         s_agc = e_agc;
@@ -477,6 +499,7 @@ int run_impl(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings, int6
         PM_HIP(hipEventRecord(b->loop_end, Lp->stream));
         PM_HIP(hipStreamWaitEvent(B->stream, b->loop_end, 0));
     }
+    if (so) PM_HIP(hipStreamWaitEvent(B->stream, b->slice_done[(chunks - 1) & 1], 0));      // the last slicers end a sliced run
     // the run is complete on the caller's context once the back stream gets here; the next run waits for this point on both streams
     PM_HIP(hipEventRecord(b->run_done, B->stream));
     b->ran = true;

@@ -109,6 +109,13 @@ class LoopBatch:
             self._loop = Context.borrowed(h, self.ctx.device) if h else False
         return self._loop or None
 
+    @property
+    def slicing(self):
+        """The engine's slicer context (a sliced run's row slicers, beside the matched filters of the next chunk), borrowed, for profile_read()."""
+        if getattr(self, "_slicing", None) is None:
+            self._slicing = Context.borrowed(lib().pm_lbatch_slice_ctx(self._h), self.ctx.device)
+        return self._slicing
+
     def _bits(self, r, nout, slot):
         stride = ((nout + 63) // 64 + 1 + 7) // 8 * 8
         streams = r * self.chains
