@@ -63,6 +63,7 @@ def test_batch_engine_at_full_size(workload, check_ids):
         packets = process_recordings_device(sets, recs, stages=stages)
     finally:
         close_engines()
+    assert stages.get("fused_slicers")          # the slicers ran inside the engine (pm_lbatch_run_sliced): that is the path checked here
     key = lambda pk: [(p.streamaddress, bytes(bytearray(p.data)), p.BytesCorrected) for p in pk]
     for r, rec in enumerate(recs):
         ref_stages = {}
