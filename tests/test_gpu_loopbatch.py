@@ -452,3 +452,45 @@ def test_recordings_executor_deferred_batches_and_the_way_back(monkeypatch):
         for c in range(len(lines)):
             for a, b in zip(pk(again[k][c]), pk(want[k][c])):
                 assert np.array_equal(a, b), (k, c)
+
+
+@pytest.mark.parametrize("cfg,rate", [("bpsk_300.json", 48000), ("qpsk_2400.json", 48000)])
+def test_sliced_runs_on_short_and_unaligned_recordings(cfg, rate):
+    """The edges of a sliced run: recordings barely longer than the chain's filters (one output, a few outputs, one word and a bit), and
+    recordings that do not start on a 16-byte boundary (the engine then finds the AGC's `normal` the reference's way, chunk by chunk):
+    bytes, addresses and end states equal run() + slice_batch."""
+    import pymodem_amd
+    from pymodem_amd import chain_builder as cb
+    from pymodem_amd.loop_batch import LoopBatch
+    from pymodem_amd.slicer import slice_batch
+    ctx = pymodem_amd.Context.default()
+    group = group_modems(cfg, rate, [1500.0, 1510.0])
+    modems = [m for _, m in group]
+
+    def slicers():
+        return [cb.build_chain(rate, line)[2] for line, _ in group]
+    eng = LoopBatch(modems, recordings=3, ctx=ctx, chunk=2048)
+    try:
+        shortest = 1 - eng.geometry(0)[0]                     # samples that give one output
+        for n, shift in [(shortest, 0), (shortest + 5, 0), (shortest + 70, 0), (shortest + 2048 + 3, 0), (9000 + shortest, 3), (9000 + shortest, 5)]:
+            base = [ctx.upload(noise_i16(n + 8, seed=900 + k + n % 97, sigma=4000.0)) for k in range(3)]
+            dev = [b.view(shift, n) for b in base]            # shift != 0: int16 pointers off the 16-byte grid
+            run = eng.run_sliced(dev, slicers())
+            ctx.sync()
+            assert run.ok()
+            got = run.fetch(0, run.rows)
+            bitmaps = eng.run(dev)
+            ctx.sync()
+            assert run.nout == bitmaps[0][0].n and run.nout == n - shortest + 1
+            C = len(group)
+            for k in range(3):
+                sls = slicers()
+                want = slice_batch(sls, [sl.sign_bitmaps(bitmaps[k][c]) for c, sl in enumerate(sls)], ctx)
+                for c in range(C):
+                    g, w = got[k * C + c], want[c]
+                    assert np.array_equal(g.data, w.data) and np.array_equal(g.address, w.address), (cfg, n, shift, k, c)
+                    mine = slicers()[c]
+                    run.state_into(k * C + c, mine)
+                    assert bytes(mine._state) == bytes(sls[c]._state), (cfg, n, shift, k, c)
+    finally:
+        eng.close()
