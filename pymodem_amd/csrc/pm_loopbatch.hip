@@ -204,7 +204,15 @@ int pm_lbatch_create(pm_ctx *ctx, const pm_lbatch_desc *desc, pm_lbatch **out)
             if ((rc = pm_ctx_create_cumask(ctx->device, mine, nw, &b->loop))) break;
             if ((rc = pm_ctx_create_cumask(ctx->device, rest, nw, &b->front))) break;
             if ((rc = pm_ctx_create_cumask(ctx->device, rest, nw, &b->tail))) break;
-            if ((rc = pm_ctx_create_cumask(ctx->device, rest, nw, &b->slice))) break;
+            // The row slicers share the LOOPS' units: those hold three (or fewer) loop waves on four SIMDs, a slicer wave -- a dependent
+            // chain with a word of loads per 64 samples and no LDS -- takes the fourth.  On the filters' units it waited for issue slots
+            // behind their waves (0.82 ms of kernel time per qpsk recording, 0.35 here) and took 7 % of that half's capacity, which is
+            // the half that sets the pace of a 3072-recording qpsk run: engine 3.47-3.49 -> 3.34-3.44 ms per recording (the loops
+            // themselves 2.97 -> 3.16-3.31), bpsk_300 0.611 -> 0.588 (profiles/r04_loop_sweep.txt)
+#ifndef PM_LBATCH_SLICE_ON_LOOP_CUS
+#define PM_LBATCH_SLICE_ON_LOOP_CUS 1
+#endif
+            if ((rc = pm_ctx_create_cumask(ctx->device, PM_LBATCH_SLICE_ON_LOOP_CUS ? mine : rest, nw, &b->slice))) break;
             b->loop->tune = ctx->tune;
             hipError_t e1 = hipEventCreateWithFlags(&b->loop_go, hipEventDisableTiming), e2 = hipEventCreateWithFlags(&b->loop_end, hipEventDisableTiming);
             if (e1 != hipSuccess || e2 != hipSuccess) { rc = pm_set_error(PM_ERR_HIP, "hipEventCreate failed"); break; }
