@@ -20,6 +20,9 @@
 // roundings of the recombination  +  the reference's own (K + 1) u sum|h| 32768: pm_bpf8_error() returns the sum, the sweep adds
 // sqrt2 m times that to the bound of its sliding magnitudes -- 0.1 % of the certified decision's slack, no sample more goes to the
 // exact recomputation, which now starts from the audio (sweep_exact_kernel<true>).
+//
+// Second consumer (round 4): the carrier-loop engine's max(band-passed recording) (bpf8_max_kernel below) -- up to 241 taps (four
+// 64-column blocks of the band instead of three) and two tap digits (its values only choose candidates; the reference's sum decides).
 #include "pm_common.h"
 #include <cmath>
 #include <cstring>
