@@ -494,3 +494,38 @@ def test_sliced_runs_on_short_and_unaligned_recordings(cfg, rate):
                     assert bytes(mine._state) == bytes(sls[c]._state), (cfg, n, shift, k, c)
     finally:
         eng.close()
+
+
+def test_sliced_run_of_the_qpsk_modem():
+    """QPSKModem (psk.py:197-476: one input, two low-passed arms) through a sliced run with a quadrature slicer: bytes, addresses and
+    end states equal run() + slice_batch."""
+    import pymodem_amd
+    from pymodem_amd import chain_builder as cb
+    from pymodem_amd.loop_batch import LoopBatch
+    from pymodem_amd.slicer import slice_batch
+    ctx = pymodem_amd.Context.default()
+    spec = {"type": "qpsk", "config": "2400", "options": {}}
+    modems = [cb.ModemConfigurator(48000, spec)]
+
+    def slicers():
+        return [cb.SlicerConfigurator(48000, {"type": "quadrature", "config": "qpsk_2400", "options": {}})]
+    recs = [noise_i16(20011, seed=17 + k, sigma=3000.0) for k in range(3)]
+    eng = LoopBatch(modems, recordings=3, ctx=ctx, chunk=4096)
+    try:
+        dev = [ctx.upload(r) for r in recs]
+        run = eng.run_sliced(dev, slicers())
+        ctx.sync()
+        assert run.ok()
+        got = run.fetch(0, run.rows)
+        bitmaps = eng.run(dev)
+        ctx.sync()
+        for k in range(3):
+            sls = slicers()
+            want = slice_batch(sls, [sls[0].sign_bitmaps(bitmaps[k][0])], ctx)[0]
+            assert len(want.data) > 100
+            assert np.array_equal(got[k].data, want.data) and np.array_equal(got[k].address, want.address), k
+            mine = slicers()[0]
+            run.state_into(k, mine)
+            assert bytes(mine._state) == bytes(sls[0]._state), k
+    finally:
+        eng.close()
