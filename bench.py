@@ -316,8 +316,9 @@ INT8_PEAK_TOPS = 5000.0         # MI355X dense int8 matrix peak: 2x the BF16 rat
 
 def matrix_roofline(native, args, modems, my, prof):
     """The native executor's certified sums as what they are since round 3: int8 products on the matrix pipe.  Algorithmic products per
-    launch = taps x (sample digits x tap digits) x outputs -- 2 x 6 for the band-pass, 4 x 5 per low-pass stream -- against the launch
-    times of the same HIP-event profile (in the pipeline, beside the other stream's kernels and the slicers)."""
+    launch = taps x digit pairs x outputs, the digit pairs as the LIBRARY reports them from its kernels' own constants
+    (pm_matrix_digit_pairs: 2 x 4 for the band-pass, 8 of 3 x 3 per low-pass stream since round 4) -- against the launch times of the
+    same HIP-event profile (in the pipeline, beside the other stream's kernels and the slicers)."""
     try:
         if not native or args.workload != "afsk_1200_super_opt" or os.environ.get("PM_PIPE_LPF8") == "0":
             return None
@@ -328,8 +329,12 @@ def matrix_roofline(native, args, modems, my, prof):
             key = modems[c].mark_key() if hasattr(modems[c], "mark_key") else c
             sweeps[key] = sweeps.get(key, 0) + 1
         streams = sum(2 if cnt > 1 else 1 for cnt in sweeps.values())            # low-pass streams per recording: two per sweep, one per lone chain
-        lp_ops, bp_ops = 2.0 * 20 * ml * n * streams, 2.0 * 12 * mb * n
-        out = {"bound": "mfma", "peak": INT8_PEAK_TOPS, "unit": "TOP/s",
+        from pymodem_amd import lib
+        bp_pairs, lp_pairs = lib().pm_matrix_digit_pairs(0), lib().pm_matrix_digit_pairs(1)
+        if bp_pairs <= 0 or lp_pairs <= 0:
+            return {"error": "pm_matrix_digit_pairs"}
+        lp_ops, bp_ops = 2.0 * lp_pairs * ml * n * streams, 2.0 * bp_pairs * mb * n
+        out = {"bound": "mfma", "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "digit_pairs": {"band_pass": bp_pairs, "low_pass_per_stream": lp_pairs},
                "note": "int8 digit products of the certified sums (exact int32 accumulation, v_mfma_i32_16x16x64_i8), 2 ops per product, per "
                        "recording / the class's summed launch time per recording; a micro-benchmark of the instruction alone sustains 2 830 TOP/s "
                        "on this chip (tools/ubench/mfma_i8.hip); the kernels also run their sliding sums, digit split, recombination and "
@@ -1139,7 +1144,7 @@ def measure(args, env):
                               "note": "2 flops per fma of the FIR sums (epilogue sqrt / sign tests not counted) / the same HIP-event time; "
                                       "sustained_peak_measured is the rate a pure v_fma_f64 register loop holds on this chip (clock under f64 load)"
                                       + ("; NATIVE EXECUTOR: the low-pass and band-pass sums counted here are computed as int8 digit products on "
-                                         "the matrix pipe (20 resp. 12 int8 products per tap and sample, exact, recombined in f64): `achieved` is "
+                                         "the matrix pipe (8 resp. 8 int8 digit products per tap and sample -- roofline_matrix.digit_pairs -- exact, recombined in f64): `achieved` is "
                                          "the rate of the f64 sums they stand for, an EQUIVALENT rate -- it may exceed what the vector pipe "
                                          "sustains and is not a utilisation of it" if native_exec[0] else "")},
             "roofline_matrix": matrix_roofline(native_exec[0], args, modems, my, prof),

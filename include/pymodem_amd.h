@@ -120,6 +120,10 @@ int pm_fir_valid_i16_limbs(pm_ctx *ctx, const int16_t *d_x, int64_t n, const dou
  * over ALL 2^24 binary32 values of the binades 2^exponent and 2^(exponent + 1), in units of the result's last place x 1024 (rounded up),
  * against the correctly rounded binary64 root.  Test entry. */
 int pm_ubench_sqrt_f32(pm_ctx *ctx, int exponent, int64_t *h_worst_ulp_1024);
+/* int8 digit products (v_mfma_i32_16x16x64_i8 operand pairs) per tap and output that the matrix-pipe kernels compute: stage 0 = the
+ * certified sweeps' band-pass (sample digits x tap digits), 1 = their low-pass, per stream, 2 = the batch engine's matched filters.
+ * From the kernels' own constants: what a measurement prices their launches with.  < 0: no such stage. */
+int pm_matrix_digit_pairs(int stage);
 /* max(numpy.convolve(row, h, 'valid')) per row -- AGC.apply's `normal` (agc.py:67) over the band-passed recording (psk.py:165, :710) --
  * WITHOUT writing the band-passed rows: matrix-pipe values with the bound above pick the outputs that could be the maximum, the
  * reference's own sum (one fma per tap, ascending input index) decides among them; h_max[r] is bit for bit max() of pm_fir_valid_i16.

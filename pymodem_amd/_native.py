@@ -219,6 +219,7 @@ _SIGS = {
     "pm_fir_rows_f64": ([_vp, _vp, _i64, _int, _i64, _vp, _int, _vp, _i64, _int], _int),
     "pm_fir_rows_signs_f64": ([_vp, _vp, _i64, _int, _i64, _vp, _int, _vp, _i64, _int], _int),
     "pm_ubench_sqrt_f32": ([_vp, _int, ctypes.POINTER(_i64)], _int),
+    "pm_matrix_digit_pairs": ([_int], _int),
     "pm_bpf8_rows_max_i16": ([_vp, _vp, _i64, _int, _i64, _vp, _int, _vp, ctypes.POINTER(_i64)], _int),
     "pm_fir8_rows_signs_f64": ([_vp, _vp, _i64, _int, _i64, _vp, _int, _vp, _i64, ctypes.POINTER(_i64)], _int),
     "pm_afsk_correlate": ([_vp, _vp, _i64, _vp, _vp, _vp, _vp, _int, _vp], _int),

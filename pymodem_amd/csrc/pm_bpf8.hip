@@ -348,6 +348,7 @@ void pm_bpf8_plan_destroy(pm_bpf8_plan *p)
 }
 
 double pm_bpf8_error(const pm_bpf8_plan *p) { return p ? p->err : 0.0; }
+int pm_bpf8_digit_pairs(void) { return 2 * kMaxDigits; }      // tile_values: two sample digits x the tap digits of the sweeps' plan, every pair computed
 int pm_bpf8_taps(const pm_bpf8_plan *p) { return p ? p->m : 0; }
 
 int pm_bpf8_run(pm_ctx *ctx, const pm_bpf8_plan *p, const int16_t *d_audio, int64_t n, double *d_y, int *d_clear, int nclear)

@@ -12,11 +12,15 @@ constexpr int kSweepRing = 64;
 constexpr int kSweepCap = 65536;        // uncertain (sample, modem) pairs a certified sweep's list holds; more: the exact chains take over
 
 // Counter and mailbox words of the certified sweeps of ONE recording, owned by whoever runs recordings side by side (pm_pipe.hip):
-// sweep k counts its uncertain samples in d_count[k] and its last launch leaves the count in the page-locked h_mail[k].  The
-// words belong to the recording from its submission until its owner has read the mail -- no ring, no arithmetic on sequence numbers.
+// sweep k counts the uncertain samples it could not decide itself in d_count[k], and the count arrives in the page-locked h_mail[k]
+// when the recording's demod stage has finished.  With d_list (round 5) a matrix-pipe sweep decides its uncertain samples inside its
+// workgroups and only what a workgroup could not take goes to d_list[k * kSweepCap ..], with no launch behind the sweep: the owner
+// runs pm_afsk_sweep_exact_list over a list that is not empty.  The words belong to the recording from its submission until its
+// owner is through with them -- no ring, no arithmetic on sequence numbers.
 struct pm_sweep_cells {
-    int *d_count = nullptr;
-    int *h_mail = nullptr;
+    int *d_count = nullptr;                 // nsweeps words, zero when the recording's demod stage starts (pm_bpf8_run clears them)
+    int *h_mail = nullptr;                  // nsweeps words
+    unsigned long long *d_list = nullptr;   // nullptr (every sweep ends with a launch that works its list off), or nsweeps * kSweepCap entries
 };
 
 // Diagnostic switches of the launchers: read from the environment ONCE, when a context is made (pm_tuning_from_env in
@@ -39,6 +43,7 @@ struct pm_tuning {
     int loop_vec = 1;                  // PM_LOOP_VEC=0: the direct loop shape moves its blocks with eight-byte accesses, a lane a row
     int lbatch_loop_cus = -1;          // PM_LBATCH_LOOP_CUS: compute units the batch engine's carrier loops have to themselves (0: none, -1: by size)
     int agc_rows_prio = 2;             // PM_AGC_ROWS_PRIO: wave priority of the rows AGC (the loops run at 3)
+    int sweep_no_tail = 0;             // PM_SWEEP_NO_TAIL: the matrix-pipe sweep sends every uncertain sample to the list (round 4), none to its own workgroup's exact chain
 };
 pm_tuning pm_tuning_from_env();
 
@@ -119,6 +124,8 @@ int pm_bpf8_plan_create(pm_ctx *ctx, const double *h_taps, int m, pm_bpf8_plan *
 int pm_bpf8_max_digits(void);      // PM_ERR_ARG: more than 241 taps
 void pm_bpf8_plan_destroy(pm_bpf8_plan *p);
 double pm_bpf8_error(const pm_bpf8_plan *p);
+int pm_bpf8_digit_pairs(void);     // int8 digit products per tap and output of bpf8_kernel (and of fir8_kernel: pm_fir8_digit_pairs)
+int pm_fir8_digit_pairs(void);
 int pm_bpf8_taps(const pm_bpf8_plan *p);
 // d_audio 16-byte aligned; d_clear: nclear (<= 64) ints the launch zeroes (a recording's sweep counters: the band-pass is the first
 // launch of its demod stage, the sweeps behind it on the same stream start from zero without a memset of their own)
@@ -146,6 +153,10 @@ void pm_lpf8_plan_destroy(pm_lpf8_plan *p);
 int pm_afsk_group_run_plan(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const double *d_bpf, int mb, double *d_bpf_out, double x_bound,
                            const pm_afsk_sweep_desc *h_sweeps, int nsweeps, int64_t *h_tickets, const pm_bpf8_plan *plan,
                            const pm_lpf8_plan *const *lpf8 = nullptr, const pm_sweep_cells *cells = nullptr);
+// The exact chain (afsk.py:151-166, canonical order) for the (sample, modem) pairs of a sweep's list: min(*d_count, kSweepCap) entries of
+// d_list, bits into h_bits[modem].  d_audio / d_bpf / mb: where the sweep's input came from (pm_afsk_group_run_plan with a plan).
+int pm_afsk_sweep_exact_list(pm_ctx *ctx, const int16_t *d_audio, const double *d_bpf, int mb, const pm_afsk_sweep_desc *w, uint64_t *const *h_bits,
+                             const unsigned long long *d_list, const int *d_count);
 
 // pm_codec_fetch_batch into rows whose payload fields are already zero wherever a packet will not write (pm_pipe.hip keeps its row blocks
 // that way): per packet the bytes it has, not the 1280 of the field

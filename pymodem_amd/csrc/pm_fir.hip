@@ -969,6 +969,81 @@ __global__ __launch_bounds__(kThreads) void afsk_slide_lpf_kernel(const double *
     sweep_combine<R, ONE>(a, b, go, nout, G, P, E, list, count, cap);
 }
 
+// The exact chain for single samples needs to know where the sweep's input came from.  AUDIO (src.audio != nullptr): the band-passed
+// stream the sweep saw was itself a value with a bound (pm_bpf8.hip), so the recomputation starts one stage earlier -- the mc + ml - 1
+// band-pass outputs under the entry from the int16 audio, the reference's sum in fir_valid_kernel's order.
+struct SweepSource {
+    const int16_t *audio;            // nullptr: d_x is the reference's band-passed stream
+    const double *bpf;
+    int mb;
+    double e_x;                      // |d_x[k] - reference's band-pass output|
+};
+
+// What the fused matrix-pipe kernel needs to decide its own uncertain samples (round 5): the exact chain's operands.
+struct SweepTail {
+    const double *space;             // the modems' own space taps (gain folded in, afsk.py:144-145): modem g at space + 2 g mc
+    const double *lpf;               // the low-pass taps in binary64
+    int lds_ok;                      // the exact chain's work space fits the kernel's LDS image: uncertain samples are decided in place
+    SweepSource src;
+};
+constexpr int kTailCap = 48;         // uncertain (sample, modem) pairs a workgroup decides itself (0.06 per workgroup on average); more go to the list
+
+// The exact chain of ONE (sample, modem) pair by a whole workgroup, every sum in the canonical order of fir_valid_kernel /
+// afsk_correlate_kernel (= sweep_exact_kernel below, value for value): the mc + ml - 1 band-pass outputs under the entry (one thread
+// each, from the audio; or read from x), the ml correlator-bank outputs (one thread each, four sums side by side), the low-pass sum
+// (thread 0).  `dd`: (2 ml + 2 mc + 2 mb - 2 + 4 mc + ...) doubles of LDS nobody else uses any more.  Ends with a barrier.
+template <int THREADS>
+__device__ __forceinline__ void sweep_tail_entry(double *__restrict__ dd, int t, const double *__restrict__ x, const double *__restrict__ mi,
+                                                 const double *__restrict__ mq, const double *__restrict__ si, const double *__restrict__ sq, int mc,
+                                                 const double *__restrict__ lpf, int ml, const SweepSource &src, int64_t k, unsigned long long *__restrict__ bits)
+{
+    const int nw = ml + mc - 1, mb = src.audio ? src.mb : 0, na = src.audio ? nw + mb - 1 : 0;
+    double *xw = dd + ml, *aw = xw + nw, *tb = aw + na, *tc = tb + mb, *tl = tc + 4 * mc;
+    if (src.audio) {
+        for (int p = t; p < na; p += THREADS) aw[p] = (double)src.audio[k + p];
+        for (int i = t; i < mb; i += THREADS) tb[i] = src.bpf[mb - 1 - i];
+    } else {
+        for (int p = t; p < nw; p += THREADS) xw[p] = x[k + p];
+    }
+    for (int i = t; i < mc; i += THREADS) {
+        tc[4 * i + 0] = mi[mc - 1 - i];
+        tc[4 * i + 1] = mq[mc - 1 - i];
+        tc[4 * i + 2] = si[mc - 1 - i];
+        tc[4 * i + 3] = sq[mc - 1 - i];
+    }
+    for (int i = t; i < ml; i += THREADS) tl[i] = lpf[ml - 1 - i];
+    __syncthreads();
+    if (src.audio) {
+        for (int p = t; p < nw; p += THREADS) {
+            double acc = 0.0;
+            for (int i = 0; i < mb; ++i) acc = __builtin_fma(tb[i], aw[p + i], acc);
+            xw[p] = acc;
+        }
+        __syncthreads();
+    }
+    for (int j = t; j < ml; j += THREADS) {
+        double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+        for (int i = 0; i < mc; ++i) {
+            const double v = xw[j + i];
+            a = __builtin_fma(tc[4 * i + 0], v, a);
+            b = __builtin_fma(tc[4 * i + 1], v, b);
+            c = __builtin_fma(tc[4 * i + 2], v, c);
+            d = __builtin_fma(tc[4 * i + 3], v, d);
+        }
+        dd[j] = __builtin_sqrt(a * a + b * b) - __builtin_sqrt(c * c + d * d);
+    }
+    __syncthreads();
+    if (t == 0) {
+        double acc = 0.0;
+        for (int j = 0; j < ml; ++j) acc = __builtin_fma(tl[j], dd[j], acc);
+        unsigned long long *w = bits + (k >> 6);
+        const unsigned long long bit = 1ull << (k & 63);
+        if (acc >= 0.0) atomicOr(w, bit); else atomicAnd(w, ~bit);
+    }
+    __syncthreads();
+}
+inline size_t sweep_tail_doubles(int mc, int ml, int mb) { return (size_t)2 * ml + (size_t)(ml + mc - 1) * 2 + 2 * (size_t)mb + 4 * (size_t)mc; }
+
 // The same kernel with its low-passes on the int8 matrix pipe (v_mfma_i32_16x16x64_i8; the band-pass went there first: pm_bpf8.hip).
 // The low-pass sums are 2/3 of afsk_slide_lpf_kernel's vector instructions and feed nothing but the certified decision, and the int8
 // MFMA is the one matrix instruction that was measured to run BESIDE vector f64 work (tools/ubench/mfma_i8.hip).  So: the magnitudes a
@@ -1012,7 +1087,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PM_LPF
                                                                    const double *__restrict__ mq, const double *__restrict__ ui,
                                                                    const double *__restrict__ uq, int m, SlideTones T, Lpf8Args Q, int ml,
                                                                    int64_t nout, int G, SweepArgs P, double E, unsigned long long *__restrict__ list,
-                                                                   int *__restrict__ count, int cap, int region0)
+                                                                   int *__restrict__ count, int cap, int region0, SweepTail TL)
 {
     extern __shared__ double xs[];
     constexpr int L = kFuseRun, TILE = kThreads * 8;
@@ -1020,6 +1095,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PM_LPF
     const int64_t tile0 = (int64_t)blockIdx.x * TILE;
     const int nmag = TILE + ml - 1, nruns = (nmag + L - 1) / L, xspan = nruns * L + m - 1;
     double *tp = xs + region0;
+    // the workgroup's own list of uncertain (sample, modem) pairs, decided by the exact chain before the workgroup ends (sweep_tail_entry):
+    // behind the band operands in the dynamic block -- as a static array it moved the block's start off its 16-byte boundary (232 bytes
+    // of static LDS) and every ds_read_b128 of the planes went the slow way: this kernel 0.33 -> 1.4 ms in the pipeline
+    unsigned *const wl = reinterpret_cast<unsigned *>(reinterpret_cast<int4v *>(tp + 4 * m) + 2 * kL8Dig * 64);
+    unsigned &wl_n = wl[kTailCap];
+    if (t == 0) wl_n = 0;
     if (((uintptr_t)x & 15) == 0 && tile0 + TILE <= n) {
         double2v v[4];
 #pragma unroll
@@ -1235,11 +1316,28 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PM_LPF
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
                     if (16 * v < lim && !(fabs(y[v]) > Ecmp)) {
-                        const int idx = atomicAdd(count, 1);
-                        if (idx < cap) list[idx] = ((unsigned long long)g << 48) | (unsigned long long)(go + 64 * g4 + 16 * v + r);
+                        const unsigned mine = TL.lds_ok ? atomicAdd(&wl_n, 1u) : (unsigned)kTailCap;
+                        if (mine < (unsigned)kTailCap) {
+                            wl[mine] = ((unsigned)g << 16) | (unsigned)(tl + 64 * g4 + 16 * v + r);
+                        } else {
+                            const int idx = atomicAdd(count, 1);
+                            if (idx < cap) list[idx] = ((unsigned long long)g << 48) | (unsigned long long)(go + 64 * g4 + 16 * v + r);
+                        }
                     }
             }
         }
+    }
+    // The workgroup's own uncertain samples, by the reference's chain, here: one in sixteen workgroups has one (750 + 220 per recording of
+    // 28 000 workgroups), and it costs that workgroup a few microseconds -- as a launch of its own behind this one the same work sat on the demod
+    // stream's critical path, twice per recording, waiting for slots among the other stream's workgroups (86 us per launch against 11 alone).
+    __syncthreads();                                         // (vmcnt too: this workgroup's bitmap words are in memory before an atomic touches them)
+    const int ne = (int)(wl_n < (unsigned)kTailCap ? wl_n : (unsigned)kTailCap);
+    for (int e = 0; e < ne; ++e) {
+        const unsigned ent = wl[e];
+        const int g = (int)(ent >> 16);
+        const double *si = TL.space + (size_t)g * 2 * m;
+        sweep_tail_entry<kThreads>(xs, t, x, mi, mq, si, si + m, m, TL.lpf, ml, TL.src, tile0 + (int64_t)(ent & 0xFFFFu),
+                                   reinterpret_cast<unsigned long long *>(P.bits[g]));
     }
 }
 
@@ -1247,12 +1345,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PM_LPF
 // sum in the canonical order of afsk_correlate_kernel / fir_valid_kernel.  Runs after fir_sweep_kernel (its bitmap bytes are final).
 // AUDIO: the band-passed stream the sweep saw was itself a value with a bound (pm_bpf8.hip), so the recomputation starts one stage
 // earlier -- the mc + ml - 1 band-pass outputs under the entry from the int16 audio, the reference's sum in fir_valid_kernel's order.
-struct SweepSource {
-    const int16_t *audio;            // nullptr: d_x is the reference's band-passed stream
-    const double *bpf;
-    int mb;
-    double e_x;                      // |d_x[k] - reference's band-pass output|
-};
 template <bool AUDIO>
 __global__ __launch_bounds__(64) void sweep_exact_kernel(const double *__restrict__ x, const double *__restrict__ mi, const double *__restrict__ mq,
                                                          const double *__restrict__ space, int mc, const double *__restrict__ lpf, int ml,
@@ -1353,6 +1445,12 @@ __global__ __launch_bounds__(64) void sweep_exact_kernel(const double *__restric
         }
         __syncthreads();
     }
+}
+
+__global__ void sweep_mail_kernel(const int *__restrict__ count, int *__restrict__ mail, int n)
+{
+    if ((int)threadIdx.x < n) mail[threadIdx.x] = count[threadIdx.x];
+    __threadfence_system();
 }
 
 // One 64-bit word per wave per step: lane l tests sample 64*w + l, the ballot is the word.
@@ -1737,9 +1835,15 @@ constexpr int kExactGrid = 4096;
 static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound, const double *d_mark_i, const double *d_mark_q,
                        const double *d_unit_i, const double *d_unit_q, const double *d_space, const double *h_gains, int groups, int m,
                        const double *d_lpf, int ml, double lpf_abs_sum, uint64_t *const *h_bits, const pm_afsk_tones *tones,
-                       const SweepSource *src = nullptr, const pm_lpf8_plan *lpf8 = nullptr, int *own_count = nullptr, int *own_mail = nullptr)
+                       const SweepSource *src = nullptr, const pm_lpf8_plan *lpf8 = nullptr, int *own_count = nullptr, int *own_mail = nullptr,
+                       unsigned long long *own_list = nullptr)
 {
     PM_CTX(ctx);
+    // own_list (with own_count): the recording's own list of kSweepCap entries -- a sweep on the matrix pipe then decides its uncertain
+    // samples inside its workgroups, counts what did not fit (normally nothing) in own_count, NO launch follows it and own_mail is not
+    // written: the caller mails the counters of all the recording's sweeps at once (sweep_mail_kernel) and whoever reads the mail runs
+    // pm_afsk_sweep_exact_list over a list that is not empty
+    PM_ARG(!own_list || own_count);
     // own_count / own_mail: the caller's counter and mailbox word for this sweep (pm_sweep_cells: zeroed by an earlier launch on this
     // stream, read by the caller when the stream has passed this sweep); the context's ring stays where it is
     PM_ARG((own_count == nullptr) == (own_mail == nullptr) && (!own_count || ctx->sweep_deferred));
@@ -1773,7 +1877,7 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
     if (int rc = pm_scratch_reserve(ctx, 2 * b_m + b_a + b_list + 256 + b_w + b_c)) return rc;
     char *base = (char *)ctx->d_scratch;
     double *M = (double *)base, *S = (double *)(base + b_m), *A = (double *)(base + 2 * b_m);
-    unsigned long long *list = (unsigned long long *)(base + 2 * b_m + b_a);
+    unsigned long long *list = own_list ? own_list : (unsigned long long *)(base + 2 * b_m + b_a);
     // The counter of uncertain samples lives in a small ring of its own (not in the scratch block, which the next call on this
     // context re-carves and may re-allocate: pm_afsk_sweep_last reads it later).  All slots start at zero; the last launch of a
     // sweep clears the slot the next sweep will use, so there is no memset on the stream.
@@ -1854,19 +1958,25 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
         const int nmag = kThreads * 8 + ml - 1, nruns = (nmag + kFuseRun - 1) / kFuseRun, pspan = nruns * kFuseRun + m - 1;
         const size_t xdoubles = (size_t)pspan + pspan / kFuseRun + 2, pdoubles = (size_t)(one ? 1 : 2) * kL8Dig * kL8Plane / 8;
         const int region0 = (int)((std::max(xdoubles, pdoubles) + 1) / 2 * 2);
-        const size_t lds = ((size_t)region0 + 4 * (size_t)m) * sizeof(double) + 2 * kL8Dig * 64 * 16;      // x window | planes, templates, band operands
+        const size_t lds = ((size_t)region0 + 4 * (size_t)m) * sizeof(double) + 2 * kL8Dig * 64 * 16 + (kTailCap + 4) * sizeof(unsigned);      // x window | planes, templates, band operands, the workgroup's list
         PmProf prof(ctx, PM_K_FIR_F64);
         const double nlp = one ? 1.0 : 2.0;
         prof.work((double)n * 8 + (double)groups * nl / 8,
                   (4.0 * m / kFuseRun + 18.0) * (double)nc + nlp * 2.0 * ml * (double)nl + 2.0 * groups * (double)nl);
+        SweepTail TL;
+        TL.space = d_space;
+        TL.lpf = d_lpf;
+        TL.src = src ? *src : SweepSource{nullptr, nullptr, 0, 0.0};
+        TL.lds_ok = sweep_tail_doubles(m, ml, src ? src->mb : 0) <= (size_t)region0 && !ctx->tune.sweep_no_tail;
         auto go8 = [&](auto kernel) -> int {
             if (int rc = allow_lds(kernel, lds)) return rc;
             hipLaunchKernelGGL(kernel, dim3((unsigned)ntiles), dim3(kThreads), lds, ctx->stream, d_x, n, d_mark_i, d_mark_q, d_unit_i, d_unit_q, m, T,
-                               Q, ml, nl, groups, P, E, list, count, cap, region0);
+                               Q, ml, nl, groups, P, E, list, count, cap, region0, TL);
             return PM_OK;
         };
         if (int rc = one ? go8(afsk_slide_lpf8_kernel<true>) : go8(afsk_slide_lpf8_kernel<false>)) return rc;
         PM_HIP(hipGetLastError());
+        if (own_list) { ring.ok = true; return PM_OK; }      // nothing follows on this stream: the caller mails the count
     } else if (fused) {
         PM_ARG(tones->tap_dev >= 0.0 && tones->tap_dev < 1e-6);
         SlideTones T{tones->mark_rot[0], tones->mark_rot[1], tones->mark_end[0], tones->mark_end[1],
@@ -2042,10 +2152,18 @@ int pm_afsk_group_run_plan(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const
         const pm_afsk_sweep_desc &w = h_sweeps[k];
         rc = sweep_signs(ctx, d_bpf_out, n - mb + 1, x_bound, w.d_mark_i, w.d_mark_q, w.d_unit_i, w.d_unit_q, w.d_space, w.h_gains, w.groups, w.m,
                          w.d_lpf, w.ml, w.lpf_abs_sum, w.h_bits, w.h_tones, plan ? &src : nullptr, lpf8 ? lpf8[k] : nullptr,
-                         cells ? cells->d_count + k : nullptr, cells ? cells->h_mail + k : nullptr);
+                         cells ? cells->d_count + k : nullptr, cells ? cells->h_mail + k : nullptr,
+                         cells && cells->d_list ? cells->d_list + (size_t)k * kSweepCap : nullptr);
         if (h_tickets && !cells) h_tickets[k] = ctx->sweep_seq - 1;
     }
     ctx->sweep_deferred = was;
+    if (rc == PM_OK && cells && cells->d_list) {
+        // One wave behind the recording's last sweep leaves every sweep's count in its page-locked word (a sweep that ended with a launch
+        // of its own has written the same value there already).  Round 4 had a 4096-workgroup launch between and behind the sweeps for
+        // this and the recomputation: 0.23 ms per recording of the demod streams' time.
+        hipLaunchKernelGGL(sweep_mail_kernel, dim3(1), dim3(64), 0, ctx->stream, cells->d_count, cells->h_mail, nsweeps);
+        if (hipGetLastError() != hipSuccess) rc = pm_set_error(PM_ERR_HIP, "pm_afsk_group_run: mailing the sweeps' counts failed");
+    }
     if (trace) {
         const auto t_2 = std::chrono::steady_clock::now();
         acc_us[0] += std::chrono::duration<double, std::micro>(t_1 - t_0).count();
@@ -2056,6 +2174,26 @@ int pm_afsk_group_run_plan(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const
         }
     }
     return rc;
+}
+
+int pm_afsk_sweep_exact_list(pm_ctx *ctx, const int16_t *d_audio, const double *d_bpf, int mb, const pm_afsk_sweep_desc *w, uint64_t *const *h_bits,
+                             const unsigned long long *d_list, const int *d_count)
+{
+    PM_CTX(ctx);
+    PM_ARG(d_audio && d_bpf && mb >= 1 && w && h_bits && d_list && d_count && w->groups >= 1 && w->groups <= kSweepMax);
+    SweepArgs P;
+    memset(&P, 0, sizeof(P));
+    for (int g = 0; g < w->groups; ++g) {
+        PM_ARG(h_bits[g] != nullptr);
+        P.gain[g] = w->h_gains[g];
+        P.bits[g] = h_bits[g];
+    }
+    PmProf prof(ctx, PM_K_SIGNS);
+    hipLaunchKernelGGL(sweep_exact_kernel<true>, dim3(kExactGrid), dim3(64), (size_t)(4 * w->ml + 6 * w->m + 2 * mb - 3) * sizeof(double), ctx->stream, (const double *)nullptr,
+                       w->d_mark_i, w->d_mark_q, w->d_space, w->m, w->d_lpf, w->ml, P, d_list, d_count, kSweepCap, (int *)nullptr, (int *)nullptr,
+                       SweepSource{d_audio, d_bpf, mb, 0.0});
+    PM_HIP(hipGetLastError());
+    return PM_OK;
 }
 
 extern "C" {
@@ -2150,6 +2288,17 @@ __global__ __launch_bounds__(256) void sqrt_f32_ulp_kernel(int e, unsigned long 
     if ((threadIdx.x & 63) == 0) atomicMax(worst, mine);
 }
 }  // namespace
+
+// int8 digit products per tap and output of the matrix-pipe kernels, from the kernels' own constants (bench.py prices the launches with them)
+extern "C" int pm_matrix_digit_pairs(int stage)
+{
+    switch (stage) {
+    case 0: return pm_bpf8_digit_pairs();                    // bpf8_kernel: the certified sweeps' band-pass
+    case 1: return kL8Dig * kL8Dig - 1;                      // afsk_slide_lpf8_kernel, per low-pass stream: all pairs but x0 q0
+    case 2: return pm_fir8_digit_pairs();                    // fir8_kernel: the batch engine's matched filters
+    default: return pm_set_error(PM_ERR_ARG, "pm_matrix_digit_pairs: no stage %d", stage);
+    }
+}
 
 extern "C" int pm_ubench_sqrt_f32(pm_ctx *ctx, int exponent, int64_t *h_worst_ulp_1024)
 {

@@ -373,6 +373,7 @@ void pm_fir8_plan_destroy(pm_fir8_plan *p)
     delete p;
 }
 
+int pm_fir8_digit_pairs(void) { return kDig * (kDig + 1) / 2; }      // fir8_kernel: the products of weight 256^(kDig - 1) and up
 int pm_fir8_taps(const pm_fir8_plan *p) { return p ? p->m : 0; }
 
 int pm_fir8_rows_signs(pm_ctx *ctx, const pm_fir8_plan *p, const double *d_x, int64_t x_stride, int rows, int64_t n, uint64_t *d_bits,

@@ -134,8 +134,10 @@ struct pm_pipe {
     // per-recording counter / mailbox words of the certified sweeps: block k = words [k * nsweeps, (k + 1) * nsweeps) of both
     // arrays; a block is the recording's from pm_pipe_submit until its slicer worker has read the mail, then back on the free list
     int *d_cells = nullptr, *h_cells = nullptr;
+    unsigned long long *d_lists = nullptr;               // per block: nsweeps lists of kSweepCap entries (what a matrix-pipe sweep's workgroups did not decide themselves)
     std::vector<int> free_cells;
     bool keep_slices = false, trace = false;
+    bool skip_decode = false;            // PM_PIPE_SKIP_DECODE (diagnosis only): the host stage decodes nothing -- what the GPU stages alone sustain
     int64_t next_ticket = 0, submitted = 0, finished = 0;   // submitted: tickets handed out (each is in `results` from then on)
     int64_t promised = 0;                // pm_pipe_submit_many: tickets below this will exist; pm_pipe_wait waits for them to
     bool promise_failed = false;
@@ -267,7 +269,8 @@ void slice_worker(pm_pipe *p, int wi)
                 batch.push_back(p->slice_q.front());
                 p->slice_q.pop_front();
             }
-            (void)hipEventSynchronize(batch[0]->demod_done);
+            // (a demod stream that faulted: the recording's mailbox words hold whatever the block's last user left -- its bitmaps are not sliced)
+            if (hipEventSynchronize(batch[0]->demod_done) != hipSuccess) fail(*batch[0], pm_set_error(PM_ERR_HIP, "the demod stage of recording %lld failed", (long long)batch[0]->ticket));
             batch[0]->t_ready = now_ms();
             while ((int)batch.size() < p->group) {
                 std::shared_ptr<Rec> nxt;
@@ -279,7 +282,8 @@ void slice_worker(pm_pipe *p, int wi)
                     if (!ready && (int)batch.size() >= p->min_group) break;
                     p->slice_q.pop_front();
                 }
-                (void)hipEventSynchronize(nxt->demod_done);          // already queued on the GPU: a batch of four costs what one costs
+                // already queued on the GPU: a batch of four costs what one costs
+                if (hipEventSynchronize(nxt->demod_done) != hipSuccess) fail(*nxt, pm_set_error(PM_ERR_HIP, "the demod stage of recording %lld failed", (long long)nxt->ticket));
                 nxt->t_ready = now_ms();
                 batch.push_back(nxt);
             }
@@ -287,22 +291,28 @@ void slice_worker(pm_pipe *p, int wi)
         const double t0 = now_ms();
         const int nch = p->nchains, nb = (int)batch.size();
         int rc = PM_OK;
-        // certified sweeps that overflowed are redone with the exact kernels, here
+        // What the certified sweeps left undecided is decided here, before the slicers read the bitmaps: a list that is not empty (a
+        // workgroup with more uncertain samples than it takes on itself, digital silence) by the exact chain per entry, a list that
+        // overflowed by the exact kernels over the whole recording.  Normally every word is zero and nothing is launched.
+        std::vector<int> cells_back;
         for (auto &r : batch) {
             if (!p->nsweeps) break;
-            // the recording's demod event has been waited for: its sweeps' last launches have left their counts in the mailbox words
+            // the recording's demod event has been waited for: its sweeps have left their counts in the mailbox words
             std::vector<int64_t> unc(p->nsweeps);
             for (int s = 0; s < p->nsweeps; ++s) unc[s] = ((volatile int *)p->h_cells)[(size_t)r->cell * p->nsweeps + s];
-            {
-                std::unique_lock<std::mutex> lk(p->mu);
-                p->free_cells.push_back(r->cell);
-                r->cell = -1;
-            }
             for (int s = 0; s < p->nsweeps && !r->status; ++s) {
-                if (unc[s] <= kSweepCap) continue;
+                if (unc[s] <= 0) continue;
+                if (unc[s] <= kSweepCap) {
+                    if ((rc = pm_afsk_sweep_exact_list(side, r->d_audio, p->d_bpf, p->mb, &p->sweeps[s], p->sweep_bits_store[r->slot][s].data(),
+                                                       p->d_lists + ((size_t)r->cell * p->nsweeps + s) * kSweepCap, p->d_cells + (size_t)r->cell * p->nsweeps + s)))
+                        fail(*r, rc);
+                    continue;
+                }
                 for (int c = 0; c < nch && !r->status; ++c)
                     if (p->chains[c].sweep == s && (rc = exact_chain(p, side, w, *r, c))) fail(*r, rc);
             }
+            cells_back.push_back(r->cell);                   // (its list may be read by a launch on this worker's stream: back when the batch is through)
+            r->cell = -1;
         }
         // all slicers of the batch in one pm_slice_batch (groups of <= 64 jobs), compact form, one copy to the host
         // (chains that slice the same bitmap with the same slicer share a job: jidx maps (recording, chain) to it)
@@ -440,6 +450,7 @@ void slice_worker(pm_pipe *p, int wi)
         }
         {
             std::unique_lock<std::mutex> lk(p->mu);
+            for (int cell : cells_back) p->free_cells.push_back(cell);
             for (auto &r : batch) {
                 p->slot_busy[r->slot] = 0;                       // the bitmaps are consumed and the output is on the host
                 p->host_q.push_back(r);
@@ -483,7 +494,7 @@ void host_worker(pm_pipe *p)
                 j.codec = codecs[c];
                 const int64_t cnt = r.count[c];
                 const uint8_t *base = r.block->p + r.off[c];
-                j.n = cnt;
+                j.n = p->skip_decode ? 0 : cnt;
                 j.h_data = base + kCompactHead + ((size_t)2 * cnt + 7) / 8 * 8;
                 if (!r.full_addr[c].empty()) {
                     j.h_addr = r.full_addr[c].data();
@@ -589,6 +600,7 @@ int pm_pipe_destroy(pm_pipe *p)
     for (hipEvent_t e : p->handover)
         if (e) (void)hipEventDestroy(e);
     if (p->d_cells) (void)hipFree(p->d_cells);
+    if (p->d_lists) (void)hipFree(p->d_lists);
     if (p->h_cells) (void)hipHostFree(p->h_cells);
     for (size_t i = 0; i < std::min(p->work.size(), p->side.size()); ++i) {      // (a create that failed half way: fewer contexts than blocks)
         pm_ctx *s = p->side[i];
@@ -626,6 +638,7 @@ int pm_pipe_create(pm_ctx *ctx, const pm_pipe_desc *desc, pm_pipe **out)
     p->slots = std::max(2, p->slots);
     p->keep_slices = d.keep_slices != 0;
     p->trace = getenv("PM_PIPE_TRACE") != nullptr;
+    p->skip_decode = getenv("PM_PIPE_SKIP_DECODE") != nullptr;
     p->group = d.slice_group > 0 ? std::min(d.slice_group, 16) : 4;
     p->min_group = d.slice_min_group > 0 ? std::min(d.slice_min_group, p->group) : p->group;
     p->host_threads = d.host_threads > 0 ? d.host_threads : std::max(2, std::min(8, 24 / d.nchains)) + 1;
@@ -751,6 +764,7 @@ int pm_pipe_create(pm_ctx *ctx, const pm_pipe_desc *desc, pm_pipe **out)
             // one block of counter / mailbox words per recording between submission and its slicer batch: never more than `slots`
             const size_t words = (size_t)p->slots * d.nsweeps;
             if (hipMalloc((void **)&p->d_cells, words * sizeof(int)) != hipSuccess || hipMemset(p->d_cells, 0, words * sizeof(int)) != hipSuccess ||
+                hipMalloc((void **)&p->d_lists, words * kSweepCap * sizeof(unsigned long long)) != hipSuccess ||
                 hipHostMalloc((void **)&p->h_cells, words * sizeof(int), hipHostMallocDefault) != hipSuccess) {
                 rc = pm_set_error(PM_ERR_HIP, "pm_pipe_create: no memory for the sweep counters");
                 break;
@@ -847,7 +861,8 @@ int pm_pipe_submit(pm_pipe *p, const int16_t *d_audio, int64_t n, int64_t *h_tic
             rc = pm_set_error(PM_ERR_HIP, "handing the recording to demod stream %zu failed", di);
     }
     if (!rc && p->nsweeps) {
-        const pm_sweep_cells cells{p->d_cells + (size_t)r->cell * p->nsweeps, p->h_cells + (size_t)r->cell * p->nsweeps};
+        const pm_sweep_cells cells{p->d_cells + (size_t)r->cell * p->nsweeps, p->h_cells + (size_t)r->cell * p->nsweeps,
+                                   p->d_lists + (size_t)r->cell * p->nsweeps * kSweepCap};
         rc = pm_afsk_group_run_plan(r->dctx, d_audio, n, p->d_bpf, p->mb, p->d_bpf_outs[di], p->x_bound, sw.data(), p->nsweeps, nullptr,
                                     ((uintptr_t)d_audio & 15) == 0 ? p->bpf8 : nullptr, p->lpf8.data(), &cells);
     }

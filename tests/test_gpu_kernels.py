@@ -761,7 +761,7 @@ def _sweep(ctx, x, x_bound, mark, unit, gains, lpf, sliding=False):
     return out, redo.value, space
 
 
-@pytest.mark.parametrize("sliding", [False, True, "unfused", "lpf8"])
+@pytest.mark.parametrize("sliding", [False, True, "unfused", "lpf8", "lpf8-list"])
 def test_afsk_gain_sweep_signs_are_the_exact_chain_s(ctx, sliding):
     """pm_afsk_sweep_signs / pm_afsk_sweep_signs_tones (sliding correlator sums, fused with the low-passes or not): bitmaps of a space_gain sweep from ONE unit space correlator pair and two low-passes, certified against
     the exact chain -- every bit must equal pm_afsk_correlate + pm_fir_signs_f64 with that modem's own (gain-scaled) taps, on an
@@ -769,7 +769,9 @@ def test_afsk_gain_sweep_signs_are_the_exact_chain_s(ctx, sliding):
     recomputed exactly, and past 65536 of them the exact chains of all modems run instead, decided on the device)."""
     # "unfused": sliding sums, low-passes and combine as three kernels (the path long filters fall back to); "lpf8": the fused kernel
     # with its low-passes as int8 digit products on the matrix pipe (what pm_pipe_* runs)
-    with tuned(ctx, afsk_unfused=int(sliding == "unfused"), afsk_lpf8=int(sliding == "lpf8")):
+    # ("lpf8": its uncertain samples decided by the workgroup that found them; "lpf8-list": all of them through the list and
+    # sweep_exact_kernel, as in round 4 and as a workgroup's overflow still goes)
+    with tuned(ctx, afsk_unfused=int(sliding == "unfused"), afsk_lpf8=int(sliding in ("lpf8", "lpf8-list")), sweep_no_tail=int(sliding == "lpf8-list")):
         _gain_sweep_cases(ctx, sliding)
 
 

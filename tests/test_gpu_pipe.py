@@ -16,8 +16,11 @@ def _recordings():
     from pymodem_amd import siggen
     a = siggen.recording("afsk1200_ax25", 48000, packets=6, seed=11, noise_sigma=800.0, payload_len=(20, 80))[0]
     b = siggen.recording("afsk1200_ax25", 48000, packets=3, seed=12, noise_sigma=2500.0, payload_len=(10, 40))[0]
+    gap = a.copy()                                            # squelch: stretches of digital silence inside a signal -- their workgroups certify
+    gap[len(a) // 3: len(a) // 3 + 3000] = 0                  # nothing and hand everything to the sweep's list (decided on the slicer worker)
+    gap[2 * len(a) // 3: 2 * len(a) // 3 + 700] = 0
     return {"a": a, "b": b, "half": a[: len(a) // 2].copy(), "noise": noise_i16(300000), "silence": np.zeros(250000, np.int16),
-            "whisper": np.random.default_rng(3).integers(-1, 2, 200000).astype(np.int16), "short": a[:20000].copy()}
+            "whisper": np.random.default_rng(3).integers(-1, 2, 200000).astype(np.int16), "short": a[:20000].copy(), "gap": gap}
 
 
 def _want(lines, audio, rate=48000):
@@ -40,7 +43,7 @@ def test_native_pipeline_matches_the_group_executor(config_lines, demod_streams)
     ctx.sync()
     pipe = ce.NativePipeline([cb.build_chain(48000, l) for l in lines], max(len(v) for v in recs.values()), 48000 / 40, ctx=ctx,
                               demod_streams=demod_streams)
-    order = ["a", "silence", "b", "half", "a", "noise", "whisper", "short", "b", "a", "silence", "half"] * 3
+    order = ["a", "silence", "b", "half", "gap", "a", "noise", "whisper", "short", "b", "a", "silence", "gap", "half"] * 3
     tickets = [(k, pipe.submit(dev[k])) for k in order]
     tables = []
     for k, t in tickets:

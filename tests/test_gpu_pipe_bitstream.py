@@ -99,6 +99,48 @@ def test_native_pipeline_bitstream_at_full_size_equals_the_oracle():
     pipe.close()
 
 
+def test_what_the_sweeps_leave_undecided_is_decided_by_the_reference_s_chain(config_lines):
+    """A certified sweep on the matrix pipe decides its uncertain samples inside the workgroup that found them (the reference's chain
+    from the int16 audio: afsk.py:151-166), hands a workgroup's overflow -- digital silence inside a signal: nothing there can be
+    certified -- to its list, which the slicer worker works off, and a recording whose list overflows to the exact kernels.  All
+    three against the oracle at bitstream level, every chain, the three kinds in flight together."""
+    import pymodem_amd
+    from pymodem_amd import chain_builder as cb, chain_execute as ce, siggen
+    lines = config_lines("afsk_1200_ax25_super_opt.json")
+    sig = siggen.recording("afsk1200_ax25", 48000, packets=5, seed=77, noise_sigma=1500.0, payload_len=(20, 60))[0][:330000]
+    rng = np.random.default_rng(5)
+    gap = sig.copy()
+    gap[100000:104000] = 0                                    # two workgroups' worth of silence: ~28 000 list entries per sweep of seven
+    gap[200000:200900] = 0
+    quiet = sig.copy()
+    quiet[50000:90000] = rng.integers(-2, 3, 40000)           # a stretch 70 dB down: scaled to itself, a few dozen uncertain samples per workgroup
+    hush = sig.copy()
+    hush[20000:300000] = 0                                    # more silence than the list holds: the exact kernels
+    recs = {"signal": sig, "gap": gap, "quiet": quiet, "hush": hush}
+    ctx = pymodem_amd.Context.default()
+    dev = {k: ctx.upload(v) for k, v in recs.items()}
+    ctx.sync()
+    pipe = ce.NativePipeline([cb.build_chain(48000, l) for l in lines], len(sig), 48000 / 40, ctx=ctx, keep_slices=True)
+    order = ["gap", "signal", "quiet", "hush", "gap", "quiet"]
+    tickets = [(k, pipe.submit(dev[k])) for k in order]
+    want = {k: [O.run_chain(O.build_chain(48000, l), v, canon=True) for l in lines] for k, v in recs.items()}
+    for k, t in tickets:
+        kept = [pipe.slices(t, c) for c in range(len(lines))]         # (before the table: a recording without packets is released with it)
+        table = pipe.table(t)
+        rows = _rows_by_chain(table, len(lines))
+        for c in range(len(lines)):
+            w = want[k][c]
+            sliced, plain = kept[c]
+            assert np.array_equal(sliced.data, w["slice_data"]) and np.array_equal(sliced.address, w["slice_addr"]), (k, c)
+            assert np.array_equal(plain, np.asarray(w["lfsr"], dtype=np.uint8)), (k, c)
+            got_a, _, got_d = _pk(rows[c])
+            assert [int(x) for x in got_a] == [int(p.streamaddress) for p in w["packets"]], (k, c)
+            assert got_d.tobytes() == b"".join(bytes(bytearray(p.data)) for p in w["packets"]), (k, c)
+        del table, rows
+    assert sum(len(w["packets"]) for w in want["signal"]) >= 8
+    pipe.close()
+
+
 def test_a_refused_recording_leaves_no_hole_in_the_tickets(config_lines):
     """pm_pipe_submit refuses a recording that is long enough for the band-pass but not for a chain's correlator + low-pass
     (mb <= n < mb + m + ml - 2) before a ticket exists; the submit_many behind it gets consecutive tickets and the wait on its LAST
