@@ -287,6 +287,29 @@ def main():
             out["strong"] = {"value": d3["value"], "unit": d3["unit"], "ms_per_step": d3["ms_per_step"], "steps": d3["steps"],
                              "chains_total": d3["config"]["chains_total"], "parallelism": d3["config"]["parallelism"],
                              "packets": d3.get("packets"), "scaling": "strong"}
+    if world > 1 and args.also:
+        # BASELINE configs[4]'s own curve: the 64 chains of the qpsk_2400 sweep divided over the ranks (8 per GPU at N = 8, what
+        # north_star names), every rank one engine run of as many recordings as give it 24 576 loops in flight, the packet exchange and
+        # rank 0's de-dup over all 64 chains behind it.  Every rank runs it: the collectives inside must line up.  The N = 1 point of the
+        # same curve is the one-GPU line's `also.qpsk_2400.all_64_chains_on_one_gpu`.
+        a = copy.copy(args)
+        a.workload, a.scaling, a.no_cpu_baseline, a.chains_per_gpu = "qpsk_2400", "strong", True, 64
+        per_rank = -(-64 // world)
+        rehearsal = {k: int(os.environ[k]) for k in ("BENCH_ALSO64_RECORDINGS", "BENCH_ALSO64_SAMPLES") if os.environ.get(k)}
+        a.steps = rehearsal.get("BENCH_ALSO64_RECORDINGS") or max(1, LOOPS_IN_FLIGHT_TWO // per_rank)
+        a.samples = rehearsal.get("BENCH_ALSO64_SAMPLES") or args.samples
+        a.warmup, a.loop_batch, a.loop_chunk = 1, 0, 0
+        d4 = measure(a, env)
+        if rank == 0:
+            out.setdefault("also", {})["qpsk_2400_64"] = {
+                "value": d4["value"], "unit": d4["unit"], "ms_per_step": d4["ms_per_step"], "steps": d4["steps"], "n_gpus": world, "scaling": "strong",
+                "chains_total": d4["config"]["chains_total"], "chains_per_gpu": d4["config"]["chains_per_gpu"],
+                "samples_per_recording": a.samples, "parallelism": d4["config"]["parallelism"], "loop_batch": d4["config"].get("loop_batch"),
+                "ms_per_step_by_rank": d4.get("ms_per_step_by_rank"), "packets": d4.get("packets"),
+                "gpu_kernel_ms_per_step": d4.get("gpu_kernel_ms_per_step"),
+                "what": "BASELINE configs[4]: 64 replicated qpsk_2400 chains at swept carriers over one synthetic recording per step, the chains "
+                        "divided over the GPUs (contiguous blocks: one front end per GPU), one packet exchange + rank 0's de-dup over all 64",
+                **({"rehearsal": rehearsal} if rehearsal else {})}
     if rank == 0:
         if cpu_line is not None:
             out["cpu_baseline"] = cpu_line
@@ -546,7 +569,24 @@ def measure(args, env):
         def after_(rest, st):
             rows = rest()
             t_f = time.perf_counter()
-            if use_dist or len(my) < 4:
+            if use_dist and len(rows) > 8:
+                # A run's recordings through the exchange as the pipelined executor's go: packed rows handed to dist.Exchanger in order on
+                # THIS thread (the collectives must come in the same order on every rank), eight recordings per all_gather, two
+                # collectives outstanding, and rank 0's indexing + de-dup of the gathered streams on four threads beside them
+                # (one collective and one de-dup per recording, one after the other: 3072 x ~3 ms behind a 14-second engine run)
+                from concurrent.futures import ThreadPoolExecutor
+                ex = pdist.Exchanger(nchains, coll_device, batch=int(os.environ.get("PYMODEM_AMD_EXCHANGE_BATCH", "8")))
+                ex.depth = 2
+                with ThreadPoolExecutor(max_workers=4) as fin:
+                    pending = []
+                    for rr in rows:
+                        pending.append(fin.submit(lambda f: dedupe(f.result()), ex.step(dict(zip(my, rr)))))
+                        while len(pending) > 24 and pending[0].done():
+                            res[0] = pending.pop(0).result()
+                    ex.flush()
+                    for p_ in pending:
+                        res[0] = p_.result()
+            elif use_dist or len(my) < 4:
                 for rr in rows:                                   # (collectives: in order, on this thread; one chain: nothing to share out)
                     res[0] = finish(rr)
             else:

@@ -235,11 +235,13 @@ def test_bench_launches_its_own_ranks_and_relays_their_exit_code():
 def test_bench_two_ranks_by_itself():
     """The scaling bench's command with N = 2 and nothing around it: two ranks share the one GPU of the test box
     over gloo, rank 0's ONE line comes back through the parent with n_gpus 2, the CPU baseline the parent measured before any rank
-    existed, and the strong-scaling figure beside the weak one."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    existed, the strong-scaling figure beside the weak one -- and `also.qpsk_2400_64`, BASELINE configs[4]'s own curve point: the 64
+    chains of the qpsk sweep divided over the ranks (32 each here), one engine run per rank, the exchange and rank 0's de-dup over
+    all 64 behind it (here at rehearsal size -- 12 recordings of 400 000 samples -- the driver's command runs it in full)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BENCH_ALSO64_RECORDINGS="12", BENCH_ALSO64_SAMPLES="400000")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "4", "--warmup", "1", "--also", "0",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "4", "--warmup", "1",
                         "--cpu-sample", "480000"], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
@@ -249,3 +251,7 @@ def test_bench_two_ranks_by_itself():
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
     assert d["config"]["chains_total"] == 16
     assert d["strong"]["chains_total"] == 8 and d["strong"]["value"] > 0
+    q = d["also"]["qpsk_2400_64"]
+    assert q["chains_total"] == 64 and q["chains_per_gpu"] == 32 and q["n_gpus"] == 2 and q["scaling"] == "strong"
+    assert q["steps"] == 12 and q["value"] > 0 and q["rehearsal"]["BENCH_ALSO64_SAMPLES"] == 400000
+    assert q["packets"] is not None
