@@ -1032,7 +1032,30 @@ def measure(args, env):
     # the same kernels with the GPU to themselves (one more step, strictly sequential, outside the timed region): in the pipelined
     # run two or more streams share the CUs, which stretches every kernel's duration
     alone = {}
-    if args.overlap and not loop_wl:
+    if native_exec[0] and args.overlap >= 2 and not loop_wl and not exchanging and args.steps > 1:
+        # The native executor's own kernels with the GPU to themselves: the same pipeline, ONE recording in flight -- submitted, and its
+        # result taken (demod, slicers and host stage drained) before the next is submitted.  Its demod stage then runs on one stream with
+        # nothing beside it: the matrix-pipe kernels the timed region ran (round 4 timed the Python-sequenced path's binary64 kernels here).
+        npipe = native_pipe("native")
+        bufs = audio_ring(npipe.slots + 2)
+
+        def one_alone(i):
+            npipe.unique(npipe.submit(bufs[i % len(bufs)]))
+        for i in range(2):                                    # both demod streams once, unprofiled
+            one_alone(i)
+        fence()
+        watched = [ctx] + list(native_sides)
+        for c_ in watched:
+            c_.profile(True)
+        for i in range(6):                                    # three recordings per demod stream
+            one_alone(i)
+        fence()
+        for c_ in watched:
+            for name, (ms, cnt) in c_.profile_read().items():
+                a0 = alone.get(name, (0.0, 0))
+                alone[name] = (a0[0] + ms, a0[1] + cnt)
+            c_.profile(False)
+    elif args.overlap and not loop_wl:
         saved, args.overlap = args.overlap, 0
         if args.steps > 1:                                    # (not for the one-step carrier-loop workloads: 5-8 s per step)
             run_steps(1)                                      # the sequential path's own buffers and first launches
@@ -1162,10 +1185,10 @@ def measure(args, env):
                          "alone": None if alone_ms is None else {
                              "avg_kernel_ms": round(alone_ms, 5), "achieved": round(per_launch_bytes / (alone_ms * 1e-3) / 1e9, 2),
                              "frac": round(per_launch_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                             "note": "same kernel class in three extra sequential steps after the timed region, no other stream on the GPU"
-                                     + (" -- through the Python-sequenced path, i.e. the BINARY64 kernels of this class; the native executor's "
-                                        "matrix-pipe kernels alone: 0.188 ms (seven-chain sweep) and 0.124 ms (one chain), 0.06 ms for the band-pass "
-                                        "(tools/sweep_probe.py with PM_AFSK_LPF8=1, tools/bpf8_probe.py; DESIGN.md 4.2, profiles/r04_sweep_probe.txt)" if native_exec[0] else "")},
+                             "note": ("the same kernels through the same executor with ONE recording in flight (submitted, its result taken, then "
+                                      "the next): six extra recordings after the timed region, no other stream on the GPU while a demod stage runs"
+                                      if native_exec[0] and args.overlap >= 2 and not exchanging and args.steps > 1 else
+                                      "same kernel class in three extra sequential steps after the timed region, no other stream on the GPU")},
                          "note": "achieved = algorithmic bytes of the timed launches / their HIP-event time inside the timed region (where "
                                  "the slicer streams share the CUs).  Above ~40 taps a FIR is bound by the vector-f64 FMA pipe, not by "
                                  "HBM: see roofline_fp64 for that fraction (DESIGN.md 4.1-4.2).  For the AFSK workloads the class fir_f64 is "

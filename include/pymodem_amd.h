@@ -222,6 +222,13 @@ int pm_afsk_sweep_last(pm_ctx *ctx, int64_t *h_uncertain);
  * pm_afsk_sweep_mode(ctx, 1) they are not enqueued: take a ticket after the call, and once the sweep has FINISHED (stream or event
  * synchronised) ask pm_afsk_sweep_result; if *h_uncertain > *h_capacity the sweep's bitmaps are not valid and the caller runs the
  * exact path for those modems (pm_afsk_correlate + pm_fir_signs_f64).  Tickets stay valid for 63 further sweeps on the context. */
+/* WHO COUNTS WHERE.  The entry points of this block -- pm_afsk_sweep_signs, pm_afsk_sweep_signs_tones, pm_afsk_group_run,
+ * pm_afsk_sweep_last / _ticket / _result / _results -- count a sweep's uncertain samples in a ring of 64 counters that belongs to the
+ * CONTEXT (a ticket is a sequence number into it).  They are for one thread per context: submitting sweeps on a context from one
+ * thread and asking for their results from another is not supported, and a result must be asked for within 63 further sweeps.
+ * The pipelined executor (pm_pipe_*) does NOT use the ring: each of its recordings owns its counters, mailbox words and overflow
+ * list from submission until its slicer batch has read them (csrc/pm_common.h: pm_sweep_cells), its matrix-pipe sweeps decide their
+ * uncertain samples inside the workgroup that found them, and nothing is shared between its threads. */
 /* One chain group's demod stage in one call: band-pass on the int16 audio into d_bpf_out (n - mb + 1 doubles), then every sweep of
  * h_sweeps on it (as pm_afsk_sweep_signs / _tones would run them, fallback deferred), h_tickets[k] = the ticket of sweep k. */
 typedef struct pm_afsk_sweep_desc {

@@ -817,7 +817,9 @@ class _PipeRows:
 
     def __init__(self, pipe, ticket, ptr, nbytes):
         self._pipe, self._ticket = pipe, ticket
-        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
+        # read-only: the rows are the library's (a pooled block it keeps zero wherever no packet has written); a consumer that wants to
+        # change a row copies it
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, True), "version": 3}
         pipe._live += 1
 
     def __del__(self):

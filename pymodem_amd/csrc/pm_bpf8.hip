@@ -376,11 +376,10 @@ int pm_bpf8_rows_max(pm_ctx *ctx, const pm_bpf8_plan *p, const int16_t *const *d
     PM_ARG(p != nullptr && d_rows != nullptr && d_keys != nullptr && d_out != nullptr && rows >= 1 && n >= p->m && p->device == ctx->device);
     PM_ARG(p->digits == kMaxDigitsOfMax);
     const int64_t nout = n - p->m + 1, wgs = pm_cdiv(nout, (int64_t)kWgOut);
-    PM_ARG(wgs < (1LL << 31));
+    PM_ARG(wgs <= 65535);                                     // (268 M samples per row; checked before anything is enqueued)
     PM_HIP(hipMemsetAsync(d_keys, 0, sizeof(unsigned long long) * (size_t)rows, ctx->stream));       // key 0: below every value
     PmProf prof(ctx, PM_K_FIR_I16);
     prof.work((double)rows * (double)n * 2, 2.0 * p->m * (double)nout * rows);
-    PM_ARG(wgs <= 65535);                                     // (268 M samples per row)
     for (int r0 = 0; r0 < rows; r0 += 1 << 20) {
         const dim3 grid((unsigned)std::min(1 << 20, rows - r0), (unsigned)wgs);
         if (p->kb == 3) hipLaunchKernelGGL((bpf8_max_kernel<3, kMaxDigitsOfMax>), grid, dim3(256), 0, ctx->stream, d_rows, r0, n, p->d_btab, p->sc, p->err, p->d_taps, p->m, d_keys, d_redone);

@@ -1015,7 +1015,10 @@ __device__ __forceinline__ void sweep_tail_entry(double *__restrict__ dd, int t,
     __syncthreads();
     if (src.audio) {
         for (int p = t; p < nw; p += THREADS) {
+            // (unrolled: the operands of the next fmas are on their way from LDS while the chain waits for its own latency -- a
+            // workgroup with an entry holds its slot for as long as this takes, and alone the kernel ends with its last such workgroup)
             double acc = 0.0;
+#pragma unroll 8
             for (int i = 0; i < mb; ++i) acc = __builtin_fma(tb[i], aw[p + i], acc);
             xw[p] = acc;
         }
@@ -1023,6 +1026,7 @@ __device__ __forceinline__ void sweep_tail_entry(double *__restrict__ dd, int t,
     }
     for (int j = t; j < ml; j += THREADS) {
         double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+#pragma unroll 4
         for (int i = 0; i < mc; ++i) {
             const double v = xw[j + i];
             a = __builtin_fma(tc[4 * i + 0], v, a);
@@ -1035,6 +1039,7 @@ __device__ __forceinline__ void sweep_tail_entry(double *__restrict__ dd, int t,
     __syncthreads();
     if (t == 0) {
         double acc = 0.0;
+#pragma unroll 8
         for (int j = 0; j < ml; ++j) acc = __builtin_fma(tl[j], dd[j], acc);
         unsigned long long *w = bits + (k >> 6);
         const unsigned long long bit = 1ull << (k & 63);
@@ -1566,11 +1571,19 @@ int pm_fir_rows(pm_ctx *ctx, bool i16, const void *d_x, int64_t x_stride, const 
     PM_ARG(d_x_ptrs || rows == 1 || x_stride >= n);
     const int64_t nout = n - m + 1;
     PM_ARG(rows == 1 || (d_y ? y_stride >= nout : bits_stride >= (nout + 63) / 64));
-    FirRows A{d_x, x_stride, d_x_ptrs, x_off, d_y, y_stride, d_bits, bits_stride};
     const bool vec = x_aligned16 && (!d_y || ((((uintptr_t)d_y) & 15) == 0 && y_stride % 2 == 0));
     const bool neg = (flags & PM_FIR_NEGATE) != 0;
-    if (i16) return neg ? fir_rows_launch2<int16_t, true>(ctx, A, vec, rows, n, d_taps, m) : fir_rows_launch2<int16_t, false>(ctx, A, vec, rows, n, d_taps, m);
-    return neg ? fir_rows_launch2<double, true>(ctx, A, vec, rows, n, d_taps, m) : fir_rows_launch2<double, false>(ctx, A, vec, rows, n, d_taps, m);
+    // rows are the grid's y dimension: more than 65535 of them (the batch engine's R x C streams go up to 2^20) in several launches
+    constexpr int kRowsPerLaunch = 65535;
+    for (int r0 = 0; r0 < rows; r0 += kRowsPerLaunch) {
+        const int nr = std::min(kRowsPerLaunch, rows - r0);
+        FirRows A{d_x ? (const void *)((const char *)d_x + (size_t)r0 * (size_t)x_stride * (i16 ? 2 : 8)) : nullptr, x_stride, d_x_ptrs ? d_x_ptrs + r0 : nullptr, x_off,
+                  d_y ? d_y + (int64_t)r0 * y_stride : nullptr, y_stride, d_bits ? d_bits + (int64_t)r0 * bits_stride : nullptr, bits_stride};
+        const int rc = i16 ? (neg ? fir_rows_launch2<int16_t, true>(ctx, A, vec, nr, n, d_taps, m) : fir_rows_launch2<int16_t, false>(ctx, A, vec, nr, n, d_taps, m))
+                           : (neg ? fir_rows_launch2<double, true>(ctx, A, vec, nr, n, d_taps, m) : fir_rows_launch2<double, false>(ctx, A, vec, nr, n, d_taps, m));
+        if (rc) return rc;
+    }
+    return PM_OK;
 }
 
 template <int G>

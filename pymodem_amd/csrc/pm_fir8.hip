@@ -380,40 +380,47 @@ int pm_fir8_rows_signs(pm_ctx *ctx, const pm_fir8_plan *p, const double *d_x, in
                        int64_t bits_stride, int *d_count, int64_t x_room)
 {
     PM_CTX(ctx);
-    PM_ARG(p != nullptr && d_x != nullptr && d_bits != nullptr && rows >= 1 && rows <= 65535 && n >= p->m && p->device == ctx->device);
+    PM_ARG(p != nullptr && d_x != nullptr && d_bits != nullptr && rows >= 1 && n >= p->m && p->device == ctx->device);
     PM_ARG(x_room == 0 || x_room >= n);
     const int64_t nout = n - p->m + 1, words = (nout + 63) / 64, wgs = pm_cdiv(nout, (int64_t)kWgOut);
     PM_ARG(bits_stride >= words && wgs < (1LL << 31));
-    // the undecided outputs' mask: one word per bitmap word, in the context's work block (this launch pair is its only user)
-    if (int rc = pm_scratch_reserve(ctx, (size_t)rows * (size_t)words * 8)) return rc;
-    Fir8Args A;
-    A.x = d_x;
-    A.x_stride = x_stride;
-    A.x_room = x_room ? x_room : n;
-    A.aligned16 = (((uintptr_t)d_x) & 15) == 0 && (rows == 1 || x_stride % 2 == 0);
-    A.bits = d_bits;
-    A.bits_stride = bits_stride;
-    A.mask = (uint64_t *)ctx->d_scratch;
-    A.mask_stride = words;
-    A.c1 = p->c1;
-    A.c2 = p->c2;
-    {
-        PmProf prof(ctx, PM_K_FIR_F64);
-        prof.work((double)rows * ((double)n * 8 + (double)nout / 8), 2.0 * p->m * (double)nout * rows);      // the flops of the sums it stands for
-        const dim3 grid((unsigned)wgs, (unsigned)rows);
-        switch (p->J) {
-        case 1: hipLaunchKernelGGL(fir8_kernel<1>, grid, dim3(256), 0, ctx->stream, A, n, nout, p->d_btab); break;
-        case 2: hipLaunchKernelGGL(fir8_kernel<2>, grid, dim3(256), 0, ctx->stream, A, n, nout, p->d_btab); break;
-        case 3: hipLaunchKernelGGL(fir8_kernel<3>, grid, dim3(256), 0, ctx->stream, A, n, nout, p->d_btab); break;
-        default: hipLaunchKernelGGL(fir8_kernel<4>, grid, dim3(256), 0, ctx->stream, A, n, nout, p->d_btab); break;
+    // Rows are the grid's y dimension (at most 65535): more rows -- the batch engine sends R x C streams through here, up to 2^20 -- go
+    // in batches, one after the other on the stream.  The undecided outputs' mask (one word per bitmap word, in the context's work
+    // block: this launch pair is its only user) is a batch's, reused by the next: its size is bounded whatever `rows` is.
+    constexpr int kRowsPerLaunch = 65535;
+    const int per = std::min(rows, kRowsPerLaunch);
+    if (int rc = pm_scratch_reserve(ctx, (size_t)per * (size_t)words * 8)) return rc;
+    for (int r0 = 0; r0 < rows; r0 += per) {
+        const int nr = std::min(per, rows - r0);
+        Fir8Args A;
+        A.x = d_x + (int64_t)r0 * x_stride;
+        A.x_stride = x_stride;
+        A.x_room = x_room ? x_room : n;
+        A.aligned16 = (((uintptr_t)d_x) & 15) == 0 && (rows == 1 || x_stride % 2 == 0);
+        A.bits = d_bits + (int64_t)r0 * bits_stride;
+        A.bits_stride = bits_stride;
+        A.mask = (uint64_t *)ctx->d_scratch;
+        A.mask_stride = words;
+        A.c1 = p->c1;
+        A.c2 = p->c2;
+        {
+            PmProf prof(ctx, PM_K_FIR_F64);
+            prof.work((double)nr * ((double)n * 8 + (double)nout / 8), 2.0 * p->m * (double)nout * nr);      // the flops of the sums it stands for
+            const dim3 grid((unsigned)wgs, (unsigned)nr);
+            switch (p->J) {
+            case 1: hipLaunchKernelGGL(fir8_kernel<1>, grid, dim3(256), 0, ctx->stream, A, n, nout, p->d_btab); break;
+            case 2: hipLaunchKernelGGL(fir8_kernel<2>, grid, dim3(256), 0, ctx->stream, A, n, nout, p->d_btab); break;
+            case 3: hipLaunchKernelGGL(fir8_kernel<3>, grid, dim3(256), 0, ctx->stream, A, n, nout, p->d_btab); break;
+            default: hipLaunchKernelGGL(fir8_kernel<4>, grid, dim3(256), 0, ctx->stream, A, n, nout, p->d_btab); break;
+            }
+            PM_HIP(hipGetLastError());
         }
-        PM_HIP(hipGetLastError());
-    }
-    {
-        PmProf prof(ctx, PM_K_SIGNS);
-        hipLaunchKernelGGL(fir8_exact_kernel, dim3((unsigned)pm_cdiv(words, 256 * kScanSteps), (unsigned)rows), dim3(256), 0, ctx->stream, d_x, x_stride, p->d_hrev, p->m,
-                           d_bits, bits_stride, A.mask, A.mask_stride, words, d_count);
-        PM_HIP(hipGetLastError());
+        {
+            PmProf prof(ctx, PM_K_SIGNS);
+            hipLaunchKernelGGL(fir8_exact_kernel, dim3((unsigned)pm_cdiv(words, 256 * kScanSteps), (unsigned)nr), dim3(256), 0, ctx->stream, A.x, x_stride, p->d_hrev, p->m,
+                               A.bits, bits_stride, A.mask, A.mask_stride, words, d_count);
+            PM_HIP(hipGetLastError());
+        }
     }
     return PM_OK;
 }

@@ -332,13 +332,16 @@ int pm_lbatch_run_sliced(pm_lbatch *b, const int16_t *const *h_d_audio, int reco
         const size_t words = 2 * (size_t)b->cset;
         for (hipEvent_t *ev : {&b->bits_done[0], &b->bits_done[1], &b->slice_done[0], &b->slice_done[1]})
             if (!*ev && hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) return pm_set_error(PM_ERR_HIP, "hipEventCreate failed");
-        void *q = nullptr;
-        if (int rc = pm_malloc(ctx, words * 8, &q)) return rc;
-        b->cbits_i = (uint64_t *)q;
-        if (b->two_out) {
-            if (int rc = pm_malloc(ctx, words * 8, &q)) return rc;
-            b->cbits_q = (uint64_t *)q;
-        }
+        // both sets before either is published: a call that fails half way leaves nothing behind and the next one tries again
+        void *qi = nullptr, *qq = nullptr;
+        if (int rc = pm_malloc(ctx, words * 8, &qi)) return rc;
+        if (b->two_out)
+            if (int rc = pm_malloc(ctx, words * 8, &qq)) {
+                (void)pm_free(ctx, qi);
+                return rc;
+            }
+        b->cbits_i = (uint64_t *)qi;
+        b->cbits_q = (uint64_t *)qq;
     }
     const SliceOut so{d_data, d_steps, cap, d_recs};
     return run_impl(b, h_d_audio, recordings, n, b->cbits_i, b->cbits_q, b->cstride, h_nout, &so);
@@ -480,7 +483,8 @@ int run_impl(pm_lbatch *b, const int16_t *const *h_d_audio, int recordings, int6
             if (so && t >= 2) PM_HIP(hipStreamWaitEvent(Tl->stream, b->slice_done[t & 1], 0));
             auto signs = [&](const double *f, uint64_t *bits) -> int {
                 // (a row of the output windows: Ho history slots, the chunk, slack up to the pitch -- all of it the engine's own memory)
-                if (b->fir8) return pm_fir8_rows_signs(Tl, b->fir8, f, P, RC, fn, bits + word0, bits_stride, nullptr, P - (b->Ho - back));
+                // (the switch is read per run, like the engine's others: pm_ctx_tune(fir8 = 0) on an engine that exists takes the binary64 rows kernel)
+                if (b->fir8 && B->tune.fir8) return pm_fir8_rows_signs(Tl, b->fir8, f, P, RC, fn, bits + word0, bits_stride, nullptr, P - (b->Ho - back));
                 return pm_fir_rows(Tl, false, f, P, nullptr, 0, (((uintptr_t)f) & 15) == 0, RC, fn, T + b->o_out, mo, nullptr, 0, bits + word0, bits_stride, 0);
             };
             if (int rc = signs(f0, d_bits_i)) return rc;

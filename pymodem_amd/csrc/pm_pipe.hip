@@ -80,6 +80,8 @@ struct Rec {                             // one recording on its way through
 struct RowBlock {
     pm_packet *rows = nullptr;
     int64_t cap = 0, used = 0;
+    std::vector<int32_t> lens;           // what each row's packet wrote, noted by the library when it wrote it: the caller sees the rows
+                                         // (read-only views, but memory it can reach) and a length read back from there could leave dirt in the pool
     ~RowBlock() { free(rows); }
 };
 
@@ -177,11 +179,12 @@ void rows_put(pm_pipe *p, RowBlock *b)
     // clean again: what the packets wrote -- the header and len bytes of payload per row -- back to zero
     for (int64_t k = 0; k < b->used; ++k) {
         pm_packet &q = b->rows[k];
-        const int32_t len = q.len < 0 ? 0 : q.len > PM_PKT_MAX ? PM_PKT_MAX : q.len;
+        const int32_t len = k < (int64_t)b->lens.size() ? b->lens[(size_t)k] : PM_PKT_MAX;      // (rows nobody noted: the whole field)
         memset(q.data, 0, (size_t)len);
         memset(&q, 0, offsetof(pm_packet, data));
     }
     b->used = 0;
+    b->lens.clear();
     std::unique_lock<std::mutex> lk(p->pool_mu);
     if (p->row_pool.size() < 64) p->row_pool.push_back(b);
     else delete b;
@@ -543,6 +546,13 @@ void host_worker(pm_pipe *p)
                 r.nrows = total;
                 if (!r.rows) rc = pm_set_error(PM_ERR_ARG, "out of host memory for %lld packet rows", (long long)total);
                 if (!rc) rc = pm_codec_fetch_batch_clean(codecs.data(), r.counts.data(), nch, r.rows, p->decode_threads);
+                if (r.rowblock) {                             // the packets' lengths, before anyone else can touch the rows
+                    r.rowblock->lens.resize((size_t)total);
+                    for (int64_t k = 0; k < total; ++k) {
+                        const int32_t len = r.rows[k].len;
+                        r.rowblock->lens[(size_t)k] = len < 0 ? 0 : len > PM_PKT_MAX ? PM_PKT_MAX : len;
+                    }
+                }
                 if (!rc) {
                     // PacketMetaArray.Correlate over the chains in config order (packet_meta.py:230-271)
                     r.unique_idx.resize((size_t)std::max<int64_t>(total, 1));

@@ -130,3 +130,17 @@ def test_short_rows_and_many_rows(ctx):
         assert np.array_equal(got, want), n
     got, want, _ = _both(ctx, rng.standard_normal((300, 3000)), taps)
     assert np.array_equal(got, want)
+
+
+def test_more_rows_than_a_launch_s_grid_holds(ctx):
+    """The batch engine sends R x C streams through pm_fir8_rows_signs, up to 2^20 of them, and rows are the grid's y dimension (65535 at
+    most): 70 000 short rows go in two launches (the call used to refuse them, and the engine had no other path).  Every row of
+    the second batch too must be the exact kernel's, nothing written past a row's words."""
+    rng = np.random.default_rng(70000)
+    m, n, rows = 64, 64 + 191, 70000                          # 192 outputs per row: three bitmap words
+    taps = _taps(m, rng)
+    x = rng.standard_normal((rows, n)) * np.exp(rng.uniform(-6, 6, (rows, 1)))
+    x[::997] = 0.0                                            # some rows of exact zeros
+    got, want, _ = _both(ctx, x, taps)
+    assert np.array_equal(got, want), int(np.sum(got != want))
+    assert np.array_equal(got[65530:65540], want[65530:65540]) and got[-1].any()
