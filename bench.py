@@ -362,10 +362,13 @@ def matrix_roofline(native, args, modems, my, prof):
                        "recording / the class's summed launch time per recording; a micro-benchmark of the instruction alone sustains 2 830 TOP/s "
                        "on this chip (tools/ubench/mfma_i8.hip); the kernels also run their sliding sums, digit split, recombination and "
                        "combine on the vector pipe"}
-        for cls, ops in (("fir_f64", lp_ops), ("fir_i16", bp_ops)):
+        fused = not prof["fir_i16"][1]                       # one launch per recording (afsk_fused8_kernel): band-pass and low-passes in the same class
+        if fused:
+            out["note"] += "; ONE fused launch per recording: the band-pass's and the low-passes' products are priced together against its time"
+        for cls, ops in ((("fir_f64", lp_ops + bp_ops),) if fused else (("fir_f64", lp_ops), ("fir_i16", bp_ops))):
             ms, nl_ = prof[cls]
             if nl_ and ms > 0:
-                per_rec_ms = ms / nl_ * (len(sweeps) if cls == "fir_f64" else 1)
+                per_rec_ms = ms / nl_ * (1 if fused else len(sweeps) if cls == "fir_f64" else 1)
                 out[cls] = {"int8_ops_per_recording": round(ops), "class_ms_per_recording": round(per_rec_ms, 5),
                             "achieved": round(ops / (per_rec_ms * 1e-3) / 1e12, 1), "frac": round(ops / (per_rec_ms * 1e-3) / 1e12 / INT8_PEAK_TOPS, 5)}
         return out
@@ -1198,7 +1201,19 @@ def measure(args, env):
                                  "here means little traffic, not idle hardware; its HBM-bound parts measured on their own: sliding sums "
                                  "61 % and 8-tap FIR 71-79 % of peak (DESIGN.md 4.2c, 6).  Native executor, round 3: the band-pass (class fir_i16) "
                                  "and the fused kernel's low-passes run as int8 digit products on the matrix pipe (pm_bpf8.hip, "
-                                 "afsk_slide_lpf8_kernel); bytes per launch are unchanged"},
+                                 "afsk_slide_lpf8_kernel); bytes per launch are unchanged.  Round 5: the WHOLE AFSK stage of a chain group is one "
+                                 "launch per recording (afsk_fused8_kernel: band-pass, both sweeps, exact recomputation) that reads the int16 "
+                                 "recording once and writes one bit per sample and chain -- SURVEY 8(d)'s fused bound of 2 B per sample: "
+                                 "`algorithmic_bytes_per_launch` is that (86 MB; it was 245 MB per sweep launch while the band-passed stream still "
+                                 "went through memory), so `frac` FELL while the stage got faster: the kernel is bound by vector instruction "
+                                 "issue (roofline_fp64, DESIGN.md 4.2), and `reference_dataflow` prices the same launch at the reference's own "
+                                 "stage-by-stage traffic"},
+            "reference_dataflow": None if args.workload != "afsk_1200_super_opt" else {
+                "bytes_per_sample_and_chain": 50, "bytes_per_recording": round(50.0 * args.samples * len(my)),
+                "equivalent_GBps": round(50.0 * args.samples * len(my) / max(dom_ms / max(dom_n, 1) * (1 if not prof["fir_i16"][1] else 2) + (prof["fir_i16"][0] / max(prof["fir_i16"][1], 1)), 1e-9) / 1e6, 1),
+                "note": "SURVEY 8(d): the reference's AFSK chain moves 50 B per sample and chain stage by stage (BPF 10 + correlators 16 + LPF 16 + slicer "
+                        "read 8); this is that traffic / the time of this rank's demod launches per recording -- an EQUIVALENT rate (it may exceed the "
+                        "HBM peak: the intermediates it counts never exist here), beside `roofline`, which counts what does cross HBM"},
             "roofline_fp64": {"bound": "valu_f64", "kernel": dom, "achieved": round(tflops, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(tflops / FP64_PEAK_TFLOPS, 5), "algorithmic_flops_per_launch": round(per_launch_flops),
                               "alone_frac": None if alone_ms is None else round(per_launch_flops / (alone_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5),

@@ -348,6 +348,16 @@ void pm_bpf8_plan_destroy(pm_bpf8_plan *p)
 }
 
 double pm_bpf8_error(const pm_bpf8_plan *p) { return p ? p->err : 0.0; }
+// what a kernel that runs the band-pass as a stage of its own needs (afsk_fused8_kernel, pm_fir.hip): blocks, band table, scales
+int pm_bpf8_plan_view(const pm_bpf8_plan *p, int *kb, const void **d_btab, double *scales6)
+{
+    if (!p || p->digits != kMaxDigits || !kb || !d_btab || !scales6) return pm_set_error(PM_ERR_ARG, "pm_bpf8_plan_view: not a four-digit plan");
+    *kb = p->kb;
+    *d_btab = p->d_btab;
+    for (int w = 0; w < kMaxWeights; ++w) scales6[w] = p->sc.s[w];
+    scales6[kMaxWeights] = p->sc.c0;
+    return PM_OK;
+}
 int pm_bpf8_digit_pairs(void) { return 2 * kMaxDigits; }      // tile_values: two sample digits x the tap digits of the sweeps' plan, every pair computed
 int pm_bpf8_taps(const pm_bpf8_plan *p) { return p ? p->m : 0; }
 

@@ -18,7 +18,8 @@ constexpr int kSweepCap = 65536;        // uncertain (sample, modem) pairs a cer
 // runs pm_afsk_sweep_exact_list over a list that is not empty.  The words belong to the recording from its submission until its
 // owner is through with them -- no ring, no arithmetic on sequence numbers.
 struct pm_sweep_cells {
-    int *d_count = nullptr;                 // nsweeps words, zero when the recording's demod stage starts (pm_bpf8_run clears them)
+    int *d_count = nullptr;                 // nsweeps live counters (zero when the recording's demod stage starts and again when it has mailed them)
+                                            // + with d_list nsweeps more: the counts as mailed, for pm_afsk_sweep_exact_list
     int *h_mail = nullptr;                  // nsweeps words
     unsigned long long *d_list = nullptr;   // nullptr (every sweep ends with a launch that works its list off), or nsweeps * kSweepCap entries
 };
@@ -43,6 +44,7 @@ struct pm_tuning {
     int loop_vec = 1;                  // PM_LOOP_VEC=0: the direct loop shape moves its blocks with eight-byte accesses, a lane a row
     int lbatch_loop_cus = -1;          // PM_LBATCH_LOOP_CUS: compute units the batch engine's carrier loops have to themselves (0: none, -1: by size)
     int agc_rows_prio = 2;             // PM_AGC_ROWS_PRIO: wave priority of the rows AGC (the loops run at 3)
+    int afsk_split = 0;                // PM_AFSK_SPLIT: the pipelined executor's AFSK stage as band-pass + one launch per sweep (round 4), not fused into one launch
     int sweep_no_tail = 0;             // PM_SWEEP_NO_TAIL: the matrix-pipe sweep sends every uncertain sample to the list (round 4), none to its own workgroup's exact chain
 };
 pm_tuning pm_tuning_from_env();
@@ -124,6 +126,7 @@ int pm_bpf8_plan_create(pm_ctx *ctx, const double *h_taps, int m, pm_bpf8_plan *
 int pm_bpf8_max_digits(void);      // PM_ERR_ARG: more than 241 taps
 void pm_bpf8_plan_destroy(pm_bpf8_plan *p);
 double pm_bpf8_error(const pm_bpf8_plan *p);
+int pm_bpf8_plan_view(const pm_bpf8_plan *p, int *kb, const void **d_btab, double *scales6);   // the plan's blocks (3 / 4), band table and 5 scales + constant
 int pm_bpf8_digit_pairs(void);     // int8 digit products per tap and output of bpf8_kernel (and of fir8_kernel: pm_fir8_digit_pairs)
 int pm_fir8_digit_pairs(void);
 int pm_bpf8_taps(const pm_bpf8_plan *p);

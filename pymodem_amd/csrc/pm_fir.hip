@@ -15,6 +15,7 @@
 // (18 dwords: conflict-free for ds_read_b64).  Results go back through the same LDS image so that
 // the global stores are coalesced (lane-contiguous 8 B).
 #include "pm_common.h"
+#include "pm_bpf8_dev.h"
 #include <chrono>
 #include <cmath>
 #include <vector>
@@ -1087,45 +1088,19 @@ struct Lpf8Args {
 #ifndef PM_LPF8_WAVES
 #define PM_LPF8_WAVES 4          // waves per SIMD the fused matrix-pipe kernel is compiled for (-DPM_LPF8_WAVES=5: measured, profiles/r04_lpf8_occupancy.txt)
 #endif
+// One workgroup's tile of a certified sweep from the band-passed window in LDS (xs, slide_slot layout): sliding sums, digit planes,
+// low-pass(es) on the matrix pipe, certified combine -- the body of afsk_slide_lpf8_kernel, and of afsk_fused8_kernel once per sweep.
+// planes: kL8Dig digit planes per stream (may lie over xs: nobody reads the window after the sliding sums); tp: 4 m doubles; bl: the
+// band operands; wl: the workgroup's list of uncertain (sweep, modem, sample) entries, wl[kTailCap] their count; wmax8: 8 floats.
 template <bool ONE>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PM_LPF8_WAVES, PM_LPF8_WAVES))) void afsk_slide_lpf8_kernel(const double *__restrict__ x, int64_t n, const double *__restrict__ mi,
-                                                                   const double *__restrict__ mq, const double *__restrict__ ui,
-                                                                   const double *__restrict__ uq, int m, SlideTones T, Lpf8Args Q, int ml,
-                                                                   int64_t nout, int G, SweepArgs P, double E, unsigned long long *__restrict__ list,
-                                                                   int *__restrict__ count, int cap, int region0, SweepTail TL)
+__device__ __forceinline__ void lpf8_sweep_tile(double *__restrict__ xs, unsigned char *__restrict__ planes, double *__restrict__ tp, int4v *__restrict__ bl,
+                                                unsigned *__restrict__ wl, float *__restrict__ wmax8, int sweep, bool lds_ok, int t, int64_t tile0,
+                                                const double *__restrict__ mi, const double *__restrict__ mq, const double *__restrict__ ui,
+                                                const double *__restrict__ uq, int m, const SlideTones &T, const Lpf8Args &Q, int ml, int64_t nout, int G,
+                                                const SweepArgs &P, double E, unsigned long long *__restrict__ list, int *__restrict__ count, int cap)
 {
-    extern __shared__ double xs[];
     constexpr int L = kFuseRun, TILE = kThreads * 8;
-    const int t = threadIdx.x;
-    const int64_t tile0 = (int64_t)blockIdx.x * TILE;
-    const int nmag = TILE + ml - 1, nruns = (nmag + L - 1) / L, xspan = nruns * L + m - 1;
-    double *tp = xs + region0;
-    // the workgroup's own list of uncertain (sample, modem) pairs, decided by the exact chain before the workgroup ends (sweep_tail_entry):
-    // behind the band operands in the dynamic block -- as a static array it moved the block's start off its 16-byte boundary (232 bytes
-    // of static LDS) and every ds_read_b128 of the planes went the slow way: this kernel 0.33 -> 1.4 ms in the pipeline
-    unsigned *const wl = reinterpret_cast<unsigned *>(reinterpret_cast<int4v *>(tp + 4 * m) + 2 * kL8Dig * 64);
-    unsigned &wl_n = wl[kTailCap];
-    if (t == 0) wl_n = 0;
-    if (((uintptr_t)x & 15) == 0 && tile0 + TILE <= n) {
-        double2v v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const double2v *>(x + tile0 + 2 * (q * kThreads + t));
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int s0 = slide_slot<L>(2 * (q * kThreads + t));
-            xs[s0] = v[q].x;
-            xs[s0 + 1] = v[q].y;
-        }
-        for (int p = TILE + t; p < xspan; p += kThreads) {
-            const int64_t gi = tile0 + p;
-            xs[slide_slot<L>(p)] = gi < n ? x[gi] : 0.0;
-        }
-    } else {
-        for (int p = t; p < xspan; p += kThreads) {
-            const int64_t gi = tile0 + p;
-            xs[slide_slot<L>(p)] = gi < n ? x[gi] : 0.0;
-        }
-    }
+    const int nmag = TILE + ml - 1, nruns = (nmag + L - 1) / L;
     for (int i = t; i < m; i += kThreads) {
         tp[4 * i + 0] = mi[m - 1 - i];
         tp[4 * i + 1] = mq[m - 1 - i];
@@ -1156,7 +1131,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PM_LPF
         vmaxf = fmaxf(vmaxf, __shfl_xor(vmaxf, off));
         if (ONE) vsumf = fmaxf(vsumf, __shfl_xor(vsumf, off));
     }
-    __shared__ float wmaxf[2][kThreads / 64];
+    float (*wmaxf)[kThreads / 64] = reinterpret_cast<float (*)[kThreads / 64]>(wmax8);      // (dynamic block: a static array would move its start)
     if ((t & 63) == 0) {
         wmaxf[0][t >> 6] = vmaxf;
         wmaxf[1][t >> 6] = vsumf;
@@ -1213,7 +1188,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PM_LPF
     const double Ecmp = scalable ? ceil((ldexp(E, Q.S + s2) + Q.gfac * (Q.c_tap * (vmax * scale) + Q.c_q)) * (1.0 + 1e-9) * (1.0 / 256.0)) + 2.0
                                  : __builtin_inf();
 #endif
-    unsigned char *planes = reinterpret_cast<unsigned char *>(xs);
     if (t < nruns) {
         static_assert(L % 4 == 0, "four magnitudes per plane word");
         auto put = [&](const auto (&val)[L], int stream) {
@@ -1246,7 +1220,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PM_LPF
     }
     const int lane = t & 63, wave = t >> 6, r = lane & 15, g4 = lane >> 4;
     // the band operands (3 digits x 2 blocks x 64 lanes x 16 bytes) behind the templates
-    int4v *bl = reinterpret_cast<int4v *>(tp + 4 * m);
     for (int i = t; i < 2 * kL8Dig * 64; i += kThreads) bl[i] = Q.btab[i];
     lds_barrier();
     const int64_t nout64 = ((nout + 63) >> 6) * 64;
@@ -1321,9 +1294,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PM_LPF
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
                     if (16 * v < lim && !(fabs(y[v]) > Ecmp)) {
-                        const unsigned mine = TL.lds_ok ? atomicAdd(&wl_n, 1u) : (unsigned)kTailCap;
+                        const unsigned mine = lds_ok ? atomicAdd(&wl[kTailCap], 1u) : (unsigned)kTailCap;
                         if (mine < (unsigned)kTailCap) {
-                            wl[mine] = ((unsigned)g << 16) | (unsigned)(tl + 64 * g4 + 16 * v + r);
+                            wl[mine] = ((unsigned)sweep << 20) | ((unsigned)g << 16) | (unsigned)(tl + 64 * g4 + 16 * v + r);
                         } else {
                             const int idx = atomicAdd(count, 1);
                             if (idx < cap) list[idx] = ((unsigned long long)g << 48) | (unsigned long long)(go + 64 * g4 + 16 * v + r);
@@ -1332,18 +1305,179 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PM_LPF
             }
         }
     }
+}
+
+template <bool ONE>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PM_LPF8_WAVES, PM_LPF8_WAVES))) void afsk_slide_lpf8_kernel(const double *__restrict__ x, int64_t n, const double *__restrict__ mi,
+                                                                   const double *__restrict__ mq, const double *__restrict__ ui,
+                                                                   const double *__restrict__ uq, int m, SlideTones T, Lpf8Args Q, int ml,
+                                                                   int64_t nout, int G, SweepArgs P, double E, unsigned long long *__restrict__ list,
+                                                                   int *__restrict__ count, int cap, int region0, SweepTail TL)
+{
+    extern __shared__ double xs[];
+    constexpr int L = kFuseRun, TILE = kThreads * 8;
+    const int t = threadIdx.x;
+    const int64_t tile0 = (int64_t)blockIdx.x * TILE;
+    const int nmag = TILE + ml - 1, nruns = (nmag + L - 1) / L, xspan = nruns * L + m - 1;
+    double *tp = xs + region0;
+    // the workgroup's own list of uncertain (sample, modem) pairs, decided by the exact chain before the workgroup ends (sweep_tail_entry):
+    // behind the band operands in the dynamic block -- as a static array it moved the block's start off its 16-byte boundary (232 bytes
+    // of static LDS) and every ds_read_b128 of the planes went the slow way: this kernel 0.33 -> 1.4 ms in the pipeline
+    int4v *const bl = reinterpret_cast<int4v *>(tp + 4 * m);
+    unsigned *const wl = reinterpret_cast<unsigned *>(bl + 2 * kL8Dig * 64);
+    float *const wmax8 = reinterpret_cast<float *>(wl + kTailCap + 4);
+    if (t == 0) wl[kTailCap] = 0;
+    if (((uintptr_t)x & 15) == 0 && tile0 + TILE <= n) {
+        double2v v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const double2v *>(x + tile0 + 2 * (q * kThreads + t));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int s0 = slide_slot<L>(2 * (q * kThreads + t));
+            xs[s0] = v[q].x;
+            xs[s0 + 1] = v[q].y;
+        }
+        for (int p = TILE + t; p < xspan; p += kThreads) {
+            const int64_t gi = tile0 + p;
+            xs[slide_slot<L>(p)] = gi < n ? x[gi] : 0.0;
+        }
+    } else {
+        for (int p = t; p < xspan; p += kThreads) {
+            const int64_t gi = tile0 + p;
+            xs[slide_slot<L>(p)] = gi < n ? x[gi] : 0.0;
+        }
+    }
+    lpf8_sweep_tile<ONE>(xs, reinterpret_cast<unsigned char *>(xs), tp, bl, wl, wmax8, 0, TL.lds_ok != 0, t, tile0, mi, mq, ui, uq, m, T, Q, ml, nout, G, P, E,
+                         list, count, cap);
     // The workgroup's own uncertain samples, by the reference's chain, here: one in sixteen workgroups has one (750 + 220 per recording of
     // 28 000 workgroups), and it costs that workgroup a few microseconds -- as a launch of its own behind this one the same work sat on the demod
     // stream's critical path, twice per recording, waiting for slots among the other stream's workgroups (86 us per launch against 11 alone).
     __syncthreads();                                         // (vmcnt too: this workgroup's bitmap words are in memory before an atomic touches them)
-    const int ne = (int)(wl_n < (unsigned)kTailCap ? wl_n : (unsigned)kTailCap);
+    const int ne = (int)(wl[kTailCap] < (unsigned)kTailCap ? wl[kTailCap] : (unsigned)kTailCap);
     for (int e = 0; e < ne; ++e) {
         const unsigned ent = wl[e];
-        const int g = (int)(ent >> 16);
+        const int g = (int)(ent >> 16) & 15;
         const double *si = TL.space + (size_t)g * 2 * m;
         sweep_tail_entry<kThreads>(xs, t, x, mi, mq, si, si + m, m, TL.lpf, ml, TL.src, tile0 + (int64_t)(ent & 0xFFFFu),
                                    reinterpret_cast<unsigned long long *>(P.bits[g]));
     }
+}
+
+// ---- ONE launch per recording for the AFSK stage of a chain group (round 5): band-pass, every sweep, every uncertain sample -------------
+// Round 4's stage was three launches and 0.78 GB of traffic per recording: bpf8_kernel wrote the band-passed stream (230 MB of binary64),
+// each of the two sweep kernels read it back -- an intermediate SURVEY 8(d) prices at zero.  Here a workgroup owns 2048 outputs of every
+// sweep: it stages the int16 audio under them ONCE as digit planes, runs the band-pass on the matrix pipe (bpf8_kernel's arithmetic,
+// pm_bpf8_dev.h) for the 2048 + (ml - 1) + (m - 1) values the longest sweep needs -- straight into the sliding sums' LDS window, never into
+// memory -- then each sweep's tile from that window (lpf8_sweep_tile: the sweeps differ in tones, span and gains, not in their input),
+// then the exact chain for whatever it could not certify.  What crosses HBM: 2 bytes per sample in, one bit per sample and chain out;
+// the halo (mb + m + ml - 3 = 305 samples per 2048, 15 %) is band-passed twice, which costs 2 of the 9 + 16 + 8 matrix tiles per workgroup.
+struct FusedSweep {
+    const double *mi, *mq, *ui, *uq;     // templates (mark pair, unit-gain space pair)
+    const double *space, *lpf;           // the exact chain's operands: the modems' own space taps, the low-pass in binary64
+    int m, ml, G, one;
+    SlideTones T;
+    Lpf8Args Q;
+    SweepArgs P;
+    double E;
+    unsigned long long *list;
+    int *count;
+    int64_t nout;
+};
+struct FusedArgs {
+    FusedSweep s[2];
+    const int16_t *audio;
+    int64_t n, nb;                       // samples; band-pass outputs (n - mb + 1)
+    const pm_bpf8_dev::i4 *bp_btab;
+    pm_bpf8_dev::Scales sc;
+    SweepSource src;
+    int xs_span;                         // band-passed values a workgroup needs: the largest runs * L + m - 1 of the sweeps
+    int aplane;                          // bytes of an audio digit plane
+    int xw_doubles, plane_bytes, mmax;   // LDS layout: window | planes | templates | band operands | list | maxima
+    int lds_ok, cap;
+};
+
+#ifndef PM_FUSED8_WAVES
+#define PM_FUSED8_WAVES 5       // compiled for five waves per SIMD (96 registers): the LDS block admits four workgroups, and four of its waves then leave a SIMD room for a slicer wave (slice_walk_kernel: 88 registers) beside them
+#endif
+template <int KB, bool ONE0, int NS, bool ONE1>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PM_FUSED8_WAVES, PM_FUSED8_WAVES))) void afsk_fused8_kernel(FusedArgs A)
+{
+    extern __shared__ double xs[];
+    constexpr int L = kFuseRun, TILE = kThreads * 8;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t tile0 = (int64_t)blockIdx.x * TILE;
+    unsigned char *const planes = reinterpret_cast<unsigned char *>(xs + A.xw_doubles);
+    double *const tp = reinterpret_cast<double *>(planes + A.plane_bytes);
+    int4v *const bl = reinterpret_cast<int4v *>(tp + 4 * A.mmax);
+    unsigned *const wl = reinterpret_cast<unsigned *>(bl + 2 * kL8Dig * 64);
+    float *const wmax8 = reinterpret_cast<float *>(wl + kTailCap + 4);
+    if (t == 0) wl[kTailCap] = 0;
+    // the audio under the workgroup as two digit planes (in the low-pass planes' place: those come later); the band's operands come from
+    // the plan's table block by block (in registers for the kernel's life they took it from 97 to 121: no room left on a SIMD for a
+    // slicer wave beside four of these, and the slicers are the other half of the pipeline)
+    unsigned char *const ap0 = planes, *const ap1 = planes + A.aplane;
+    pm_bpf8_dev::stage_planes_rt(A.audio, A.n, tile0, t, kThreads, ap0, ap1, A.aplane);
+    {
+        lds_barrier();
+        // band-pass tiles of 256 values, waves taking turns, into the window (positions past the stream: 0.0, as the split kernels stage them)
+        const int r = lane & 15, g = lane >> 4;
+        const int ntiles = (A.xs_span + 255) >> 8;
+        for (int q = wave; q < ntiles; q += kThreads / 64) {
+            double val[4];
+            const pm_bpf8_dev::i4 *bt = A.bp_btab;
+            asm volatile("" : "+s"(bt));                     // (opaque per tile: hoisted out of this loop the operands are 48 registers again)
+            pm_bpf8_dev::tile_values_tab<KB, 4>(ap0, ap1, bt, q * 256, lane, A.sc, val);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int p = q * 256 + 16 * (4 * g + v) + r;
+                if (p < A.xs_span) xs[slide_slot<L>(p)] = tile0 + p < A.nb ? val[v] : 0.0;
+            }
+        }
+    }
+    lds_barrier();
+    {
+        const FusedSweep &S = A.s[0];
+        if (tile0 < ((S.nout + 63) >> 6) * 64)               // (uniform: a sweep with a longer correlator has fewer outputs)
+            lpf8_sweep_tile<ONE0>(xs, planes, tp, bl, wl, wmax8, 0, A.lds_ok != 0, t, tile0, S.mi, S.mq, S.ui, S.uq, S.m, S.T, S.Q, S.ml, S.nout, S.G, S.P, S.E,
+                                  S.list, S.count, A.cap);
+    }
+    if (NS == 2) {
+        lds_barrier();                                       // every wave is through with the first sweep's templates, planes and band
+        const FusedSweep &S = A.s[1];
+        if (tile0 < ((S.nout + 63) >> 6) * 64)
+            lpf8_sweep_tile<ONE1>(xs, planes, tp, bl, wl, wmax8, 1, A.lds_ok != 0, t, tile0, S.mi, S.mq, S.ui, S.uq, S.m, S.T, S.Q, S.ml, S.nout, S.G, S.P, S.E,
+                                  S.list, S.count, A.cap);
+    }
+    // the workgroup's own uncertain samples, by the reference's chain from the audio (see afsk_slide_lpf8_kernel)
+    __syncthreads();
+    const int ne = (int)(wl[kTailCap] < (unsigned)kTailCap ? wl[kTailCap] : (unsigned)kTailCap);
+    for (int e = 0; e < ne; ++e) {
+        const unsigned ent = wl[e];
+        const int g = (int)(ent >> 16) & 15;
+        const int64_t k = tile0 + (int64_t)(ent & 0xFFFFu);
+        if (NS == 1 || (ent >> 20) == 0) {
+            const FusedSweep &S = A.s[0];
+            const double *si = S.space + (size_t)g * 2 * S.m;
+            sweep_tail_entry<kThreads>(xs, t, nullptr, S.mi, S.mq, si, si + S.m, S.m, S.lpf, S.ml, A.src, k, reinterpret_cast<unsigned long long *>(S.P.bits[g]));
+        } else {
+            const FusedSweep &S = A.s[1];
+            const double *si = S.space + (size_t)g * 2 * S.m;
+            sweep_tail_entry<kThreads>(xs, t, nullptr, S.mi, S.mq, si, si + S.m, S.m, S.lpf, S.ml, A.src, k, reinterpret_cast<unsigned long long *>(S.P.bits[g]));
+        }
+    }
+}
+
+// every sweep's counter into its page-locked word, and the counters back to zero for the block's next recording (the fused launch has
+// no band-pass kernel in front of it to clear them); `keep` holds the counts for whoever works a list off later
+__global__ void sweep_mail_reset_kernel(int *__restrict__ count, int *__restrict__ keep, int *__restrict__ mail, int n)
+{
+    if ((int)threadIdx.x < n) {
+        const int c = count[threadIdx.x];
+        keep[threadIdx.x] = c;
+        mail[threadIdx.x] = c;
+        count[threadIdx.x] = 0;
+    }
+    __threadfence_system();
 }
 
 // The exact chain for single samples: correlator bank of modem g at the ml positions the low-pass needs, then the low-pass, every
@@ -1450,12 +1584,6 @@ __global__ __launch_bounds__(64) void sweep_exact_kernel(const double *__restric
         }
         __syncthreads();
     }
-}
-
-__global__ void sweep_mail_kernel(const int *__restrict__ count, int *__restrict__ mail, int n)
-{
-    if ((int)threadIdx.x < n) mail[threadIdx.x] = count[threadIdx.x];
-    __threadfence_system();
 }
 
 // One 64-bit word per wave per step: lane l tests sample 64*w + l, the ballot is the word.
@@ -1971,7 +2099,7 @@ static int sweep_signs(pm_ctx *ctx, const double *d_x, int64_t n, double x_bound
         const int nmag = kThreads * 8 + ml - 1, nruns = (nmag + kFuseRun - 1) / kFuseRun, pspan = nruns * kFuseRun + m - 1;
         const size_t xdoubles = (size_t)pspan + pspan / kFuseRun + 2, pdoubles = (size_t)(one ? 1 : 2) * kL8Dig * kL8Plane / 8;
         const int region0 = (int)((std::max(xdoubles, pdoubles) + 1) / 2 * 2);
-        const size_t lds = ((size_t)region0 + 4 * (size_t)m) * sizeof(double) + 2 * kL8Dig * 64 * 16 + (kTailCap + 4) * sizeof(unsigned);      // x window | planes, templates, band operands, the workgroup's list
+        const size_t lds = ((size_t)region0 + 4 * (size_t)m) * sizeof(double) + 2 * kL8Dig * 64 * 16 + (kTailCap + 4) * sizeof(unsigned) + 32;      // x window | planes, templates, band operands, the workgroup's list, its waves' maxima
         PmProf prof(ctx, PM_K_FIR_F64);
         const double nlp = one ? 1.0 : 2.0;
         prof.work((double)n * 8 + (double)groups * nl / 8,
@@ -2133,6 +2261,119 @@ int pm_afsk_group_run(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const doub
 
 }  // extern "C"
 
+// The fused launch of pm_afsk_group_run_plan (afsk_fused8_kernel): what each sweep's certified decision needs is worked out as
+// sweep_signs works it out, sweep by sweep.  -> PM_OK and *fused = true when the launch was made; *fused = false (and nothing enqueued) when
+// the group does not qualify and the caller takes the split path.
+static int afsk_group_run_fused(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const double *d_bpf, int mb, double x_bound, const pm_afsk_sweep_desc *h_sweeps,
+                                int nsweeps, const pm_bpf8_plan *plan, const pm_lpf8_plan *const *lpf8, const pm_sweep_cells *cells, bool *fused)
+{
+    *fused = false;
+    if (!plan || !lpf8 || !cells || !cells->d_list || nsweeps < 1 || nsweeps > 2 || ctx->tune.afsk_split || ctx->tune.afsk_unfused || ctx->tune.fuse_run == 16 ||
+        ((uintptr_t)d_audio & 15) != 0)
+        return PM_OK;
+    int kb = 0;
+    const void *btab = nullptr;
+    double sc6[6];
+    if (pm_bpf8_plan_view(plan, &kb, &btab, sc6) != PM_OK || (kb != 3 && kb != 4)) return PM_OK;
+    FusedArgs A;
+    memset(&A, 0, sizeof(A));
+    const int64_t nb = n - mb + 1;
+    const double e_x = pm_bpf8_error(plan);
+    if (!(e_x >= 0.0 && e_x < 1e-6 * x_bound)) return PM_OK;
+    int xs_span = 0, mmax = 0, tail_doubles = 0;
+    bool two_streams = false;
+    for (int k = 0; k < nsweeps; ++k) {
+        const pm_afsk_sweep_desc &w = h_sweeps[k];
+        const pm_lpf8_plan *q = lpf8[k];
+        if (!q || !w.h_tones || w.m < 2 || w.ml + 15 > 128 || q->ml != w.ml || w.groups < 1 || w.groups > kSweepMax || !w.h_bits || !w.h_gains) return PM_OK;
+        if (!(w.h_tones->tap_dev >= 0.0 && w.h_tones->tap_dev < 1e-6) || !(w.lpf_abs_sum > 0.0 && w.lpf_abs_sum < 1e300)) return PM_OK;
+        if (nb < (int64_t)w.m + w.ml - 1) return PM_OK;
+        FusedSweep &S = A.s[k];
+        S.mi = w.d_mark_i; S.mq = w.d_mark_q; S.ui = w.d_unit_i; S.uq = w.d_unit_q;
+        S.space = w.d_space; S.lpf = w.d_lpf;
+        S.m = w.m; S.ml = w.ml; S.G = w.groups;
+        S.one = w.groups == 1;
+        double gmax = 0.0;
+        for (int g = 0; g < w.groups; ++g) {
+            if (!w.h_bits[g] || !(w.h_gains[g] >= 0.0 && w.h_gains[g] < 1e100)) return PM_OK;
+            S.P.gain[g] = w.h_gains[g];
+            S.P.bits[g] = w.h_bits[g];
+            gmax = std::max(gmax, w.h_gains[g]);
+        }
+        const pm_afsk_tones *tn = w.h_tones;
+        S.T = SlideTones{tn->mark_rot[0], tn->mark_rot[1], tn->mark_end[0], tn->mark_end[1], tn->space_rot[0], tn->space_rot[1], tn->space_end[0], tn->space_end[1]};
+        // E: sweep_signs' bound, with the band-passed stream a value within e_x of the reference's (see there)
+        double e_slide = slide_bound(tn, w.m, x_bound, kFuseRun);
+        e_slide = e_slide * (1.0 + e_x / x_bound) + 1.4143 * w.m * e_x;
+        S.E = 1e-10 * w.lpf_abs_sum * (1.0 + gmax) * (double)w.m * 1.4143 * x_bound + w.lpf_abs_sum * (1.0 + gmax) * e_slide;
+        S.Q.S = q->S;
+        S.Q.c_tap = q->tapq_int;
+        S.Q.c_q = 0.5 * q->qabs + q->dlow;
+        S.Q.gfac = S.one ? 1.0 : 1.0 + gmax;
+        S.Q.qabs = q->qabs;
+        S.Q.btab = (const int4v *)q->d_btab;
+        S.list = cells->d_list + (size_t)k * kSweepCap;
+        S.count = cells->d_count + k;
+        S.nout = nb - w.m - w.ml + 2;
+        const int nmag = kThreads * 8 + w.ml - 1, nruns = (nmag + kFuseRun - 1) / kFuseRun;
+        if (nruns > kThreads) return PM_OK;
+        xs_span = std::max(xs_span, nruns * kFuseRun + w.m - 1);
+        mmax = std::max(mmax, w.m);
+        tail_doubles = std::max(tail_doubles, (int)sweep_tail_doubles(w.m, w.ml, mb));
+        two_streams = two_streams || !S.one;
+    }
+    A.audio = d_audio;
+    A.n = n;
+    A.nb = nb;
+    A.bp_btab = (const pm_bpf8_dev::i4 *)btab;
+    for (int w = 0; w < 5; ++w) A.sc.s[w] = sc6[w];
+    A.sc.c0 = sc6[5];
+    A.src = SweepSource{d_audio, d_bpf, mb, e_x};
+    A.xs_span = xs_span;
+    const int btiles = (xs_span + 255) / 256;
+    A.aplane = (btiles * 256 + 64 * kb + 15) / 16 * 16;      // what the last tile's band reads: 256 (tile) + 64 kb - 16 bytes past its first
+    A.xw_doubles = (xs_span + xs_span / kFuseRun + 2 + 1) / 2 * 2;
+    A.plane_bytes = std::max((two_streams ? 2 : 1) * kL8Dig * kL8Plane, 2 * A.aplane);
+    A.plane_bytes = (A.plane_bytes + 15) / 16 * 16;
+    A.mmax = mmax;
+    A.cap = kSweepCap;
+    A.lds_ok = (size_t)tail_doubles * 8 <= (size_t)A.xw_doubles * 8 + (size_t)A.plane_bytes && !ctx->tune.sweep_no_tail;
+    const size_t lds = (size_t)A.xw_doubles * 8 + (size_t)A.plane_bytes + 4 * (size_t)mmax * 8 + 2 * kL8Dig * 64 * 16 + (kTailCap + 4) * sizeof(unsigned) + 32;
+    if (lds > 64 * 1024) return PM_OK;
+    int64_t tiles = 0;
+    double bits_out = 0.0, flops = 2.0 * mb * (double)nb;
+    for (int k = 0; k < nsweeps; ++k) {
+        tiles = std::max(tiles, pm_cdiv(A.s[k].nout, (int64_t)kThreads * 8));
+        bits_out += (double)A.s[k].G * (double)A.s[k].nout / 8;
+        flops += (4.0 * A.s[k].m / kFuseRun + 18.0) * (double)(nb - A.s[k].m + 1) + (A.s[k].one ? 1.0 : 2.0) * 2.0 * A.s[k].ml * (double)A.s[k].nout +
+                 2.0 * A.s[k].G * (double)A.s[k].nout;
+    }
+    PM_ARG(tiles >= 1 && tiles < (1LL << 31));
+    {
+        PmProf prof(ctx, PM_K_FIR_F64);
+        prof.work((double)n * 2 + bits_out, flops);          // the recording in, the bitmaps out: nothing else crosses HBM
+        auto go = [&](auto kernel) -> int {
+            if (int rc = allow_lds(kernel, lds)) return rc;
+            hipLaunchKernelGGL(kernel, dim3((unsigned)tiles), dim3(kThreads), lds, ctx->stream, A);
+            return PM_OK;
+        };
+        int rc = PM_OK;
+        const bool o0 = A.s[0].one != 0, o1 = nsweeps == 2 && A.s[1].one != 0;
+#define PM_FUSED_GO(KB)                                                                                                             \
+        rc = nsweeps == 1 ? (o0 ? go(afsk_fused8_kernel<KB, true, 1, false>) : go(afsk_fused8_kernel<KB, false, 1, false>))              \
+                          : (o0 ? (o1 ? go(afsk_fused8_kernel<KB, true, 2, true>) : go(afsk_fused8_kernel<KB, true, 2, false>))          \
+                                : (o1 ? go(afsk_fused8_kernel<KB, false, 2, true>) : go(afsk_fused8_kernel<KB, false, 2, false>)));
+        if (kb == 3) { PM_FUSED_GO(3) } else { PM_FUSED_GO(4) }
+#undef PM_FUSED_GO
+        if (rc) return rc;
+        PM_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(sweep_mail_reset_kernel, dim3(1), dim3(64), 0, ctx->stream, cells->d_count, cells->d_count + nsweeps, cells->h_mail, nsweeps);
+    PM_HIP(hipGetLastError());
+    *fused = true;
+    return PM_OK;
+}
+
 int pm_afsk_group_run_plan(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const double *d_bpf, int mb, double *d_bpf_out, double x_bound,
                            const pm_afsk_sweep_desc *h_sweeps, int nsweeps, int64_t *h_tickets, const pm_bpf8_plan *plan,
                            const pm_lpf8_plan *const *lpf8, const pm_sweep_cells *cells)
@@ -2149,6 +2390,14 @@ int pm_afsk_group_run_plan(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const
     const auto t_0 = std::chrono::steady_clock::now();
     SweepSource src{d_audio, d_bpf, mb, plan ? pm_bpf8_error(plan) : 0.0};
     PM_ARG(!cells || (cells->d_count && cells->h_mail));
+    if (plan && cells && cells->d_list) {
+        // one launch for the whole stage where the group qualifies (all sweeps on the matrix pipe, at most two): afsk_fused8_kernel
+        bool fused = false;
+        for (int k = 0; k < nsweeps; ++k) PM_ARG(h_sweeps[k].h_tones != nullptr);
+        PM_ARG(pm_bpf8_taps(plan) == mb);
+        if (int rc = afsk_group_run_fused(ctx, d_audio, n, d_bpf, mb, x_bound, h_sweeps, nsweeps, plan, lpf8, cells, &fused)) return rc;
+        if (fused) return PM_OK;
+    }
     if (plan) {
         PM_ARG(pm_bpf8_taps(plan) == mb);
         for (int k = 0; k < nsweeps; ++k) PM_ARG(h_sweeps[k].h_tones != nullptr);
@@ -2174,7 +2423,7 @@ int pm_afsk_group_run_plan(pm_ctx *ctx, const int16_t *d_audio, int64_t n, const
         // One wave behind the recording's last sweep leaves every sweep's count in its page-locked word (a sweep that ended with a launch
         // of its own has written the same value there already).  Round 4 had a 4096-workgroup launch between and behind the sweeps for
         // this and the recomputation: 0.23 ms per recording of the demod streams' time.
-        hipLaunchKernelGGL(sweep_mail_kernel, dim3(1), dim3(64), 0, ctx->stream, cells->d_count, cells->h_mail, nsweeps);
+        hipLaunchKernelGGL(sweep_mail_reset_kernel, dim3(1), dim3(64), 0, ctx->stream, cells->d_count, cells->d_count + nsweeps, cells->h_mail, nsweeps);
         if (hipGetLastError() != hipSuccess) rc = pm_set_error(PM_ERR_HIP, "pm_afsk_group_run: mailing the sweeps' counts failed");
     }
     if (trace) {

@@ -116,7 +116,7 @@ struct pm_pipe {
     // per worker: slicer output blocks on the device
     struct Work {
         uint8_t *d_out = nullptr, *d_dense = nullptr;
-        size_t out_bytes = 0, dense_bytes = 0, tmp_n = 0;
+        size_t out_bytes = 0, dense_bytes = 0, tmp_n = 0, host_bytes = 0;
         double *d_tmp = nullptr;
         bool reserved = false;
     };
@@ -139,6 +139,7 @@ struct pm_pipe {
     unsigned long long *d_lists = nullptr;               // per block: nsweeps lists of kSweepCap entries (what a matrix-pipe sweep's workgroups did not decide themselves)
     std::vector<int> free_cells;
     bool keep_slices = false, trace = false;
+    bool host_copy = false;              // PM_PIPE_HOST_COPY: the slicers' compact output through a device block and a copy (round 4), not written to the host block by the kernel
     bool skip_decode = false;            // PM_PIPE_SKIP_DECODE (diagnosis only): the host stage decodes nothing -- what the GPU stages alone sustain
     int64_t next_ticket = 0, submitted = 0, finished = 0;   // submitted: tickets handed out (each is in `results` from then on)
     int64_t promised = 0;                // pm_pipe_submit_many: tickets below this will exist; pm_pipe_wait waits for them to
@@ -307,7 +308,7 @@ void slice_worker(pm_pipe *p, int wi)
                 if (unc[s] <= 0) continue;
                 if (unc[s] <= kSweepCap) {
                     if ((rc = pm_afsk_sweep_exact_list(side, r->d_audio, p->d_bpf, p->mb, &p->sweeps[s], p->sweep_bits_store[r->slot][s].data(),
-                                                       p->d_lists + ((size_t)r->cell * p->nsweeps + s) * kSweepCap, p->d_cells + (size_t)r->cell * p->nsweeps + s)))
+                                                       p->d_lists + ((size_t)r->cell * p->nsweeps + s) * kSweepCap, p->d_cells + (size_t)r->cell * 2 * p->nsweeps + p->nsweeps + s)))
                         fail(*r, rc);
                     continue;
                 }
@@ -382,26 +383,27 @@ void slice_worker(pm_pipe *p, int wi)
         if (rc == PM_ERR_CAPACITY) rc = run(false);
         const double t_b = now_ms();          // a stream with more than 1.5x its nominal symbol count: the full bound
         std::shared_ptr<HostBlock> hb;
+        double t_c = t_b, t_d = t_b;
         std::vector<int64_t> offs(jobs.size());
         if (!rc) {
             size_t dense_cap = 0;
             for (size_t j = 0; j < caps.size(); ++j)
                 dense_cap += kCompactHead + ((size_t)2 * jobs[j].count + 7) / 8 * 8 + ((size_t)jobs[j].count + 7) / 8 * 8;
-            if (w.dense_bytes < dense_cap) {
+            // The compact kernel writes the batch's output STRAIGHT into a page-locked host block (the device reaches it over the link:
+            // hipHostMalloc memory is mapped) -- no device-side block, no copy operation behind the kernel.  As a copy of its own the
+            // 8 MB took 0.2 ms in steady state but 4-12 ms whenever the demod streams had a dozen recordings queued (the first batches
+            // of a run, every batch of a short one): the driver's 20-step figure was 0.81 or 1.1 ms per step by the luck of that
+            // (gpurun_out r5m; PM_PIPE_HOST_COPY=1 brings the copy back for comparison).
+            const bool direct = !p->host_copy;
+            if (!direct && w.dense_bytes < dense_cap) {
                 if (w.d_dense) { (void)pm_free(side, w.d_dense); w.d_dense = nullptr; w.dense_bytes = 0; }
                 void *q = nullptr;
                 const size_t want = dense_cap * 3 / 2 * (size_t)p->group / (size_t)nb + 4096;
                 if (!(rc = pm_malloc(side, want, &q))) { w.d_dense = (uint8_t *)q; w.dense_bytes = want; }
             }
-            size_t used = 0, at = 0;
-            for (size_t j0 = 0; j0 < jobs.size() && !rc; j0 += 64) {
-                const int nj = (int)std::min<size_t>(64, jobs.size() - j0);
-                size_t u = 0;
-                rc = pm_slice_compact(side, jobs.data() + j0, nj, w.d_dense + at, w.dense_bytes - at, offs.data() + j0, &u);
-                for (int k = 0; k < nj; ++k) offs[j0 + k] += (int64_t)at;
-                at += (u + 255) & ~(size_t)255;
-                used = at;
-            }
+            // (host blocks in one size class: what a full batch needs, half as much again)
+            const size_t padded = dense_cap + 256 * ((jobs.size() + 63) / 64);
+            if (w.host_bytes < padded) w.host_bytes = padded * 3 / 2 * (size_t)p->group / (size_t)nb + 4096;
             if (!rc && !w.reserved) {
                 // first batch of this worker: the stream's work block (checkpoints, symbol bitmaps, lists: ~150 MB per recording) sized
                 // for a full batch now -- growing it later is a free + malloc in the middle of the pipeline -- and the host blocks made
@@ -410,23 +412,36 @@ void slice_worker(pm_pipe *p, int wi)
                 if (!(rc = pm_ctx_scratch(side, 0, &have))) rc = pm_ctx_scratch(side, have * (size_t)p->group / (size_t)nb, nullptr);
                 std::vector<std::shared_ptr<HostBlock>> warm;
                 for (int k = 0; k < 4 && !rc; ++k) {
-                    warm.push_back(block_get(p, w.dense_bytes, w.dense_bytes));
-                    if (!warm.back()) rc = pm_set_error(PM_ERR_HIP, "hipHostMalloc of %zu bytes failed", w.dense_bytes);
+                    warm.push_back(block_get(p, w.host_bytes, w.host_bytes));
+                    if (!warm.back()) rc = pm_set_error(PM_ERR_HIP, "hipHostMalloc of %zu bytes failed", w.host_bytes);
                 }
             }
             if (!rc) {
-                hb = block_get(p, used, w.dense_bytes);
-                if (!hb) rc = pm_set_error(PM_ERR_HIP, "hipHostMalloc of %zu bytes failed", w.dense_bytes);
-                if (!rc && hipMemcpyAsync(hb->p, w.d_dense, used, hipMemcpyDeviceToHost, side->stream) != hipSuccess) rc = pm_set_error(PM_ERR_HIP, "copy of the slicer output failed");
-                if (!rc && hipStreamSynchronize(side->stream) != hipSuccess) rc = pm_set_error(PM_ERR_HIP, "slicer stream failed");
+                hb = block_get(p, padded, w.host_bytes);
+                if (!hb) rc = pm_set_error(PM_ERR_HIP, "hipHostMalloc of %zu bytes failed", w.host_bytes);
             }
+            t_c = now_ms();
+            uint8_t *const dst = direct ? (hb ? hb->p : nullptr) : w.d_dense;
+            const size_t dst_bytes = direct ? (hb ? hb->bytes : 0) : w.dense_bytes;
+            size_t used = 0, at = 0;
+            for (size_t j0 = 0; j0 < jobs.size() && !rc; j0 += 64) {
+                const int nj = (int)std::min<size_t>(64, jobs.size() - j0);
+                size_t u = 0;
+                rc = pm_slice_compact(side, jobs.data() + j0, nj, dst + at, dst_bytes - at, offs.data() + j0, &u);
+                for (int k = 0; k < nj; ++k) offs[j0 + k] += (int64_t)at;
+                at += (u + 255) & ~(size_t)255;
+                used = at;
+            }
+            t_d = now_ms();
+            if (!rc && !direct && hipMemcpyAsync(hb->p, w.d_dense, used, hipMemcpyDeviceToHost, side->stream) != hipSuccess) rc = pm_set_error(PM_ERR_HIP, "copy of the slicer output failed");
+            if (!rc && hipStreamSynchronize(side->stream) != hipSuccess) rc = pm_set_error(PM_ERR_HIP, "slicer stream failed");
         }
         // a failed batch may have walkers or copies enqueued that still read the bitmaps: the slots go back when the stream is empty
         if (rc) (void)hipStreamSynchronize(side->stream);
         const double t1 = now_ms();
         if (p->trace)
-            fprintf(stderr, "[pm_pipe] worker %d batch of %d (first %lld): demod done at %.2f, collected %.2f, sweeps checked +%.2f, sliced +%.2f, on the host +%.2f ms\n", wi, nb,
-                    (long long)batch[0]->ticket, batch[0]->t_ready - p->t_origin, t0 - p->t_origin, t_a - t0, t_b - t_a, t1 - t_b);
+            fprintf(stderr, "[pm_pipe] worker %d batch of %d (first %lld): demod done at %.2f, collected %.2f, sweeps checked +%.2f, sliced +%.2f, on the host +%.2f ms (host block +%.2f, compact enqueued +%.2f, until it is there +%.2f)\n", wi, nb,
+                    (long long)batch[0]->ticket, batch[0]->t_ready - p->t_origin, t0 - p->t_origin, t_a - t0, t_b - t_a, t1 - t_b, t_c - t_b, t_d - t_c, t1 - t_d);
         for (int b = 0; b < nb; ++b) {
             Rec &r = *batch[b];
             if (rc && !r.status) fail(r, rc);
@@ -649,6 +664,7 @@ int pm_pipe_create(pm_ctx *ctx, const pm_pipe_desc *desc, pm_pipe **out)
     p->keep_slices = d.keep_slices != 0;
     p->trace = getenv("PM_PIPE_TRACE") != nullptr;
     p->skip_decode = getenv("PM_PIPE_SKIP_DECODE") != nullptr;
+    p->host_copy = getenv("PM_PIPE_HOST_COPY") != nullptr;
     p->group = d.slice_group > 0 ? std::min(d.slice_group, 16) : 4;
     p->min_group = d.slice_min_group > 0 ? std::min(d.slice_min_group, p->group) : p->group;
     p->host_threads = d.host_threads > 0 ? d.host_threads : std::max(2, std::min(8, 24 / d.nchains)) + 1;
@@ -772,8 +788,9 @@ int pm_pipe_create(pm_ctx *ctx, const pm_pipe_desc *desc, pm_pipe **out)
         }
         if (d.nsweeps) {
             // one block of counter / mailbox words per recording between submission and its slicer batch: never more than `slots`
+            // (device words per recording and sweep: the live counter and the count as mailed)
             const size_t words = (size_t)p->slots * d.nsweeps;
-            if (hipMalloc((void **)&p->d_cells, words * sizeof(int)) != hipSuccess || hipMemset(p->d_cells, 0, words * sizeof(int)) != hipSuccess ||
+            if (hipMalloc((void **)&p->d_cells, 2 * words * sizeof(int)) != hipSuccess || hipMemset(p->d_cells, 0, 2 * words * sizeof(int)) != hipSuccess ||
                 hipMalloc((void **)&p->d_lists, words * kSweepCap * sizeof(unsigned long long)) != hipSuccess ||
                 hipHostMalloc((void **)&p->h_cells, words * sizeof(int), hipHostMallocDefault) != hipSuccess) {
                 rc = pm_set_error(PM_ERR_HIP, "pm_pipe_create: no memory for the sweep counters");
@@ -871,7 +888,7 @@ int pm_pipe_submit(pm_pipe *p, const int16_t *d_audio, int64_t n, int64_t *h_tic
             rc = pm_set_error(PM_ERR_HIP, "handing the recording to demod stream %zu failed", di);
     }
     if (!rc && p->nsweeps) {
-        const pm_sweep_cells cells{p->d_cells + (size_t)r->cell * p->nsweeps, p->h_cells + (size_t)r->cell * p->nsweeps,
+        const pm_sweep_cells cells{p->d_cells + (size_t)r->cell * 2 * p->nsweeps, p->h_cells + (size_t)r->cell * p->nsweeps,
                                    p->d_lists + (size_t)r->cell * p->nsweeps * kSweepCap};
         rc = pm_afsk_group_run_plan(r->dctx, d_audio, n, p->d_bpf, p->mb, p->d_bpf_outs[di], p->x_bound, sw.data(), p->nsweeps, nullptr,
                                     ((uintptr_t)d_audio & 15) == 0 ? p->bpf8 : nullptr, p->lpf8.data(), &cells);
@@ -888,6 +905,7 @@ int pm_pipe_submit(pm_pipe *p, const int16_t *d_audio, int64_t n, int64_t *h_tic
         // back only when the stream has passed them.  The ticket is finished, with the error.
         fail(*r, rc);
         (void)hipStreamSynchronize(r->dctx->stream);
+        if (r->cell >= 0) (void)hipMemset(p->d_cells + (size_t)r->cell * 2 * p->nsweeps, 0, 2 * sizeof(int) * (size_t)p->nsweeps);      // (a stage that stopped half way never mailed and reset them)
         {
             std::unique_lock<std::mutex> lk(p->mu);
             p->slot_busy[r->slot] = 0;

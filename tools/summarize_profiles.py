@@ -37,11 +37,11 @@ for name, ctr in [("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")]:
         res.setdefault(k, {})[ctr + "_KB_avg_per_launch"] = round(v / n, 1)
         res[k][ctr + "_launches"] = n
 CLASSES = {"fir_i16": ["fir_valid_kernel<short", "fir_short_signs_i16_kernel", "fir_rows_kernel<short", "bpf8_kernel", "bpf8_max_kernel", "bpf8_max_finish_kernel"],
-           "fir_f64": ["fir_valid_kernel<double", "fir_sweep_kernel", "afsk_slide_lpf_kernel", "afsk_slide_lpf8_kernel", "fir_rows_kernel<double", "fir8_kernel"],
+           "fir_f64": ["fir_valid_kernel<double", "fir_sweep_kernel", "afsk_slide_lpf_kernel", "afsk_slide_lpf8_kernel", "afsk_fused8_kernel", "fir_rows_kernel<double", "fir8_kernel"],
            "loop": ["loop_kernel", "loop_direct_kernel"], "agc": ["agc_rows_kernel", "rows_max_kernel", "rows_max_fold_kernel", "agc_rows_prepare_kernel", "agc_iter_kernel",
                                             "max_partial_kernel", "agc_scale_kernel"],
            "afsk_correlate": ["afsk_correlate_kernel", "afsk_slide_kernel"],
-           "signs": ["signs_kernel", "sweep_exact_kernel", "fir8_exact_kernel", "afsk_group_kernel", "fir_signs_batch_kernel", "pack_group_taps_kernel"],
+           "signs": ["signs_kernel", "sweep_exact_kernel", "sweep_mail_reset_kernel", "fir8_exact_kernel", "afsk_group_kernel", "fir_signs_batch_kernel", "pack_group_taps_kernel"],
            "slice_iter": ["slice_walk_kernel", "slice_iter_kernel", "rowslice_kernel"],
            "slice_emit": ["slice_count_kernel", "slice_scan_kernel", "slice_pack_kernel", "slice_compact_kernel", "rows_gather_kernel"]}
 out = {"workload": workload, "samples": samples,
