@@ -448,13 +448,16 @@ __global__ __launch_bounds__(1024) void slice_scan_kernel(const JobDev *__restri
 // byte range: it is assembled in LDS and written out by the whole workgroup, addresses as coalesced 8-byte stores, data as whole
 // dwords; only the first and the last dword of the range can hold bits of a neighbouring workgroup and go out as atomicOr.
 constexpr int kPackBytes = 2048;
-constexpr int kEmitWordsMax = 8;       // words per emit chunk at most (slice_pack_kernel stages 256 chunks of them in LDS)
+constexpr int kEmitWordsMax = 4;       // words per emit chunk at most (slice_pack_kernel stages 256 chunks of them in LDS).  Round 5: 8 -> 4 and
+                                       // 32-bit staged addresses took the kernel from 51 KB of LDS to 26: the demod kernel beside it fills a CU's
+                                       // 160 KB with four 40 KB workgroups, and a 51 KB workgroup -- at any priority -- waited until two of them
+                                       // retired at once (1.5 ms per batch in the pipeline for a kernel that takes 0.2 alone)
 __global__ __launch_bounds__(kBlock) void slice_pack_kernel(const JobDev *__restrict__ jobs, int njobs, int lc_words, int64_t total_chunks,
                                                         const uint64_t *__restrict__ symmap, const uint64_t *__restrict__ offset,
                                                         const uint8_t *__restrict__ prevsym)
 {
     __shared__ uint32_t lb[kPackBytes / 4 + 1];
-    __shared__ long long la[kPackBytes + 4];
+    __shared__ uint32_t la[kPackBytes + 4];                 // a byte's address as 1 + its distance in samples from the workgroup's first word (0: none)
     // the workgroup's words of the symbol bitmap and of the (in-phase) sign bitmap, loaded once, coalesced: lane by lane the reads
     // are 32-64 bytes apart and every cache line is fetched several times (PMC round 1: 6.5 x the algorithmic read)
     __shared__ uint64_t s_sym[kBlock * kEmitWordsMax], s_bi[kBlock * kEmitWordsMax];
@@ -488,17 +491,18 @@ __global__ __launch_bounds__(kBlock) void slice_pack_kernel(const JobDev *__rest
         __syncthreads();
     }
     // one byte's bits (and, from the lane that completes the byte, its address: never 0, addresses are 1-based)
+    const int64_t wg0 = c0 * lc_words, wg1 = min(wg0 + (int64_t)kBlock * lc_words, J.nwords);
+    const long long addr_base = (long long)(J.addr0 + (wg0 << 6));      // address = addr_base + (the 32-bit value staged)
     auto put = [&](uint64_t idx, uint32_t bits8, long long address) {
         if (staged) {
             const int rel = (int)(idx - base);
             atomicOr(&lb[rel >> 2], bits8 << ((rel & 3) * 8));
-            if (address) la[rel] = address;
+            if (address) la[rel] = (uint32_t)(address - addr_base);      // in 1 .. 64 * 256 * kEmitWordsMax
         } else if (idx < cap) {
             atomicOr(&J.data32[idx >> 2], bits8 << ((idx & 3) * 8));
             if (address) J.addr[idx] = address;
         }
     };
-    const int64_t wg0 = c0 * lc_words, wg1 = min(wg0 + (int64_t)kBlock * lc_words, J.nwords);
     {
         const uint64_t *smg = symmap + J.word0;
         for (int64_t i = t; i < wg1 - wg0; i += kBlock) {
@@ -556,8 +560,8 @@ __global__ __launch_bounds__(kBlock) void slice_pack_kernel(const JobDev *__rest
     if (!staged) return;
     __syncthreads();
     for (int i = t; i < span; i += kBlock) {
-        const long long a = la[i];
-        if (a && base + i < cap) J.addr[base + i] = a;
+        const uint32_t a = la[i];
+        if (a && base + i < cap) J.addr[base + i] = addr_base + (long long)a;
     }
     const int nd = (span + 3) / 4;
     for (int d = t; d < nd; d += kBlock) {
