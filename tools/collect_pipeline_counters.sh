@@ -30,6 +30,6 @@ for f in sorted(glob.glob("gpurun_out/pipeline_counters/pass*/*/*_counter_collec
         out[k][c] = {"launches": n, "avg": v / n}
 json.dump(out, open("gpurun_out/pipeline_counters/summary.json", "w"), indent=1)
 for k in sorted(out):
-    if any(s in k for s in ("lpf8", "bpf8", "sweep_exact", "slice_walk")):
+    if any(s in k for s in ("lpf8", "bpf8", "fused8", "sweep_exact", "slice_walk", "slice_pack")):
         print(k, {c: round(v["avg"]) for c, v in sorted(out[k].items())})
 PY

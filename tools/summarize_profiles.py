@@ -59,6 +59,10 @@ for k, v in sorted(res.items()):
     out["kernels"][k] = v
 for cls, prefixes in CLASSES.items():
     names = [k for k in out["kernels"] if any(k.startswith(p) for p in prefixes)]
+    # the headline's timed region launches ONE kernel of this class (afsk_fused8_kernel); the same process also runs the Python-sequenced
+    # executor's binary64 kernels in its upload leg (value_with_h2d_overlapped): the class figure bench.py quotes is the timed kernel's
+    if cls == "fir_f64" and any(k.startswith("afsk_fused8_kernel") for k in names):
+        names = [k for k in names if k.startswith("afsk_fused8_kernel")]
     n = sum(out["kernels"][k].get("FETCH_SIZE_launches", 0) for k in names)
     if n:
         total = sum(out["kernels"][k]["traffic_bytes_per_launch"] * out["kernels"][k].get("FETCH_SIZE_launches", 0) for k in names)
