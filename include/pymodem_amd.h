@@ -566,10 +566,13 @@ int64_t pm_correlate_strided(void *h_records, int64_t stride, const int64_t *h_c
 /* ---- pipelined executor for an AFSK chain group: one call per recording -------------------------
  * What pymodem.py:140-163 does with a process per chain and a queue -- every chain of the config on the same recording, the
  * packets of all of them de-duplicated -- as a pipeline over RECORDINGS that lives entirely inside the library:
- *   pm_pipe_submit   launches pm_afsk_group_run for the recording on the context's stream (band-pass + certified sweeps of every
- *                    chain), records an event, returns; blocks only while all bitmap slots are in use
- *   slicer threads   (own high-priority streams) wait for the event, take up to `slice_group` consecutive recordings, redo an
- *                    overflowed sweep with the exact kernels, run pm_slice_batch + pm_slice_compact, copy the output to the host
+ *   pm_pipe_submit   launches the recording's demod stage on one of the demod streams -- for an AFSK group of up to two certified
+ *                    sweeps ONE kernel: band-pass, every sweep and the exact chain for whatever it cannot certify, the int16 audio read
+ *                    once and one bit per sample and chain written (csrc/pm_fir.hip: afsk_fused8_kernel; other groups: band-pass + a
+ *                    launch per sweep) -- records an event, returns; blocks only while all bitmap slots are in use
+ *   slicer threads   (own high-priority streams) wait for the event, take up to `slice_group` consecutive recordings, work off what a
+ *                    sweep left on its list (normally nothing; an overflowed list: the exact kernels), run pm_slice_batch +
+ *                    pm_slice_compact, whose output the kernel writes into a page-locked host block
  *   host threads     pm_host_decode_batch + pm_codec_fetch_batch (LFSR + AX.25/IL2P per chain, fresh stage objects per recording
  *                    as chain_builder.py makes them) and pm_correlate over the chains in config order
  *   pm_pipe_wait     the recording's packet rows, per-chain counts and the de-dup result, in the library's memory until
