@@ -1169,6 +1169,7 @@ def measure(args, env):
                                         "data-path collective; one packet gather per recording)" if loop_wl else None)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "binding_resource": valu_issue(args, dom, alone_ms, avg_ms),
                          "traffic_source": None if traffic is None else "committed rocprofv3 PMC passes of this workload (profiles/*_pmc.json: FETCH_SIZE "
                                            "and WRITE_SIZE in separate runs, x1024, FETCH doubled per the gfx950 note), per launch of this kernel class; "
                                            "counters cannot be read from inside the process",
@@ -1278,6 +1279,38 @@ def dist_info(use_dist):
         every = None
     return {"world_size": seen, "backend": dist.get_backend(), "rank0_of": seen,
             "ranks_seen_by_rccl": seen if dist.get_backend() == "nccl" else 0, "device_and_local_rank_by_rank": every}
+
+
+def valu_issue(args, kernel_class, alone_ms, pipeline_ms):
+    """What does bind the headline's dominant kernel, from the committed SQ counter passes (profiles/*_pipeline_kernel_counters.json,
+    tools/collect_pipeline_counters.sh): vector instructions per launch x 4 cycles (a wave64 instruction occupies its SIMD's 16-lane
+    vector pipe for four) over the SIMD cycles of the launch at the nominal 2.4 GHz on 1024 SIMDs.  None when no profile matches."""
+    import glob
+    if args.workload != "afsk_1200_super_opt" or kernel_class != "fir_f64" or args.samples != 28_800_000:
+        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pipeline_kernel_counters.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:                                         # noqa: BLE001
+            continue
+        k = [n for n in d if n.startswith("afsk_fused8_kernel")]
+        if not k:
+            continue
+        c = d[k[0]]
+        valu, mfma_busy = c["SQ_INSTS_VALU"]["avg"], c["SQ_VALU_MFMA_BUSY_CYCLES"]["avg"]
+        simd_cycles = lambda ms: ms * 1e-3 * 2.4e9 * 1024
+        out = {"resource": "vector instruction issue", "kernel": k[0], "vector_instructions_per_launch": round(valu),
+               "matrix_busy_cycles_per_launch": round(mfma_busy), "source": os.path.basename(path),
+               "note": "vector instructions x 4 cycles / (launch time x 2.4 GHz x 1024 SIMDs): the share of the chip's SIMD cycles the launch spends "
+                       "issuing vector instructions -- the resource this kernel is bound by; the HBM roofline above counts its 86 MB of traffic "
+                       "and stays at a few percent whatever the kernel does"}
+        if alone_ms:
+            out["simd_cycle_frac_alone"] = round(4.0 * valu / simd_cycles(alone_ms), 4)
+            out["matrix_pipe_frac_alone"] = round(mfma_busy / simd_cycles(alone_ms), 4)
+        if pipeline_ms:
+            out["simd_cycle_frac_in_pipeline_per_launch"] = round(4.0 * valu / simd_cycles(pipeline_ms), 4)
+        return out
+    return None
 
 
 def pmc_traffic(args, kernel_class):
