@@ -141,6 +141,41 @@ def test_what_the_sweeps_leave_undecided_is_decided_by_the_reference_s_chain(con
     pipe.close()
 
 
+@pytest.mark.parametrize("picked", [[0, 1, 3, 4], [2, 5], [0, 1, 2, 3, 4, 5]])
+def test_native_pipeline_on_the_bundled_recording_equals_the_reference(golden, config_lines, picked):
+    """The one recording the reference ships (afsk_300_il2pc_noise.wav, 8 kHz: a 187-tap band-pass, i.e. the FOUR-block band of the
+    matrix-pipe band-pass) through the native executor with the AFSK correlator chains of configs/afsk_300_ax25.json, against what the
+    reference itself produced (tests/golden/wav_chains.npz): slicer bytes, addresses, LFSR bytes, packets.  Four chains = two sweeps of
+    two (one fused launch, both sweeps many-chain), two chains = one sweep (one fused launch), all six = three sweeps (the split path:
+    band-pass + a launch per sweep)."""
+    import os
+    import pymodem_amd
+    from conftest import GOLDEN, read_wav_pcm16
+    from pymodem_amd import chain_builder as cb, chain_execute as ce
+    g = golden("wav_chains")
+    rate, audio = read_wav_pcm16(os.path.join(GOLDEN, "afsk_300_il2pc_noise.wav"))
+    lines = config_lines("afsk_300_ax25.json")
+    ctx = pymodem_amd.Context.default()
+    d = ctx.upload(audio)
+    ctx.sync()
+    pipe = ce.NativePipeline([cb.build_chain(rate, lines[c]) for c in picked], len(audio), rate / 40, ctx=ctx, keep_slices=True)
+    tickets = [pipe.submit(d) for _ in range(3)]
+    for t in tickets:
+        kept = [pipe.slices(t, k) for k in range(len(picked))]
+        table = pipe.table(t)
+        rows = _rows_by_chain(table, len(picked))
+        for k, c in enumerate(picked):
+            prefix = f"afsk_300_ax25__c{c}"
+            sliced, plain = kept[k]
+            assert np.array_equal(sliced.data, g[prefix + "_slice_data"]), prefix
+            assert np.array_equal(sliced.address, g[prefix + "_slice_addr"]), prefix
+            assert np.array_equal(plain, g[prefix + "_lfsr_data"]), prefix
+            a, corr, data = _pk(rows[k])
+            assert np.array_equal(a, g[prefix + "_pkt_addr"]) and np.array_equal(data, g[prefix + "_pkt_data"]), prefix
+        del table, rows
+    pipe.close()
+
+
 def test_a_refused_recording_leaves_no_hole_in_the_tickets(config_lines):
     """pm_pipe_submit refuses a recording that is long enough for the band-pass but not for a chain's correlator + low-pass
     (mb <= n < mb + m + ml - 2) before a ticket exists; the submit_many behind it gets consecutive tickets and the wait on its LAST
