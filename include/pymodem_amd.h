@@ -643,6 +643,11 @@ int pm_pipe_wait(pm_pipe *pipe, int64_t ticket, pm_pipe_result *out);
  * their stream addresses (slicer.py:59-107), and what stream_unscramble_8bit made of them (lfsr.py:22-52), *h_count entries each,
  * in the library's memory until pm_pipe_release.  Any of the three pointers may be NULL. */
 int pm_pipe_slices(pm_pipe *pipe, int64_t ticket, int chain, const uint8_t **h_data, const int64_t **h_addr, const uint8_t **h_plain, int64_t *h_count);
+/* A finished recording's SIGN BITMAP for one chain -- bit k = (modem.demod(audio)[k] >= 0), what its slicer read (slicer.py:85) -- copied
+ * to h_words (`words` 64-bit words from the bitmap's start).  Pipelines made with keep_slices only, and only while the recording's
+ * bitmap slot has not been taken by a later submission (fewer than pm_pipe_slots() submissions since): PM_ERR_ARG otherwise.  Test entry:
+ * the demod stage's output compared bit by bit, whatever the slicer makes of it. */
+int pm_pipe_bitmap(pm_pipe *pipe, int64_t ticket, int chain, uint64_t *h_words, int64_t words);
 int pm_pipe_slots(pm_pipe *pipe);                        /* recordings between demod and slicer at most, as pm_pipe_create settled it */
 int pm_pipe_release(pm_pipe *pipe, int64_t ticket);      /* the result's memory */
 int pm_pipe_drain(pm_pipe *pipe);                        /* every recording submitted so far is through */

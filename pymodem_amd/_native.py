@@ -257,6 +257,7 @@ _SIGS = {
     "pm_pipe_wait": ([_vp, _i64, ctypes.POINTER(PipeResult)], _int),
     "pm_pipe_release": ([_vp, _i64], _int),
     "pm_pipe_slices": ([_vp, _i64, _int, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i64)], _int),
+    "pm_pipe_bitmap": ([_vp, _i64, _int, _vp, _i64], _int),
     "pm_pipe_slots": ([_vp], _int),
     "pm_pipe_drain": ([_vp], _int),
     "pm_pipe_stats": ([_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)], _int),

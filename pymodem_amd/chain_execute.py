@@ -1077,6 +1077,15 @@ class NativePipeline:
         plain = np.ctypeslib.as_array(ctypes.cast(q, ctypes.POINTER(ctypes.c_uint8)), (n,)).copy()
         return AddressedArray(data, addr), plain
 
+    def bitmap(self, ticket, chain, nout):
+        """A finished recording's sign bitmap for one chain as a bool array of nout entries: bit k = (demod output k >= 0), what the
+        chain's slicer read (pipelines made with keep_slices=True, before `slots` further recordings have been submitted)."""
+        self._wait(ticket)
+        words = (int(nout) + 63) // 64
+        buf = np.zeros(max(words, 1), dtype=np.uint64)
+        check(lib().pm_pipe_bitmap(self._h, int(ticket), int(chain), buf.ctypes.data_as(ctypes.c_void_p), max(words, 1)))
+        return np.unpackbits(buf.view(np.uint8), bitorder="little")[: int(nout)].astype(bool)
+
     def release(self, ticket):
         check(lib().pm_pipe_release(self._h, int(ticket)))
 

@@ -1040,6 +1040,24 @@ int pm_pipe_slices(pm_pipe *p, int64_t ticket, int chain, const uint8_t **h_data
     return PM_OK;
 }
 
+int pm_pipe_bitmap(pm_pipe *p, int64_t ticket, int chain, uint64_t *h_words, int64_t words)
+{
+    PM_ARG(p != nullptr && h_words != nullptr && chain >= 0 && chain < p->nchains && words >= 1 && (size_t)words <= p->bits_words);
+    if (!p->keep_slices) return pm_set_error(PM_ERR_ARG, "pm_pipe_bitmap: the pipeline was made without keep_slices");
+    int slot = -1;
+    {
+        std::unique_lock<std::mutex> lk(p->mu);
+        auto it = p->results.find(ticket);
+        if (it == p->results.end() || !it->second->done) return pm_set_error(PM_ERR_ARG, "pm_pipe_bitmap: recording %lld is unknown, released or still in flight", (long long)ticket);
+        if (it->second->status) return pm_set_error(it->second->status, "%s", it->second->error.c_str());
+        if (p->next_ticket - ticket > p->slots) return pm_set_error(PM_ERR_ARG, "pm_pipe_bitmap: recording %lld's bitmaps have been overwritten (%d slots)", (long long)ticket, p->slots);
+        slot = it->second->slot;
+    }
+    PM_CTX(p->ctx);
+    PM_HIP(hipMemcpy(h_words, p->d_bits[(size_t)slot * p->nchains + p->bit_owner[chain]], (size_t)words * 8, hipMemcpyDeviceToHost));
+    return PM_OK;
+}
+
 int pm_pipe_stats(pm_pipe *p, int64_t *h_batches, int64_t *h_batch_recordings, double *h_slice_busy_ms, double *h_host_busy_ms)
 {
     PM_ARG(p != nullptr);

@@ -88,6 +88,10 @@ def test_native_pipeline_bitstream_at_full_size_equals_the_oracle():
             sliced, plain = pipe.slices(t, c)
             assert np.array_equal(sliced.data, w["slice_data"]) and np.array_equal(sliced.address, w["slice_addr"]), c
             assert np.array_equal(plain, np.asarray(w["lfsr"], dtype=np.uint8)), c
+            # ... and the demod stage on its own: every one of the 28.8 M sign bits the slicer read is the oracle's (round 5: pm_pipe_bitmap)
+            want_bits = np.asarray(w["demod"]) >= 0
+            got_bits = pipe.bitmap(t, c, len(want_bits))
+            assert np.array_equal(got_bits, want_bits), (c, int(np.count_nonzero(got_bits != want_bits)))
             got_a, got_c, got_d = _pk(rows[c])
             assert [int(x) for x in got_a] == [int(p.streamaddress) for p in w["packets"]], c
             assert got_d.tobytes() == b"".join(bytes(bytearray(p.data)) for p in w["packets"]), c
@@ -173,6 +177,42 @@ def test_native_pipeline_on_the_bundled_recording_equals_the_reference(golden, c
             a, corr, data = _pk(rows[k])
             assert np.array_equal(a, g[prefix + "_pkt_addr"]) and np.array_equal(data, g[prefix + "_pkt_data"]), prefix
         del table, rows
+    pipe.close()
+
+
+def test_fused_launch_at_the_edges_of_its_tiles(config_lines):
+    """Recording lengths that put the last output of a sweep on, just before and just after the boundaries the fused kernel works in --
+    a bitmap word (64), a matrix tile (256), a workgroup (2048) -- for BOTH sweeps of the headline config at once (their correlators
+    are 40 and 60 taps long: the seven-chain sweep has 20 outputs fewer, so one of them ends a word / tile / workgroup where the other
+    does not), down to a single output.  The SIGN BITMAP of every chain, bit for bit, against the oracle's demodulated stream (and
+    nothing set past its last bit), and the slicer's bytes and addresses; several lengths in flight."""
+    import pymodem_amd
+    from pymodem_amd import chain_builder as cb, chain_execute as ce
+    lines = config_lines("afsk_1200_ax25_super_opt.json")
+    chains = [cb.build_chain(48000, l) for l in lines]
+    mb, ml = len(chains[0][1].input_bpf), len(chains[0][1].output_lpf)
+    m0 = max(len(ch[1].mark_correlator_i) for ch in chains)   # the longest correlator: its sweep has the fewest outputs
+    least = mb + m0 + ml - 2                                   # samples for ONE output of that sweep
+    rng = np.random.default_rng(2048)
+    base = np.clip(np.rint(rng.standard_normal(least + 3 * 2048 + 200) * 6000), -32768, 32767).astype(np.int16)
+    outs = [1, 2, 20, 21, 63, 64, 65, 84, 85, 255, 256, 257, 276, 2047, 2048, 2049, 2068, 2069, 4096, 4097, 6143, 6144, 6165]
+    ctx = pymodem_amd.Context.default()
+    pipe = ce.NativePipeline(chains, len(base), 48000 / 40, ctx=ctx, keep_slices=True)
+    dev = {k: ctx.upload(base[: least + k - 1].copy()) for k in outs}
+    ctx.sync()
+    for g0 in range(0, len(outs), 8):                         # (eight in flight: a bitmap slot is reused sixteen submissions later)
+        for k, t in [(k, pipe.submit(dev[k])) for k in outs[g0:g0 + 8]]:
+            audio = base[: least + k - 1]
+            for c, line in enumerate(lines):
+                w = O.run_chain(O.build_chain(48000, line), audio, canon=True)
+                sliced, _ = pipe.slices(t, c)
+                assert np.array_equal(sliced.data, w["slice_data"]) and np.array_equal(sliced.address, w["slice_addr"]), (k, c)
+                want = np.asarray(w["demod"]) >= 0
+                words = (len(want) + 63) // 64 * 64
+                got = pipe.bitmap(t, c, words)
+                assert np.array_equal(got[: len(want)], want), (k, c, int(np.count_nonzero(got[: len(want)] != want)))
+                assert not got[len(want):].any(), (k, c)         # bits past the last output of the last word are zero
+            pipe.release(t)
     pipe.close()
 
 
