@@ -468,6 +468,7 @@ void pm_lpf8_plan_destroy(pm_lpf8_plan *p)
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->d_btab) (void)hipFree(p->d_btab);
+    if (p->d_tpl) (void)hipFree(p->d_tpl);
     delete p;
 }
 

@@ -44,6 +44,7 @@ struct pm_tuning {
     int loop_vec = 1;                  // PM_LOOP_VEC=0: the direct loop shape moves its blocks with eight-byte accesses, a lane a row
     int lbatch_loop_cus = -1;          // PM_LBATCH_LOOP_CUS: compute units the batch engine's carrier loops have to themselves (0: none, -1: by size)
     int agc_rows_prio = 2;             // PM_AGC_ROWS_PRIO: wave priority of the rows AGC (the loops run at 3)
+    int sweep_lds_templates = 0;       // PM_SWEEP_LDS_TEMPLATES: the fused kernel's sliding sums read their templates from LDS (as the split kernel does), not through the scalar cache
     int afsk_split = 0;                // PM_AFSK_SPLIT: the pipelined executor's AFSK stage as band-pass + one launch per sweep (round 4), not fused into one launch
     int sweep_no_tail = 0;             // PM_SWEEP_NO_TAIL: the matrix-pipe sweep sends every uncertain sample to the list (round 4), none to its own workgroup's exact chain
 };
@@ -146,6 +147,11 @@ struct pm_lpf8_plan {
     double dlow = 0;                 // bound on the digit product the kernel leaves out: 128 sum|q_0|
     double hmax = 0;
     void *d_btab = nullptr;
+    // made by the fused launch the first time it meets the sweep's templates (pm_fir.hip: afsk_group_run_fused): the four correlator
+    // templates reversed and interleaved, for scalar loads; tpl_src / tpl_m say which templates it was made from
+    void *d_tpl = nullptr;
+    const void *tpl_src[4] = {nullptr, nullptr, nullptr, nullptr};
+    int tpl_m = 0;
 };
 int pm_lpf8_plan_create(pm_ctx *ctx, const double *h_taps, int ml, pm_lpf8_plan **out);
 void pm_lpf8_plan_destroy(pm_lpf8_plan *p);

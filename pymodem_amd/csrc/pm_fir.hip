@@ -580,29 +580,61 @@ __device__ __forceinline__ void slide_run(const double *__restrict__ xs, const d
 // kernel adds to its bound in units of its integers; what it saves is the binary64 reciprocal-square-root seed and its Newton step (six
 // instructions of which one is quarter-rate) -- twice per sample.  Radicands below binary32's normal range give roots below 2^-63 either
 // way: the kernel only scales workgroups whose largest magnitude is above 2^-21, so that is below 2^-20 of a unit.
+// (tg: nullptr, or the same four templates -- reversed and interleaved, tg[4 i + f] = h_f[m - 1 - i] -- in DEVICE memory, read through the
+// constant address space: uniform addresses, so the loads are scalar loads and the taps reach the fma as scalar operands.  From LDS every
+// lane of a wave fetched the same 32 bytes per tap beside its own 8 of the window: 40 bytes per lane and tap against an LDS pipe of 128
+// bytes per cycle for the whole CU -- 20 cycles per tap and wave for 16 cycles of fma; the start sums were bound by that, not by the
+// vector pipe (taking 15 % of the kernel's vector instructions out of them changed nothing: round 5, gpurun_out r5aa).)
+typedef const double __attribute__((address_space(4))) *const_f64_ptr;
 template <int L>
 __device__ __forceinline__ void slide_run_f32(const double *__restrict__ xs, const double *__restrict__ tp, int run, int m, const SlideTones &T,
-                                              float (&mv)[L], float (&sv)[L])
+                                              float (&mv)[L], float (&sv)[L], const double *tg = nullptr)
 {
     const double *xr = xs + run * (L + 1);
     double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
-    {
-        const double2v *tq = reinterpret_cast<const double2v *>(tp);
+    if (tg) {
+        const_f64_ptr tq = (const_f64_ptr)tg;                 // NOLINT: only a C-style cast changes the address space
+        const double *xb = xr;
         int i = 0;
-        for (; i + 4 <= m; i += 4) {
+        for (; i + L <= m; i += L, xb += L + 1, tq += 4 * L) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double v = xr[slide_slot<L>(i + q)];
-                const double2v h01 = tq[2 * (i + q)], h23 = tq[2 * (i + q) + 1];
+            for (int j = 0; j < L; ++j) {
+                const double v = xb[j];
+                a = __builtin_fma(tq[4 * j + 0], v, a);
+                b = __builtin_fma(tq[4 * j + 1], v, b);
+                c = __builtin_fma(tq[4 * j + 2], v, c);
+                d = __builtin_fma(tq[4 * j + 3], v, d);
+            }
+        }
+        for (int j = 0; i + j < m; ++j) {
+            const double v = xb[j];
+            a = __builtin_fma(tq[4 * j + 0], v, a);
+            b = __builtin_fma(tq[4 * j + 1], v, b);
+            c = __builtin_fma(tq[4 * j + 2], v, c);
+            d = __builtin_fma(tq[4 * j + 3], v, d);
+        }
+    } else {
+        // The run's window starts on a block boundary of the padded layout (slot(L run) = (L + 1) run), so its taps go in blocks of L
+        // whose L values are CONSECUTIVE doubles, one pad apart from block to block: every LDS address of a block is the block's base
+        // plus an immediate.  (Round 5: as slide_slot(i + q) per tap -- a division by 12 each -- the start sums spent 20 vector
+        // instructions on addresses for every 16 fma, 15 % of the fused kernel's vector instructions.)  Same taps, same order, same sums.
+        const double2v *tq = reinterpret_cast<const double2v *>(tp);
+        const double *xb = xr;
+        int i = 0;
+        for (; i + L <= m; i += L, xb += L + 1, tq += 2 * L) {
+#pragma unroll
+            for (int j = 0; j < L; ++j) {
+                const double v = xb[j];
+                const double2v h01 = tq[2 * j], h23 = tq[2 * j + 1];
                 a = __builtin_fma(h01.x, v, a);
                 b = __builtin_fma(h01.y, v, b);
                 c = __builtin_fma(h23.x, v, c);
                 d = __builtin_fma(h23.y, v, d);
             }
         }
-        for (; i < m; ++i) {
-            const double v = xr[slide_slot<L>(i)];
-            const double2v h01 = tq[2 * i], h23 = tq[2 * i + 1];
+        for (int j = 0; i + j < m; ++j) {                    // fewer than L taps left: inside one block
+            const double v = xb[j];
+            const double2v h01 = tq[2 * j], h23 = tq[2 * j + 1];
             a = __builtin_fma(h01.x, v, a);
             b = __builtin_fma(h01.y, v, b);
             c = __builtin_fma(h23.x, v, c);
@@ -707,6 +739,16 @@ __global__ void pack_group_taps_kernel(const double *__restrict__ mi, const doub
     if (idx >= m * F) return;
     const int i = idx / F, f = idx % F, k = m - 1 - i;
     w[idx] = f == 0 ? mi[k] : f == 1 ? mq[k] : sp[(size_t)(f - 2) * m + k];
+}
+
+// tg[4 i + f] = h_f[m - 1 - i], f = mark i, mark q, unit-gain space i, space q: the sliding sums' templates as one table (afsk_fused8_kernel)
+__global__ void pack_templates_kernel(const double *__restrict__ mi, const double *__restrict__ mq, const double *__restrict__ ui, const double *__restrict__ uq, int m,
+                                      double *__restrict__ tg)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 4 * m) return;
+    const int i = idx >> 2, f = idx & 3, k = m - 1 - i;
+    tg[idx] = f == 0 ? mi[k] : f == 1 ? mq[k] : f == 2 ? ui[k] : uq[k];
 }
 
 template <int G, bool VEC>
@@ -1097,20 +1139,22 @@ __device__ __forceinline__ void lpf8_sweep_tile(double *__restrict__ xs, unsigne
                                                 unsigned *__restrict__ wl, float *__restrict__ wmax8, int sweep, bool lds_ok, int t, int64_t tile0,
                                                 const double *__restrict__ mi, const double *__restrict__ mq, const double *__restrict__ ui,
                                                 const double *__restrict__ uq, int m, const SlideTones &T, const Lpf8Args &Q, int ml, int64_t nout, int G,
-                                                const SweepArgs &P, double E, unsigned long long *__restrict__ list, int *__restrict__ count, int cap)
+                                                const SweepArgs &P, double E, unsigned long long *__restrict__ list, int *__restrict__ count, int cap,
+                                                const double *tg = nullptr)
 {
     constexpr int L = kFuseRun, TILE = kThreads * 8;
     const int nmag = TILE + ml - 1, nruns = (nmag + L - 1) / L;
-    for (int i = t; i < m; i += kThreads) {
-        tp[4 * i + 0] = mi[m - 1 - i];
-        tp[4 * i + 1] = mq[m - 1 - i];
-        tp[4 * i + 2] = ui[m - 1 - i];
-        tp[4 * i + 3] = uq[m - 1 - i];
-    }
+    if (!tg)
+        for (int i = t; i < m; i += kThreads) {
+            tp[4 * i + 0] = mi[m - 1 - i];
+            tp[4 * i + 1] = mq[m - 1 - i];
+            tp[4 * i + 2] = ui[m - 1 - i];
+            tp[4 * i + 3] = uq[m - 1 - i];
+        }
     lds_barrier();
 #if PM_LPF8_F32MAG
     float mv[L], sv[L];
-    if (t < nruns) slide_run_f32<L>(xs, tp, t, m, T, mv, sv);
+    if (t < nruns) slide_run_f32<L>(xs, tp, t, m, T, mv, sv, tg);
     // the workgroup's largest value (what the planes will hold) and, for one stream, the largest mark + gain * space (what its roots'
     // errors scale with: the difference may be far smaller than either)
     float vmaxf = 0.0f, vsumf = 0.0f;
@@ -1374,6 +1418,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PM_LPF
 struct FusedSweep {
     const double *mi, *mq, *ui, *uq;     // templates (mark pair, unit-gain space pair)
     const double *space, *lpf;           // the exact chain's operands: the modems' own space taps, the low-pass in binary64
+    const double *tg;                    // the four templates reversed and interleaved (pm_lpf8_plan::d_tpl): scalar loads in the sliding sums
     int m, ml, G, one;
     SlideTones T;
     Lpf8Args Q;
@@ -1439,14 +1484,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PM_FUS
         const FusedSweep &S = A.s[0];
         if (tile0 < ((S.nout + 63) >> 6) * 64)               // (uniform: a sweep with a longer correlator has fewer outputs)
             lpf8_sweep_tile<ONE0>(xs, planes, tp, bl, wl, wmax8, 0, A.lds_ok != 0, t, tile0, S.mi, S.mq, S.ui, S.uq, S.m, S.T, S.Q, S.ml, S.nout, S.G, S.P, S.E,
-                                  S.list, S.count, A.cap);
+                                  S.list, S.count, A.cap, S.tg);
     }
     if (NS == 2) {
         lds_barrier();                                       // every wave is through with the first sweep's templates, planes and band
         const FusedSweep &S = A.s[1];
         if (tile0 < ((S.nout + 63) >> 6) * 64)
             lpf8_sweep_tile<ONE1>(xs, planes, tp, bl, wl, wmax8, 1, A.lds_ok != 0, t, tile0, S.mi, S.mq, S.ui, S.uq, S.m, S.T, S.Q, S.ml, S.nout, S.G, S.P, S.E,
-                                  S.list, S.count, A.cap);
+                                  S.list, S.count, A.cap, S.tg);
     }
     // the workgroup's own uncertain samples, by the reference's chain from the audio (see afsk_slide_lpf8_kernel)
     __syncthreads();
@@ -2291,6 +2336,22 @@ static int afsk_group_run_fused(pm_ctx *ctx, const int16_t *d_audio, int64_t n, 
         FusedSweep &S = A.s[k];
         S.mi = w.d_mark_i; S.mq = w.d_mark_q; S.ui = w.d_unit_i; S.uq = w.d_unit_q;
         S.space = w.d_space; S.lpf = w.d_lpf;
+        {
+            // the four templates as ONE reversed, interleaved table (pack_group_taps_kernel's layout with F = 4), made the first time the
+            // plan meets these templates and kept with it: the kernel reads it through the scalar cache
+            pm_lpf8_plan *mq_ = const_cast<pm_lpf8_plan *>(q);
+            if (!(mq_->d_tpl && mq_->tpl_m == w.m && mq_->tpl_src[0] == w.d_mark_i && mq_->tpl_src[1] == w.d_mark_q && mq_->tpl_src[2] == w.d_unit_i &&
+                  mq_->tpl_src[3] == w.d_unit_q)) {
+                if (mq_->d_tpl) { PM_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(mq_->d_tpl); mq_->d_tpl = nullptr; }
+                PM_HIP(hipMalloc(&mq_->d_tpl, sizeof(double) * 4 * (size_t)w.m + 256));
+                hipLaunchKernelGGL(pack_templates_kernel, dim3((unsigned)pm_cdiv(4 * (int64_t)w.m, 256)), dim3(256), 0, ctx->stream, w.d_mark_i, w.d_mark_q, w.d_unit_i,
+                                   w.d_unit_q, w.m, (double *)mq_->d_tpl);
+                PM_HIP(hipGetLastError());
+                mq_->tpl_m = w.m;
+                mq_->tpl_src[0] = w.d_mark_i; mq_->tpl_src[1] = w.d_mark_q; mq_->tpl_src[2] = w.d_unit_i; mq_->tpl_src[3] = w.d_unit_q;
+            }
+            S.tg = ctx->tune.sweep_lds_templates ? nullptr : (const double *)mq_->d_tpl;
+        }
         S.m = w.m; S.ml = w.ml; S.G = w.groups;
         S.one = w.groups == 1;
         double gmax = 0.0;

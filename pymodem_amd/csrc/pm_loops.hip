@@ -80,8 +80,11 @@ __device__ __forceinline__ void nco_update(LoopRegs &L, const double2v *tab2)
     int at = idx;
     if (__builtin_expect(!(ph0 >= 0.0 && ph0 < 2.0 * kTwoPi), 0)) {
         ph = ph0;
-        while (ph >= kTwoPi) ph = ph - kTwoPi;                              // nco.py:36-37
-        while (ph < 0) ph = ph + kTwoPi;                                    // nco.py:38-39 (may round to exactly 2pi, and stays, as there)
+        // The reference's two loops, with an end every wave reaches: a phase of 1e300 (or an infinity) is its own predecessor by 2 pi, the
+        // reference would spin on it for ever, and on a GPU that is a kernel that never ends -- an input nobody ever produced, unless
+        // a launch once reads memory nobody has written.  4096 trips cover 25 000 radians per sample; beyond, the phase stays what it is.
+        for (int trip = 0; trip < 4096 && ph >= kTwoPi; ++trip) ph = ph - kTwoPi;      // nco.py:36-37
+        for (int trip = 0; trip < 4096 && ph < 0; ++trip) ph = ph + kTwoPi;            // nco.py:38-39 (may round to exactly 2pi, and stays, as there)
         idx = (int)(ph * L.index_scaling);
         at = min(max(idx, 0), 256);
     }

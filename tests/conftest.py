@@ -15,6 +15,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that stops making progress -- a kernel that never ends, a stream waiting for an event nobody records -- must fail with the
+    test's name and every thread's stack, not sit there until whoever runs the suite gives up (the longest test takes 90 s; pytest-timeout's
+    thread method dumps the stacks and ends the process, so the device context goes with it)."""
+    try:
+        import pytest_timeout  # noqa: F401
+    except ImportError:
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(360, method="thread"))
+
+
 def pytest_sessionstart(session):
     """The in-tree libraries are git-ignored build products: build them when they are missing (hipcc cross-compiles gfx950
     without a GPU; ~40 s once).  On the GPU box they arrive prebuilt with the snapshot."""
