@@ -2347,6 +2347,7 @@ static int afsk_group_run_fused(pm_ctx *ctx, const int16_t *d_audio, int64_t n, 
                 hipLaunchKernelGGL(pack_templates_kernel, dim3((unsigned)pm_cdiv(4 * (int64_t)w.m, 256)), dim3(256), 0, ctx->stream, w.d_mark_i, w.d_mark_q, w.d_unit_i,
                                    w.d_unit_q, w.m, (double *)mq_->d_tpl);
                 PM_HIP(hipGetLastError());
+                PM_HIP(hipStreamSynchronize(ctx->stream));     // once per plan: another context's launch may be the table's next reader
                 mq_->tpl_m = w.m;
                 mq_->tpl_src[0] = w.d_mark_i; mq_->tpl_src[1] = w.d_mark_q; mq_->tpl_src[2] = w.d_unit_i; mq_->tpl_src[3] = w.d_unit_q;
             }
