@@ -45,6 +45,7 @@ struct pm_tuning {
     int lbatch_loop_cus = -1;          // PM_LBATCH_LOOP_CUS: compute units the batch engine's carrier loops have to themselves (0: none, -1: by size)
     int agc_rows_prio = 2;             // PM_AGC_ROWS_PRIO: wave priority of the rows AGC (the loops run at 3)
     int sweep_lds_templates = 0;       // PM_SWEEP_LDS_TEMPLATES: the fused kernel's sliding sums read their templates from LDS (as the split kernel does), not through the scalar cache
+    int fused_lds_pad = 0;             // PM_FUSED_LDS_PAD: bytes of LDS the fused AFSK launch asks for beyond what it uses (12288: three workgroups per CU, 40960: two)
     int afsk_split = 0;                // PM_AFSK_SPLIT: the pipelined executor's AFSK stage as band-pass + one launch per sweep (round 4), not fused into one launch
     int sweep_no_tail = 0;             // PM_SWEEP_NO_TAIL: the matrix-pipe sweep sends every uncertain sample to the list (round 4), none to its own workgroup's exact chain
 };

@@ -2402,6 +2402,7 @@ static int afsk_group_run_fused(pm_ctx *ctx, const int16_t *d_audio, int64_t n, 
     A.lds_ok = (size_t)tail_doubles * 8 <= (size_t)A.xw_doubles * 8 + (size_t)A.plane_bytes && !ctx->tune.sweep_no_tail;
     const size_t lds = (size_t)A.xw_doubles * 8 + (size_t)A.plane_bytes + 4 * (size_t)mmax * 8 + 2 * kL8Dig * 64 * 16 + (kTailCap + 4) * sizeof(unsigned) + 32;
     if (lds > 64 * 1024) return PM_OK;
+    const size_t lds_launch = lds + (size_t)std::max(0, ctx->tune.fused_lds_pad);      // (PM_FUSED_LDS_PAD: fewer workgroups per CU, to measure what occupancy is worth)
     int64_t tiles = 0;
     double bits_out = 0.0, flops = 2.0 * mb * (double)nb;
     for (int k = 0; k < nsweeps; ++k) {
@@ -2415,8 +2416,8 @@ static int afsk_group_run_fused(pm_ctx *ctx, const int16_t *d_audio, int64_t n, 
         PmProf prof(ctx, PM_K_FIR_F64);
         prof.work((double)n * 2 + bits_out, flops);          // the recording in, the bitmaps out: nothing else crosses HBM
         auto go = [&](auto kernel) -> int {
-            if (int rc = allow_lds(kernel, lds)) return rc;
-            hipLaunchKernelGGL(kernel, dim3((unsigned)tiles), dim3(kThreads), lds, ctx->stream, A);
+            if (int rc = allow_lds(kernel, lds_launch)) return rc;
+            hipLaunchKernelGGL(kernel, dim3((unsigned)tiles), dim3(kThreads), lds_launch, ctx->stream, A);
             return PM_OK;
         };
         int rc = PM_OK;

@@ -33,7 +33,7 @@ const TuneKey kTuneKeys[] = {
     {"slicer_trace", "PM_SLICER_TRACE", &pm_tuning::slicer_trace}, {"slicer_no_setprio", "PM_SLICER_NO_SETPRIO", &pm_tuning::slicer_no_setprio},
     {"fir8", "PM_FIR8", &pm_tuning::fir8}, {"bpf8_max", "PM_BPF8_MAX", &pm_tuning::bpf8_max}, {"loop_agc", "PM_LOOP_AGC", &pm_tuning::loop_agc}, {"loop_vec", "PM_LOOP_VEC", &pm_tuning::loop_vec},
     {"lbatch_loop_cus", "PM_LBATCH_LOOP_CUS", &pm_tuning::lbatch_loop_cus}, {"agc_rows_prio", "PM_AGC_ROWS_PRIO", &pm_tuning::agc_rows_prio},
-    {"sweep_no_tail", "PM_SWEEP_NO_TAIL", &pm_tuning::sweep_no_tail}, {"afsk_split", "PM_AFSK_SPLIT", &pm_tuning::afsk_split}, {"sweep_lds_templates", "PM_SWEEP_LDS_TEMPLATES", &pm_tuning::sweep_lds_templates},
+    {"sweep_no_tail", "PM_SWEEP_NO_TAIL", &pm_tuning::sweep_no_tail}, {"afsk_split", "PM_AFSK_SPLIT", &pm_tuning::afsk_split}, {"fused_lds_pad", "PM_FUSED_LDS_PAD", &pm_tuning::fused_lds_pad}, {"sweep_lds_templates", "PM_SWEEP_LDS_TEMPLATES", &pm_tuning::sweep_lds_templates},
 };
 }  // namespace
 
