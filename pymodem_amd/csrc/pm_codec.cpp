@@ -333,9 +333,130 @@ struct Ax25 : pm_codec {
     std::vector<uint8_t> data;
     static constexpr int kMin = 18, kMax = 1023;           // ax25.py:14-15
     const Ax25Entry *table = ax25_table();
-    explicit Ax25(int src) { source = src; }
+    bool skim_on;
+    explicit Ax25(int src)
+    {
+        source = src;
+        static const bool on = [] {
+            const char *e = getenv("PM_AX25_SKIM");         // =0: every byte through the table-driven decoder (rounds 2-4), for A/B runs and the tests
+            return !(e && e[0] == '0');
+        }();
+        skim_on = on;
+    }
+
+    static int trailing_ones(uint8_t b)
+    {
+        static const struct Trail {
+            uint8_t v[256];
+            Trail()
+            {
+                for (int b = 0; b < 256; ++b) {
+                    int t = 0;
+                    while (t < 8 && ((b >> t) & 1)) ++t;
+                    v[b] = (uint8_t)(t < 7 ? t : 7);
+                }
+            }
+        } trail;
+        return trail.v[b];
+    }
+
+    // ---- the skim (round 5) ----------------------------------------------------------------------------------------------------------
+    // What the decoder does with a stretch of bits is decided by three bit patterns: a zero behind exactly five ones is dropped
+    // (ax25.py:69-71), a zero behind exactly six is a flag (:72-89), the seventh one of a run and every one after it clear the bit and byte
+    // counters (:36-39) -- and the zero that ends such a run is not appended.  Flags and run ends are the decoder's RESETS; between two of
+    // them every bit but the dropped zeros is appended.  So whether a flag closes a frame -- at least 18 bytes and 7 bits counted since the
+    // last reset (:74-81) -- follows from positions and a count of dropped zeros, 64 bits at a time, and only a flag that DOES close one
+    // (one in fourteen on noise) needs the bytes: the table-driven decoder below is then run from the flag before it, where the registers
+    // are known (everything cleared; what the byte register still holds of older bits never reaches a completed byte).  The collected
+    // bytes survive run ends (:36-39 clear counters only), which is why that run starts at the last FLAG, not at the last reset.
+    // Exact as long as the byte counter does not pass its limit between two resets (it then clears the ones counter in mid-run, :41-50,
+    // and the patterns stop telling what the decoder sees): 8000 bits without a reset and the rest of the call goes through the table.
+    // One core of the build container, ns per byte: random bits 4.45 -> 2.29, four ones in five (the space-heavy chains between packets:
+    // runs end everywhere) 12.3 -> 3.5, the headline's streams (two thirds of their bits inside frames, which need their bytes) 4.4 -> 4.5.
+    static uint64_t load_bits(const uint8_t *p, int64_t have)
+    {
+        uint64_t x = 0;
+        memcpy(&x, p, (size_t)(have < 8 ? have : 8));       // (little-endian host: the stream's first byte in bits 0..7)
+        // the stream's bits are the bytes' from the top (ax25.py:30-31, :91-92): turned round inside each byte, bit i of x is stream bit i
+        x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+        x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+        x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+        return x;
+    }
+
+    void reposition(const uint8_t *d, int64_t sb)
+    {
+        // byte sb holds a flag's closing zero: whatever the registers are in front of it, they are the decoder's own behind it -- and with
+        // no byte counted the flag itself closes nothing
+        wb = 0;
+        nbytes = 0;
+        nbits = 0;
+        data.clear();
+        ones = trailing_ones(d[sb - 1]);
+    }
 
     void feed_many(const uint8_t *d, const int64_t *a, int64_t n) override
+    {
+        if (!skim_on || n < 24) {
+            run(d, a, 0, n);
+            return;
+        }
+        const int k = ones < 8 ? ones : 8;
+        uint64_t prev = k >= 7 ? 0xFFull << 56 : (k ? ~0ull << (64 - k) : 0);       // the bits in front of the call: `ones` ones behind a zero
+        int64_t R = 0, T0 = (int64_t)nbytes * 8 + nbits;      // R: first bit after the last reset; T0: bits counted before the call
+        int64_t cumS = 0, sAtR = 0;                           // dropped zeros before this word / before R
+        int64_t LF = -1;                                      // first bit after the last flag of this call
+        int64_t cursor = 0;                                   // bytes the registers have taken
+        bool first = true;
+        auto take_from_last_flag = [&](int64_t upto) {
+            if (LF >= 0) {
+                const int64_t sb = (LF - 1) >> 3;
+                if (sb >= cursor && sb > 0) {
+                    reposition(d, sb);
+                    cursor = sb;
+                }
+            }
+            run(d, a, cursor, upto);
+            cursor = upto;
+        };
+        for (int64_t w0 = 0; w0 < n; w0 += 8) {
+            const int64_t have = n - w0;
+            const uint64_t w = load_bits(d + w0, have);
+            const uint64_t valid = have >= 8 ? ~0ull : (1ull << (8 * have)) - 1;
+            const uint64_t e1 = (w << 1) | (prev >> 63), e2 = (w << 2) | (prev >> 62), e3 = (w << 3) | (prev >> 61), e4 = (w << 4) | (prev >> 60),
+                           e5 = (w << 5) | (prev >> 59), e6 = (w << 6) | (prev >> 58), e7 = (w << 7) | (prev >> 57);
+            const uint64_t o5 = e1 & e2 & e3 & e4 & e5;
+            const uint64_t S = ~w & o5 & ~e6 & valid;           // dropped zeros
+            uint64_t ev = ~w & o5 & e6 & valid;                 // zeros behind six ones or more: flags and run ends
+            while (ev) {
+                const int i = __builtin_ctzll(ev);
+                ev &= ev - 1;
+                const int64_t P = w0 * 8 + i;
+                const int64_t span = T0 + (P - R);
+                if (span >= 8000) {                          // the byte counter may have passed its limit: no more skimming in this call
+                    take_from_last_flag(n);
+                    return;
+                }
+                const int64_t sHere = cumS + __builtin_popcountll(S & ((1ull << i) - 1));
+                if (!((e7 >> i) & 1)) {
+                    const int64_t T = span - (sHere - sAtR);  // bits counted at the flag's zero
+                    if (first || ((T & 7) == 7 && T >= 8 * kMin + 7)) take_from_last_flag((P >> 3) + 1);
+                    first = false;
+                    LF = P + 1;
+                }
+                R = P + 1;
+                T0 = 0;
+                sAtR = sHere;
+            }
+            cumS += __builtin_popcountll(S);
+            prev = w;
+        }
+        // the registers as the call leaves them: the bytes since the last flag, the counters since the last reset
+        take_from_last_flag(n);
+    }
+
+    // bytes [k0, k1) through the registers, eight bits at a time (round 2)
+    void run(const uint8_t *d, const int64_t *a, int64_t k0, int64_t k1)
     {
         // the collected bytes as a raw buffer while this call runs (one slot of slack: a byte is stored whether or not it is
         // complete and the length moves on only if it is -- no branch on the data)
@@ -349,19 +470,8 @@ struct Ax25 : pm_codec {
         // distinguishes): a function of that byte alone, so the look-up of byte k + 1 does not wait for the entry of byte k -- the
         // chain through the table was what a byte cost (20 cycles; the other counters are one-cycle additions).  The one exception,
         // a completed byte clearing the counter at the length limit, goes through the bit-serial path, which hands its own count on.
-        static const struct Trail {
-            uint8_t v[256];
-            Trail()
-            {
-                for (int b = 0; b < 256; ++b) {
-                    int t = 0;
-                    while (t < 8 && ((b >> t) & 1)) ++t;
-                    v[b] = (uint8_t)(t < 7 ? t : 7);
-                }
-            }
-        } trail;
         int ones_in = ones < 7 ? ones : 7;
-        for (int64_t k = 0; k < n; ++k) {
+        for (int64_t k = k0; k < k1; ++k) {
             const uint8_t byte = d[k];
             const Ax25Entry &e = table[ones_in * 256 + byte];
             // near the length limit a completed byte may clear the ones counter in mid-byte (byte_done): bit by bit there
@@ -375,7 +485,7 @@ struct Ax25 : pm_codec {
                 buf = data.data();
                 continue;
             }
-            ones_in = trail.v[byte];
+            ones_in = trailing_ones(byte);
             if (__builtin_expect(e.nsteps == 1 && e.step[0].op < 16, 1)) {           // nine bytes in ten: eight bits' worth of appends
                 const unsigned cnt = e.step[0].op;
                 const unsigned x = (wb & 0x7F) | ((unsigned)e.step[0].bits << 7);

@@ -58,6 +58,42 @@ def test_ax25_matches_oracle_on_random_streams(p_one):
     assert p_one != 0.5 or len(want) > 0
 
 
+@pytest.mark.parametrize("p_one", [0.5, 0.6, 0.75, 0.4])
+def test_ax25_in_pieces_of_any_size_matches_oracle(p_one):
+    """The decoder's registers carry over between calls (ax25.py:17-23) and the native decoder skims whole calls 64 bits at a time for the
+    flags that can close a frame: pieces of 1 ... 3000 bytes, cut anywhere -- inside flags, runs of ones, stuffed zeros -- with real frames
+    planted between the random bits, must give the reference's packets, addresses and order."""
+    from pymodem_amd import siggen
+    from pymodem_amd.codecs import AX25Codec
+    from pymodem_amd.data_classes import AddressedArray
+    rng = np.random.default_rng(int(p_one * 1000))
+    bits = []
+    for k in range(60):
+        frame = siggen.ax25_ui_frame("CQ", f"N0CAL{k % 10}", [int(c) for c in rng.integers(32, 127, int(rng.integers(1, 120)))])
+        fb = np.array(siggen.ax25_hdlc_bits(frame), dtype=np.uint8)
+        if k % 7 == 3:
+            fb[int(rng.integers(20, len(fb) - 20))] ^= 1                      # a damaged frame: closes (or not) wherever the bits say
+        if k % 11 == 5:
+            fb = np.concatenate([fb[:len(fb) // 2], np.ones(9, dtype=np.uint8), fb[len(fb) // 2:]])     # an abort in mid-frame: the bytes stay
+        bits.append(fb)
+        bits.append((rng.random(int(rng.integers(0, 6000))) < p_one).astype(np.uint8))
+    b = np.concatenate(bits)
+    data = np.packbits(b[:len(b) // 8 * 8])
+    n = len(data)
+    addr = np.cumsum(rng.integers(1, 50, n)).astype(np.int64)
+    want = pk(O.AX25Codec(ident="x").decode(data, addr))
+    assert len(want) >= 40
+    for trial in range(4):
+        c = AX25Codec(ident="x")
+        got, at = [], 0
+        top = [3000, 200, 30, 9][trial]
+        while at < n:
+            step = int(rng.integers(1, top))
+            got += c.decode(AddressedArray(data[at:at + step], addr[at:at + step]))
+            at += step
+        assert pk(got) == want, (p_one, trial, len(got), len(want))
+
+
 def test_ax25_frames_longer_than_a_row():
     """A flag after a long stretch without one closes a frame of any length in the reference (the byte counter wraps at 1023, the bytes
     stay: ax25.py:41-47).  The native row keeps the first PM_PKT_MAX bytes; address, count, CRC fields and validity are the whole
