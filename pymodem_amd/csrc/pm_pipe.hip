@@ -667,7 +667,9 @@ int pm_pipe_create(pm_ctx *ctx, const pm_pipe_desc *desc, pm_pipe **out)
     p->host_copy = getenv("PM_PIPE_HOST_COPY") != nullptr;
     p->group = d.slice_group > 0 ? std::min(d.slice_group, 16) : 4;
     p->min_group = d.slice_min_group > 0 ? std::min(d.slice_min_group, p->group) : p->group;
-    p->host_threads = d.host_threads > 0 ? d.host_threads : std::max(2, std::min(8, 24 / d.nchains)) + 1;
+    // recordings in the host stage at a time: four for the headline's eight chains (each spreads its chains over decode_threads), twelve
+    // for fsk_9600's three -- 9 / 10 / 12 / 14 there: 0.37-0.39 / 0.25-0.32 / 0.26-0.31 / 0.20-0.33 ms per step (profiles/r05_executor_knobs.txt)
+    p->host_threads = d.host_threads > 0 ? d.host_threads : std::max(2, std::min(12, 36 / d.nchains));
     p->decode_threads = d.decode_threads > 0 ? d.decode_threads : d.nchains;
     p->address_distance = d.address_distance;
     p->x_bound = d.x_bound;
