@@ -245,3 +245,45 @@ def test_a_refused_recording_leaves_no_hole_in_the_tickets(config_lines):
     for t in [first] + list(range(start, start + 4)):
         assert pipe.unique(t) == got[0]
     pipe.close()
+
+
+@pytest.mark.parametrize("cfg,rate", [("afsk_1200_ax25_super_opt.json", 44100), ("afsk_1200_ax25_super_opt.json", 96000), ("afsk_1200_ax25_super_opt.json", 22050),
+                                      ("afsk_1200.json", 44100), ("afsk_1200.json", 12000), ("afsk_300_ax25.json", 11025)])
+def test_native_pipeline_at_other_sample_rates_equals_the_oracle(config_lines, cfg, rate):
+    """Every filter of an AFSK chain is designed for the recording's sample rate (afsk.py:39-147: band-pass, correlator and low-pass
+    lengths all scale with it), so other rates are other kernels' worth of shapes: tap counts that are not multiples of anything, runs of
+    digits of other lengths, groups that do or do not qualify for the fused launch (pm_afsk_group_run_plan decides; the split launches
+    take the rest).  Signal and noise, two recordings in flight, every chain at bitstream level and bit by bit."""
+    import pymodem_amd
+    from pymodem_amd import chain_builder as cb, chain_execute as ce, siggen
+    lines = config_lines(cfg)
+    mode = "afsk300_ax25" if cfg.startswith("afsk_300") else "afsk1200_ax25"
+    sig = siggen.recording(mode, rate, packets=3, seed=rate % 97, noise_sigma=900.0, payload_len=(20, 50))[0]
+    n = min(len(sig), 40 * rate // 10)
+    a0 = np.ascontiguousarray(sig[:n])
+    a1 = noise_i16(n, seed=rate % 89, sigma=5000.0)
+    ctx = pymodem_amd.Context.default()
+    dev = [ctx.upload(a0), ctx.upload(a1)]
+    ctx.sync()
+    pipe = ce.NativePipeline([cb.build_chain(rate, l) for l in lines], n, rate / 40, ctx=ctx, keep_slices=True)
+    tickets = [pipe.submit(b) for b in dev]
+    found = 0
+    for t, a in zip(tickets, (a0, a1)):
+        want = [O.run_chain(O.build_chain(rate, line), a, canon=True) for line in lines]
+        for c, w in enumerate(want):                          # (slices and bitmaps first: a table without rows gives its ticket back)
+            sliced, plain = pipe.slices(t, c)
+            want_bits = np.asarray(w["demod"]) >= 0
+            got_bits = pipe.bitmap(t, c, len(want_bits))
+            assert np.array_equal(got_bits, want_bits), (cfg, rate, c, int(np.count_nonzero(got_bits != want_bits)))
+            assert np.array_equal(sliced.data, w["slice_data"]) and np.array_equal(sliced.address, w["slice_addr"]), (cfg, rate, c)
+            assert np.array_equal(plain, np.asarray(w["lfsr"], dtype=np.uint8)), (cfg, rate, c)
+        table = pipe.table(t)
+        rows = _rows_by_chain(table, len(lines))
+        for c, w in enumerate(want):
+            got_a, got_c, got_d = _pk(rows[c])
+            assert [int(x) for x in got_a] == [int(p.streamaddress) for p in w["packets"]], (cfg, rate, c)
+            assert got_d.tobytes() == b"".join(bytes(bytearray(p.data)) for p in w["packets"]), (cfg, rate, c)
+            found += len(w["packets"])
+        del table, rows
+    pipe.close()
+    assert found >= 1 or rate < 20000, (cfg, rate, found)
