@@ -95,3 +95,16 @@ def read_wav_pcm16(path):
             return rate, np.frombuffer(b[pos + 8:pos + 8 + sz], dtype="<i2").copy()
         pos += 8 + sz + (sz & 1)
     raise ValueError("no data chunk")
+
+
+def oracle_chains(jobs, rate=48000, workers=8):
+    """[(config line, int16 audio), ...] -> futures of O.run_chain(O.build_chain(rate, line), audio, canon=True), on a thread pool: the
+    oracle's filters, loops and slicers are C behind ctypes (no interpreter lock while they run), so the checker's minute of one host core
+    per full-size chain lies beside the GPU run it checks and beside the other chains' -- the suite's wall time, not its coverage."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    O.fir_canon(np.ones(4), np.ones(2))                       # the library and its tables are loaded before any thread asks for them
+    pool = ThreadPoolExecutor(max_workers=max(1, min(workers, len(jobs))))
+    futures = [pool.submit(lambda l=line, a=audio: O.run_chain(O.build_chain(rate, l), a, canon=True)) for line, audio in jobs]
+    pool.shutdown(wait=False)
+    return futures

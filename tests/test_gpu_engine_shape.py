@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import bench
-from conftest import noise_i16
+from conftest import noise_i16, oracle_chains
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -48,6 +48,7 @@ def _run(workload, mode, recordings, nchains, pairs, n=N):
     ctx.sync()
     audios = [dev.get(r, filler) for r in range(recordings)]
     sets = [[cb.build_chain(48000, line) for line in lines] for _ in range(recordings)]
+    wanted = oracle_chains([(lines[c], host[r]) for r, c in pairs])
     stages = {}
     try:
         packets = lb.process_recordings_device(sets, audios, ctx, chunk=65536, stages=stages)
@@ -60,8 +61,8 @@ def _run(workload, mode, recordings, nchains, pairs, n=N):
     assert loops_have_their_own_units, "the loops did not get compute units of their own (CU-masked streams)"
     assert recordings * nchains > 2048                        # pm_loops.hip loop_shape(): the direct kernel from 2049 loops
     total = 0
-    for r, c in pairs:
-        want = O.run_chain(O.build_chain(48000, lines[c]), host[r], canon=True)
+    for k, (r, c) in enumerate(pairs):
+        want = wanted[k].result()
         got = stages["sliced"][r][c]
         assert len(got.data) > 30
         assert np.array_equal(got.data, want["slice_data"]), (workload, r, c, "slicer bytes")

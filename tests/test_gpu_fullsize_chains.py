@@ -1,12 +1,13 @@
 """End-to-end parity at BASELINE size under the driver's `-m gpu` run: whole chains of the bench workloads over the full 10-minute
 (28.8 M-sample) packet-bearing bench buffer, group executor on the GPU against the oracle in canonical FIR order -- slicer bytes,
 stream addresses and packets (payload, address, corrected bytes) must be identical.  fsk_9600 = BASELINE configs[2] (three chains
-on one front end), bpsk_300 = configs[1], two chains of the qpsk_2400 sweep = configs[4], two of the AFSK gain sweep = configs[3].
-The oracle side costs about a minute of one host core in all."""
+on one front end), bpsk_300 = configs[1], the eight chains a GPU carries of the qpsk_2400 sweep = configs[4], three of the AFSK gain sweep =
+configs[3] (all eight: tests/test_gpu_pipe_bitstream.py).  The oracle side runs on a thread pool beside the GPU (conftest.oracle_chains)."""
 import numpy as np
 import pytest
 
 import bench
+from conftest import oracle_chains
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -21,19 +22,20 @@ def _buffer(workload):
     return bench.make_buffer(a)
 
 
-@pytest.mark.parametrize("workload,chain_ids", [("fsk_9600", [0, 1, 2]), ("bpsk_300", [0]), ("qpsk_2400", [0, 5]),
-                                                ("afsk_1200_super_opt", [0, 7])])
+@pytest.mark.parametrize("workload,chain_ids", [("fsk_9600", [0, 1, 2]), ("bpsk_300", [0]), ("qpsk_2400", [0, 1, 2, 3, 4, 5, 6, 7]),
+                                                ("afsk_1200_super_opt", [0, 3, 7])])
 def test_chains_at_full_size_match_the_oracle(workload, chain_ids):
     from pymodem_amd import chain_builder as cb, chain_execute as ce
     audio = _buffer(workload)
     factory = bench.WORKLOADS[workload][0]
     lines = [factory(c) for c in chain_ids]
     chains = [cb.build_chain(48000, line) for line in lines]
+    wanted = oracle_chains([(line, audio) for line in lines])
     stages = {}
     packets = ce.process_chains_device(chains, audio, stages=stages)
     total = 0
     for k, line in enumerate(lines):
-        want = O.run_chain(O.build_chain(48000, line), audio, canon=True)
+        want = wanted[k].result()
         got = stages["sliced"][k]
         assert len(got.data) > 10000
         assert np.array_equal(got.data, want["slice_data"]), f"{workload} chain {chain_ids[k]}: slicer bytes differ"
@@ -45,7 +47,7 @@ def test_chains_at_full_size_match_the_oracle(workload, chain_ids):
     assert total > 0            # (the inverted fsk_9600 chain decodes nothing, in the reference too)
 
 
-@pytest.mark.parametrize("workload,check_ids", [("bpsk_300", [0]), ("qpsk_2400", [0, 5])])
+@pytest.mark.parametrize("workload,check_ids", [("bpsk_300", [0]), ("qpsk_2400", [0, 1, 2, 3, 4, 5, 6, 7])])
 def test_batch_engine_at_full_size(workload, check_ids):
     """The carrier-loop batch engine (pymodem_amd.loop_batch: every recording x chain of a run in flight, 110 time chunks) at
     BASELINE size: two different recordings x all the workload's chains per GPU.  Recording 0 = the bench buffer: the checked chains
@@ -58,6 +60,7 @@ def test_batch_engine_at_full_size(workload, check_ids):
     factory, cpg, _ = bench.WORKLOADS[workload]
     lines = [factory(c) for c in range(cpg)]
     sets = [[cb.build_chain(48000, line) for line in lines] for _ in recs]
+    wanted = oracle_chains([(lines[c], audio) for c in check_ids])
     stages = {}
     try:
         packets = process_recordings_device(sets, recs, stages=stages)
@@ -74,8 +77,8 @@ def test_batch_engine_at_full_size(workload, check_ids):
             assert np.array_equal(got.data, want.data) and np.array_equal(got.address, want.address), (workload, r, c)
             assert key(packets[r][c]) == key(ref[c]), (workload, r, c)
     total = 0
-    for c in check_ids:
-        want = O.run_chain(O.build_chain(48000, lines[c]), audio, canon=True)
+    for k, c in enumerate(check_ids):
+        want = wanted[k].result()
         got = stages["sliced"][0][c]
         assert np.array_equal(got.data, want["slice_data"]) and np.array_equal(got.address, want["slice_addr"]), (workload, c)
         assert key(packets[0][c]) == key(want["packets"]), (workload, c)
