@@ -605,7 +605,7 @@ typedef struct pm_pipe_desc {
     int32_t slice_min_group;         /* a batch waits for this many recordings while later ones are queued (0 = slice_group) */
     int32_t demod_streams;           /* recordings take turns on this many demod streams: the context's own and further ones of the
                                         pipeline's, each with its own band-passed stream and sweep state (0 = 2) */
-    int32_t host_threads;            /* recordings in the host stage at once (0 = as chain_execute.RecordingPipeline chooses) */
+    int32_t host_threads;            /* recordings in the host stage at once (0 = min(12, 36 / chains), at least 2) */
     int32_t decode_threads;          /* threads inside one recording's host stage (0 = one per chain) */
     double address_distance;         /* PacketMetaArray.Correlate (packet_meta.py:230); < 0: no de-dup here (the chains are a part of
                                         the config: the rows go to the exchange, rank 0 de-duplicates), unique = 0 */
