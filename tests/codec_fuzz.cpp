@@ -45,6 +45,37 @@ int main()
             if (pm_codec_fetch(h, rows.data(), pend, &cnt)) return 3;
             for (int64_t k = 0; k < cnt; ++k) { mix(rows[(size_t)k].data, (size_t)rows[(size_t)k].len); mix(&rows[(size_t)k].streamaddress, 8); mix(&rows[(size_t)k].calculated_crc, 4); }
             total += cnt;
+            // the wire form of the rows (the multi-GPU exchange): packed into an exact-size block, unpacked and indexed from it, truncated
+            // streams refused, the de-dup on the dense heads equal to the de-dup on the full rows
+            if (cnt > 0) {
+                const int64_t need = pm_packets_pack(rows.data(), cnt, nullptr, 0);
+                if (need <= 0) return 4;
+                std::vector<uint8_t> wire((size_t)need);
+                if (pm_packets_pack(rows.data(), cnt, wire.data(), need) != need) return 5;
+                std::vector<pm_packet> back((size_t)cnt);
+                if (pm_packets_unpack(wire.data(), need, back.data(), cnt) != cnt) return 6;
+                for (int64_t k = 0; k < cnt; ++k)
+                    if (back[(size_t)k].streamaddress != rows[(size_t)k].streamaddress || back[(size_t)k].len != rows[(size_t)k].len ||
+                        memcmp(back[(size_t)k].data, rows[(size_t)k].data, (size_t)rows[(size_t)k].len) != 0)
+                        return 7;
+                std::vector<pm_packet_head> heads((size_t)cnt);
+                std::vector<int64_t> at((size_t)cnt);
+                if (pm_packets_index(wire.data(), need, heads.data(), at.data(), cnt) != cnt) return 8;
+                for (int64_t cut : {need - 1, need / 2, (int64_t)39, (int64_t)1}) {
+                    if (cut <= 0 || cut >= need) continue;
+                    std::vector<uint8_t> part(wire.begin(), wire.begin() + cut);          // exact size: reading past the cut is reading past the block
+                    (void)pm_packets_unpack(part.data(), cut, back.data(), cnt);
+                    (void)pm_packets_index(part.data(), cut, heads.data(), at.data(), cnt);
+                }
+                if (pm_packets_index(wire.data(), need, heads.data(), at.data(), cnt) != cnt) return 9;
+                std::vector<int64_t> u1((size_t)cnt), u2((size_t)cnt);
+                std::vector<int32_t> c1((size_t)cnt), c2((size_t)cnt);
+                const int64_t counts[1] = {cnt};
+                const int64_t k1 = pm_correlate(rows.data(), counts, 1, 1200.0, u1.data(), c1.data(), cnt);
+                const int64_t k2 = pm_correlate_strided(heads.data(), (int64_t)sizeof(pm_packet_head), counts, 1, 1200.0, u2.data(), c2.data(), cnt);
+                if (k1 < 0 || k1 != k2 || memcmp(u1.data(), u2.data(), (size_t)k1 * 8) != 0) return 10;
+                mix(&k1, 8);
+            }
             pm_codec_destroy(h);
         }
     }
