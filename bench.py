@@ -670,10 +670,16 @@ def measure(args, env):
             while taken < len(tickets) - 48:                  # results do not pile up: 7 MB of packet rows each
                 npipe.unique(tickets[taken])
                 taken += 1
+        _tt = [time.perf_counter()]
         for t in tickets[taken:-1]:
             npipe.unique(t)
+            _tt.append(time.perf_counter())
         res = npipe.table(tickets[-1]) if tickets else None
+        _tt.append(time.perf_counter())
         npipe.drain()
+        _tt.append(time.perf_counter())
+        if os.environ.get("BENCH_TAIL_TRACE"):
+            print("[tail] submits done -> each unique -> table -> drain (ms):", [round((x - _tt[0]) * 1e3, 3) for x in _tt], file=sys.stderr)
         # the pace between the 6th recording done and the 5th-from-last: the steady state, without fill and drain (as for the Python executor)
         done = sorted(npipe.done_at_ms.pop(t) for t in tickets if t in npipe.done_at_ms)
         if pace:
@@ -994,8 +1000,11 @@ def measure(args, env):
         pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(28)
     else:
         result = run_steps(args.steps)
+    _t1 = time.perf_counter()
     fence()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("BENCH_TAIL_TRACE"):
+        print(f"[tail] run_steps {(_t1 - t0) * 1e3:.3f} ms, fence {(time.perf_counter() - _t1) * 1e3:.3f} ms", file=sys.stderr)
     if os.environ.get("BENCH_TIMELINE"):
         print("[timeline] timed region ends", file=sys.stderr, flush=True)
     host_cpu_ms = (time.process_time() - cpu0) / max(args.steps, 1) * 1e3     # all threads of this process, native ones included
