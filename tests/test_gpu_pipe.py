@@ -70,6 +70,40 @@ def test_native_pipeline_matches_the_group_executor(config_lines, demod_streams)
     del keep
 
 
+def test_released_rows_come_back_clean(config_lines):
+    """A recording's packet rows go back to the pipeline's pool when its result is released, still written in, and are zeroed off the
+    releasing thread (an idle host worker, or the next taker that finds no clean block: rows_retire / rows_get in pm_pipe.hip).  Whatever a
+    later recording gets must hold zeros wherever its own packets did not write: whole rows -- the 1280-byte payload fields to their ends --
+    against the group executor's, with results taken and released one at a time so that blocks are re-used while others wait to be cleaned,
+    and recordings with many long packets followed by recordings with few short ones (or none)."""
+    import pymodem_amd
+    from pymodem_amd import chain_builder as cb, chain_execute as ce
+    lines = config_lines(CFG)
+    recs = _recordings()
+    want = {k: _want(lines, v)[0] for k, v in recs.items() if k in ("a", "b", "half", "short", "silence")}
+    ctx = pymodem_amd.Context.default()
+    dev = {k: ctx.upload(recs[k]) for k in want}
+    ctx.sync()
+    pipe = ce.NativePipeline([cb.build_chain(48000, l) for l in lines], max(len(recs[k]) for k in want), 48000 / 40, ctx=ctx)
+    order = ["a", "b", "a", "short", "half", "silence", "b", "a", "short", "b", "half", "a"] * 3
+    tickets = [(k, pipe.submit(dev[k])) for k in order[:6]]
+    nxt = 6
+    seen = 0
+    while tickets:
+        k, t = tickets.pop(0)
+        rows = pipe.rows(t)                                   # views of the library's memory: released when the last of them is gone
+        for c in range(len(lines)):
+            assert np.array_equal(rows[c], want[k][c]) or (
+                len(rows[c]) == len(want[k][c]) and all(np.array_equal(rows[c][f], want[k][c][f]) for f in rows[c].dtype.names if f != "correlated_count")), (k, c, seen)
+            seen += len(rows[c])
+        del rows
+        if nxt < len(order):
+            tickets.append((order[nxt], pipe.submit(dev[order[nxt]])))
+            nxt += 1
+    assert seen > 100
+    pipe.close()
+
+
 def test_native_pipeline_rows_equal_the_oracle(config_lines):
     """Straight against the CPU restatement for one recording: slicer-to-packet results per chain."""
     import pymodem_amd
