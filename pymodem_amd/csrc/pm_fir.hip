@@ -1448,6 +1448,9 @@ template <int KB, bool ONE0, int NS, bool ONE1>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PM_FUSED8_WAVES, PM_FUSED8_WAVES))) void afsk_fused8_kernel(FusedArgs A)
 {
     extern __shared__ double xs[];
+#if defined(PM_FUSED8_PRIO) && PM_FUSED8_PRIO > 0
+    __builtin_amdgcn_s_setprio(PM_FUSED8_PRIO);              // (measurement builds: this kernel's waves above the slicers' walkers at the issue port -- profiles/r05_executor_knobs.txt)
+#endif
     constexpr int L = kFuseRun, TILE = kThreads * 8;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t tile0 = (int64_t)blockIdx.x * TILE;
